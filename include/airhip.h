@@ -1,0 +1,209 @@
+/* airhip.h - C ABI of the MI355X-native PCAIR / PCPFLAREINV solve phase.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.  A PETSc
+ * plugin or any C / Fortran (bind(C)) / ctypes caller binds exactly
+ * these symbols.  Every function returns 0 on success (PETSC_SUCCESS convention) and a
+ * negative AIRHIP_ERR_* code otherwise; airhip_last_error() returns the message.  Library
+ * code never aborts the process (the reference's Fortran callbacks MPI_Abort,
+ * src/FC_Smooth.F90:449-452).
+ *
+ * Reference interfaces each entry point replaces (paths in PFLAREProject/PFLARE):
+ *   airhip_pcair_create        PCCreate_AIR                 src/PCAIR.c:3601-3644
+ *   airhip_pcair_set_option    PCSetFromOptions_AIR_c /     src/PCAIR.c:2777-3033,
+ *                              PCAIRSet* setters            include/pflare.h:121-243
+ *   airhip_pcair_setup         PCSetUp_AIR_c -> setup_air_pcmg   src/PCAIR.c:182-201,
+ *                                                           src/AIR_MG_Setup.F90:44
+ *   airhip_pcair_set_level /   the per-level state of air_multigrid_data filled by the
+ *   airhip_pcair_set_coarse /  reference's own setup         src/AIR_Data_Type.F90:284-360
+ *   airhip_pcair_finalize
+ *   airhip_pcair_apply         PCApply_AIR_c -> PCApply_AIR_Shell -> PCMG Kaskade cycle ->
+ *                              mg_FC_point_richardson / mg_coarse_shell_apply
+ *                              src/PCAIR.c:150-166, src/PCAIR_Shell.F90:170-188,
+ *                              src/FC_Smooth.F90:29-49,421-640
+ *   airhip_pcair_destroy       PCDestroy_AIR_c / destroy_air_data  src/PCAIR_Shell.F90:192-211
+ *   airhip_pcinv_*             PCCreate_PFLAREINV / PCSetUp_PFLAREINV_c / PCApply_PFLAREINV_c
+ *                              src/PCPFLAREINV.c:887-951, 689-783, 618-626
+ *   airhip_ksp_solve           KSPSolve (PETSc KSPRICHARDSON / KSPGMRES), the caller of PCApply
+ *   airhip_mat_*               MatMult on a device-resident AIJ matrix (PETSc MatMult_SeqAIJ*)
+ *
+ * Vectors are raw device pointers (HIP) to fp64 data owned by the caller.  Matrices are
+ * handed over as host CSR (int64 row pointers, int32 column indices sorted ascending, fp64
+ * values - what MatSeqAIJGetCSR / MatGetRowIJ give) and copied to the device at set time.
+ */
+#ifndef AIRHIP_H
+#define AIRHIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AIRHIP_OK 0
+#define AIRHIP_ERR_ARG (-1)
+#define AIRHIP_ERR_STATE (-2)
+#define AIRHIP_ERR_HIP (-3)
+#define AIRHIP_ERR_UNSUPPORTED (-4)
+#define AIRHIP_ERR_INTERNAL (-5)
+
+/* PCPFLAREINVType (include/pflare.h of the reference) */
+#define AIRHIP_INV_POWER 0
+#define AIRHIP_INV_ARNOLDI 1
+#define AIRHIP_INV_NEWTON 2
+#define AIRHIP_INV_NEUMANN 3
+#define AIRHIP_INV_WJACOBI 6
+#define AIRHIP_INV_JACOBI 7
+#define AIRHIP_INV_NEWTON_NO_EXTRA 8
+
+/* kinds of approximate inverse as applied in the solve phase */
+#define AIRHIP_OP_NONE 0
+#define AIRHIP_OP_ASSEMBLED 1 /* CSR                                   */
+#define AIRHIP_OP_DIAG 2      /* vector (MATDIAGONAL)                  */
+#define AIRHIP_OP_HORNER 3    /* monomial coefficients, matrix-free    */
+#define AIRHIP_OP_NEWTON 4    /* Newton-basis roots, matrix-free       */
+
+typedef struct {
+  int64_t m, n;
+  const int64_t* rowptr; /* m+1 */
+  const int32_t* col;    /* nnz, ascending within a row */
+  const double* val;     /* nnz */
+} airhip_csr;
+
+/* An approximate inverse (assembled Mat or MatShell + mat_ctxtype in the reference). */
+typedef struct {
+  int kind;              /* AIRHIP_OP_*                                               */
+  airhip_csr mat;        /* ASSEMBLED                                                 */
+  const double* diag;    /* DIAG: n entries                                           */
+  int ncoef;             /* HORNER: coefficients[ncoef] constant term first;          */
+  const double* coef;    /*         NEWTON: ncoef roots, real parts                   */
+  const double* coef_im; /* NEWTON: imaginary parts                                   */
+  int diag_scale;        /* q(D^-1 A) D^-1                                            */
+  int neumann;           /* operator is I - D^-1 A (Neumann series)                   */
+} airhip_invop;
+
+typedef struct airhip_pcair_s* airhip_pcair;
+typedef struct airhip_pcinv_s* airhip_pcinv;
+typedef struct airhip_mat_s* airhip_mat;
+
+const char* airhip_last_error(void);
+int airhip_version(void);
+/* number of HIP devices visible / select the device used by subsequently created objects */
+int airhip_device_count(int* count);
+int airhip_set_device(int device);
+
+/* ---------------------------------------------------------------- synthetic operators */
+/* tests/adv_1d.c:80-105 and tests/adv_diff_fd.c:366-586.  The CSR arrays are owned by the
+ * returned handle; release with airhip_hostmat_destroy. */
+typedef struct airhip_hostmat_s* airhip_hostmat;
+int airhip_gen_adv_1d(int64_t n, airhip_hostmat* out);
+int airhip_gen_adv_diff_fd(int dim, int64_t M, int64_t N, int64_t P, double u, double v, double w,
+                           int unit_velocity, double alpha, double L_x, double L_y, double L_z,
+                           int adv_nondim, airhip_hostmat* out);
+int airhip_hostmat_from_csr(const airhip_csr* A, airhip_hostmat* out); /* deep copy */
+int airhip_hostmat_get(airhip_hostmat A, airhip_csr* view);
+int airhip_hostmat_destroy(airhip_hostmat* A);
+
+/* ---------------------------------------------------------------------------- PCAIR */
+int airhip_pcair_create(airhip_pcair* pc);
+/* name without the "-pc_air_" prefix, value as it would appear on a PETSc command line,
+ * e.g. ("a_drop","1e-3"), ("inverse_type","power"), ("smooth_type","ff"), ("a_lump","1").
+ * Also accepted: ("mg_coarse_ksp_max_it","10") for -mg_coarse_ksp_type richardson. */
+int airhip_pcair_set_option(airhip_pcair pc, const char* name, const char* value);
+/* Full setup from the operator: host hierarchy construction + device upload. */
+int airhip_pcair_setup(airhip_pcair pc, const airhip_csr* A);
+
+/* Bring-your-own hierarchy (e.g. built by PFLARE's own setup under PETSc).  Levels are
+ * numbered 0 (finest) .. no_levels-2, all index lists and matrices in the reference's
+ * level-local numbering: F,C ascending row indices of the level operator; A_ff (n_f x n_f)
+ * or aff_diag (n_f, when A_ff is MATDIAGONAL); A_fc (n_f x n_c); Z (n_c x n_f, the Z block
+ * of R=[Z I]); W either one-point (wcol[n_f], -1 = empty row) or general CSR (n_f x n_c);
+ * optional A_cf, A_cc, inv_cc for C smoothing; smooth_order as in air_options. */
+int airhip_pcair_begin_levels(airhip_pcair pc, int no_levels, const airhip_csr* A_top);
+int airhip_pcair_set_level(airhip_pcair pc, int level, int64_t n, int64_t n_f, int64_t n_c,
+                           const int32_t* F, const int32_t* C,
+                           const airhip_csr* A_ff, const double* aff_diag,
+                           const airhip_csr* A_fc, const airhip_invop* inv_ff,
+                           const airhip_csr* Z, const int32_t* wcol, const airhip_csr* W,
+                           const airhip_csr* A_cf, const airhip_csr* A_cc, const airhip_invop* inv_cc,
+                           const int* smooth_order10);
+int airhip_pcair_set_coarse(airhip_pcair pc, const airhip_csr* A_coarse, const airhip_invop* inv,
+                            int coarse_richardson_its);
+int airhip_pcair_finalize(airhip_pcair pc);
+
+/* y = M x : one AIR V-cycle, natural ordering, device pointers; runs on the library's
+ * stream and is complete on return only after airhip_pcair_sync (or a later solve). */
+int airhip_pcair_apply(airhip_pcair pc, const double* d_x, double* d_y);
+int airhip_pcair_sync(airhip_pcair pc);
+int airhip_pcair_destroy(airhip_pcair* pc);
+
+/* hierarchy inspection / export (host arrays valid until the next setup / destroy) */
+int airhip_pcair_num_levels(airhip_pcair pc, int* no_levels);
+int airhip_pcair_level_sizes(airhip_pcair pc, int level, int64_t* n, int64_t* n_f, int64_t* n_c,
+                             int* aff_diag, int* one_point, int64_t* nnz_A);
+/* which: "F","C" (int32 index lists via idx/len), "A_ff","A_fc","A_cf","A_cc","Z","W","M_ff",
+ * "M_cc" (CSR), "aff_diag","M_ff_diag","M_cc_diag" (vector via vec/len), "wcol" (idx). */
+int airhip_pcair_level_get(airhip_pcair pc, int level, const char* which, airhip_csr* csr,
+                           const int32_t** idx, const double** vec, int64_t* len);
+int airhip_pcair_level_inv(airhip_pcair pc, int level, int which_c, airhip_invop* inv); /* level == no_levels-1: coarse */
+int airhip_pcair_level_smooth_order(airhip_pcair pc, int level, int* smooth_order10);
+int airhip_pcair_coarse_get(airhip_pcair pc, airhip_csr* A_coarse);
+/* complexities as printed by -pc_air_print_stats_timings (src/AIR_MG_Stats.F90:79-382) and
+ * the algorithmic bytes of one V-cycle */
+int airhip_pcair_complexities(airhip_pcair pc, double* grid, double* op, double* cycle, double* storage,
+                              double* cycle_alg_bytes);
+int airhip_pcair_setup_times(airhip_pcair pc, double* host_setup_s, double* upload_s);
+/* free the host copy of the hierarchy (export functions then fail with AIRHIP_ERR_STATE) */
+int airhip_pcair_release_host(airhip_pcair pc);
+/* run the V-cycle through a captured HIP graph (default off) */
+int airhip_pcair_use_graph(airhip_pcair pc, int on);
+
+/* per-kernel HIP-event timing of the V-cycle kernels (on the launch stream) */
+int airhip_pcair_profile(airhip_pcair pc, int on);
+int airhip_pcair_profile_reset(airhip_pcair pc);
+int airhip_pcair_profile_count(airhip_pcair pc, int* n);
+int airhip_pcair_profile_get(airhip_pcair pc, int i, const char** name, int* level, double* alg_bytes,
+                             int64_t* calls, double* total_ms);
+
+/* ------------------------------------------------------------------------ PCPFLAREINV */
+int airhip_pcinv_create(airhip_pcinv* pc);
+/* names: "type" (power|arnoldi|newton|neumann|wjacobi|jacobi), "poly_order", "sparsity_order",
+ * "matrix_free", "diag_scale" */
+int airhip_pcinv_set_option(airhip_pcinv pc, const char* name, const char* value);
+int airhip_pcinv_setup(airhip_pcinv pc, const airhip_csr* A);
+int airhip_pcinv_apply(airhip_pcinv pc, const double* d_x, double* d_y);
+int airhip_pcinv_sync(airhip_pcinv pc);
+int airhip_pcinv_get_inv(airhip_pcinv pc, airhip_invop* inv);
+int airhip_pcinv_destroy(airhip_pcinv* pc);
+
+/* ------------------------------------------------------------------ device matrices */
+int airhip_mat_create(const airhip_csr* A, airhip_mat* out);
+int airhip_mat_mult(airhip_mat A, const double* d_x, double* d_y); /* y = A x, synchronous */
+int airhip_mat_destroy(airhip_mat* A);
+
+/* ---------------------------------------------------------------------------- KSP */
+typedef struct {
+  int type;      /* 0 richardson, 1 gmres                                   */
+  int pc_side;   /* 0 left, 1 right (gmres)                                  */
+  int norm_type; /* richardson: 0 preconditioned, 1 unpreconditioned         */
+  double rtol, atol, dtol;
+  int max_it;
+  int restart;
+} airhip_ksp_options;
+typedef struct {
+  int its;
+  int reason;      /* KSPConvergedReason values: 2 RTOL, 3 ATOL, -3 ITS, -4 DTOL, -5 BREAKDOWN */
+  double rnorm;
+  double solve_ms; /* HIP-event time of the solve on the library stream                */
+} airhip_ksp_result;
+void airhip_ksp_default_options(airhip_ksp_options* o);
+/* Solve A x = b (natural ordering, device pointers; x holds the initial guess).  Exactly one
+ * of pcair / pcinv may be non-null (both null: unpreconditioned); with pcair the operator is
+ * the one given to its setup and `A` may be null.  history (may be null) receives up to
+ * history_cap residual norms, *history_len their count. */
+int airhip_ksp_solve(const airhip_ksp_options* o, airhip_mat A, airhip_pcair pcair, airhip_pcinv pcinv,
+                     const double* d_b, double* d_x, airhip_ksp_result* res,
+                     double* history, int history_cap, int* history_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AIRHIP_H */

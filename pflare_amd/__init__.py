@@ -1,0 +1,7 @@
+"""pflare_amd - MI355X-native PCAIR / PCPFLAREINV solve phase.
+
+Only what the hot path needs: `csrc/` (HIP kernels, host setup, C ABI -> libairhip.so) and the
+host-side mirror of the reference's plugin interface (`pc.py`).
+"""
+from ._lib import AirhipError, LIB_PATH, lib  # noqa: F401
+from .pc import KSP, PCAIR, PCPFLAREINV, DeviceMat, HostMat  # noqa: F401

@@ -1,0 +1,137 @@
+"""ctypes binding of libairhip.so (include/airhip.h).  Fails loudly when the native library
+is missing - there is no Python or CPU fallback for the solve phase."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libairhip.so")
+
+
+class airhip_csr(C.Structure):
+    _fields_ = [("m", C.c_int64), ("n", C.c_int64), ("rowptr", C.POINTER(C.c_int64)),
+                ("col", C.POINTER(C.c_int32)), ("val", C.POINTER(C.c_double))]
+
+
+class airhip_invop(C.Structure):
+    _fields_ = [("kind", C.c_int), ("mat", airhip_csr), ("diag", C.POINTER(C.c_double)),
+                ("ncoef", C.c_int), ("coef", C.POINTER(C.c_double)), ("coef_im", C.POINTER(C.c_double)),
+                ("diag_scale", C.c_int), ("neumann", C.c_int)]
+
+
+class airhip_ksp_options(C.Structure):
+    _fields_ = [("type", C.c_int), ("pc_side", C.c_int), ("norm_type", C.c_int), ("rtol", C.c_double),
+                ("atol", C.c_double), ("dtol", C.c_double), ("max_it", C.c_int), ("restart", C.c_int)]
+
+
+class airhip_ksp_result(C.Structure):
+    _fields_ = [("its", C.c_int), ("reason", C.c_int), ("rnorm", C.c_double), ("solve_ms", C.c_double)]
+
+
+# every symbol include/airhip.h declares (tests check that the library exports all of them)
+DECLARED_SYMBOLS = [
+    "airhip_last_error", "airhip_version", "airhip_device_count", "airhip_set_device",
+    "airhip_gen_adv_1d", "airhip_gen_adv_diff_fd", "airhip_hostmat_from_csr", "airhip_hostmat_get",
+    "airhip_hostmat_destroy",
+    "airhip_pcair_create", "airhip_pcair_set_option", "airhip_pcair_setup", "airhip_pcair_begin_levels",
+    "airhip_pcair_set_level", "airhip_pcair_set_coarse", "airhip_pcair_finalize", "airhip_pcair_apply",
+    "airhip_pcair_sync", "airhip_pcair_destroy", "airhip_pcair_num_levels", "airhip_pcair_level_sizes",
+    "airhip_pcair_level_get", "airhip_pcair_level_inv", "airhip_pcair_level_smooth_order",
+    "airhip_pcair_coarse_get", "airhip_pcair_complexities", "airhip_pcair_setup_times",
+    "airhip_pcair_release_host", "airhip_pcair_use_graph", "airhip_pcair_profile",
+    "airhip_pcair_profile_reset", "airhip_pcair_profile_count", "airhip_pcair_profile_get",
+    "airhip_pcinv_create", "airhip_pcinv_set_option", "airhip_pcinv_setup", "airhip_pcinv_apply",
+    "airhip_pcinv_sync", "airhip_pcinv_get_inv", "airhip_pcinv_destroy",
+    "airhip_mat_create", "airhip_mat_mult", "airhip_mat_destroy",
+    "airhip_ksp_default_options", "airhip_ksp_solve",
+]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C pflare_amd/csrc`).  pflare_amd has no pure-Python fallback.")
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    L.airhip_last_error.restype = C.c_char_p
+    vp = C.c_void_p
+    pvp = C.POINTER(C.c_void_p)
+    pcsr = C.POINTER(airhip_csr)
+    pinv = C.POINTER(airhip_invop)
+    pd = C.POINTER(C.c_double)
+    pi32 = C.POINTER(C.c_int32)
+    pi64 = C.POINTER(C.c_int64)
+    pint = C.POINTER(C.c_int)
+    sig = {
+        "airhip_device_count": [pint],
+        "airhip_set_device": [C.c_int],
+        "airhip_gen_adv_1d": [C.c_int64, pvp],
+        "airhip_gen_adv_diff_fd": [C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double,
+                                   C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, pvp],
+        "airhip_hostmat_from_csr": [pcsr, pvp],
+        "airhip_hostmat_get": [vp, pcsr],
+        "airhip_hostmat_destroy": [pvp],
+        "airhip_pcair_create": [pvp],
+        "airhip_pcair_set_option": [vp, C.c_char_p, C.c_char_p],
+        "airhip_pcair_setup": [vp, pcsr],
+        "airhip_pcair_setup_host_only": [vp, pcsr],
+        "airhip_pcair_begin_levels": [vp, C.c_int, pcsr],
+        "airhip_pcair_set_level": [vp, C.c_int, C.c_int64, C.c_int64, C.c_int64, pi32, pi32, pcsr, pd, pcsr, pinv,
+                                   pcsr, pi32, pcsr, pcsr, pcsr, pinv, pint],
+        "airhip_pcair_set_coarse": [vp, pcsr, pinv, C.c_int],
+        "airhip_pcair_finalize": [vp],
+        "airhip_pcair_apply": [vp, vp, vp],
+        "airhip_pcair_sync": [vp],
+        "airhip_pcair_destroy": [pvp],
+        "airhip_pcair_num_levels": [vp, pint],
+        "airhip_pcair_level_sizes": [vp, C.c_int, pi64, pi64, pi64, pint, pint, pi64],
+        "airhip_pcair_level_get": [vp, C.c_int, C.c_char_p, pcsr, C.POINTER(pi32), C.POINTER(pd), pi64],
+        "airhip_pcair_level_inv": [vp, C.c_int, C.c_int, pinv],
+        "airhip_pcair_level_smooth_order": [vp, C.c_int, pint],
+        "airhip_pcair_coarse_get": [vp, pcsr],
+        "airhip_pcair_complexities": [vp, pd, pd, pd, pd, pd],
+        "airhip_pcair_setup_times": [vp, pd, pd],
+        "airhip_pcair_release_host": [vp],
+        "airhip_pcair_use_graph": [vp, C.c_int],
+        "airhip_pcair_profile": [vp, C.c_int],
+        "airhip_pcair_profile_reset": [vp],
+        "airhip_pcair_profile_count": [vp, pint],
+        "airhip_pcair_profile_get": [vp, C.c_int, C.POINTER(C.c_char_p), pint, pd, pi64, pd],
+        "airhip_pcinv_create": [pvp],
+        "airhip_pcinv_set_option": [vp, C.c_char_p, C.c_char_p],
+        "airhip_pcinv_setup": [vp, pcsr],
+        "airhip_pcinv_setup_host_only": [vp, pcsr],
+        "airhip_pcinv_apply": [vp, vp, vp],
+        "airhip_pcinv_sync": [vp],
+        "airhip_pcinv_get_inv": [vp, pinv],
+        "airhip_pcinv_destroy": [pvp],
+        "airhip_mat_create": [pcsr, pvp],
+        "airhip_mat_mult": [vp, vp, vp],
+        "airhip_mat_destroy": [pvp],
+        "airhip_ksp_default_options": [C.POINTER(airhip_ksp_options)],
+        "airhip_ksp_solve": [C.POINTER(airhip_ksp_options), vp, vp, vp, vp, vp, C.POINTER(airhip_ksp_result), pd,
+                             C.c_int, pint],
+    }
+    for name, args in sig.items():
+        f = getattr(L, name)
+        f.argtypes = args
+        f.restype = None if name == "airhip_ksp_default_options" else C.c_int
+    _lib = L
+    return L
+
+
+class AirhipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"airhip error {code}: {msg}")
+        self.code = code
+
+
+def check(code):
+    if code != 0:
+        raise AirhipError(code, lib().airhip_last_error().decode())

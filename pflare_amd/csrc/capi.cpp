@@ -1,0 +1,696 @@
+// extern "C" boundary of libairhip (see include/airhip.h).
+#include "../../include/airhip.h"
+#include "host/air.hpp"
+#include "device/pcair_dev.hpp"
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+using namespace airhip;
+
+static thread_local std::string g_err;
+const char* airhip_last_error(void) { return g_err.c_str(); }
+int airhip_version(void) { return 100; }
+
+#define API_BEGIN try {
+#define API_END                                                                      \
+  }                                                                                  \
+  catch (const std::bad_alloc&) { g_err = "out of host memory"; return AIRHIP_ERR_INTERNAL; } \
+  catch (const std::exception& e) {                                                  \
+    g_err = e.what();                                                                \
+    return (g_err.find("HIP error") != std::string::npos) ? AIRHIP_ERR_HIP : AIRHIP_ERR_INTERNAL; \
+  }                                                                                  \
+  return AIRHIP_OK;
+#define REQUIRE(cond, code, msg) do { if (!(cond)) { g_err = msg; return code; } } while (0)
+
+int airhip_device_count(int* count) {
+  API_BEGIN
+  REQUIRE(count, AIRHIP_ERR_ARG, "null argument");
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
+  *count = c;
+  API_END
+}
+int airhip_set_device(int device) {
+  API_BEGIN
+  HIP_CHECK(hipSetDevice(device));
+  API_END
+}
+
+// ------------------------------------------------------------------------ host matrices
+struct airhip_hostmat_s { Csr A; };
+
+static void view_csr(const airhip_csr* a, Csr& out) {
+  out.m = a->m; out.n = a->n;
+  out.rp.view(a->rowptr, a->m + 1);
+  int64_t nnz = a->rowptr[a->m];
+  out.ci.view(a->col, nnz);
+  out.v.view(a->val, nnz);
+}
+static Csr copy_csr(const airhip_csr* a) {
+  Csr v; view_csr(a, v);
+  return v.clone();
+}
+static void expose_csr(const Csr& A, airhip_csr* v) {
+  v->m = A.m; v->n = A.n; v->rowptr = A.rp.data(); v->col = A.ci.data(); v->val = A.v.data();
+}
+
+int airhip_gen_adv_1d(int64_t n, airhip_hostmat* out) {
+  API_BEGIN
+  REQUIRE(out && n > 0, AIRHIP_ERR_ARG, "bad argument");
+  auto* h = new airhip_hostmat_s; h->A = gen_adv_1d(n); *out = h;
+  API_END
+}
+int airhip_gen_adv_diff_fd(int dim, int64_t M, int64_t N, int64_t P, double u, double v, double w,
+                           int unit_velocity, double alpha, double L_x, double L_y, double L_z,
+                           int adv_nondim, airhip_hostmat* out) {
+  API_BEGIN
+  REQUIRE(out && (dim == 2 || dim == 3) && M > 1 && N > 1 && (dim == 2 || P > 1), AIRHIP_ERR_ARG,
+          "Grid dimensions must be at least 2 points in each active direction");
+  if (alpha != 0.0 && adv_nondim > 0) { g_err = "Non-dimensional advection only applies without diffusion"; return AIRHIP_ERR_ARG; }
+  FdOptions o; o.dim = dim; o.M = M; o.N = N; o.P = P; o.u = u; o.v = v; o.w = w;
+  o.unit_velocity = unit_velocity != 0; o.alpha = alpha; o.L_x = L_x; o.L_y = L_y; o.L_z = L_z; o.adv_nondim = adv_nondim;
+  auto* h = new airhip_hostmat_s; h->A = gen_adv_diff_fd(o); *out = h;
+  API_END
+}
+int airhip_hostmat_from_csr(const airhip_csr* A, airhip_hostmat* out) {
+  API_BEGIN
+  REQUIRE(A && out, AIRHIP_ERR_ARG, "null argument");
+  auto* h = new airhip_hostmat_s; h->A = copy_csr(A); *out = h;
+  API_END
+}
+int airhip_hostmat_get(airhip_hostmat A, airhip_csr* view) {
+  API_BEGIN
+  REQUIRE(A && view, AIRHIP_ERR_ARG, "null argument");
+  expose_csr(A->A, view);
+  API_END
+}
+int airhip_hostmat_destroy(airhip_hostmat* A) {
+  API_BEGIN
+  if (A && *A) { delete *A; *A = nullptr; }
+  API_END
+}
+
+// ------------------------------------------------------------------------------ options
+static bool parse_bool(const char* v) {
+  if (!v || !*v) return true;
+  std::string s(v);
+  return !(s == "0" || s == "false" || s == "no" || s == "False" || s == "FALSE");
+}
+static int parse_inv_type(const char* v) {
+  std::string s(v);
+  if (s == "power") return INV_POWER;
+  if (s == "arnoldi") return INV_ARNOLDI;
+  if (s == "newton") return INV_NEWTON;
+  if (s == "newton_no_extra") return INV_NEWTON_NO_EXTRA;
+  if (s == "neumann") return INV_NEUMANN;
+  if (s == "wjacobi") return INV_WJACOBI;
+  if (s == "jacobi") return INV_JACOBI;
+  if (s == "sai" || s == "isai") return -2;
+  char* end = nullptr; long k = std::strtol(v, &end, 10);
+  if (end && *end == 0) return (int)k;
+  return -1;
+}
+
+struct airhip_pcair_s {
+  AirOptions opt;
+  std::unique_ptr<Hierarchy> H;
+  Csr A_top;                      // owned copy of the operator (kept only until upload unless BYO)
+  std::unique_ptr<DevPCAIR> dev;
+  std::unique_ptr<DevKSP> ksp;
+  DBuf<double> kb, kx;            // Krylov rhs / solution in hierarchical ordering
+  double host_setup_s = 0, upload_s = 0;
+  bool use_graph = false, profile = false;
+  bool byo = false; int byo_levels = 0;
+  double op_nnz_top = 0;
+};
+
+int airhip_pcair_create(airhip_pcair* pc) {
+  API_BEGIN
+  REQUIRE(pc, AIRHIP_ERR_ARG, "null argument");
+  *pc = new airhip_pcair_s;
+  API_END
+}
+
+int airhip_pcair_set_option(airhip_pcair pc, const char* name, const char* value) {
+  API_BEGIN
+  REQUIRE(pc && name, AIRHIP_ERR_ARG, "null argument");
+  AirOptions& o = pc->opt;
+  std::string k(name);
+  if (k.rfind("-pc_air_", 0) == 0) k = k.substr(8);
+  else if (k.rfind("pc_air_", 0) == 0) k = k.substr(7);
+  const char* v = value ? value : "";
+  auto I = [&]() { return std::atoi(v); };
+  auto D = [&]() { return std::atof(v); };
+  auto inv = [&](int& dst) -> int {
+    int t = parse_inv_type(v);
+    if (t == -2) { g_err = "inverse types sai/isai are not supported by this build"; return AIRHIP_ERR_UNSUPPORTED; }
+    if (t < 0) { g_err = std::string("unknown inverse type ") + v; return AIRHIP_ERR_ARG; }
+    dst = t; return 0;
+  };
+  int rc = 0;
+  if (k == "max_levels") o.max_levels = I();
+  else if (k == "coarse_eq_limit") o.coarse_eq_limit = I();
+  else if (k == "auto_truncate_start_level") o.auto_truncate_start_level = I();
+  else if (k == "auto_truncate_tol") o.auto_truncate_tol = D();
+  else if (k == "strong_threshold") o.strong_threshold = D();
+  else if (k == "ddc_its") o.ddc_its = I();
+  else if (k == "ddc_fraction") o.ddc_fraction = D();
+  else if (k == "max_luby_steps") o.max_luby_steps = I();
+  else if (k == "smooth_type") { if (o.set_smooth_type(v) != 0) { g_err = "bad smooth_type"; return AIRHIP_ERR_ARG; } }
+  else if (k == "diag_scale_polys") o.diag_scale_polys = parse_bool(v);
+  else if (k == "matrix_free_polys") o.matrix_free_polys = parse_bool(v);
+  else if (k == "one_point_classical_prolong") o.one_point_classical_prolong = parse_bool(v);
+  else if (k == "inverse_type") { rc = inv(o.inverse_type); if (!rc) { /* C smoothing follows F unless set */ } }
+  else if (k == "poly_order") o.poly_order = I();
+  else if (k == "inverse_sparsity_order") o.inverse_sparsity_order = I();
+  else if (k == "c_inverse_type") rc = inv(o.c_inverse_type);
+  else if (k == "c_poly_order") o.c_poly_order = I();
+  else if (k == "c_inverse_sparsity_order") o.c_inverse_sparsity_order = I();
+  else if (k == "coarsest_inverse_type") rc = inv(o.coarsest_inverse_type);
+  else if (k == "coarsest_poly_order") o.coarsest_poly_order = I();
+  else if (k == "coarsest_inverse_sparsity_order") o.coarsest_inverse_sparsity_order = I();
+  else if (k == "coarsest_matrix_free_polys") o.coarsest_matrix_free_polys = parse_bool(v);
+  else if (k == "coarsest_diag_scale_polys") o.coarsest_diag_scale_polys = parse_bool(v);
+  else if (k == "r_drop") o.r_drop = D();
+  else if (k == "a_drop") o.a_drop = D();
+  else if (k == "a_lump") o.a_lump = parse_bool(v);
+  else if (k == "print_stats_timings") o.print_stats_timings = parse_bool(v);
+  else if (k == "mg_coarse_ksp_max_it" || k == "-mg_coarse_ksp_max_it") o.coarse_richardson_its = I();
+  else if (k == "seed") o.seed = (uint64_t)std::atoll(v);
+  else if (k == "processor_agglom" || k == "subcomm" || k == "coarsest_subcomm") { /* no-ops on one device */ }
+  else if (k == "symmetric" || k == "z_type" || k == "cf_splitting_type" || k == "full_smoothing_up_and_down" ||
+           k == "constrain_z" || k == "constrain_w" || k == "improve_z_its" || k == "improve_w_its" ||
+           k == "strong_r_threshold" || k == "reuse_sparsity" || k == "lair_distance") {
+    bool is_default = (std::string(v) == "0" || std::string(v) == "false" || std::string(v) == "" ) ||
+                      (k == "z_type" && std::string(v) == "product") || (k == "cf_splitting_type" && std::string(v) == "pmisr_ddc");
+    if (!is_default) { g_err = "option -pc_air_" + k + " is outside this build's scope (SURVEY 8f)"; return AIRHIP_ERR_UNSUPPORTED; }
+  } else { g_err = "unknown option -pc_air_" + k; return AIRHIP_ERR_ARG; }
+  if (rc) return rc;
+  API_END
+}
+
+static void finish_device(airhip_pcair pc) {
+  double t0 = now_s();
+  pc->dev = std::make_unique<DevPCAIR>();
+  pc->dev->upload(*pc->H, pc->A_top);
+  pc->dev->set_use_graph(pc->use_graph);
+  pc->dev->set_profile(pc->profile);
+  pc->ksp.reset();
+  pc->kb.release(); pc->kx.release();
+  pc->op_nnz_top = (double)pc->A_top.nnz();
+  pc->upload_s = now_s() - t0;
+}
+
+int airhip_pcair_setup(airhip_pcair pc, const airhip_csr* A) {
+  API_BEGIN
+  REQUIRE(pc && A && A->rowptr && A->m == A->n && A->m > 0, AIRHIP_ERR_ARG, "PCAIR needs a square CSR operator");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    g_err = "no HIP device: the PCAIR solve phase has no CPU fallback"; return AIRHIP_ERR_HIP;
+  }
+  pc->dev.reset(); pc->H.reset();
+  view_csr(A, pc->A_top);
+  double t0 = now_s();
+  pc->H = setup_air(pc->A_top, pc->opt);
+  pc->host_setup_s = now_s() - t0;
+  pc->byo = false;
+  finish_device(pc);
+  pc->A_top = Csr();   // drop the view of the caller's arrays
+  API_END
+}
+
+// Host-only setup: builds the hierarchy without touching a device (used by CPU-side tests of
+// the setup and by hierarchy export); apply / solve calls then fail with AIRHIP_ERR_STATE.
+extern "C" int airhip_pcair_setup_host_only(airhip_pcair pc, const airhip_csr* A) {
+  API_BEGIN
+  REQUIRE(pc && A && A->rowptr && A->m == A->n && A->m > 0, AIRHIP_ERR_ARG, "PCAIR needs a square CSR operator");
+  pc->dev.reset(); pc->H.reset();
+  Csr view; view_csr(A, view);
+  double t0 = now_s();
+  pc->H = setup_air(view, pc->opt);
+  pc->host_setup_s = now_s() - t0;
+  pc->op_nnz_top = (double)view.nnz();
+  pc->byo = false;
+  API_END
+}
+
+// ---- bring-your-own hierarchy
+static void fill_inv(const airhip_invop* in, InvOp& out, int64_t n) {
+  out = InvOp();
+  if (!in) return;
+  out.kind = (InvOp::Kind)in->kind;
+  out.diag_scale = in->diag_scale != 0; out.neumann = in->neumann != 0;
+  if (in->kind == AIRHIP_OP_ASSEMBLED) out.mat = copy_csr(&in->mat);
+  else if (in->kind == AIRHIP_OP_DIAG) { out.d.alloc(n); std::memcpy(out.d.data(), in->diag, sizeof(double) * n); }
+  else if (in->kind == AIRHIP_OP_HORNER) {
+    out.coeffs.assign(in->coef, in->coef + in->ncoef);
+    int nz = 0; for (int k = 0; k + 1 < in->ncoef; k++) if (in->coef[k] != 0.0) nz++;
+    out.spmvs = nz;
+  } else if (in->kind == AIRHIP_OP_NEWTON) {
+    out.re.assign(in->coef, in->coef + in->ncoef);
+    out.im.assign(in->coef_im, in->coef_im + in->ncoef);
+    // SpMV count of petsc_newton (src/Gmres_Poly_Newton.F90:763-875)
+    int i = 0, cnt = 0, nr = in->ncoef;
+    while (i <= nr - 2) {
+      if (out.im[i] == 0.0) { if (std::fabs(out.re[i]) < TOL_ZERO) { i++; continue; } cnt++; i++; }
+      else { if (out.re[i] * out.re[i] + out.im[i] * out.im[i] < TOL_ZERO) { i += 2; continue; } cnt++; if (i <= nr - 3) cnt++; i += 2; }
+    }
+    out.spmvs = cnt;
+  }
+}
+
+int airhip_pcair_begin_levels(airhip_pcair pc, int no_levels, const airhip_csr* A_top) {
+  API_BEGIN
+  REQUIRE(pc && no_levels >= 1 && A_top, AIRHIP_ERR_ARG, "bad argument");
+  pc->dev.reset();
+  pc->H = std::make_unique<Hierarchy>();
+  pc->H->opt = pc->opt;
+  pc->H->levels.resize(no_levels - 1);
+  pc->A_top = copy_csr(A_top);
+  pc->byo = true; pc->byo_levels = no_levels;
+  API_END
+}
+
+int airhip_pcair_set_level(airhip_pcair pc, int level, int64_t n, int64_t n_f, int64_t n_c,
+                           const int32_t* F, const int32_t* C, const airhip_csr* A_ff, const double* aff_diag,
+                           const airhip_csr* A_fc, const airhip_invop* inv_ff, const airhip_csr* Z,
+                           const int32_t* wcol, const airhip_csr* W, const airhip_csr* A_cf,
+                           const airhip_csr* A_cc, const airhip_invop* inv_cc, const int* smooth_order10) {
+  API_BEGIN
+  REQUIRE(pc && pc->byo && pc->H, AIRHIP_ERR_STATE, "call airhip_pcair_begin_levels first");
+  REQUIRE(level >= 0 && level < pc->byo_levels - 1, AIRHIP_ERR_ARG, "level out of range");
+  REQUIRE(F && C && A_fc && inv_ff && Z && (A_ff || aff_diag) && (wcol || W) && n == n_f + n_c, AIRHIP_ERR_ARG, "missing level data");
+  auto Lp = std::make_unique<Level>();
+  Level& L = *Lp;
+  L.n = n; L.n_f = n_f; L.n_c = n_c;
+  L.F.alloc(n_f); std::memcpy(L.F.data(), F, sizeof(int32_t) * n_f);
+  L.C.alloc(n_c); std::memcpy(L.C.data(), C, sizeof(int32_t) * n_c);
+  if (aff_diag) { L.aff_diag = true; L.aff_d.alloc(n_f); std::memcpy(L.aff_d.data(), aff_diag, sizeof(double) * n_f); }
+  else L.A_ff = copy_csr(A_ff);
+  L.A_fc = copy_csr(A_fc);
+  L.Z = copy_csr(Z);
+  fill_inv(inv_ff, L.inv_ff, n_f);
+  if (wcol) { L.one_point = true; L.wcol.alloc(n_f); std::memcpy(L.wcol.data(), wcol, sizeof(int32_t) * n_f); }
+  else { L.one_point = false; L.W = copy_csr(W); }
+  bool any_c = false;
+  for (int i = 0; i < 10; i++) { L.smooth_order[i] = smooth_order10 ? smooth_order10[i] : pc->opt.smooth_order[i]; if (L.smooth_order[i] < 0) any_c = true; }
+  if (A_cf) L.A_cf = copy_csr(A_cf);
+  if (any_c) {
+    REQUIRE(A_cf && A_cc && inv_cc, AIRHIP_ERR_ARG, "C smoothing needs A_cf, A_cc and inv_cc");
+    L.A_cc = copy_csr(A_cc);
+    fill_inv(inv_cc, L.inv_cc, n_c);
+    for (int i = 0; i < 10; i++) pc->H->opt.smooth_order[i] = L.smooth_order[i];   // any_c_smooths() of the hierarchy
+  }
+  L.nnz_A = (level == 0) ? pc->A_top.nnz() : 0;
+  pc->H->levels[level] = std::move(Lp);
+  API_END
+}
+
+int airhip_pcair_set_coarse(airhip_pcair pc, const airhip_csr* A_coarse, const airhip_invop* inv, int coarse_richardson_its) {
+  API_BEGIN
+  REQUIRE(pc && pc->byo && pc->H && A_coarse && inv, AIRHIP_ERR_STATE, "bad state / argument");
+  pc->H->coarse_A = copy_csr(A_coarse);
+  fill_inv(inv, pc->H->coarse_inv, A_coarse->m);
+  pc->H->opt.coarse_richardson_its = coarse_richardson_its;
+  API_END
+}
+
+int airhip_pcair_finalize(airhip_pcair pc) {
+  API_BEGIN
+  REQUIRE(pc && pc->byo && pc->H, AIRHIP_ERR_STATE, "nothing to finalize");
+  for (auto& l : pc->H->levels) REQUIRE(l != nullptr, AIRHIP_ERR_STATE, "a level was not set");
+  REQUIRE(!pc->H->coarse_A.empty(), AIRHIP_ERR_STATE, "coarse level was not set");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    g_err = "no HIP device: the PCAIR solve phase has no CPU fallback"; return AIRHIP_ERR_HIP;
+  }
+  finish_device(pc);
+  API_END
+}
+
+int airhip_pcair_apply(airhip_pcair pc, const double* d_x, double* d_y) {
+  API_BEGIN
+  REQUIRE(pc && pc->dev, AIRHIP_ERR_STATE, "PCAIR is not set up on a device");
+  REQUIRE(d_x && d_y, AIRHIP_ERR_ARG, "null vector");
+  pc->dev->apply_natural(d_x, d_y);
+  API_END
+}
+int airhip_pcair_sync(airhip_pcair pc) {
+  API_BEGIN
+  REQUIRE(pc && pc->dev, AIRHIP_ERR_STATE, "PCAIR is not set up on a device");
+  HIP_CHECK(hipStreamSynchronize(pc->dev->stream()));
+  API_END
+}
+int airhip_pcair_destroy(airhip_pcair* pc) {
+  API_BEGIN
+  if (pc && *pc) { delete *pc; *pc = nullptr; }
+  API_END
+}
+
+int airhip_pcair_num_levels(airhip_pcair pc, int* no_levels) {
+  API_BEGIN
+  REQUIRE(pc && no_levels, AIRHIP_ERR_ARG, "null argument");
+  if (pc->H) *no_levels = pc->H->no_levels();
+  else if (pc->dev) *no_levels = pc->dev->no_levels();
+  else { g_err = "not set up"; return AIRHIP_ERR_STATE; }
+  API_END
+}
+
+int airhip_pcair_level_sizes(airhip_pcair pc, int level, int64_t* n, int64_t* n_f, int64_t* n_c, int* aff_diag,
+                             int* one_point, int64_t* nnz_A) {
+  API_BEGIN
+  REQUIRE(pc && pc->H, AIRHIP_ERR_STATE, "host hierarchy not available");
+  const int L = pc->H->no_levels();
+  REQUIRE(level >= 0 && level < L, AIRHIP_ERR_ARG, "level out of range");
+  if (level == L - 1) {
+    if (n) *n = pc->H->coarse_A.m; if (n_f) *n_f = 0; if (n_c) *n_c = 0; if (aff_diag) *aff_diag = 0; if (one_point) *one_point = 0;
+    if (nnz_A) *nnz_A = pc->H->coarse_A.nnz();
+  } else {
+    const Level& lv = *pc->H->levels[level];
+    if (n) *n = lv.n; if (n_f) *n_f = lv.n_f; if (n_c) *n_c = lv.n_c; if (aff_diag) *aff_diag = lv.aff_diag; if (one_point) *one_point = lv.one_point;
+    if (nnz_A) *nnz_A = lv.nnz_A;
+  }
+  API_END
+}
+
+static void expose_inv(const InvOp& in, airhip_invop* out) {
+  std::memset(out, 0, sizeof(*out));
+  out->kind = (int)in.kind; out->diag_scale = in.diag_scale; out->neumann = in.neumann;
+  if (in.kind == InvOp::ASSEMBLED) expose_csr(in.mat, &out->mat);
+  else if (in.kind == InvOp::DIAG) out->diag = in.d.data();
+  else if (in.kind == InvOp::HORNER) { out->ncoef = (int)in.coeffs.size(); out->coef = in.coeffs.data(); }
+  else if (in.kind == InvOp::NEWTON) { out->ncoef = (int)in.re.size(); out->coef = in.re.data(); out->coef_im = in.im.data(); }
+}
+
+int airhip_pcair_level_get(airhip_pcair pc, int level, const char* which, airhip_csr* csr, const int32_t** idx,
+                           const double** vec, int64_t* len) {
+  API_BEGIN
+  REQUIRE(pc && pc->H && which, AIRHIP_ERR_STATE, "host hierarchy not available");
+  REQUIRE(level >= 0 && level < pc->H->no_levels() - 1, AIRHIP_ERR_ARG, "level out of range");
+  const Level& lv = *pc->H->levels[level];
+  std::string w(which);
+  auto give_csr = [&](const Csr& A) -> int { if (!csr || A.empty()) { g_err = "matrix not available: " + w; return AIRHIP_ERR_STATE; } expose_csr(A, csr); return 0; };
+  auto give_idx = [&](const Arr<int32_t>& a) -> int { if (!idx || !len) { g_err = "null out"; return AIRHIP_ERR_ARG; } *idx = a.data(); *len = a.size(); return 0; };
+  auto give_vec = [&](const Arr<double>& a) -> int { if (!vec || !len || !a.data()) { g_err = "vector not available: " + w; return AIRHIP_ERR_STATE; } *vec = a.data(); *len = a.size(); return 0; };
+  int rc = 0;
+  if (w == "F") rc = give_idx(lv.F);
+  else if (w == "C") rc = give_idx(lv.C);
+  else if (w == "wcol") rc = give_idx(lv.wcol);
+  else if (w == "A_ff") rc = give_csr(lv.A_ff);
+  else if (w == "A_fc") rc = give_csr(lv.A_fc);
+  else if (w == "A_cf") rc = give_csr(lv.A_cf);
+  else if (w == "A_cc") rc = give_csr(lv.A_cc);
+  else if (w == "Z") rc = give_csr(lv.Z);
+  else if (w == "W") rc = give_csr(lv.W);
+  else if (w == "M_ff") rc = give_csr(lv.inv_ff.mat);
+  else if (w == "M_cc") rc = give_csr(lv.inv_cc.mat);
+  else if (w == "aff_diag") rc = give_vec(lv.aff_d);
+  else if (w == "M_ff_diag") rc = give_vec(lv.inv_ff.d);
+  else if (w == "M_cc_diag") rc = give_vec(lv.inv_cc.d);
+  else { g_err = "unknown item " + w; return AIRHIP_ERR_ARG; }
+  if (rc) return rc;
+  API_END
+}
+
+int airhip_pcair_level_inv(airhip_pcair pc, int level, int which_c, airhip_invop* inv) {
+  API_BEGIN
+  REQUIRE(pc && pc->H && inv, AIRHIP_ERR_STATE, "host hierarchy not available");
+  const int L = pc->H->no_levels();
+  REQUIRE(level >= 0 && level < L, AIRHIP_ERR_ARG, "level out of range");
+  if (level == L - 1) expose_inv(pc->H->coarse_inv, inv);
+  else expose_inv(which_c ? pc->H->levels[level]->inv_cc : pc->H->levels[level]->inv_ff, inv);
+  API_END
+}
+
+int airhip_pcair_level_smooth_order(airhip_pcair pc, int level, int* so) {
+  API_BEGIN
+  REQUIRE(pc && pc->H && so, AIRHIP_ERR_STATE, "host hierarchy not available");
+  REQUIRE(level >= 0 && level < pc->H->no_levels() - 1, AIRHIP_ERR_ARG, "level out of range");
+  for (int i = 0; i < 10; i++) so[i] = pc->H->levels[level]->smooth_order[i];
+  API_END
+}
+
+int airhip_pcair_coarse_get(airhip_pcair pc, airhip_csr* A) {
+  API_BEGIN
+  REQUIRE(pc && pc->H && A, AIRHIP_ERR_STATE, "host hierarchy not available");
+  expose_csr(pc->H->coarse_A, A);
+  API_END
+}
+
+int airhip_pcair_complexities(airhip_pcair pc, double* grid, double* op, double* cycle, double* storage, double* cyc_bytes) {
+  API_BEGIN
+  REQUIRE(pc && pc->H, AIRHIP_ERR_STATE, "host hierarchy not available");
+  const Hierarchy& H = *pc->H;
+  // src/AIR_MG_Stats.F90:79-382
+  double rows = 0, opn = 0, stor = 0, cyc = 0;
+  auto inv_nnz = [](const InvOp& I, double n) { return I.kind == InvOp::ASSEMBLED ? (double)I.mat.nnz() : (I.kind == InvOp::DIAG ? n : 0.0); };
+  for (auto& lp : H.levels) {
+    const Level& l = *lp;
+    rows += l.n; opn += l.nnz_A;
+    double aff = l.aff_diag ? (double)l.n_f : (double)l.A_ff.nnz();
+    double nnzW = 0;
+    if (l.one_point) { for (int64_t i = 0; i < l.n_f; i++) nnzW += l.wcol[i] >= 0 ? 1 : 0; } else nnzW = (double)l.W.nnz();
+    double Rn = (double)l.Z.nnz() + l.n_c, Pn = nnzW + l.n_c;
+    stor += aff + l.A_fc.nnz() + inv_nnz(l.inv_ff, l.n_f) + Rn + Pn;
+    int g = 0, sf = 0, gc = 0, sc = 0;
+    for (int s : l.smooth_order) { if (s > 0) { g++; sf += s; } else if (s < 0) { gc++; sc += -s; } }
+    bool mf = l.inv_ff.kind == InvOp::HORNER || l.inv_ff.kind == InvOp::NEWTON;
+    double invw = mf ? (l.inv_ff.kind == InvOp::HORNER ? (double)l.inv_ff.coeffs.size() : (double)l.inv_ff.spmvs + 1) * aff : inv_nnz(l.inv_ff, l.n_f);
+    cyc += sf * (invw + aff) + g * (double)l.A_fc.nnz() + Rn + Pn;
+    if (gc) {
+      stor += l.A_cc.nnz() + inv_nnz(l.inv_cc, l.n_c) + l.A_cf.nnz();
+      bool mfc = l.inv_cc.kind == InvOp::HORNER || l.inv_cc.kind == InvOp::NEWTON;
+      double invc = mfc ? (double)l.inv_cc.coeffs.size() * l.A_cc.nnz() : inv_nnz(l.inv_cc, l.n_c);
+      cyc += sc * (invc + (double)l.A_cc.nnz()) + gc * (double)l.A_cf.nnz();
+    }
+  }
+  const double top_nnz = H.levels.empty() ? (double)H.coarse_A.nnz() : (double)H.levels[0]->nnz_A;
+  const double top_rows = H.levels.empty() ? (double)H.coarse_A.m : (double)H.levels[0]->n;
+  if (!H.levels.empty()) {
+    rows += H.coarse_A.m;
+    bool mf = H.coarse_inv.kind == InvOp::HORNER || H.coarse_inv.kind == InvOp::NEWTON;
+    double cn = (double)H.coarse_A.nnz();
+    opn += cn;
+    if (mf) { stor += cn; cyc += (H.coarse_inv.kind == InvOp::HORNER ? (double)H.coarse_inv.coeffs.size() : (double)H.coarse_inv.spmvs + 1) * cn; }
+    else { stor += inv_nnz(H.coarse_inv, H.coarse_A.m); cyc += inv_nnz(H.coarse_inv, H.coarse_A.m); if (H.opt.coarse_richardson_its > 1) stor += cn; }
+  } else { rows = top_rows; opn = top_nnz; }
+  if (grid) *grid = rows / top_rows;
+  if (op) *op = opn / top_nnz;
+  if (cycle) *cycle = cyc / top_nnz;
+  if (storage) *storage = stor / top_nnz;
+  if (cyc_bytes) *cyc_bytes = pc->dev ? pc->dev->cycle_alg_bytes() : 0.0;
+  API_END
+}
+
+int airhip_pcair_setup_times(airhip_pcair pc, double* host_setup_s, double* upload_s) {
+  API_BEGIN
+  REQUIRE(pc, AIRHIP_ERR_ARG, "null argument");
+  if (host_setup_s) *host_setup_s = pc->host_setup_s;
+  if (upload_s) *upload_s = pc->upload_s;
+  API_END
+}
+int airhip_pcair_release_host(airhip_pcair pc) {
+  API_BEGIN
+  REQUIRE(pc, AIRHIP_ERR_ARG, "null argument");
+  pc->H.reset(); pc->A_top = Csr();
+  API_END
+}
+int airhip_pcair_use_graph(airhip_pcair pc, int on) {
+  API_BEGIN
+  REQUIRE(pc, AIRHIP_ERR_ARG, "null argument");
+  pc->use_graph = on != 0;
+  if (pc->dev) pc->dev->set_use_graph(pc->use_graph);
+  API_END
+}
+int airhip_pcair_profile(airhip_pcair pc, int on) {
+  API_BEGIN
+  REQUIRE(pc, AIRHIP_ERR_ARG, "null argument");
+  pc->profile = on != 0;
+  if (pc->dev) { if (!on) pc->dev->resolve_events(); pc->dev->set_profile(pc->profile); }
+  API_END
+}
+int airhip_pcair_profile_reset(airhip_pcair pc) {
+  API_BEGIN
+  REQUIRE(pc && pc->dev, AIRHIP_ERR_STATE, "not set up");
+  pc->dev->reset_stats();
+  API_END
+}
+int airhip_pcair_profile_count(airhip_pcair pc, int* n) {
+  API_BEGIN
+  REQUIRE(pc && pc->dev && n, AIRHIP_ERR_STATE, "not set up");
+  pc->dev->resolve_events();
+  *n = (int)pc->dev->stats().size();
+  API_END
+}
+int airhip_pcair_profile_get(airhip_pcair pc, int i, const char** name, int* level, double* alg_bytes, int64_t* calls, double* total_ms) {
+  API_BEGIN
+  REQUIRE(pc && pc->dev, AIRHIP_ERR_STATE, "not set up");
+  const auto& st = pc->dev->stats();
+  REQUIRE(i >= 0 && i < (int)st.size(), AIRHIP_ERR_ARG, "index out of range");
+  if (name) *name = st[i].name.c_str();
+  if (level) *level = st[i].level;
+  if (alg_bytes) *alg_bytes = st[i].alg_bytes;
+  if (calls) *calls = st[i].calls;
+  if (total_ms) *total_ms = st[i].ms;
+  API_END
+}
+
+// ------------------------------------------------------------------------ PCPFLAREINV
+// A PCPFLAREINV is a PCAIR hierarchy with no levels whose "coarse solver" is the
+// approximate inverse of the whole operator (PCApply_PFLAREINV_c = one MatMult with it).
+struct airhip_pcinv_s {
+  int type = INV_ARNOLDI, poly_order = 6, sparsity_order = 1;
+  bool matrix_free = false, diag_scale = false;
+  uint64_t seed = 1;
+  airhip_pcair_s inner;
+};
+
+int airhip_pcinv_create(airhip_pcinv* pc) {
+  API_BEGIN
+  REQUIRE(pc, AIRHIP_ERR_ARG, "null argument");
+  *pc = new airhip_pcinv_s;
+  API_END
+}
+int airhip_pcinv_set_option(airhip_pcinv pc, const char* name, const char* value) {
+  API_BEGIN
+  REQUIRE(pc && name, AIRHIP_ERR_ARG, "null argument");
+  std::string k(name);
+  if (k.rfind("-pc_pflareinv_", 0) == 0) k = k.substr(14);
+  else if (k.rfind("pc_pflareinv_", 0) == 0) k = k.substr(13);
+  const char* v = value ? value : "";
+  if (k == "type") {
+    int t = parse_inv_type(v);
+    if (t == -2) { g_err = "inverse types sai/isai are not supported by this build"; return AIRHIP_ERR_UNSUPPORTED; }
+    if (t < 0) { g_err = std::string("unknown inverse type ") + v; return AIRHIP_ERR_ARG; }
+    pc->type = t;
+  } else if (k == "poly_order" || k == "order") pc->poly_order = std::atoi(v);
+  else if (k == "sparsity_order") pc->sparsity_order = std::atoi(v);
+  else if (k == "matrix_free") pc->matrix_free = parse_bool(v);
+  else if (k == "diag_scale") pc->diag_scale = parse_bool(v);
+  else if (k == "seed") pc->seed = (uint64_t)std::atoll(v);
+  else { g_err = "unknown option -pc_pflareinv_" + k; return AIRHIP_ERR_ARG; }
+  API_END
+}
+
+static void pcinv_build_host(airhip_pcinv pc, const Csr& A) {
+  auto H = std::make_unique<Hierarchy>();
+  OpView v; v.A = &A; v.n = A.m;
+  build_inverse(v, pc->type, pc->poly_order, pc->sparsity_order, pc->matrix_free, pc->diag_scale, pc->seed, H->coarse_inv, nullptr);
+  H->coarse_A = A.clone();
+  pc->inner.H = std::move(H);
+}
+
+int airhip_pcinv_setup(airhip_pcinv pc, const airhip_csr* A) {
+  API_BEGIN
+  REQUIRE(pc && A && A->m == A->n && A->m > 0, AIRHIP_ERR_ARG, "PCPFLAREINV needs a square CSR operator");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    g_err = "no HIP device: the PCPFLAREINV apply has no CPU fallback"; return AIRHIP_ERR_HIP;
+  }
+  Csr view; view_csr(A, view);
+  pcinv_build_host(pc, view);
+  view_csr(A, pc->inner.A_top);
+  finish_device(&pc->inner);
+  pc->inner.A_top = Csr();
+  API_END
+}
+extern "C" int airhip_pcinv_setup_host_only(airhip_pcinv pc, const airhip_csr* A) {
+  API_BEGIN
+  REQUIRE(pc && A && A->m == A->n && A->m > 0, AIRHIP_ERR_ARG, "PCPFLAREINV needs a square CSR operator");
+  Csr view; view_csr(A, view);
+  pcinv_build_host(pc, view);
+  API_END
+}
+int airhip_pcinv_apply(airhip_pcinv pc, const double* d_x, double* d_y) {
+  REQUIRE(pc, AIRHIP_ERR_ARG, "null argument");
+  return airhip_pcair_apply(&pc->inner, d_x, d_y);
+}
+int airhip_pcinv_sync(airhip_pcinv pc) {
+  REQUIRE(pc, AIRHIP_ERR_ARG, "null argument");
+  return airhip_pcair_sync(&pc->inner);
+}
+int airhip_pcinv_get_inv(airhip_pcinv pc, airhip_invop* inv) {
+  API_BEGIN
+  REQUIRE(pc && pc->inner.H && inv, AIRHIP_ERR_STATE, "not set up");
+  expose_inv(pc->inner.H->coarse_inv, inv);
+  API_END
+}
+int airhip_pcinv_destroy(airhip_pcinv* pc) {
+  API_BEGIN
+  if (pc && *pc) { delete *pc; *pc = nullptr; }
+  API_END
+}
+
+// ------------------------------------------------------------------- device matrices
+struct airhip_mat_s { SellMat A; hipStream_t stream = nullptr; int64_t n = 0; std::unique_ptr<DevKSP> ksp; };
+
+int airhip_mat_create(const airhip_csr* A, airhip_mat* out) {
+  API_BEGIN
+  REQUIRE(A && out, AIRHIP_ERR_ARG, "null argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_err = "no HIP device"; return AIRHIP_ERR_HIP; }
+  auto* m = new airhip_mat_s;
+  HIP_CHECK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+  Csr view; view_csr(A, view);
+  upload_sell(view, nullptr, nullptr, m->A, m->stream);
+  m->n = A->m;
+  *out = m;
+  API_END
+}
+int airhip_mat_mult(airhip_mat A, const double* d_x, double* d_y) {
+  API_BEGIN
+  REQUIRE(A && d_x && d_y, AIRHIP_ERR_ARG, "null argument");
+  SpmvEpi e; e.out = d_y;
+  launch_spmv(A->A, d_x, e, A->stream);
+  HIP_CHECK(hipStreamSynchronize(A->stream));
+  API_END
+}
+int airhip_mat_destroy(airhip_mat* A) {
+  API_BEGIN
+  if (A && *A) { sell_free((*A)->A); if ((*A)->stream) (void)hipStreamDestroy((*A)->stream); delete *A; *A = nullptr; }
+  API_END
+}
+
+// ------------------------------------------------------------------------------- KSP
+void airhip_ksp_default_options(airhip_ksp_options* o) {
+  if (!o) return;
+  o->type = 1; o->pc_side = 0; o->norm_type = 0; o->rtol = 1e-5; o->atol = 1e-50; o->dtol = 1e4; o->max_it = 10000; o->restart = 30;
+}
+
+int airhip_ksp_solve(const airhip_ksp_options* o, airhip_mat A, airhip_pcair pcair, airhip_pcinv pcinv,
+                     const double* d_b, double* d_x, airhip_ksp_result* res, double* history, int history_cap,
+                     int* history_len) {
+  API_BEGIN
+  REQUIRE(o && d_b && d_x && res, AIRHIP_ERR_ARG, "null argument");
+  REQUIRE(!(pcair && pcinv), AIRHIP_ERR_ARG, "give at most one preconditioner");
+  KspOptions ko; ko.type = o->type; ko.pc_side = o->pc_side; ko.norm_type = o->norm_type; ko.rtol = o->rtol;
+  ko.atol = o->atol; ko.dtol = o->dtol; ko.max_it = o->max_it; ko.restart = o->restart;
+  REQUIRE(ko.restart >= 1 && ko.restart <= 60, AIRHIP_ERR_ARG, "restart must be in [1,60]");
+  KspResult r;
+  airhip_pcair_s* pc = pcair ? pcair : (pcinv ? &pcinv->inner : nullptr);
+  if (pc) {
+    REQUIRE(pc->dev, AIRHIP_ERR_STATE, "preconditioner is not set up on a device");
+    DevPCAIR& dev = *pc->dev;
+    const int64_t n = dev.n();
+    if (!pc->ksp) { pc->ksp = std::make_unique<DevKSP>(n); pc->kb.alloc(n); pc->kx.alloc(n); }
+    dev.to_permuted(d_b, pc->kb.p);
+    dev.to_permuted(d_x, pc->kx.p);
+    KspOperator op; op.A = &dev.A_perm(); op.stream = dev.stream();
+    op.pc = [&dev](const double* in, double* out) { dev.apply_permuted(in, out); };
+    r = pc->ksp->solve(op, ko, pc->kb.p, pc->kx.p);
+    dev.to_natural(pc->kx.p, d_x);
+    HIP_CHECK(hipStreamSynchronize(dev.stream()));
+  } else {
+    REQUIRE(A, AIRHIP_ERR_ARG, "an operator is required without a preconditioner");
+    if (!A->ksp) A->ksp = std::make_unique<DevKSP>(A->n);
+    KspOperator op; op.A = &A->A; op.stream = A->stream;
+    r = A->ksp->solve(op, ko, d_b, d_x);
+    HIP_CHECK(hipStreamSynchronize(A->stream));
+  }
+  res->its = r.its; res->reason = r.reason; res->rnorm = r.rnorm; res->solve_ms = r.solve_ms;
+  int nh = (int)r.history.size();
+  if (history && history_cap > 0) { int c = std::min(nh, history_cap); std::memcpy(history, r.history.data(), sizeof(double) * c); }
+  if (history_len) *history_len = nh;
+  API_END
+}

@@ -1,0 +1,81 @@
+// Device-side data structures and kernel launchers of the PCAIR solve phase (gfx950).
+//
+// Layout decisions:
+//  * matrices live in HBM as SELL-64: rows grouped in slices of 64 (one wavefront), each
+//    slice padded to its longest row and stored column-major inside the slice so that lane
+//    l of a wave streams row l with fully coalesced 512-B (values) / 256-B (indices) wave
+//    loads; no cross-lane reduction is needed.
+//  * level vectors use a hierarchical F/C ordering: the level-l vector is [x_F | x_C] and
+//    x_C *is* the level-(l+1) vector, so the level-l vector is a suffix of the level-1
+//    vector.  Gathers/scatters (VecISCopy) and the identity blocks of R=[Z I], P=[W;I]
+//    disappear from the solve phase.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <vector>
+#include <string>
+
+namespace airhip {
+
+struct SellMat {
+  int64_t m = 0, n = 0;          // rows, cols
+  int64_t nnz = 0;               // true non-zeros
+  int64_t padded = 0;            // stored entries (multiple of 64)
+  int64_t nslices = 0;
+  int64_t* slice_ptr = nullptr;  // [nslices+1], entry offsets (multiples of 64)
+  int32_t* col = nullptr;        // [padded]
+  double* val = nullptr;         // [padded]
+  bool valid() const { return slice_ptr != nullptr; }
+  // algorithmic bytes of one SpMV with this operator: S(X) of SURVEY 8(d)
+  double s_bytes() const { return 12.0 * nnz + 4.0 * (m + 1) + 8.0 * m + 8.0 * n; }
+};
+
+// out_i = alpha * s_i + beta * z_i + gamma * w_i,  s = (A x)_i [ * dscale_i ]
+// optional auxiliary update in the same pass:  y2_i += delta * (aux_out ? out_i : w2_i)
+struct SpmvEpi {
+  double alpha = 1.0;
+  const double* z = nullptr; double beta = 0.0;
+  const double* w = nullptr; double gamma = 0.0;
+  const double* dscale = nullptr;     // multiply s by dscale_i (holds 1/d)
+  double* out = nullptr;
+  double* y2 = nullptr; const double* w2 = nullptr; double delta = 0.0; int aux_out = 0;
+};
+
+void launch_spmv(const SellMat& A, const double* x, const SpmvEpi& e, hipStream_t s);
+
+// Fused first stage of an F-point relaxation with a one-point prolongator:
+//   acc = (A_fc x_c)_i ; t4 = b_f_i - acc ; x0 = x_c[wcol_i] (0 if wcol_i < 0)
+//   diag mode (aff_d, minv != null):  x_f_i = x0 + minv_i * (t4 - aff_d_i * x0)
+//   split mode                     :  t4_out_i = t4 ; x_f_i = x0
+void launch_fc_first(const SellMat& A_fc, const int32_t* wcol, const double* b_f, const double* x_c,
+                     const double* aff_d, const double* minv, double* t4_out, double* x_f, hipStream_t s);
+
+// vector kernels (n elements)
+void launch_axpby(int64_t n, double a, const double* x, double b, const double* y, double* out, hipStream_t s);  // out = a x + b y
+// out = alpha * (a .* b) + beta * z   (z may be null)
+void launch_pointwise_mult(int64_t n, double alpha, const double* a, const double* b, double beta, const double* z, double* out, hipStream_t s);
+void launch_diag_residual_update(int64_t n, const double* d, const double* minv, const double* t4, double* x, hipStream_t s); // x += minv.*(t4 - d.*x)
+void launch_gather(int64_t n, const int32_t* idx, const double* in, double* out, hipStream_t s);   // out[i] = in[idx[i]]
+void launch_scatter(int64_t n, const int32_t* idx, const double* in, double* out, hipStream_t s);  // out[idx[i]] = in[i]
+void launch_fill(int64_t n, double v, double* out, hipStream_t s);
+// dots[k] = <w, V_k>, k < nv (V_k = V + k*ld); two-stage deterministic reduction using `scratch`
+void launch_mdot(int64_t n, const double* w, const double* V, int64_t ld, int nv, double* scratch, double* dots, hipStream_t s);
+// w += sum_k coef[k] V_k  (coef on device)
+void launch_maxpy(int64_t n, double* w, const double* V, int64_t ld, int nv, const double* coef, hipStream_t s);
+int mdot_scratch_doubles(int nv);
+
+// CSR (device) -> SELL-64 conversion.  rowsrc (may be null): destination row r takes source
+// row rowsrc[r]; colmap (may be null): column c becomes colmap[c].
+void sell_from_csr_device(int64_t m, int64_t n, const int64_t* d_rp, const int32_t* d_ci, const double* d_v,
+                          const int32_t* d_rowsrc, const int32_t* d_colmap, SellMat& out, hipStream_t s);
+void sell_free(SellMat& A);
+
+#define HIP_CHECK(expr)                                                                       \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess)                                                                     \
+      throw std::runtime_error(std::string("HIP error ") + hipGetErrorString(_e) + " at " +   \
+                               __FILE__ + ":" + std::to_string(__LINE__));                    \
+  } while (0)
+
+}  // namespace airhip

@@ -1,0 +1,201 @@
+// Outer Krylov solvers on the device with PETSc semantics: KSPRICHARDSON (scale 1) and
+// KSPGMRES (restart 30, classical Gram-Schmidt without refinement, Givens-rotated
+// Hessenberg residual estimate, happy-breakdown tolerance 1e-30, KSPConvergedDefault with
+// the zero-rhs / non-zero-guess special case).  These are the callers of PCApply
+// (SURVEY.md 8a-a19); the reference leaves them to PETSc.
+#include "pcair_dev.hpp"
+#include <cmath>
+
+namespace airhip {
+
+namespace {
+struct ConvState { double bnorm = 0, rnorm0 = 0, ttol = 0; };
+// KSPConvergedDefault
+int converged_default(ConvState& st, int it, double rnorm, const KspOptions& o) {
+  if (it == 0) {
+    double snorm = st.bnorm;
+    if (snorm == 0.0) snorm = rnorm;   // zero RHS and non-zero initial guess
+    st.rnorm0 = snorm;
+    st.ttol = std::max(o.rtol * snorm, o.atol);
+  }
+  if (std::isnan(rnorm) || std::isinf(rnorm)) return -9;
+  if (rnorm <= st.ttol) return rnorm < o.atol ? 3 : 2;
+  if (rnorm >= o.dtol * st.rnorm0) return -4;
+  return 0;
+}
+}  // namespace
+
+DevKSP::DevKSP(int64_t n) : n_(n) {
+  w_.alloc(n); t_.alloc(n);
+  scratch_.alloc(mdot_scratch_doubles(64));
+  ddots_.alloc(64); dcoef_.alloc(64);
+}
+
+double DevKSP::norm2(const double* v, hipStream_t s) {
+  launch_mdot(n_, v, v, 0, 1, scratch_.p, ddots_.p, s);
+  double h = 0.0;
+  HIP_CHECK(hipMemcpyAsync(&h, ddots_.p, sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  return std::sqrt(h);
+}
+
+KspResult DevKSP::solve(const KspOperator& op, const KspOptions& o, const double* d_b, double* d_x) {
+  hipEvent_t e0, e1;
+  HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+  HIP_CHECK(hipStreamSynchronize(op.stream));
+  HIP_CHECK(hipEventRecord(e0, op.stream));
+  KspResult r = (o.type == 0) ? richardson(op, o, d_b, d_x) : gmres(op, o, d_b, d_x);
+  HIP_CHECK(hipEventRecord(e1, op.stream));
+  HIP_CHECK(hipEventSynchronize(e1));
+  float ms = 0.f; HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  r.solve_ms = ms;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return r;
+}
+
+// r = b - A x
+static void residual(const KspOperator& op, const double* b, const double* x, double* r) {
+  SpmvEpi e; e.out = r; e.alpha = -1.0; e.z = b; e.beta = 1.0;
+  launch_spmv(*op.A, x, e, op.stream);
+}
+
+KspResult DevKSP::richardson(const KspOperator& op, const KspOptions& o, const double* b, double* x) {
+  KspResult R;
+  hipStream_t s = op.stream;
+  const bool prec = (o.norm_type == 0);
+  double* r = w_.p; double* z = t_.p;
+  ConvState st;
+  double bn = norm2(b, s);
+  if (prec && bn != 0.0) { if (op.pc) op.pc(b, z); else HIP_CHECK(hipMemcpyAsync(z, b, 8 * (size_t)n_, hipMemcpyDeviceToDevice, s)); bn = norm2(z, s); }
+  st.bnorm = bn;
+  auto apply_pc = [&](const double* in, double* out) {
+    if (op.pc) op.pc(in, out); else HIP_CHECK(hipMemcpyAsync(out, in, 8 * (size_t)n_, hipMemcpyDeviceToDevice, s));
+  };
+  residual(op, b, x, r);
+  double rnorm = 0.0;
+  int reason = 0, its = 0;
+  for (int i = 0; i < o.max_it; i++) {
+    if (prec) { apply_pc(r, z); rnorm = norm2(z, s); } else rnorm = norm2(r, s);
+    R.history.push_back(rnorm);
+    reason = converged_default(st, i, rnorm, o);
+    if (reason) break;
+    if (!prec) apply_pc(r, z);
+    launch_axpby(n_, 1.0, z, 1.0, x, x, s);
+    its++;
+    residual(op, b, x, r);
+  }
+  if (!reason) {
+    if (prec) { apply_pc(r, z); rnorm = norm2(z, s); } else rnorm = norm2(r, s);
+    R.history.push_back(rnorm);
+    if (its >= o.max_it) { reason = converged_default(st, its, rnorm, o); if (!reason) reason = -3; }
+  }
+  R.its = its; R.reason = reason; R.rnorm = rnorm;
+  return R;
+}
+
+KspResult DevKSP::gmres(const KspOperator& op, const KspOptions& o, const double* b, double* x) {
+  KspResult R;
+  hipStream_t s = op.stream;
+  const int m = o.restart;
+  const bool right = (o.pc_side == 1);
+  if (v_alloc_ < m + 1) { V_.alloc((int64_t)(m + 1) * n_); v_alloc_ = m + 1; }
+  auto Vk = [&](int k) { return V_.p + (int64_t)k * n_; };
+  auto apply_pc = [&](const double* in, double* out) {
+    if (op.pc) op.pc(in, out); else HIP_CHECK(hipMemcpyAsync(out, in, 8 * (size_t)n_, hipMemcpyDeviceToDevice, s));
+  };
+  ConvState st;
+  double bn = norm2(b, s);
+  if (!right && bn != 0.0) { apply_pc(b, t_.p); bn = norm2(t_.p, s); }
+  st.bnorm = bn;
+
+  int its = 0, reason = 0;
+  double rnorm = 0.0;
+  const double haptol = 1e-30;
+  bool first = true;
+  std::vector<double> hh((size_t)(m + 2) * (m + 1)), cs(m + 1), sn(m + 1), grs(m + 2), lhh(m + 1), nrs(m + 1);
+  auto H = [&](int i, int j) -> double& { return hh[(size_t)j * (m + 2) + i]; };
+  while (!reason) {
+    // V0 = (B)(b - A x)
+    if (right) residual(op, b, x, Vk(0));
+    else { residual(op, b, x, w_.p); apply_pc(w_.p, Vk(0)); }
+    double res = norm2(Vk(0), s);
+    rnorm = res;
+    if (first) {
+      R.history.push_back(res);
+      if (res == 0.0) { reason = 3; break; }
+      reason = converged_default(st, its, res, o);
+      first = false;
+      if (reason) break;
+    }
+    launch_axpby(n_, 1.0 / res, Vk(0), 0.0, nullptr, Vk(0), s);
+    std::fill(hh.begin(), hh.end(), 0.0);
+    grs[0] = res;
+    int it = 0;
+    bool hapend = false;
+    while (!reason && it < m && its < o.max_it) {
+      double* w = Vk(it + 1);
+      if (right) { apply_pc(Vk(it), t_.p); SpmvEpi e; e.out = w; launch_spmv(*op.A, t_.p, e, s); }
+      else { SpmvEpi e; e.out = t_.p; launch_spmv(*op.A, Vk(it), e, s); apply_pc(t_.p, w); }
+      // classical Gram-Schmidt: one multi-dot, one multi-axpy
+      launch_mdot(n_, w, V_.p, n_, it + 1, scratch_.p, ddots_.p, s);
+      HIP_CHECK(hipMemcpyAsync(lhh.data(), ddots_.p, sizeof(double) * (it + 1), hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+      for (int j = 0; j <= it; j++) { H(j, it) = lhh[j]; nrs[j] = -lhh[j]; }
+      HIP_CHECK(hipMemcpyAsync(dcoef_.p, nrs.data(), sizeof(double) * (it + 1), hipMemcpyHostToDevice, s));
+      launch_maxpy(n_, w, V_.p, n_, it + 1, dcoef_.p, s);
+      double tt = norm2(w, s);
+      if (tt != 0.0) launch_axpby(n_, 1.0 / tt, w, 0.0, nullptr, w, s);
+      H(it + 1, it) = tt;
+      double hapbnd = grs[it] != 0.0 ? std::fabs(tt / grs[it]) : haptol;
+      if (hapbnd > haptol) hapbnd = haptol;
+      if (tt < hapbnd) hapend = true;
+      // KSPGMRESUpdateHessenberg
+      for (int j = 0; j < it; j++) {
+        double t1 = H(j, it);
+        H(j, it) = cs[j] * t1 + sn[j] * H(j + 1, it);
+        H(j + 1, it) = -sn[j] * t1 + cs[j] * H(j + 1, it);
+      }
+      if (!hapend) {
+        double t = std::sqrt(H(it, it) * H(it, it) + H(it + 1, it) * H(it + 1, it));
+        if (t == 0.0) { reason = -5; break; }
+        cs[it] = H(it, it) / t; sn[it] = H(it + 1, it) / t;
+        grs[it + 1] = -sn[it] * grs[it];
+        grs[it] = cs[it] * grs[it];
+        H(it, it) = cs[it] * H(it, it) + sn[it] * H(it + 1, it);
+        res = std::fabs(grs[it + 1]);
+      } else res = 0.0;
+      it++; its++;
+      rnorm = res;
+      R.history.push_back(res);
+      reason = converged_default(st, its, res, o);
+      if (hapend) { if (!reason) reason = -5; break; }
+    }
+    // KSPGMRESBuildSoln
+    if (it > 0) {
+      const int k = it - 1;
+      std::fill(nrs.begin(), nrs.end(), 0.0);
+      if (H(k, k) != 0.0) {
+        nrs[k] = grs[k] / H(k, k);
+        for (int ii = 1; ii <= k; ii++) {
+          const int kk = k - ii;
+          double tsum = grs[kk];
+          for (int j = kk + 1; j <= k; j++) tsum -= H(kk, j) * nrs[j];
+          nrs[kk] = tsum / H(kk, kk);
+        }
+      }
+      HIP_CHECK(hipMemcpyAsync(dcoef_.p, nrs.data(), sizeof(double) * it, hipMemcpyHostToDevice, s));
+      if (right) {
+        launch_fill(n_, 0.0, w_.p, s);
+        launch_maxpy(n_, w_.p, V_.p, n_, it, dcoef_.p, s);
+        apply_pc(w_.p, t_.p);
+        launch_axpby(n_, 1.0, t_.p, 1.0, x, x, s);
+      } else launch_maxpy(n_, x, V_.p, n_, it, dcoef_.p, s);
+      HIP_CHECK(hipStreamSynchronize(s));   // nrs (host) is reused by the next cycle
+    }
+    if (!reason && its >= o.max_it) reason = -3;
+  }
+  R.its = its; R.reason = reason; R.rnorm = rnorm;
+  return R;
+}
+
+}  // namespace airhip

@@ -1,0 +1,447 @@
+// Device hierarchy upload, the AIR V-cycle (Kaskade: restrict the rhs down, coarse
+// apply, prolong + FC-point relaxation up) and the matrix-free polynomial applies.
+//
+// Reference semantics followed: PCMG Kaskade wiring
+// src/AIR_MG_Setup.F90:967-1156; mg_FC_point_richardson / f_smooths / c_smooths
+// src/FC_Smooth.F90:421-640; petsc_horner src/Gmres_Poly.F90:1418-1484; petsc_newton
+// src/Gmres_Poly_Newton.F90:763-875; Neumann shell src/Neumann_Poly.F90:19-55.
+#include "pcair_dev.hpp"
+#include <cstdio>
+
+namespace airhip {
+
+void upload_sell(const Csr& A, const int32_t* d_rowsrc, const int32_t* d_colmap, SellMat& out, hipStream_t s) {
+  DBuf<int64_t> rp; DBuf<int32_t> ci; DBuf<double> v;
+  rp.upload(A.rp.data(), A.m + 1);
+  ci.upload(A.ci.data(), A.nnz());
+  v.upload(A.v.data(), A.nnz());
+  sell_from_csr_device(A.m, A.n, rp.p, ci.p, v.p, d_rowsrc, d_colmap, out, s);
+}
+
+double DevInv::alg_bytes() const {
+  if (kind == InvOp::ASSEMBLED) return mat.s_bytes();
+  if (kind == InvOp::DIAG) return 12.0 * n + 4.0 * (n + 1) + 8.0 * n + 8.0 * n;
+  if (Aop) return spmvs * Aop->s_bytes();
+  return 0.0;
+}
+
+DevPCAIR::DevPCAIR() { HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking)); }
+
+DevPCAIR::~DevPCAIR() {
+  if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
+  for (auto e : event_pool_) (void)hipEventDestroy(e);
+  for (auto& p : pending_) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+  sell_free(A_perm_); sell_free(coarse_A_);
+  if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+// ---------------------------------------------------------------------------------------
+// profiling helpers: HIP events on the launch stream around every kernel
+// ---------------------------------------------------------------------------------------
+int DevPCAIR::stat_id(const char* name, int level, double bytes) {
+  std::string key = std::string(name) + "@" + std::to_string(level);
+  auto it = stat_index_.find(key);
+  if (it != stat_index_.end()) return it->second;
+  KernelStat k; k.name = name; k.level = level; k.alg_bytes = bytes;
+  stats_.push_back(k);
+  stat_index_[key] = (int)stats_.size() - 1;
+  return (int)stats_.size() - 1;
+}
+void DevPCAIR::begin_kernel(int stat) {
+  if (!profile_) return;
+  hipEvent_t a;
+  if (!event_pool_.empty()) { a = event_pool_.back(); event_pool_.pop_back(); } else HIP_CHECK(hipEventCreate(&a));
+  HIP_CHECK(hipEventRecord(a, stream_));
+  cur_a_ = a; cur_stat_ = stat;
+}
+void DevPCAIR::end_kernel() {
+  if (!profile_) return;
+  hipEvent_t b;
+  if (!event_pool_.empty()) { b = event_pool_.back(); event_pool_.pop_back(); } else HIP_CHECK(hipEventCreate(&b));
+  HIP_CHECK(hipEventRecord(b, stream_));
+  pending_.push_back({cur_a_, b, cur_stat_});
+}
+void DevPCAIR::resolve_events() {
+  if (pending_.empty()) return;
+  HIP_CHECK(hipStreamSynchronize(stream_));
+  for (auto& p : pending_) {
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, p.a, p.b));
+    stats_[p.stat].calls++; stats_[p.stat].ms += ms;
+    event_pool_.push_back(p.a); event_pool_.push_back(p.b);
+  }
+  pending_.clear();
+}
+void DevPCAIR::reset_stats() { resolve_events(); for (auto& s : stats_) { s.calls = 0; s.ms = 0.0; } }
+
+void DevPCAIR::spmv(const SellMat& A, const double* x, const SpmvEpi& e, const char* name, int level, double bytes_override) {
+  int id = -1;
+  if (profile_) { id = stat_id(name, level, bytes_override >= 0 ? bytes_override : A.s_bytes()); begin_kernel(id); }
+  launch_spmv(A, x, e, stream_);
+  if (profile_) end_kernel();
+}
+
+// ---------------------------------------------------------------------------------------
+// upload
+// ---------------------------------------------------------------------------------------
+void DevPCAIR::upload_inv(const InvOp& h, DevInv& d, const SellMat* Aop, const double* host_diag_of_op) {
+  d.kind = h.kind; d.coeffs = h.coeffs; d.re = h.re; d.im = h.im;
+  d.diag_scale = h.diag_scale; d.neumann = h.neumann; d.spmvs = h.spmvs;
+  if (h.kind == InvOp::ASSEMBLED) { d.n = h.mat.m; upload_sell(h.mat, nullptr, nullptr, d.mat, stream_); }
+  else if (h.kind == InvOp::DIAG) { d.n = h.d.size(); d.d.upload(h.d.data(), h.d.size()); }
+  else if (h.kind == InvOp::HORNER || h.kind == InvOp::NEWTON) {
+    d.Aop = Aop; d.n = Aop->m;
+    d.t1.alloc(d.n); d.t2.alloc(d.n); d.t3.alloc(d.n);
+    if (h.diag_scale) {
+      std::vector<double> di(d.n);
+      for (int64_t i = 0; i < d.n; i++) di[i] = 1.0 / host_diag_of_op[i];
+      d.dinv.upload(di.data(), d.n);
+      d.rhs.alloc(d.n);
+    }
+  }
+}
+
+void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top) {
+  const int L = H.no_levels();
+  n_ = A_top.m;
+  any_c_ = H.opt.any_c_smooths();
+  coarse_richardson_its_ = H.opt.coarse_richardson_its;
+  levels_.clear();
+  off_.assign(L, 0);
+  for (int l = 0; l + 1 < L; l++) off_[l + 1] = off_[l] + H.levels[l]->n_f;
+
+  // hierarchical permutations, coarsest level first: perm[l][i] = position of natural
+  // index i of level l inside the level-l vector [F_l | level l+1 ...]
+  std::vector<std::vector<int32_t>> perm(L);
+  {
+    const int64_t nL = H.coarse_A.m;
+    perm[L - 1].resize(nL);
+    for (int64_t i = 0; i < nL; i++) perm[L - 1][i] = (int32_t)i;
+    for (int l = L - 2; l >= 0; l--) {
+      const Level& Lv = *H.levels[l];
+      perm[l].resize(Lv.n);
+      int32_t* p = perm[l].data();
+      const int32_t* pn = perm[l + 1].data();
+#pragma omp parallel for schedule(static)
+      for (int64_t i = 0; i < Lv.n_f; i++) p[Lv.F[i]] = (int32_t)i;
+#pragma omp parallel for schedule(static)
+      for (int64_t j = 0; j < Lv.n_c; j++) p[Lv.C[j]] = (int32_t)(Lv.n_f + pn[j]);
+    }
+  }
+  auto inverse = [](const std::vector<int32_t>& p) {
+    std::vector<int32_t> ip(p.size());
+    const int64_t n = (int64_t)p.size();
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) ip[p[i]] = (int32_t)i;
+    return ip;
+  };
+
+  // top-level operator in hierarchical ordering (outer Krylov works in that ordering)
+  {
+    std::vector<int32_t> ip = inverse(perm[0]);
+    perm_.upload(perm[0].data(), n_);
+    iperm_.upload(ip.data(), n_);
+    upload_sell(A_top, iperm_.p, perm_.p, A_perm_, stream_);
+  }
+
+  cycle_bytes_ = 0.0;
+  for (int l = 0; l + 1 < L; l++) {
+    const Level& h = *H.levels[l];
+    auto dl = std::make_unique<DevLevel>();
+    DevLevel& d = *dl;
+    d.n = h.n; d.n_f = h.n_f; d.n_c = h.n_c; d.aff_diag = h.aff_diag; d.one_point = h.one_point; d.nnz_A = h.nnz_A;
+    for (int i = 0; i < 10; i++) d.smooth_order[i] = h.smooth_order[i];
+    // permutation of the coarse (level l+1) numbering
+    DBuf<int32_t> pc, ipc;
+    std::vector<int32_t> ipn = inverse(perm[l + 1]);
+    pc.upload(perm[l + 1].data(), h.n_c);
+    ipc.upload(ipn.data(), h.n_c);
+
+    upload_sell(h.A_fc, nullptr, pc.p, d.A_fc, stream_);           // rows F-order, cols permuted coarse
+    upload_sell(h.Z, ipc.p, nullptr, d.Z, stream_);                 // rows permuted coarse, cols F-order
+    std::vector<double> affd_host;
+    bool mf = (h.inv_ff.kind == InvOp::HORNER || h.inv_ff.kind == InvOp::NEWTON);
+    if (h.aff_diag) {
+      d.aff_d.upload(h.aff_d.data(), h.n_f);
+      if (mf) {  // matrix-free polynomial over a diagonal operator: keep one code path
+        Csr D = csr_from_diag(h.aff_d.data(), h.n_f);
+        upload_sell(D, nullptr, nullptr, d.A_ff, stream_);
+      }
+      affd_host.assign(h.aff_d.data(), h.aff_d.data() + h.n_f);
+    } else {
+      upload_sell(h.A_ff, nullptr, nullptr, d.A_ff, stream_);
+      if (mf && h.inv_ff.diag_scale) { affd_host.resize(h.n_f); get_diagonal(h.A_ff, affd_host.data()); }
+    }
+    upload_inv(h.inv_ff, d.inv_ff, &d.A_ff, affd_host.empty() ? nullptr : affd_host.data());
+    if (h.one_point) {
+      std::vector<int32_t> wc(h.n_f);
+      const int32_t* pn = perm[l + 1].data();
+      for (int64_t i = 0; i < h.n_f; i++) wc[i] = h.wcol[i] >= 0 ? pn[h.wcol[i]] : -1;
+      d.wcol.upload(wc.data(), h.n_f);
+    } else upload_sell(h.W, nullptr, pc.p, d.W, stream_);
+    d.t4.alloc(h.n_f); d.r.alloc(h.n_f);
+    if (any_c_) {
+      upload_sell(h.A_cf, ipc.p, nullptr, d.A_cf, stream_);
+      upload_sell(h.A_cc, ipc.p, pc.p, d.A_cc, stream_);
+      // inverse of A_cc lives in the permuted coarse numbering as well
+      if (h.inv_cc.kind == InvOp::ASSEMBLED) {
+        d.inv_cc.kind = InvOp::ASSEMBLED; d.inv_cc.n = h.n_c;
+        upload_sell(h.inv_cc.mat, ipc.p, pc.p, d.inv_cc.mat, stream_);
+      } else if (h.inv_cc.kind == InvOp::DIAG) {
+        std::vector<double> dd(h.n_c);
+        for (int64_t j = 0; j < h.n_c; j++) dd[perm[l + 1][j]] = h.inv_cc.d[j];
+        d.inv_cc.kind = InvOp::DIAG; d.inv_cc.n = h.n_c; d.inv_cc.d.upload(dd.data(), h.n_c);
+      } else {
+        std::vector<double> dg;
+        if (h.inv_cc.diag_scale) {
+          std::vector<double> nat(h.n_c); get_diagonal(h.A_cc, nat.data());
+          dg.resize(h.n_c);
+          for (int64_t j = 0; j < h.n_c; j++) dg[perm[l + 1][j]] = nat[j];
+        }
+        upload_inv(h.inv_cc, d.inv_cc, &d.A_cc, dg.empty() ? nullptr : dg.data());
+      }
+      d.t4c.alloc(h.n_c); d.rc.alloc(h.n_c);
+    }
+    // algorithmic bytes of this level, identity blocks of R/P included as the
+    // reference counts them
+    auto S = [](double nnz, double m, double n) { return 12.0 * nnz + 4.0 * (m + 1) + 8.0 * m + 8.0 * n; };
+    double nnzW = h.one_point ? 0.0 : (double)h.W.nnz();
+    if (h.one_point) for (int64_t i = 0; i < h.n_f; i++) nnzW += h.wcol[i] >= 0 ? 1 : 0;
+    cycle_bytes_ += S((double)h.Z.nnz() + h.n_c, h.n_c, h.n) + S(nnzW + h.n_c, h.n, h.n_c);
+    int g = 0, sf = 0, gc = 0, sc = 0;
+    for (int i = 0; i < 10; i++) { int s = h.smooth_order[i]; if (s > 0) { g++; sf += s; } else if (s < 0) { gc++; sc += -s; } }
+    double affB = h.aff_diag ? S(h.n_f, h.n_f, h.n_f) : d.A_ff.s_bytes();
+    cycle_bytes_ += g * d.A_fc.s_bytes() + sf * (affB + d.inv_ff.alg_bytes());
+    if (any_c_) cycle_bytes_ += gc * d.A_cf.s_bytes() + sc * (d.A_cc.s_bytes() + d.inv_cc.alg_bytes());
+    levels_.push_back(std::move(dl));
+  }
+  // coarse level
+  {
+    const bool mf = (H.coarse_inv.kind == InvOp::HORNER || H.coarse_inv.kind == InvOp::NEWTON);
+    if (mf || coarse_richardson_its_ > 0) upload_sell(H.coarse_A, nullptr, nullptr, coarse_A_, stream_);
+    std::vector<double> dg;
+    if (mf && H.coarse_inv.diag_scale) { dg.resize(H.coarse_A.m); get_diagonal(H.coarse_A, dg.data()); }
+    upload_inv(H.coarse_inv, coarse_inv_, &coarse_A_, dg.empty() ? nullptr : dg.data());
+    coarse_inv_.n = H.coarse_A.m;
+    if (coarse_richardson_its_ > 0) coarse_r_.alloc(H.coarse_A.m);
+    cycle_bytes_ += coarse_inv_.alg_bytes();
+  }
+  cb_.alloc(n_); cx_.alloc(n_);
+  b_ptr_.assign(L, nullptr);
+  b_sep_.clear(); b_sep_.resize(L);
+  b_ptr_[0] = cb_.p;
+  for (int l = 1; l < L; l++) {
+    if (any_c_) { b_sep_[l].alloc(n_ - off_[l]); b_ptr_[l] = b_sep_[l].p; }
+    else b_ptr_[l] = cb_.p + off_[l];
+  }
+  HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+double DevPCAIR::storage_bytes() const {
+  double b = 0;
+  auto sb = [&](const SellMat& m) { if (m.valid()) b += 12.0 * m.padded + 8.0 * (m.nslices + 1); };
+  sb(A_perm_); sb(coarse_A_); sb(coarse_inv_.mat);
+  for (auto& l : levels_) { sb(l->A_ff); sb(l->A_fc); sb(l->A_cf); sb(l->A_cc); sb(l->Z); sb(l->W); sb(l->inv_ff.mat); sb(l->inv_cc.mat); }
+  return b;
+}
+
+// ---------------------------------------------------------------------------------------
+// approximate inverse application: x (+)= M r
+// ---------------------------------------------------------------------------------------
+void DevPCAIR::apply_inv(DevInv& I, const double* r, double* x, bool add, int lvl, const char* tag) {
+  const int64_t n = I.n;
+  if (I.kind == InvOp::ASSEMBLED) {
+    SpmvEpi e; e.alpha = 1.0; e.out = x;
+    if (add) { e.z = x; e.beta = 1.0; }
+    spmv(I.mat, r, e, tag, lvl);
+    return;
+  }
+  if (I.kind == InvOp::DIAG) {
+    int id = -1;
+    if (profile_) { id = stat_id(tag, lvl, I.alg_bytes()); begin_kernel(id); }
+    launch_pointwise_mult(n, 1.0, I.d.p, r, 1.0, add ? x : nullptr, x, stream_);
+    if (profile_) end_kernel();
+    return;
+  }
+  const SellMat& A = *I.Aop;
+  const double* rr = r;
+  if (I.diag_scale) {   // MF_VEC_RHS = D^-1 x  (src/Gmres_Poly.F90:1406)
+    launch_pointwise_mult(n, 1.0, I.dinv.p, r, 0.0, nullptr, I.rhs.p, stream_);
+    rr = I.rhs.p;
+  }
+  if (I.kind == InvOp::HORNER) {
+    const std::vector<double>& c = I.coeffs;
+    const int m = (int)c.size() - 1;
+    std::vector<int> steps;
+    for (int k = m - 1; k >= 0; k--) if (c[k] != 0.0) steps.push_back(k);
+    if (steps.empty()) { launch_axpby(n, c[m], rr, 1.0, add ? x : nullptr, x, stream_); return; }
+    const double* cur = rr;       // holds y / lead, with `lead` the scalar still to be applied
+    double lead = c[m];
+    for (size_t si = 0; si < steps.size(); si++) {
+      const int k = steps[si];
+      const bool last = (si + 1 == steps.size());
+      double* out = last ? (add ? I.t3.p : x) : ((cur == I.t1.p) ? I.t2.p : I.t1.p);
+      SpmvEpi e; e.out = out;
+      // y_new = op(lead * cur) + c_k rr with op = A | D^-1 A | I - D^-1 A   (all linear)
+      if (I.neumann) { e.alpha = -lead; e.dscale = I.dinv.p; e.z = cur; e.beta = lead; }
+      else { e.alpha = lead; if (I.diag_scale) e.dscale = I.dinv.p; }
+      e.w = rr; e.gamma = c[k];
+      if (last && add) { e.y2 = x; e.delta = 1.0; e.aux_out = 1; }
+      spmv(A, cur, e, tag, lvl);
+      cur = out; lead = 1.0;
+    }
+    return;
+  }
+  // Newton basis (Loe et al. Alg. 3); y accumulates straight into x
+  const std::vector<double>& re = I.re; const std::vector<double>& im = I.im;
+  const int nr = (int)re.size();
+  if (!add) launch_fill(n, 0.0, x, stream_);
+  const double* t = rr;
+  auto next_t = [&]() { return (t == I.t1.p) ? I.t2.p : I.t1.p; };
+  int i = 0;
+  while (i <= nr - 2) {
+    if (im[i] == 0.0) {
+      if (std::fabs(re[i]) < TOL_ZERO) { i++; continue; }
+      double* tn = next_t();
+      SpmvEpi e; e.out = tn; e.alpha = -1.0 / re[i]; e.z = t; e.beta = 1.0;
+      if (I.diag_scale) e.dscale = I.dinv.p;
+      e.y2 = x; e.w2 = t; e.delta = 1.0 / re[i]; e.aux_out = 0;
+      spmv(A, t, e, tag, lvl);
+      t = tn; i++;
+    } else {
+      const double sq = re[i] * re[i] + im[i] * im[i];
+      if (sq < TOL_ZERO) { i += 2; continue; }
+      SpmvEpi e; e.out = I.t3.p; e.alpha = -1.0; e.z = t; e.beta = 2.0 * re[i];
+      if (I.diag_scale) e.dscale = I.dinv.p;
+      e.y2 = x; e.delta = 1.0 / sq; e.aux_out = 1;
+      spmv(A, t, e, tag, lvl);
+      if (i <= nr - 3) {
+        double* tn = next_t();
+        SpmvEpi e2; e2.out = tn; e2.alpha = -1.0 / sq; e2.z = t; e2.beta = 1.0;
+        if (I.diag_scale) e2.dscale = I.dinv.p;
+        spmv(A, I.t3.p, e2, tag, lvl);
+        t = tn;
+      }
+      i += 2;
+    }
+  }
+  if (im[nr - 1] == 0.0 && std::fabs(re[nr - 1]) > TOL_ZERO)
+    launch_axpby(n, 1.0 / re[nr - 1], t, 1.0, x, x, stream_);
+}
+
+// ---------------------------------------------------------------------------------------
+// FC relaxation
+// ---------------------------------------------------------------------------------------
+void DevPCAIR::f_smooths(DevLevel& L, int li, bool first, int its) {
+  double* x_f = xvec(li); double* x_c = x_f + L.n_f;
+  const double* b_f = bvec(li);
+  const bool diag_inv = L.aff_diag && L.inv_ff.kind == InvOp::DIAG;
+  if (first && L.one_point) {
+    // prolongation x_f = W x_c fused with t4 = b_f - A_fc x_c (and the whole smooth when A_ff
+    // and its inverse are diagonal and a single F smooth is requested)
+    const bool full = diag_inv && its == 1;
+    int id = -1;
+    if (profile_) { id = stat_id(full ? "fc_first_diag(A_fc+W)" : "fc_first(A_fc+W)", li, L.A_fc.s_bytes()); begin_kernel(id); }
+    launch_fc_first(L.A_fc, L.wcol.p, b_f, x_c, full ? L.aff_d.p : nullptr, full ? L.inv_ff.d.p : nullptr, L.t4.p, x_f, stream_);
+    if (profile_) end_kernel();
+    if (full) return;
+  } else {
+    if (first) { SpmvEpi e; e.out = x_f; spmv(L.W, x_c, e, "prolong(W)", li); }
+    SpmvEpi e; e.out = L.t4.p; e.alpha = -1.0; e.z = b_f; e.beta = 1.0;
+    spmv(L.A_fc, x_c, e, "t4=b_f-A_fc*x_c", li);
+  }
+  for (int it = 0; it < its; it++) {
+    if (diag_inv) {
+      launch_diag_residual_update(L.n_f, L.aff_d.p, L.inv_ff.d.p, L.t4.p, x_f, stream_);
+      continue;
+    }
+    if (L.aff_diag) launch_pointwise_mult(L.n_f, -1.0, L.aff_d.p, x_f, 1.0, L.t4.p, L.r.p, stream_);
+    else { SpmvEpi e; e.out = L.r.p; e.alpha = -1.0; e.z = L.t4.p; e.beta = 1.0; spmv(L.A_ff, x_f, e, "r=t4-A_ff*x_f", li); }
+    apply_inv(L.inv_ff, L.r.p, x_f, true, li, "x_f+=M_ff*r");
+  }
+}
+
+void DevPCAIR::c_smooths(DevLevel& L, int li, bool first, int its) {
+  double* x_f = xvec(li); double* x_c = x_f + L.n_f;
+  const double* b_c = bvec(li) + L.n_f;
+  if (first) {   // prolongation has not been applied yet
+    if (L.one_point) launch_gather(L.n_f, L.wcol.p, x_c, x_f, stream_);   // wcol < 0 -> 0 (no W entry)
+    else { SpmvEpi e; e.out = x_f; spmv(L.W, x_c, e, "prolong(W)", li); }
+  }
+  SpmvEpi e; e.out = L.t4c.p; e.alpha = -1.0; e.z = b_c; e.beta = 1.0;
+  spmv(L.A_cf, x_f, e, "t4c=b_c-A_cf*x_f", li);
+  for (int it = 0; it < its; it++) {
+    SpmvEpi e2; e2.out = L.rc.p; e2.alpha = -1.0; e2.z = L.t4c.p; e2.beta = 1.0;
+    spmv(L.A_cc, x_c, e2, "rc=t4c-A_cc*x_c", li);
+    apply_inv(L.inv_cc, L.rc.p, x_c, true, li, "x_c+=M_cc*rc");
+  }
+}
+
+void DevPCAIR::vcycle() {
+  const int L = no_levels();
+  // DOWN: b_{l+1} = b_c + Z b_f (identity block of R=[Z I] is the in-place b_c)
+  for (int l = 0; l + 1 < L; l++) {
+    DevLevel& Lv = *levels_[l];
+    SpmvEpi e; e.out = bvec(l + 1); e.alpha = 1.0; e.z = bvec(l) + Lv.n_f; e.beta = 1.0;
+    spmv(Lv.Z, bvec(l), e, "restrict(b_c+=Z*b_f)", l);
+  }
+  // COARSE: x_L = M_L b_L (KSPPREONLY) or N Richardson steps
+  {
+    double* xL = xvec(L - 1); const double* bL = bvec(L - 1);
+    if (coarse_richardson_its_ <= 0) apply_inv(coarse_inv_, bL, xL, false, L - 1, "coarse x=M*b");
+    else {
+      launch_fill(coarse_inv_.n, 0.0, xL, stream_);
+      for (int it = 0; it < coarse_richardson_its_; it++) {
+        const double* r = bL;
+        if (it > 0) {
+          SpmvEpi e; e.out = coarse_r_.p; e.alpha = -1.0; e.z = bL; e.beta = 1.0;
+          spmv(coarse_A_, xL, e, "coarse r=b-A*x", L - 1);
+          r = coarse_r_.p;
+        }
+        apply_inv(coarse_inv_, r, xL, true, L - 1, "coarse x+=M*r");
+      }
+    }
+  }
+  // UP: x_l = P x_{l+1} (x_c is in place), then FC relaxation
+  for (int l = L - 2; l >= 0; l--) {
+    DevLevel& Lv = *levels_[l];
+    bool first = true;
+    for (int i = 0; i < 10; i++) {
+      int s = Lv.smooth_order[i];
+      if (s == 0) break;
+      if (s > 0) f_smooths(Lv, l, first, s); else c_smooths(Lv, l, first, -s);
+      first = false;
+    }
+  }
+}
+
+void DevPCAIR::run_cycle() {
+  if (want_graph_ && !profile_) {
+    if (!graph_exec_) {
+      hipGraph_t g;
+      HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+      vcycle();
+      HIP_CHECK(hipStreamEndCapture(stream_, &g));
+      HIP_CHECK(hipGraphInstantiate(&graph_exec_, g, nullptr, nullptr, 0));
+      HIP_CHECK(hipGraphDestroy(g));
+    }
+    HIP_CHECK(hipGraphLaunch(graph_exec_, stream_));
+  } else vcycle();
+}
+
+void DevPCAIR::apply_permuted(const double* r, double* z) {
+  HIP_CHECK(hipMemcpyAsync(cb_.p, r, sizeof(double) * (size_t)n_, hipMemcpyDeviceToDevice, stream_));
+  run_cycle();
+  HIP_CHECK(hipMemcpyAsync(z, cx_.p, sizeof(double) * (size_t)n_, hipMemcpyDeviceToDevice, stream_));
+}
+
+void DevPCAIR::to_permuted(const double* nat, double* perm) { launch_gather(n_, iperm_.p, nat, perm, stream_); }
+void DevPCAIR::to_natural(const double* perm, double* nat) { launch_gather(n_, perm_.p, perm, nat, stream_); }
+
+void DevPCAIR::apply_natural(const double* d_x, double* d_y) {
+  launch_gather(n_, iperm_.p, d_x, cb_.p, stream_);
+  run_cycle();
+  launch_gather(n_, perm_.p, cx_.p, d_y, stream_);
+}
+
+}  // namespace airhip

@@ -1,0 +1,167 @@
+// Device-resident PCAIR hierarchy, the V-cycle driver and the outer Krylov solvers.
+#pragma once
+#include "dev.hpp"
+#include "../host/air.hpp"
+#include <map>
+#include <functional>
+#include <memory>
+
+namespace airhip {
+
+// Device buffer with ownership
+template <class T>
+struct DBuf {
+  T* p = nullptr; int64_t n = 0;
+  DBuf() = default;
+  DBuf(const DBuf&) = delete; DBuf& operator=(const DBuf&) = delete;
+  DBuf(DBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+  DBuf& operator=(DBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
+  ~DBuf() { release(); }
+  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+  void alloc(int64_t n_) { release(); n = n_; HIP_CHECK(hipMalloc(&p, sizeof(T) * (size_t)(n_ > 0 ? n_ : 1))); }
+  void upload(const T* h, int64_t n_) { alloc(n_); if (n_ > 0) HIP_CHECK(hipMemcpy(p, h, sizeof(T) * (size_t)n_, hipMemcpyHostToDevice)); }
+};
+
+// Upload a host CSR and convert it to SELL-64 on the device (rows/cols optionally permuted).
+void upload_sell(const Csr& A, const int32_t* d_rowsrc, const int32_t* d_colmap, SellMat& out, hipStream_t s);
+
+struct DevInv {
+  InvOp::Kind kind = InvOp::NONE;
+  int64_t n = 0;
+  SellMat mat;                   // ASSEMBLED
+  DBuf<double> d;                // DIAG
+  std::vector<double> coeffs, re, im;
+  bool diag_scale = false, neumann = false;
+  int spmvs = 0;
+  const SellMat* Aop = nullptr;  // operator of the matrix-free polynomial (not owned)
+  DBuf<double> dinv;             // 1/diag(Aop) for the scaled variants
+  DBuf<double> t1, t2, t3, rhs;  // matrix-free temporaries
+  ~DevInv() { sell_free(mat); }
+  // algorithmic bytes of one application (T(M) of SURVEY 8d)
+  double alg_bytes() const;
+};
+
+struct DevLevel {
+  int64_t n = 0, n_f = 0, n_c = 0;
+  bool aff_diag = false;
+  DBuf<double> aff_d;
+  SellMat A_ff, A_fc, A_cf, A_cc, Z, W;
+  bool one_point = true;
+  DBuf<int32_t> wcol;
+  DevInv inv_ff, inv_cc;
+  int smooth_order[10] = {0};
+  DBuf<double> t4, r, t4c, rc;
+  int64_t nnz_A = 0;
+  ~DevLevel() { sell_free(A_ff); sell_free(A_fc); sell_free(A_cf); sell_free(A_cc); sell_free(Z); sell_free(W); }
+};
+
+struct KernelStat { std::string name; int level; double alg_bytes; int64_t calls = 0; double ms = 0.0; };
+
+struct PendingEvent { hipEvent_t a, b; int stat; };
+
+class DevPCAIR {
+ public:
+  DevPCAIR();
+  ~DevPCAIR();
+  // Build the device hierarchy from a host hierarchy; A_top is the fine operator (natural order).
+  void upload(const Hierarchy& H, const Csr& A_top);
+  int64_t n() const { return n_; }
+  int no_levels() const { return (int)levels_.size() + 1; }
+
+  // z = M r in the hierarchical ordering (r, z: device vectors of size n; r is preserved)
+  void apply_permuted(const double* r, double* z);
+  // y = M x in natural ordering (PCApply_AIR semantics)
+  void apply_natural(const double* d_x, double* d_y);
+  // natural <-> hierarchical ordering
+  void to_permuted(const double* nat, double* perm);
+  void to_natural(const double* perm, double* nat);
+
+  const SellMat& A_perm() const { return A_perm_; }
+  hipStream_t stream() const { return stream_; }
+  double cycle_alg_bytes() const { return cycle_bytes_; }
+  double storage_bytes() const;
+
+  void set_profile(bool on) { profile_ = on; }
+  void reset_stats();
+  void resolve_events();
+  const std::vector<KernelStat>& stats() const { return stats_; }
+
+  void set_use_graph(bool on) { want_graph_ = on; }
+  std::vector<std::unique_ptr<DevLevel>> levels_;
+  DevInv coarse_inv_;
+  SellMat coarse_A_;
+  int coarse_richardson_its_ = 0;
+  std::vector<int64_t> off_;     // off_[l]: start of the level-l vector inside the level-1 vector
+
+ private:
+  void vcycle();                                        // cb_ -> cx_
+  void run_cycle();                                     // vcycle, through a HIP graph when enabled
+  void f_smooths(DevLevel& L, int li, bool first, int its);
+  void c_smooths(DevLevel& L, int li, bool first, int its);
+  void apply_inv(DevInv& I, const double* r, double* x, bool add, int stat_level, const char* tag);
+  void spmv(const SellMat& A, const double* x, const SpmvEpi& e, const char* name, int level, double bytes_override = -1);
+  int stat_id(const char* name, int level, double bytes);
+  void begin_kernel(int stat);
+  void end_kernel();
+  void upload_inv(const InvOp& h, DevInv& d, const SellMat* Aop, const double* host_diag_of_op);
+  double* bvec(int l) { return b_ptr_[l]; }
+  double* xvec(int l) { return cx_.p + off_[l]; }
+
+  int64_t n_ = 0;
+  hipStream_t stream_ = nullptr;
+  bool any_c_ = false;
+  DBuf<double> cb_, cx_;          // level-1 rhs / solution in hierarchical ordering
+  std::vector<DBuf<double>> b_sep_;   // separate rhs per level when C smoothing keeps b_c alive
+  std::vector<double*> b_ptr_;
+  DBuf<int32_t> perm_, iperm_;    // natural -> hierarchical and back (level 1)
+  SellMat A_perm_;
+  DBuf<double> coarse_r_;
+  double cycle_bytes_ = 0.0;
+  // profiling
+  bool profile_ = false;
+  std::vector<KernelStat> stats_;
+  std::map<std::string, int> stat_index_;
+  std::vector<PendingEvent> pending_;
+  std::vector<hipEvent_t> event_pool_;
+  int cur_stat_ = -1; hipEvent_t cur_a_ = nullptr;
+  // graph
+  bool want_graph_ = false;
+  hipGraphExec_t graph_exec_ = nullptr;
+};
+
+// ---------------------------------------------------------------------------------------
+// Outer Krylov (PETSc KSPRICHARDSON / KSPGMRES semantics) on the device
+// ---------------------------------------------------------------------------------------
+struct KspOptions {
+  int type = 1;            // 0 richardson, 1 gmres
+  int pc_side = 0;         // 0 left, 1 right
+  int norm_type = 0;       // richardson: 0 preconditioned, 1 unpreconditioned
+  double rtol = 1e-5, atol = 1e-50, dtol = 1e4;
+  int max_it = 10000;
+  int restart = 30;
+};
+struct KspResult { int its = 0; int reason = 0; double rnorm = 0.0; double solve_ms = 0.0; std::vector<double> history; };
+
+// Generic preconditioner callback in whatever ordering the operator uses.
+struct KspOperator {
+  const SellMat* A = nullptr;
+  hipStream_t stream = nullptr;
+  // z = M r ; null = identity
+  std::function<void(const double*, double*)> pc;
+};
+
+class DevKSP {
+ public:
+  explicit DevKSP(int64_t n);
+  ~DevKSP() = default;
+  KspResult solve(const KspOperator& op, const KspOptions& o, const double* d_b, double* d_x);
+ private:
+  double norm2(const double* v, hipStream_t s);
+  KspResult richardson(const KspOperator& op, const KspOptions& o, const double* b, double* x);
+  KspResult gmres(const KspOperator& op, const KspOptions& o, const double* b, double* x);
+  int64_t n_;
+  DBuf<double> V_, w_, t_, scratch_, ddots_, dcoef_;
+  int v_alloc_ = 0;
+};
+
+}  // namespace airhip

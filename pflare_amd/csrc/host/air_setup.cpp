@@ -1,0 +1,266 @@
+// PCAIR hierarchy construction: the level loop of setup_air_pcmg
+// (src/AIR_MG_Setup.F90:138-962) with the operator construction of
+// src/AIR_Operators_Setup.F90:36-1085, default AIRG path (z_type product, PMISR+DDC,
+// no reuse, no processor agglomeration, no near-nullspace constraints).
+#include "air.hpp"
+#include <cstdio>
+
+namespace airhip {
+
+int AirOptions::set_smooth_type(const char* s) {
+  // src/PCAIR_Interfaces.F90:1821-1882: "ffc" -> (2,-1,0,...)
+  int out[10] = {0}; int n = 0;
+  for (const char* p = s; *p; p++) {
+    int val;
+    if (*p == 'f' || *p == 'F') val = 1; else if (*p == 'c' || *p == 'C') val = -1; else return -1;
+    if (n > 0 && ((out[n - 1] > 0) == (val > 0))) out[n - 1] += val;
+    else { if (n == 10) return -1; out[n++] = val; }
+  }
+  if (n == 0) return -1;
+  for (int i = 0; i < 10; i++) smooth_order[i] = out[i];
+  return 0;
+}
+
+// one-point classical prolongator (src/Grid_Transfer.F90:94-220)
+static void one_point_W(const Csr& A_fc, Arr<int32_t>& wcol) {
+  wcol.alloc(A_fc.m);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < A_fc.m; i++) {
+    double best = -1.0; int32_t col = -1;
+    for (int64_t k = A_fc.rp[i]; k < A_fc.rp[i + 1]; k++) {
+      double a = std::fabs(A_fc.v[k]);
+      if (a > best) { best = a; col = A_fc.ci[k]; }
+    }
+    wcol[i] = col;
+  }
+}
+
+// R = [Z I] in level ordering (src/Grid_Transfer.F90:588-815)
+static Csr build_R(const Csr& Z, const Arr<int32_t>& F, const Arr<int32_t>& C, int64_t n) {
+  const int64_t nc = C.size();
+  Csr R; R.m = nc; R.n = n; R.rp.alloc(nc + 1);
+#pragma omp parallel for schedule(static)
+  for (int64_t j = 0; j <= nc; j++) R.rp[j] = (j < nc ? Z.rp[j] : Z.rp[nc]) + j;
+  R.ci.alloc(R.rp[nc]); R.v.alloc(R.rp[nc]);
+#pragma omp parallel for schedule(static)
+  for (int64_t j = 0; j < nc; j++) {
+    int64_t o = R.rp[j]; const int32_t cj = C[j]; bool placed = false;
+    for (int64_t k = Z.rp[j]; k < Z.rp[j + 1]; k++) {
+      int32_t col = F[Z.ci[k]];
+      if (!placed && col > cj) { R.ci[o] = cj; R.v[o] = 1.0; o++; placed = true; }
+      R.ci[o] = col; R.v[o] = Z.v[k]; o++;
+    }
+    if (!placed) { R.ci[o] = cj; R.v[o] = 1.0; o++; }
+  }
+  return R;
+}
+
+// P = [W; I] in level ordering (src/Grid_Transfer.F90:329-461)
+static Csr build_P(const Level& L) {
+  const int64_t n = L.n, nc = L.n_c;
+  Csr P; P.m = n; P.n = nc;
+  Arr<int64_t> cnt(n);
+  Arr<int32_t> where(n);   // >=0: index into F ; <0: -(index into C)-1
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < L.n_f; i++) where[L.F[i]] = (int32_t)i;
+#pragma omp parallel for schedule(static)
+  for (int64_t j = 0; j < nc; j++) where[L.C[j]] = -(int32_t)j - 1;
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < n; r++) {
+    int32_t w = where[r];
+    if (w < 0) cnt[r] = 1;
+    else cnt[r] = L.one_point ? (L.wcol[w] >= 0 ? 1 : 0) : (L.W.rp[w + 1] - L.W.rp[w]);
+  }
+  P.rp.alloc(n + 1);
+  exclusive_scan(cnt.data(), n, P.rp.data());
+  P.ci.alloc(P.rp[n]); P.v.alloc(P.rp[n]);
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < n; r++) {
+    int32_t w = where[r]; int64_t o = P.rp[r];
+    if (w < 0) { P.ci[o] = -w - 1; P.v[o] = 1.0; }
+    else if (L.one_point) { if (L.wcol[w] >= 0) { P.ci[o] = L.wcol[w]; P.v[o] = 1.0; } }
+    else for (int64_t k = L.W.rp[w]; k < L.W.rp[w + 1]; k++) { P.ci[o] = L.W.ci[k]; P.v[o] = L.W.v[k]; o++; }
+  }
+  return P;
+}
+
+static void negate(Csr& A) {
+  const int64_t nnz = A.nnz();
+#pragma omp parallel for schedule(static)
+  for (int64_t k = 0; k < nnz; k++) A.v[k] = -A.v[k];
+}
+
+static void coarse_solver(const Csr& A, const AirOptions& o, InvOp& op) {
+  OpView v; v.A = &A; v.n = A.m;
+  build_inverse(v, o.coarsest_inverse_type, o.coarsest_poly_order, o.coarsest_inverse_sparsity_order,
+                o.coarsest_matrix_free_polys, o.coarsest_diag_scale_polys, o.seed, op, nullptr);
+}
+
+std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o) {
+  auto H = std::make_unique<Hierarchy>();
+  H->opt = o;
+  H->timers.assign(8, 0.0);
+  Csr owned;              // level operators below the top are owned here
+  const Csr* cur = &A0;
+  const bool any_c = o.any_c_smooths();
+  bool auto_truncated = false;
+  const double t_setup = now_s();
+
+  for (int our_level = 1; our_level < o.max_levels; our_level++) {
+    const int64_t n = cur->m;
+    // ---- auto truncation test (AIR_MG_Setup.F90:158-256)
+    if (o.auto_truncate_start_level != -1 && our_level >= o.auto_truncate_start_level) {
+      double t0 = now_s();
+      InvOp cop;
+      coarse_solver(*cur, o, cop);
+      Arr<double> rnd(n), sol(n), tmp(n);
+      const uint64_t key = rng_key(o.seed + 7919);   // distinct stream from the polynomial RHS
+#pragma omp parallel for schedule(static)
+      for (int64_t i = 0; i < n; i++) rnd[i] = uniform01(key, (uint64_t)i);
+      double nb = 0.0, nr = 0.0;
+      OpView v; v.A = cur; v.n = n;
+      host_apply_inv(cop, v, rnd.data(), sol.data());
+      spmv(*cur, sol.data(), tmp.data());
+#pragma omp parallel for schedule(static) reduction(+ : nb, nr)
+      for (int64_t i = 0; i < n; i++) { nb += rnd[i] * rnd[i]; double d = tmp[i] - rnd[i]; nr += d * d; }
+      if (std::sqrt(nr) / std::sqrt(nb) < o.auto_truncate_tol) { auto_truncated = true; H->coarse_inv = std::move(cop); }
+      H->timers[7] += now_s() - t0;
+    }
+    // ---- CF splitting
+    Arr<int32_t> markers;
+    int64_t n_f = 0, n_c = 0;
+    if (!auto_truncated) {
+      double t0 = now_s();
+      compute_cf_splitting(*cur, o, markers);
+#pragma omp parallel for schedule(static) reduction(+ : n_f)
+      for (int64_t i = 0; i < n; i++) n_f += (markers[i] == F_POINT) ? 1 : 0;
+      n_c = n - n_f;
+      H->timers[0] += now_s() - t0;
+    }
+    const bool cont = !auto_truncated && (n_c > o.coarse_eq_limit && n_f != 0);
+    if (!cont) break;
+
+    auto Lp = std::make_unique<Level>();
+    Level& L = *Lp;
+    L.n = n; L.n_f = n_f; L.n_c = n_c; L.nnz_A = cur->nnz();
+    // index sets + position-within-set map
+    double t0 = now_s();
+    Arr<int32_t> newidx(n);
+    {
+      Arr<int64_t> isf(n), pre(n + 1);
+#pragma omp parallel for schedule(static)
+      for (int64_t i = 0; i < n; i++) isf[i] = markers[i] == F_POINT ? 1 : 0;
+      exclusive_scan(isf.data(), n, pre.data());
+      L.F.alloc(n_f); L.C.alloc(n_c);
+#pragma omp parallel for schedule(static)
+      for (int64_t i = 0; i < n; i++) {
+        if (markers[i] == F_POINT) { newidx[i] = (int32_t)pre[i]; L.F[pre[i]] = (int32_t)i; }
+        else { newidx[i] = (int32_t)(i - pre[i]); L.C[i - pre[i]] = (int32_t)i; }
+      }
+    }
+    split_fc(*cur, markers.data(), newidx.data(), L.F, L.C, L.A_ff, L.A_fc, L.A_cf, any_c ? &L.A_cc : nullptr);
+    H->timers[1] += now_s() - t0;
+
+    for (int i = 0; i < 10; i++) L.smooth_order[i] = o.smooth_order[i];
+    int inv_type_aff = o.inverse_type, sparsity_aff = o.inverse_sparsity_order;
+    // diagonal A_ff detection (AIR_MG_Setup.F90:456-522)
+    L.aff_diag = (o.strong_threshold == 0.0) ? true : is_diag_only(L.A_ff);
+    if (L.aff_diag) {
+      L.aff_d.alloc(n_f);
+      get_diagonal(L.A_ff, L.aff_d.data());
+      L.A_ff = Csr();
+      sparsity_aff = 0;
+      if (inv_type_aff != INV_WJACOBI && o.poly_order > 2)
+        for (int i = 0; i < 10; i++) if (L.smooth_order[i] > 0) L.smooth_order[i] = 1;
+    }
+    // ---- A_ff^-1 for smoothing and for the grid transfers
+    t0 = now_s();
+    OpView aff; aff.n = n_f;
+    if (L.aff_diag) aff.diag = L.aff_d.data(); else aff.A = &L.A_ff;
+    InvOp inv_asm;
+    build_inverse(aff, inv_type_aff, o.poly_order, sparsity_aff, o.matrix_free_polys, o.diag_scale_polys,
+                  o.seed, L.inv_ff, &inv_asm);
+    const InvOp& invZ = (inv_asm.kind != InvOp::NONE) ? inv_asm : L.inv_ff;
+    if (invZ.kind != InvOp::ASSEMBLED && invZ.kind != InvOp::DIAG)
+      throw std::runtime_error("grid transfers need an assembled A_ff inverse (use a non-Newton inverse_type)");
+    if (any_c) {
+      OpView acc; acc.A = &L.A_cc; acc.n = n_c;
+      build_inverse(acc, o.c_inverse_type, o.c_poly_order, o.c_inverse_sparsity_order, o.matrix_free_polys,
+                    o.diag_scale_polys, o.seed, L.inv_cc, nullptr);
+    }
+    H->timers[2] += now_s() - t0;
+
+    // ---- W / P
+    t0 = now_s();
+    Csr Mz_store;
+    const Csr* Mz = nullptr;
+    if (invZ.kind == InvOp::ASSEMBLED) Mz = &invZ.mat;
+    else { Mz_store = csr_from_diag(invZ.d.data(), n_f); Mz = &Mz_store; }
+    if (o.one_point_classical_prolong && !o.symmetric) {
+      L.one_point = true;
+      one_point_W(L.A_fc, L.wcol);
+    } else {
+      L.one_point = false;
+      Csr W = spgemm(*Mz, L.A_fc);
+      negate(W);
+      L.W = remove_small(W, o.r_drop, 1, false, 0);
+    }
+    H->timers[3] += now_s() - t0;
+    // ---- Z / R
+    t0 = now_s();
+    {
+      Csr Zf = spgemm(L.A_cf, *Mz);
+      negate(Zf);
+      L.Z = remove_small(Zf, o.r_drop, 1, false, 0);
+    }
+    Mz_store = Csr();
+    inv_asm = InvOp();
+    H->timers[4] += now_s() - t0;
+    if (o.symmetric) throw std::runtime_error("-pc_air_symmetric is not supported by this build");
+
+    // ---- coarse operator R (A P) with drop / lump (AIR_Operators_Setup.F90:960-1085)
+    t0 = now_s();
+    Csr coarse;
+    {
+      Csr P = build_P(L);
+      Csr AP = spgemm(*cur, P);
+      P = Csr();
+      Csr R = build_R(L.Z, L.F, L.C, n);
+      Csr RAP = spgemm(R, AP);
+      AP = Csr(); R = Csr();
+      H->timers[5] += now_s() - t0;
+      t0 = now_s();
+      coarse = remove_small(RAP, o.a_drop, 1, o.a_lump, 0);
+      H->timers[6] += now_s() - t0;
+    }
+    if (!any_c) { /* A_cf is only needed again for C smoothing; keep it anyway for export */ }
+    if (o.print_stats_timings)
+      std::printf(" ~~~~~~~~~~~~ Level %d\n Global rows %lld Global F-points %lld Global C-points %lld  (nnz %lld, A_ff %s, t=%.2fs)\n",
+                  our_level, (long long)n, (long long)n_f, (long long)n_c, (long long)L.nnz_A,
+                  L.aff_diag ? "diagonal" : "sparse", now_s() - t_setup);
+    H->levels.push_back(std::move(Lp));
+    owned = std::move(coarse);
+    cur = &owned;
+  }
+
+  // ---- coarse grid solver (AIR_MG_Setup.F90:933-962, 1110-1136)
+  if (cur == &A0) H->coarse_A = A0.clone(); else H->coarse_A = std::move(owned);
+  if (!auto_truncated) {
+    double t0 = now_s();
+    if (H->levels.empty()) {
+      // "Only a single level, defaulting to Jacobi PC" (AIR_MG_Setup.F90:1167-1174)
+      H->single_level_jacobi = true;
+      const int64_t n = H->coarse_A.m;
+      H->coarse_inv.kind = InvOp::DIAG; H->coarse_inv.d.alloc(n);
+      get_diagonal(H->coarse_A, H->coarse_inv.d.data());
+      for (int64_t i = 0; i < n; i++) H->coarse_inv.d[i] = 1.0 / H->coarse_inv.d[i];
+    } else coarse_solver(H->coarse_A, o, H->coarse_inv);
+    H->timers[2] += now_s() - t0;
+  }
+  if (o.print_stats_timings)
+    std::printf(" ~~~~~~~~~~~~ Coarse grid %d\n Global rows %lld\n Total cumulative setup time : %.3f\n",
+                H->no_levels(), (long long)H->coarse_A.m, now_s() - t_setup);
+  return H;
+}
+
+}  // namespace airhip

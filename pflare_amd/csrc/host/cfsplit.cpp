@@ -1,0 +1,121 @@
+// CF splitting: PMISR (Luby rounds, smallest measure -> F) followed by the DDC cleanup.
+// Follows src/PMISR_Module.F90:121-671, src/DDC_Module.F90:221-481,
+// src/MatDiagDom.F90:98-270 and the driver src/CF_Splitting.F90:235-392 (CF_PMISR_DDC).
+#include "air.hpp"
+
+namespace airhip {
+
+static void pmisr(const Arr<int64_t>& rp, const Arr<int32_t>& ci, int64_t n, uint64_t seed,
+                  int max_luby_steps, Arr<int32_t>& markers) {
+  const uint64_t key = rng_key(seed);
+  Arr<double> measure(n);
+  Arr<uint8_t> assigned(n), in_set(n);
+  markers.alloc(n);
+  int64_t undecided = 0;
+#pragma omp parallel for schedule(static) reduction(+ : undecided)
+  for (int64_t i = 0; i < n; i++) {
+    measure[i] = uniform01(key, (uint64_t)i) + (double)(rp[i + 1] - rp[i]);
+    markers[i] = 0; assigned[i] = 0;
+    // rows without strong neighbours go straight to F (PMISR_Module.F90:409-436)
+    if (std::fabs(measure[i]) < 1.0) { assigned[i] = 1; markers[i] = F_POINT; }
+    else undecided++;
+  }
+  int loops = 0;
+  while (undecided != 0) {
+    if (max_luby_steps > 0 && loops == max_luby_steps) break;
+#pragma omp parallel for schedule(dynamic, 8192)
+    for (int64_t i = 0; i < n; i++) {
+      uint8_t in = 0;
+      if (!assigned[i]) {
+        in = 1;
+        const double mi = measure[i];
+        for (int64_t k = rp[i]; k < rp[i + 1]; k++) {
+          int32_t j = ci[k];
+          if (assigned[j]) continue;
+          double mj = measure[j];
+          if (mi > mj || (mi == mj && i > j)) { in = 0; break; }
+        }
+      }
+      in_set[i] = in;
+    }
+    // record the new F points, then mark their neighbours as assigned (-> C at the end)
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++)
+      if (in_set[i]) { assigned[i] = 1; markers[i] = F_POINT; }
+#pragma omp parallel for schedule(dynamic, 8192)
+    for (int64_t i = 0; i < n; i++)
+      if (in_set[i])
+        for (int64_t k = rp[i]; k < rp[i + 1]; k++) assigned[ci[k]] = 1;  // benign same-value race
+    loops++;
+    undecided = 0;
+#pragma omp parallel for schedule(static) reduction(+ : undecided)
+    for (int64_t i = 0; i < n; i++) undecided += assigned[i] ? 0 : 1;
+  }
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; i++) if (markers[i] == 0) markers[i] = C_POINT;
+}
+
+static void ddc(const Csr& A, double fraction_swap, Arr<int32_t>& markers) {
+  if (fraction_swap == 0.0) return;
+  const int64_t n = A.m;
+  // ratio per F row (0 for non-F rows, never read)
+  Arr<double> ratio(n);
+  int64_t fine_size = 0;
+#pragma omp parallel for schedule(static) reduction(+ : fine_size)
+  for (int64_t i = 0; i < n; i++) {
+    ratio[i] = 0.0;
+    if (markers[i] != F_POINT) continue;
+    fine_size++;
+    double diag = 0.0, off = 0.0;
+    for (int64_t k = A.rp[i]; k < A.rp[i + 1]; k++) {
+      int32_t c = A.ci[k];
+      if (markers[c] != F_POINT) continue;
+      if (c == i) diag = std::fabs(A.v[k]); else off += std::fabs(A.v[k]);
+    }
+    if (diag != 0.0) ratio[i] = off / diag;
+  }
+  int64_t search_size = fraction_swap < 0 ? fine_size : (int64_t)((double)fine_size * fraction_swap);
+  if (search_size <= 0) return;
+  const int NB = 1000;
+  auto bin_of = [&](double r) {
+    double b = std::floor(r * NB) + 1.0;
+    if (!(b == b) || b > (double)NB) return NB;   // NaN / overflow -> top bin
+    int bi = (int)b;
+    if (bi < 0) bi = NB;
+    return std::min(bi, NB);
+  };
+  std::vector<int64_t> bins(NB + 1, 0);
+#pragma omp parallel
+  {
+    std::vector<int64_t> lb(NB + 1, 0);
+#pragma omp for schedule(static) nowait
+    for (int64_t i = 0; i < n; i++) if (markers[i] == F_POINT) lb[bin_of(ratio[i])]++;
+#pragma omp critical
+    for (int b = 0; b <= NB; b++) bins[b] += lb[b];
+  }
+  double swap_val;
+  if (fraction_swap < 0) swap_val = -fraction_swap;
+  else {
+    int64_t bin_sum = 0; int bb = NB;
+    for (bb = NB; bb >= 1; bb--) { bin_sum += bins[bb]; if (bin_sum >= search_size) break; }
+    if (bb < 1) bb = 1;
+    swap_val = (double)(bb - 1) / (double)NB;
+  }
+  Arr<uint8_t> flip(n);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; i++)
+    flip[i] = (markers[i] == F_POINT && !(ratio[i] == 0.0 || ratio[i] < swap_val)) ? 1 : 0;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; i++) if (flip[i]) markers[i] = -markers[i];
+}
+
+void compute_cf_splitting(const Csr& A, const AirOptions& o, Arr<int32_t>& markers) {
+  Arr<int64_t> rp; Arr<int32_t> ci;
+  strength_graph(A, o.strong_threshold, !o.symmetric, rp, ci);
+  pmisr(rp, ci, A.m, o.seed, o.max_luby_steps, markers);
+  rp.release(); ci.release();
+  if (o.strong_threshold != 0.0)
+    for (int it = 0; it < o.ddc_its; it++) ddc(A, o.ddc_fraction, markers);
+}
+
+}  // namespace airhip

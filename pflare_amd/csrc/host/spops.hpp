@@ -1,0 +1,54 @@
+// Sparse building blocks of the host setup (OpenMP, row-parallel, deterministic).
+#pragma once
+#include "common.hpp"
+
+namespace airhip {
+
+// tests/adv_1d.c:80-105
+Csr gen_adv_1d(int64_t n);
+// tests/adv_diff_fd.c:366-586; row = (k*N + j)*M + i restricted to the box
+// [i0,i0+mi) x [j0,j0+mj) x [k0,k0+mk) when `perm` (natural -> output numbering, size M*N*P)
+// is given (multi-GPU box numbering), natural otherwise.
+struct FdOptions {
+  int dim = 2;
+  int64_t M = 11, N = 11, P = 11;
+  double u = 1.0, v = 1.0, w = 1.0;
+  bool unit_velocity = true;
+  double alpha = 0.0;
+  double L_x = 1.0, L_y = 1.0, L_z = 1.0;
+  int adv_nondim = -1;  // -1: default (alpha == 0)
+};
+Csr gen_adv_diff_fd(const FdOptions& o, const int64_t* perm = nullptr);
+
+// src/PETSc_Helper.F90:207-412
+Csr remove_small(const Csr& A, double tol, int rel, bool lump, int drop_diag);
+
+// src/SAbs.F90:16-145 reduced to what PMISR needs: the (optionally symmetrised) strength
+// adjacency, diagonal removed, sorted columns.
+void strength_graph(const Csr& A, double theta, bool symmetrize, Arr<int64_t>& rp, Arr<int32_t>& ci);
+
+// Extract A[F,F], A[F,C], A[C,F] and optionally A[C,C] in one pass
+// (MatCreateSubMatrix calls of src/AIR_MG_Setup.F90:405-451, src/AIR_Operators_Setup.F90:196-225).
+// newidx[i] = position of i inside its own set (F or C), markers[i] = F_POINT / C_POINT.
+void split_fc(const Csr& A, const int32_t* markers, const int32_t* newidx,
+              const Arr<int32_t>& F, const Arr<int32_t>& C,
+              Csr& A_ff, Csr& A_fc, Csr& A_cf, Csr* A_cc);
+
+// C = A * B, row-wise Gustavson with the accumulation order of a sequential sparse
+// accumulator (k ascending), sorted output columns.
+Csr spgemm(const Csr& A, const Csr& B);
+
+void spmv(const Csr& A, const double* x, double* y);
+// y = (A x) ./ d
+void spmv_dscale(const Csr& A, const double* d, const double* x, double* y);
+
+// src/PETSc_Helper.F90:930-1040
+Csr copy_plus_diag(const Csr& A);
+void get_diagonal(const Csr& A, double* d);
+bool is_diag_only(const Csr& A);
+Csr csr_from_diag(const double* d, int64_t n);
+// scale columns: A(:,j) *= s[j]
+void scale_cols(Csr& A, const double* s);
+void scale_rows(Csr& A, const double* s);
+
+}  // namespace airhip

@@ -1,0 +1,166 @@
+"""GPU parity: the HIP solve phase (through the C ABI) against the CPU oracle on the SAME
+hierarchy (exported from the product setup, or built by the oracle and injected through the
+bring-your-own ABI).  Tolerances follow the reference's CPU-vs-device differential test
+(PFLARE_TOL_MATFREE_13 = 1e-13 for data movement / single SpMVs, 4e-11 for accumulated fp;
+src/Pflare_Parameters.F90:209-210)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL_SPMV = 1e-13
+TOL_CYCLE = 1e-10
+
+
+def lcg_vector(n):
+    """SURVEY 8(d) microbenchmark vector: x_i = ((1103515245*(i+12345)) mod 2^31)/2^30 - 1"""
+    i = np.arange(n, dtype=np.uint64)
+    return (((np.uint64(1103515245) * (i + np.uint64(12345))) % np.uint64(2 ** 31)).astype(np.float64)
+            / float(2 ** 30) - 1.0)
+
+
+def relerr(a, b):
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+@pytest.fixture(scope="module")
+def torch_mod(gpu):
+    import torch
+    return torch
+
+
+def dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+
+
+CASES = {
+    "adv2d_25": (dict(dim=2, M=25, N=25), {}),
+    "adv2d_40_lump": (dict(dim=2, M=40, N=40), dict(a_lump=True, a_drop=1e-5, strong_threshold=0.99)),
+    "adv3d_12_lump": (dict(dim=3, M=12, N=12, P=12), dict(a_lump=True)),
+    "diff2d_16": (dict(dim=2, M=16, N=16, u=0, v=0, alpha=1.0), {}),
+    "diff2d_16_neumann": (dict(dim=2, M=16, N=16, u=0, v=0, alpha=1.0), dict(inverse_type="neumann", a_drop=1e-3)),
+    "diff2d_16_neumann_mf": (dict(dim=2, M=16, N=16, u=0, v=0, alpha=1.0),
+                             dict(inverse_type="neumann", a_drop=1e-3, matrix_free_polys=True)),
+    "adv2d_30_mf": (dict(dim=2, M=30, N=30), dict(matrix_free_polys=True)),
+    "adv2d_30_newton_coarse": (dict(dim=2, M=30, N=30),
+                               dict(coarsest_inverse_type="newton", coarsest_poly_order=10,
+                                    coarsest_matrix_free_polys=True, inverse_type="power", a_drop=1e-3,
+                                    max_levels=4)),
+    "adv2d_16_fc": (dict(dim=2, M=16, N=16), dict(smooth_type="fc")),
+    "adv2d_16_fcf": (dict(dim=2, M=16, N=16), dict(smooth_type="fcf")),
+    "diff2d_12_diagscale": (dict(dim=2, M=12, N=12, u=0, v=0, alpha=1.0), dict(diag_scale_polys=True)),
+    "diff2d_12_jacobi_exact": (dict(dim=2, M=8, N=8, u=0, v=0, alpha=1.0),
+                               dict(strong_threshold=0.0, a_drop=0.0, r_drop=0.0, inverse_type="jacobi",
+                                    mg_coarse_ksp_max_it=10)),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_spmv_and_vcycle_match_oracle(torch_mod, case):
+    torch = torch_mod
+    import pflare_amd as P
+    from oracle import air_ref as R, bridge
+    gen, opts = CASES[case]
+    hm = P.HostMat.adv_diff_fd(**gen)
+    A = bridge.to_scipy(hm.csr())
+    n = A.shape[0]
+    x = lcg_vector(n)
+
+    # K1: device SpMV vs oracle CSR SpMV
+    dm = P.DeviceMat(A)
+    y = torch.empty(n, dtype=torch.float64, device="cuda")
+    dm.mult(dev(torch, x), y)
+    assert relerr(y.cpu().numpy(), A @ x) <= TOL_SPMV
+
+    pc = P.PCAIR(**opts)
+    pc.setup(A)
+    H = bridge.hierarchy_from_product(pc, A)
+    H.coarse_richardson_its = int(opts.get("mg_coarse_ksp_max_it", 0))
+    z = torch.empty(n, dtype=torch.float64, device="cuda")
+    pc.apply(dev(torch, x), z)
+    z_ref = R.vcycle(H, x)
+    assert relerr(z.cpu().numpy(), z_ref) <= TOL_CYCLE, case
+    # second application must give the same answer (no state carried between applies)
+    z2 = torch.empty_like(z)
+    pc.apply(dev(torch, x), z2)
+    assert torch.equal(z, z2)
+    # graph replay gives bitwise the same as eager launches
+    pc.use_graph(True)
+    z3 = torch.empty_like(z)
+    pc.apply(dev(torch, x), z3)
+    pc.apply(dev(torch, x), z3)
+    assert torch.equal(z, z3)
+
+
+KSP_CASES = [
+    ("adv2d_25", "gmres", "left", "preconditioned", 1e-5, 5),          # tests/Makefile:1323  (<= 5)
+    ("adv3d_12_lump", "gmres", "right", "preconditioned", 1e-10, 6),   # tests/Makefile:543-545 shape
+    ("adv2d_40_lump", "gmres", "right", "preconditioned", 1e-10, 6),   # tests/Makefile:1121-1133
+    ("diff2d_16_neumann", "gmres", "left", "preconditioned", 1e-5, 6),
+    ("diff2d_16_neumann_mf", "gmres", "left", "preconditioned", 1e-5, 6),
+    ("adv2d_30_newton_coarse", "richardson", "left", "preconditioned", 1e-5, 8),
+    ("diff2d_12_jacobi_exact", "richardson", "left", "unpreconditioned", 1e-5, 1),  # tests/Makefile:421-424
+    ("adv2d_16_fc", "gmres", "left", "preconditioned", 1e-5, 3),       # tests/Makefile:300 (<= 3)
+]
+
+
+@pytest.mark.parametrize("case,ktype,side,norm,rtol,bound", KSP_CASES)
+def test_ksp_iteration_counts_match_oracle(torch_mod, case, ktype, side, norm, rtol, bound):
+    torch = torch_mod
+    import pflare_amd as P
+    from oracle import air_ref as R, bridge
+    gen, opts = CASES[case]
+    A = bridge.to_scipy(P.HostMat.adv_diff_fd(**gen).csr())
+    n = A.shape[0]
+    pc = P.PCAIR(**opts).setup(A)
+    H = bridge.hierarchy_from_product(pc, A)
+    H.coarse_richardson_its = int(opts.get("mg_coarse_ksp_max_it", 0))
+    b = np.zeros(n); x0 = np.ones(n)            # the reference drivers' problem: b = 0, x0 = 1
+    pcf = lambda r: R.vcycle(H, r)
+    if ktype == "gmres":
+        xr, its_r, reason_r, rn_r = R.ksp_gmres(A, pcf, b, x0, rtol=rtol, max_it=bound, pc_side=side)
+    else:
+        xr, its_r, reason_r, rn_r = R.ksp_richardson(A, pcf, b, x0, rtol=rtol, max_it=bound, norm_type=norm)
+    ksp = P.KSP(ksp_type=ktype, pc_side=side, norm_type=norm, rtol=rtol, max_it=bound)
+    xd = dev(torch, x0)
+    res = ksp.solve(dev(torch, b), xd, pc=pc)
+    assert res["reason"] > 0, (case, res)
+    assert res["its"] <= bound
+    assert res["its"] == its_r and res["reason"] == reason_r, (res, its_r, reason_r)
+    # final residual norms agree to 2 significant digits (SURVEY 8d parity gate)
+    assert abs(res["rnorm"] - rn_r) <= 0.05 * max(rn_r, 1e-300) or max(res["rnorm"], rn_r) < 1e-13
+    assert np.linalg.norm(xd.cpu().numpy() - xr) <= 1e-8 * max(1.0, np.linalg.norm(x0))
+
+
+def test_oracle_built_hierarchy_through_byo_abi(torch_mod):
+    """Hierarchy built by the ORACLE, injected through airhip_pcair_set_level: the HIP V-cycle
+    must reproduce the oracle's V-cycle on it."""
+    torch = torch_mod
+    import pflare_amd as P
+    from oracle import air_ref as R, bridge
+    A = R.gen_adv_diff_fd(2, 20, 20)
+    H = R.setup_air(A, R.AirOptions())
+    levels, cA, cinv = bridge.levels_for_product(H)
+    pc = P.PCAIR()
+    pc.set_hierarchy(A, levels, cA, cinv)
+    x = lcg_vector(A.shape[0])
+    z = torch.empty(A.shape[0], dtype=torch.float64, device="cuda")
+    pc.apply(dev(torch, x), z)
+    assert relerr(z.cpu().numpy(), R.vcycle(H, x)) <= TOL_CYCLE
+
+
+@pytest.mark.parametrize("itype,mf,order", [("arnoldi", False, 6), ("power", False, 6), ("neumann", False, 6),
+                                            ("jacobi", False, 6), ("newton", True, 10), ("arnoldi", True, 6)])
+def test_pcpflareinv_apply(torch_mod, itype, mf, order):
+    torch = torch_mod
+    import pflare_amd as P
+    from oracle import air_ref as R, bridge
+    A = R.gen_adv_diff_fd(2, 12, 12, u=0, v=0, alpha=1.0)
+    n = A.shape[0]
+    pc = P.PCPFLAREINV(type=itype, poly_order=order, matrix_free=mf).setup(A)
+    d = pc.get_inverse(n)
+    op = bridge._inv_from_dict(d, A)
+    x = lcg_vector(n)
+    y = torch.empty(n, dtype=torch.float64, device="cuda")
+    pc.apply(dev(torch, x), y)
+    assert relerr(y.cpu().numpy(), R.apply_inv(op, x)) <= 4e-11
