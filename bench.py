@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py - KSP iterations/sec of the MI355X-native PCAIR solve phase.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+
+Workload at N=1 (BASELINE.json configs[2]): 3D upwind advection from tests/adv_diff_fd.c on a 464^3
+grid (99 897 344 DoF, velocity (1,1,1)/sqrt(3), b = 0, x0 = 1), right-preconditioned GMRES(30) to
+rtol 1e-10 (tests/Makefile:543-545 options) preconditioned by PCAIR with the reference's GPU
+recipe (docs/gpus.md:34-38, docs/faq.md "Truncating the hierarchy"): -pc_air_a_lump, hierarchy
+auto-truncation and a matrix-free Newton-basis GMRES polynomial as coarse solver.
+
+A "step" is one Krylov iteration = 1 SpMV with A + 1 AIR V-cycle (PCApply) + the classical
+Gram-Schmidt update.  Exactly K iterations are timed, spread over consecutive solves of the
+reference problem (each solve restarts from x0 = 1 and runs to convergence or to the remaining
+step budget), bracketed by barrier + device synchronisation.  Inputs are resident in HBM before
+the timed region starts.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+RECIPES = {
+    # reference GPU recipe: lumping + auto truncation + Newton matrix-free coarse solver
+    "trunc": dict(a_lump=True, auto_truncate_start_level=1, auto_truncate_tol=1e-1,
+                  coarsest_inverse_type="newton", coarsest_matrix_free_polys=True, coarsest_poly_order=10),
+    # same with the GMRES-polynomial F smoother applied matrix-free (-pc_air_matrix_free_polys)
+    "trunc_mf": dict(a_lump=True, auto_truncate_start_level=1, auto_truncate_tol=1e-1, matrix_free_polys=True,
+                     coarsest_inverse_type="newton", coarsest_matrix_free_polys=True, coarsest_poly_order=10),
+    # tests/Makefile:544-545 as is (full hierarchy, assembled smoothers)
+    "full": dict(a_lump=True),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=464, help="grid points per dimension (464 -> ~1e8 DoF)")
+    ap.add_argument("--recipe", default="trunc", choices=sorted(RECIPES))
+    ap.add_argument("--max-levels", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--graph", type=int, default=0)
+    ap.add_argument("--profile-kernels", type=int, default=1)
+    ap.add_argument("--verbose", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the PCAIR solve phase has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        from pflare_amd import dist_bench
+        dist_bench.run(args, rank, world, local_rank)
+        return
+
+    import pflare_amd as P
+    P.lib().airhip_set_device(local_rank)
+    log = (lambda *a: print(*a, file=sys.stderr, flush=True)) if args.verbose else (lambda *a: None)
+
+    M = args.size
+    t0 = time.time()
+    hm = P.HostMat.adv_diff_fd(dim=3, M=M, N=M, P=M)
+    n = hm.shape[0]
+    nnzA = hm.nnz
+    log(f"[bench] operator {M}^3: n={n} nnz={nnzA} generated in {time.time()-t0:.1f}s")
+    opts = dict(RECIPES[args.recipe])
+    if args.max_levels:
+        opts["max_levels"] = args.max_levels
+    pc = P.PCAIR(**opts)
+    t0 = time.time()
+    pc.setup(hm)
+    t_setup = time.time() - t0
+    st = pc.setup_times()
+    cx = pc.complexities()
+    log(f"[bench] setup {t_setup:.1f}s (host {st['host_setup_s']:.1f}s, upload {st['upload_s']:.1f}s) levels={pc.num_levels} {cx}")
+
+    ksp_kw = dict(ksp_type="gmres", pc_side="right", rtol=1e-10, atol=1e-50)
+
+    # ---- CPU baseline: the oracle's restatement of the same KSP iteration on the same hierarchy
+    cpu = None
+    if not args.no_cpu_baseline:
+        import numpy as np
+        from oracle import c_oracle
+        cores = os.cpu_count() or 1
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except Exception:
+            pass
+        c_oracle.set_threads(cores)
+        ch = c_oracle.CHierarchy(pc, copy=False)
+        b0 = np.zeros(n); x1 = np.ones(n)
+        tc = time.time()
+        _, its_c, _, _, _ = ch.ksp(hm, b0, x1, "gmres", "right", rtol=1e-300, atol=1e-300, max_it=args.cpu_iters)
+        dt = time.time() - tc
+        cpu = {"value": its_c / dt, "unit": "KSP iterations/s", "cores": cores, "kind": "port",
+               "sample": f"{its_c} right-preconditioned GMRES iterations (SpMV + AIR V-cycle + CGS) of the same "
+                         f"{M}^3 system on the same hierarchy, C/OpenMP restatement of the reference algorithm "
+                         f"(oracle/air_oracle.c), {dt:.1f}s"}
+        del ch
+        log(f"[bench] cpu baseline: {cpu}")
+    pc.release_host()
+    del hm
+
+    b = torch.zeros(n, dtype=torch.float64, device="cuda")
+    x = torch.ones(n, dtype=torch.float64, device="cuda")
+    pc.use_graph(bool(args.graph))
+
+    # ---- reference practice: a first solve to converge (also the iteration-count check)
+    ksp = P.KSP(max_it=200, **ksp_kw)
+    res0 = ksp.solve(b, x, pc=pc)
+    log(f"[bench] converged solve: its={res0['its']} reason={res0['reason_name']} rnorm={res0['rnorm']:.3e} {res0['solve_ms']:.1f} ms")
+    its_conv = max(res0["its"], 1)
+
+    def run_iterations(k):
+        """exactly k Krylov iterations over consecutive solves of the reference problem"""
+        done = 0
+        ms = 0.0
+        while done < k:
+            x.fill_(1.0)
+            r = P.KSP(max_it=k - done, **ksp_kw).solve(b, x, pc=pc)
+            if r["its"] == 0:
+                raise RuntimeError("solver made no progress")
+            done += r["its"]
+            ms += r["solve_ms"]
+        return ms
+
+    run_iterations(args.warmup)
+    if args.profile_kernels:
+        pc.profile(True)
+        pc.profile_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ms_dev = run_iterations(args.steps)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    stats = pc.profile_stats() if args.profile_kernels else []
+    pc.profile(False)
+
+    value = args.steps / wall
+    roofline = None
+    if stats:
+        live = [s for s in stats if s["calls"] > 0]
+        dom = max(live, key=lambda s: s["total_ms"])
+        avg_ms = dom["total_ms"] / dom["calls"]
+        achieved = dom["alg_bytes"] / (avg_ms * 1e-3) / 1e9
+        tot_ms = sum(s["total_ms"] for s in live)
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "kernel": f"{dom['name']} (level {dom['level'] + 1})", "avg_launch_ms": avg_ms,
+                    "alg_bytes_per_launch": dom["alg_bytes"], "calls": dom["calls"],
+                    "share_of_vcycle_kernel_time": dom["total_ms"] / tot_ms}
+        # whole V-cycle: algorithmic bytes of one cycle / measured kernel time of one cycle
+        cycles = max(1, next((s["calls"] for s in live if s["name"].startswith("restrict") and s["level"] == 0), 1))
+        roofline["vcycle_alg_GBs"] = cx["cycle_alg_bytes"] / (tot_ms / cycles * 1e-3) / 1e9
+        roofline["vcycle_kernel_ms"] = tot_ms / cycles
+        if args.verbose:
+            for s in sorted(live, key=lambda s: -s["total_ms"])[:14]:
+                a = s["total_ms"] / s["calls"]
+                log(f"   {s['name']:28s} L{s['level']+1:<2d} calls={s['calls']:4d} avg={a:8.3f} ms  "
+                    f"{s['alg_bytes']/(a*1e-3)/1e9:8.1f} GB/s")
+    out = {
+        "metric": "KSP iterations/sec (right-preconditioned GMRES(30) + PCAIR V-cycle)",
+        "value": value, "unit": "iterations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"3D upwind advection (tests/adv_diff_fd.c) {M}^3 = {n} DoF, nnz(A)={nnzA}, b=0, x0=1, "
+                               f"GMRES(30) right PC rtol 1e-10, PCAIR recipe '{args.recipe}' {opts}",
+                   "levels": pc.num_levels, "iterations_to_rtol_1e-10": res0["its"],
+                   "converged_reason": res0["reason_name"], "converged_solve_ms": res0["solve_ms"],
+                   "cycle_complexity": cx["cycle"], "operator_complexity": cx["operator"],
+                   "storage_complexity": cx["storage"], "cycle_alg_bytes": cx["cycle_alg_bytes"],
+                   "setup_s": t_setup, "host_setup_s": st["host_setup_s"], "upload_s": st["upload_s"],
+                   "device_ms_of_timed_solves": ms_dev, "hip_graph": bool(args.graph)},
+        "roofline": roofline, "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -238,6 +238,9 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o) {
       std::printf(" ~~~~~~~~~~~~ Level %d\n Global rows %lld Global F-points %lld Global C-points %lld  (nnz %lld, A_ff %s, t=%.2fs)\n",
                   our_level, (long long)n, (long long)n_f, (long long)n_c, (long long)L.nnz_A,
                   L.aff_diag ? "diagonal" : "sparse", now_s() - t_setup);
+    if (o.print_stats_timings)
+      std::printf("   cumulative: coarsen %.2f extract %.2f inverse %.2f prolong %.2f restrict %.2f RAP %.2f drop %.2f truncate %.2f\n",
+                  H->timers[0], H->timers[1], H->timers[2], H->timers[3], H->timers[4], H->timers[5], H->timers[6], H->timers[7]);
     H->levels.push_back(std::move(Lp));
     owned = std::move(coarse);
     cur = &owned;

@@ -50,24 +50,29 @@ def as_csr(A) -> CsrArrays:
     if isinstance(A, CsrArrays):
         return A
     if isinstance(A, HostMat):
-        return A.csr()
+        v = _view_csr(A.csr_view(), copy=False)   # zero copy; keep the owner alive
+        v._owner = A
+        return v
     if hasattr(A, "indptr"):
         return CsrArrays(A.indptr, A.indices, A.data, A.shape)
     rowptr, col, val, shape = A
     return CsrArrays(rowptr, col, val, shape)
 
 
-def _view_csr(c: airhip_csr) -> CsrArrays:
-    """numpy copies of a library-owned CSR."""
+def _arr(ptr, n, copy, dtype):
+    if n == 0:
+        return np.zeros(0, dtype)
+    a = np.ctypeslib.as_array(ptr, shape=(n,))
+    return a.copy() if copy else a
+
+
+def _view_csr(c: airhip_csr, copy=True) -> CsrArrays:
+    """numpy copies (or, with copy=False, views valid until the owner is released) of a
+    library-owned CSR."""
     m, n = int(c.m), int(c.n)
-    rp = np.ctypeslib.as_array(c.rowptr, shape=(m + 1,)).copy()
+    rp = _arr(c.rowptr, m + 1, copy, np.int64)
     nnz = int(rp[-1])
-    if nnz:
-        ci = np.ctypeslib.as_array(c.col, shape=(nnz,)).copy()
-        v = np.ctypeslib.as_array(c.val, shape=(nnz,)).copy()
-    else:
-        ci = np.zeros(0, np.int32); v = np.zeros(0, np.float64)
-    return CsrArrays(rp, ci, v, (m, n))
+    return CsrArrays(rp, _arr(c.col, nnz, copy, np.int32), _arr(c.val, nnz, copy, np.float64), (m, n))
 
 
 class HostMat:
@@ -132,12 +137,12 @@ def _ptr(t):
     return C.c_void_p(int(t))
 
 
-def _invop_to_dict(inv: airhip_invop, n):
+def _invop_to_dict(inv: airhip_invop, n, copy=True):
     d = {"kind": int(inv.kind), "diag_scale": bool(inv.diag_scale), "neumann": bool(inv.neumann)}
     if inv.kind == OP_ASSEMBLED:
-        d["mat"] = _view_csr(inv.mat)
+        d["mat"] = _view_csr(inv.mat, copy)
     elif inv.kind == OP_DIAG:
-        d["d"] = np.ctypeslib.as_array(inv.diag, shape=(n,)).copy()
+        d["d"] = _arr(inv.diag, n, copy, np.float64)
     elif inv.kind == OP_HORNER:
         d["coeffs"] = np.ctypeslib.as_array(inv.coef, shape=(inv.ncoef,)).copy()
     elif inv.kind == OP_NEWTON:
@@ -266,20 +271,29 @@ class PCAIR:
         return dict(n=n.value, n_f=nf.value, n_c=nc.value, aff_diag=bool(ad.value), one_point=bool(op.value),
                     nnz_A=nnz.value)
 
-    def _get(self, level, which):
+    def _get(self, level, which, copy=True):
         c = airhip_csr(); idx = C.POINTER(C.c_int32)(); vec = C.POINTER(C.c_double)(); ln = C.c_int64()
         check(lib().airhip_pcair_level_get(self._h, level, which.encode(), C.byref(c), C.byref(idx), C.byref(vec),
                                            C.byref(ln)))
         if which in ("F", "C", "wcol"):
-            return np.ctypeslib.as_array(idx, shape=(ln.value,)).copy() if ln.value else np.zeros(0, np.int32)
+            return _arr(idx, ln.value, copy, np.int32)
         if which in ("aff_diag", "M_ff_diag", "M_cc_diag"):
-            return np.ctypeslib.as_array(vec, shape=(ln.value,)).copy()
-        return _view_csr(c)
+            return _arr(vec, ln.value, copy, np.float64)
+        return _view_csr(c, copy)
 
-    def export_level(self, level):
-        """The level's operands in the reference's level-local numbering."""
+    def export_level(self, level, copy=True):
+        """The level's operands in the reference's level-local numbering.  copy=False returns
+        views into the library's host hierarchy (valid until release_host / next setup)."""
         s = self.level_sizes(level)
         out = dict(s)
+        _g = self._get
+        self._get = lambda lv, w: _g(lv, w, copy)
+        try:
+            return self._export_level(level, s, out, copy)
+        finally:
+            self._get = _g
+
+    def _export_level(self, level, s, out, copy):
         out["F"] = self._get(level, "F"); out["C"] = self._get(level, "C")
         out["A_fc"] = self._get(level, "A_fc"); out["Z"] = self._get(level, "Z")
         out["A_cf"] = self._get(level, "A_cf")
@@ -293,23 +307,23 @@ class PCAIR:
             out["W"] = self._get(level, "W")
         inv = airhip_invop()
         check(lib().airhip_pcair_level_inv(self._h, level, 0, C.byref(inv)))
-        out["inv_ff"] = _invop_to_dict(inv, s["n_f"])
+        out["inv_ff"] = _invop_to_dict(inv, s["n_f"], copy)
         so = (C.c_int * 10)()
         check(lib().airhip_pcair_level_smooth_order(self._h, level, so))
         out["smooth_order"] = [int(v) for v in so]
         if any(v < 0 for v in out["smooth_order"]):
             out["A_cc"] = self._get(level, "A_cc")
             check(lib().airhip_pcair_level_inv(self._h, level, 1, C.byref(inv)))
-            out["inv_cc"] = _invop_to_dict(inv, s["n_c"])
+            out["inv_cc"] = _invop_to_dict(inv, s["n_c"], copy)
         return out
 
-    def export_coarse(self):
+    def export_coarse(self, copy=True):
         c = airhip_csr()
         check(lib().airhip_pcair_coarse_get(self._h, C.byref(c)))
-        A = _view_csr(c)
+        A = _view_csr(c, copy)
         inv = airhip_invop()
         check(lib().airhip_pcair_level_inv(self._h, self.num_levels - 1, 0, C.byref(inv)))
-        return A, _invop_to_dict(inv, A.shape[0])
+        return A, _invop_to_dict(inv, A.shape[0], copy)
 
     def complexities(self):
         g, o, cy, st, by = (C.c_double() for _ in range(5))
