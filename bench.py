@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--graph", type=int, default=0)
     ap.add_argument("--profile-kernels", type=int, default=1)
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--threads", type=int, default=32, help="host threads (256-core host / 8 GPUs)")
     args = ap.parse_args()
 
     import torch
@@ -69,6 +70,14 @@ def main():
 
     import pflare_amd as P
     P.lib().airhip_set_device(local_rank)
+    # host threads for the setup phase and the CPU baseline: this rank's share of the host
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    threads = int(os.environ.get("AIRHIP_NUM_THREADS", max(1, min(args.threads, cores))))
+    P.lib().airhip_set_num_threads(threads, None)
     log = (lambda *a: print(*a, file=sys.stderr, flush=True)) if args.verbose else (lambda *a: None)
 
     M = args.size
@@ -81,6 +90,8 @@ def main():
     if args.max_levels:
         opts["max_levels"] = args.max_levels
     pc = P.PCAIR(**opts)
+    if args.verbose:
+        pc.set_option("print_stats_timings", True)   # per-level progress lines (keeps long setups audible)
     t0 = time.time()
     pc.setup(hm)
     t_setup = time.time() - t0
@@ -95,12 +106,7 @@ def main():
     if not args.no_cpu_baseline:
         import numpy as np
         from oracle import c_oracle
-        cores = os.cpu_count() or 1
-        try:
-            cores = len(os.sched_getaffinity(0))
-        except Exception:
-            pass
-        c_oracle.set_threads(cores)
+        cores = c_oracle.set_threads(threads)
         ch = c_oracle.CHierarchy(pc, copy=False)
         b0 = np.zeros(n); x1 = np.ones(n)
         tc = time.time()

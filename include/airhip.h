@@ -89,6 +89,9 @@ int airhip_version(void);
 /* number of HIP devices visible / select the device used by subsequently created objects */
 int airhip_device_count(int* count);
 int airhip_set_device(int device);
+/* host threads used by the setup phase (OpenMP); returns the previous setting through *prev
+ * (may be null).  n <= 0 leaves the setting unchanged. */
+int airhip_set_num_threads(int n, int* prev);
 
 /* ---------------------------------------------------------------- synthetic operators */
 /* tests/adv_1d.c:80-105 and tests/adv_diff_fd.c:366-586.  The CSR arrays are owned by the

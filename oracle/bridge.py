@@ -32,6 +32,13 @@ def _inv_from_dict(d, A):
     raise ValueError(k)
 
 
+def _inv_from_dict_scipy(d, A):
+    """same as _inv_from_dict for dicts whose matrices are already scipy CSR"""
+    if d["kind"] == 1:
+        return R.InvOp("assembled", mat=d["mat"])
+    return _inv_from_dict(d, A)
+
+
 def hierarchy_from_product(pc, A_top) -> R.Hierarchy:
     H = R.Hierarchy(A=A_top)
     nl = pc.num_levels

@@ -37,6 +37,13 @@ int airhip_set_device(int device) {
   API_END
 }
 
+int airhip_set_num_threads(int n, int* prev) {
+  API_BEGIN
+  if (prev) *prev = omp_get_max_threads();
+  if (n > 0) omp_set_num_threads(n);
+  API_END
+}
+
 // ------------------------------------------------------------------------ host matrices
 struct airhip_hostmat_s { Csr A; };
 

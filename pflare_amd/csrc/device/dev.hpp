@@ -22,9 +22,12 @@ struct SellMat {
   int64_t nnz = 0;               // true non-zeros
   int64_t padded = 0;            // stored entries (multiple of 64)
   int64_t nslices = 0;
+  int T = 1;                     // lanes per row (power of two); a slice holds 64/T rows
   int64_t* slice_ptr = nullptr;  // [nslices+1], entry offsets (multiples of 64)
   int32_t* col = nullptr;        // [padded]
   double* val = nullptr;         // [padded]
+  int32_t* rowidx = nullptr;     // [nslices*64/T] row stored in each slot (-1: empty); rows are
+                                 // sorted by length inside windows of 2048 rows (SELL-C-sigma)
   bool valid() const { return slice_ptr != nullptr; }
   // algorithmic bytes of one SpMV with this operator: S(X) of SURVEY 8(d)
   double s_bytes() const { return 12.0 * nnz + 4.0 * (m + 1) + 8.0 * m + 8.0 * n; }

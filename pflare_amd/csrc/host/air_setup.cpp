@@ -84,12 +84,6 @@ static Csr build_P(const Level& L) {
   return P;
 }
 
-static void negate(Csr& A) {
-  const int64_t nnz = A.nnz();
-#pragma omp parallel for schedule(static)
-  for (int64_t k = 0; k < nnz; k++) A.v[k] = -A.v[k];
-}
-
 static void coarse_solver(const Csr& A, const AirOptions& o, InvOp& op) {
   OpView v; v.A = &A; v.n = A.m;
   build_inverse(v, o.coarsest_inverse_type, o.coarsest_poly_order, o.coarsest_inverse_sparsity_order,
@@ -201,17 +195,15 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o) {
       one_point_W(L.A_fc, L.wcol);
     } else {
       L.one_point = false;
-      Csr W = spgemm(*Mz, L.A_fc);
-      negate(W);
-      L.W = remove_small(W, o.r_drop, 1, false, 0);
+      SpgemmDrop d; d.enabled = true; d.tol = o.r_drop; d.negate = true;
+      L.W = spgemm(*Mz, L.A_fc, d);
     }
     H->timers[3] += now_s() - t0;
     // ---- Z / R
     t0 = now_s();
     {
-      Csr Zf = spgemm(L.A_cf, *Mz);
-      negate(Zf);
-      L.Z = remove_small(Zf, o.r_drop, 1, false, 0);
+      SpgemmDrop d; d.enabled = true; d.tol = o.r_drop; d.negate = true;
+      L.Z = spgemm(L.A_cf, *Mz, d);
     }
     Mz_store = Csr();
     inv_asm = InvOp();
@@ -226,12 +218,10 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o) {
       Csr AP = spgemm(*cur, P);
       P = Csr();
       Csr R = build_R(L.Z, L.F, L.C, n);
-      Csr RAP = spgemm(R, AP);
+      SpgemmDrop d; d.enabled = true; d.tol = o.a_drop; d.lump = o.a_lump;
+      coarse = spgemm(R, AP, d);      // drop / lump fused into the product (timer: RAP)
       AP = Csr(); R = Csr();
       H->timers[5] += now_s() - t0;
-      t0 = now_s();
-      coarse = remove_small(RAP, o.a_drop, 1, o.a_lump, 0);
-      H->timers[6] += now_s() - t0;
     }
     if (!any_c) { /* A_cf is only needed again for C smoothing; keep it anyway for export */ }
     if (o.print_stats_timings)
@@ -241,6 +231,7 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o) {
     if (o.print_stats_timings)
       std::printf("   cumulative: coarsen %.2f extract %.2f inverse %.2f prolong %.2f restrict %.2f RAP %.2f drop %.2f truncate %.2f\n",
                   H->timers[0], H->timers[1], H->timers[2], H->timers[3], H->timers[4], H->timers[5], H->timers[6], H->timers[7]);
+    if (o.print_stats_timings) std::fflush(stdout);
     H->levels.push_back(std::move(Lp));
     owned = std::move(coarse);
     cur = &owned;

@@ -555,57 +555,65 @@ void build_inverse(const OpView& A, int inverse_type, int poly_order, int sparsi
 void host_apply_inv(const InvOp& op, const OpView& A, const double* x, double* y) {
   const int64_t n = A.n;
   if (op.kind == InvOp::ASSEMBLED) { spmv(op.mat, x, y); return; }
-  if (op.kind == InvOp::DIAG) { for (int64_t i = 0; i < n; i++) y[i] = op.d[i] * x[i]; return; }
+  auto par = [&](auto&& f) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) f(i);
+  };
+  if (op.kind == InvOp::DIAG) { par([&](int64_t i) { y[i] = op.d[i] * x[i]; }); return; }
   Arr<double> d(n), rhs(n), t(n), t2(n), t3(n);
-  if (A.diag) { for (int64_t i = 0; i < n; i++) d[i] = A.diag[i]; } else get_diagonal(*A.A, d.data());
+  if (A.diag) par([&](int64_t i) { d[i] = A.diag[i]; }); else get_diagonal(*A.A, d.data());
   MatVec plain; plain.A = A;
   auto mvop = [&](const double* in, double* out) {
     plain(in, out);
     if (op.diag_scale) {
-      for (int64_t i = 0; i < n; i++) out[i] /= d[i];
-      if (op.neumann) for (int64_t i = 0; i < n; i++) out[i] = in[i] - out[i];
+      if (op.neumann) par([&](int64_t i) { out[i] = in[i] - out[i] / d[i]; });
+      else par([&](int64_t i) { out[i] /= d[i]; });
     }
   };
   const double* r = x;
-  if (op.diag_scale) { for (int64_t i = 0; i < n; i++) rhs[i] = x[i] / d[i]; r = rhs.data(); }
+  if (op.diag_scale) { par([&](int64_t i) { rhs[i] = x[i] / d[i]; }); r = rhs.data(); }
   if (op.kind == InvOp::HORNER) {
     const auto& c = op.coeffs;
-    for (int64_t i = 0; i < n; i++) y[i] = c.back() * r[i];
+    par([&](int64_t i) { y[i] = c.back() * r[i]; });
     for (int k = (int)c.size() - 2; k >= 0; k--) {
       if (c[k] == 0.0) continue;
-      for (int64_t i = 0; i < n; i++) t[i] = y[i];
+      par([&](int64_t i) { t[i] = y[i]; });
       mvop(t.data(), y);
-      for (int64_t i = 0; i < n; i++) y[i] = c[k] * r[i] + y[i];
+      const double ck = c[k];
+      par([&](int64_t i) { y[i] = ck * r[i] + y[i]; });
     }
     return;
   }
   // Newton
   const auto& re = op.re; const auto& im = op.im;
   const int nr = (int)re.size();
-  for (int64_t i = 0; i < n; i++) { t[i] = r[i]; y[i] = 0.0; }
+  par([&](int64_t i) { t[i] = r[i]; y[i] = 0.0; });
   int i = 0;
   while (i <= nr - 2) {
     if (im[i] == 0.0) {
       if (std::fabs(re[i]) < TOL_ZERO) { i++; continue; }
-      for (int64_t q = 0; q < n; q++) y[q] += (1.0 / re[i]) * t[q];
+      const double a = 1.0 / re[i];
+      par([&](int64_t q) { y[q] += a * t[q]; });
       mvop(t.data(), t2.data());
-      for (int64_t q = 0; q < n; q++) t[q] += (-1.0 / re[i]) * t2[q];
+      par([&](int64_t q) { t[q] += -a * t2[q]; });
       i++;
     } else {
-      double sq = re[i] * re[i] + im[i] * im[i];
+      const double sq = re[i] * re[i] + im[i] * im[i];
       if (sq < TOL_ZERO) { i += 2; continue; }
+      const double tr = 2 * re[i], isq = 1.0 / sq;
       mvop(t.data(), t2.data());
-      for (int64_t q = 0; q < n; q++) t2[q] = 2 * re[i] * t[q] - t2[q];
-      for (int64_t q = 0; q < n; q++) y[q] += (1.0 / sq) * t2[q];
+      par([&](int64_t q) { t2[q] = tr * t[q] - t2[q]; y[q] += isq * t2[q]; });
       if (i <= nr - 3) {
         mvop(t2.data(), t3.data());
-        for (int64_t q = 0; q < n; q++) t[q] += (-1.0 / sq) * t3[q];
+        par([&](int64_t q) { t[q] += -isq * t3[q]; });
       }
       i += 2;
     }
   }
-  if (im[nr - 1] == 0.0 && std::fabs(re[nr - 1]) > TOL_ZERO)
-    for (int64_t q = 0; q < n; q++) y[q] += (1.0 / re[nr - 1]) * t[q];
+  if (im[nr - 1] == 0.0 && std::fabs(re[nr - 1]) > TOL_ZERO) {
+    const double a = 1.0 / re[nr - 1];
+    par([&](int64_t q) { y[q] += a * t[q]; });
+  }
 }
 
 }  // namespace airhip

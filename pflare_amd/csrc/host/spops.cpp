@@ -338,7 +338,64 @@ void split_fc(const Csr& A, const int32_t* markers, const int32_t* newidx,
 // ---------------------------------------------------------------------------------------
 // SpGEMM
 // ---------------------------------------------------------------------------------------
-Csr spgemm(const Csr& A, const Csr& B) {
+namespace {
+// Per-thread sparse accumulator: open-addressing hash on the column index.  Values are
+// accumulated in the order the candidates arrive (k ascending), i.e. exactly the order of a
+// sequential Gustavson sparse accumulator, so results do not depend on the thread count.
+struct RowAcc {
+  std::vector<int32_t> key; std::vector<double> val; std::vector<int32_t> used;
+  uint32_t mask = 0;
+  void ensure(int64_t want) {
+    uint32_t cap = 64;
+    while ((int64_t)cap < 2 * want) cap <<= 1;
+    if (cap > key.size()) { key.assign(cap, -1); val.assign(cap, 0.0); mask = cap - 1; }
+  }
+  inline void add(int32_t c, double x) {
+    uint32_t h = ((uint32_t)c * 2654435761u) & mask;
+    for (;;) {
+      int32_t k = key[h];
+      if (k == c) { val[h] += x; return; }
+      if (k < 0) { key[h] = c; val[h] = x; used.push_back((int32_t)h); return; }
+      h = (h + 1) & mask;
+    }
+  }
+  // sorted (col,val) pairs of the current row into out, then reset
+  void flush(std::vector<std::pair<int32_t, double>>& out) {
+    out.clear();
+    for (int32_t h : used) { out.emplace_back(key[h], val[h]); key[h] = -1; }
+    used.clear();
+    std::sort(out.begin(), out.end(), [](const std::pair<int32_t, double>& a, const std::pair<int32_t, double>& b) { return a.first < b.first; });
+  }
+};
+
+// remove_small semantics applied to one sorted row (see remove_small above)
+inline void filter_row(int64_t i, std::vector<std::pair<int32_t, double>>& row, const SpgemmDrop& d,
+                       std::vector<std::pair<int32_t, double>>& tmp) {
+  if (d.negate) for (auto& e : row) e.second = -e.second;
+  if (!d.enabled) return;
+  double mx = 0.0;
+  for (auto& e : row) mx = std::max(mx, std::fabs(e.second));
+  const double t = d.tol * mx;       // relative to the row max including the diagonal
+  double dsum = 0.0; bool have_diag = false, need_diag = false;
+  for (auto& e : row) if (e.first == i && std::fabs(e.second) >= t) { dsum = e.second; have_diag = true; }
+  for (auto& e : row) {
+    if (std::fabs(e.second) >= t) continue;
+    if (d.lump || e.first == i) { dsum += e.second; need_diag = true; }
+  }
+  const bool write_diag = have_diag || need_diag;
+  tmp.clear();
+  bool diag_written = false;
+  for (auto& e : row) {
+    if (write_diag && !diag_written && e.first >= i) { tmp.emplace_back((int32_t)i, dsum); diag_written = true; }
+    if (e.first == i) continue;
+    if (std::fabs(e.second) >= t) tmp.push_back(e);
+  }
+  if (write_diag && !diag_written) tmp.emplace_back((int32_t)i, dsum);
+  row.swap(tmp);
+}
+}  // namespace
+
+Csr spgemm(const Csr& A, const Csr& B, const SpgemmDrop& drop) {
   if (A.n != B.m) throw std::runtime_error("spgemm: shape mismatch");
   const int64_t m = A.m;
   const int nt = omp_get_max_threads();
@@ -347,7 +404,7 @@ Csr spgemm(const Csr& A, const Csr& B) {
   std::vector<std::vector<int32_t>> tci(nt);
   std::vector<std::vector<double>> tv(nt);
   std::vector<int64_t> tlo(nt + 1);
-  // weight rows by work so the static chunks are balanced
+  // weight rows by candidate count so the static chunks are balanced
   Arr<int64_t> work(m + 1);
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < m; i++) {
@@ -358,35 +415,29 @@ Csr spgemm(const Csr& A, const Csr& B) {
   exclusive_scan(cnt.data(), m, work.data());
   const int64_t total = work[m];
   for (int t = 0; t <= nt; t++) {
-    int64_t target = total / nt * t;
     if (t == nt) { tlo[t] = m; continue; }
+    int64_t target = total / nt * t;
     tlo[t] = std::lower_bound(work.data(), work.data() + m, target) - work.data();
   }
   tlo[0] = 0;
 #pragma omp parallel num_threads(nt)
   {
     int t = omp_get_thread_num();
-    std::vector<std::pair<int32_t, double>> cand;
+    RowAcc acc;
+    std::vector<std::pair<int32_t, double>> row, tmp;
     std::vector<int32_t>& oc = tci[t];
     std::vector<double>& ov = tv[t];
-    oc.reserve((size_t)((work[tlo[t + 1]] - work[tlo[t]]) / 2 + 16));
-    ov.reserve(oc.capacity());
     for (int64_t i = tlo[t]; i < tlo[t + 1]; i++) {
-      cand.clear();
+      const int64_t ub = std::min<int64_t>(work[i + 1] - work[i], B.n);
+      acc.ensure(ub);
       for (int64_t k = A.rp[i]; k < A.rp[i + 1]; k++) {
-        int32_t j = A.ci[k]; double a = A.v[k];
-        for (int64_t q = B.rp[j]; q < B.rp[j + 1]; q++) cand.emplace_back(B.ci[q], a * B.v[q]);
+        const int32_t j = A.ci[k]; const double a = A.v[k];
+        for (int64_t q = B.rp[j]; q < B.rp[j + 1]; q++) acc.add(B.ci[q], a * B.v[q]);
       }
-      if (cand.size() > 1)
-        std::stable_sort(cand.begin(), cand.end(),
-                         [](const std::pair<int32_t, double>& x, const std::pair<int32_t, double>& y) { return x.first < y.first; });
-      int64_t c = 0;
-      for (size_t q = 0; q < cand.size();) {
-        int32_t col = cand[q].first; double s = cand[q].second; q++;
-        while (q < cand.size() && cand[q].first == col) { s += cand[q].second; q++; }
-        oc.push_back(col); ov.push_back(s); c++;
-      }
-      cnt[i] = c;
+      acc.flush(row);
+      filter_row(i, row, drop, tmp);
+      for (auto& e : row) { oc.push_back(e.first); ov.push_back(e.second); }
+      cnt[i] = (int64_t)row.size();
     }
   }
   exclusive_scan(cnt.data(), m, C.rp.data());
@@ -395,8 +446,10 @@ Csr spgemm(const Csr& A, const Csr& B) {
   {
     int t = omp_get_thread_num();
     int64_t base = C.rp[tlo[t]];
-    std::memcpy(C.ci.data() + base, tci[t].data(), tci[t].size() * sizeof(int32_t));
-    std::memcpy(C.v.data() + base, tv[t].data(), tv[t].size() * sizeof(double));
+    if (!tci[t].empty()) {
+      std::memcpy(C.ci.data() + base, tci[t].data(), tci[t].size() * sizeof(int32_t));
+      std::memcpy(C.v.data() + base, tv[t].data(), tv[t].size() * sizeof(double));
+    }
     std::vector<int32_t>().swap(tci[t]);
     std::vector<double>().swap(tv[t]);
   }

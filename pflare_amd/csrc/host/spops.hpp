@@ -35,8 +35,12 @@ void split_fc(const Csr& A, const int32_t* markers, const int32_t* newidx,
               Csr& A_ff, Csr& A_fc, Csr& A_cf, Csr* A_cc);
 
 // C = A * B, row-wise Gustavson with the accumulation order of a sequential sparse
-// accumulator (k ascending), sorted output columns.
-Csr spgemm(const Csr& A, const Csr& B);
+// accumulator (k ascending), sorted output columns.  Optionally negates the product and
+// applies remove_small (relative to the row max, never dropping the diagonal, optional
+// lumping) to each finished row before it is stored, which avoids materialising the large
+// undropped product (Z = -A_cf M with r_drop, R A P with a_drop / a_lump).
+struct SpgemmDrop { bool enabled = false; double tol = 0.0; bool lump = false; bool negate = false; };
+Csr spgemm(const Csr& A, const Csr& B, const SpgemmDrop& drop = SpgemmDrop());
 
 void spmv(const Csr& A, const double* x, double* y);
 // y = (A x) ./ d

@@ -1,0 +1,72 @@
+"""The C-ABI library loads on a machine without a GPU, exports every symbol include/airhip.h
+declares, and fails loudly (no CPU fallback) when asked to run the solve phase without a device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import pflare_amd as P
+from pflare_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    txt = open(os.path.join(ROOT, "include", "airhip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(airhip_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = P.lib()
+    names = header_functions()
+    assert len(names) >= 40
+    for name in names:
+        assert hasattr(L, name), f"libairhip.so does not export {name}"
+    assert sorted(names) == sorted(_lib.DECLARED_SYMBOLS)
+
+
+def test_error_convention_and_messages():
+    L = P.lib()
+    assert L.airhip_version() >= 100
+    h = C.c_void_p()
+    assert L.airhip_gen_adv_diff_fd(2, 1, 5, 5, 1.0, 1.0, 1.0, 1, 0.0, 1.0, 1.0, 1.0, -1, C.byref(h)) == -1
+    assert b"at least 2 points" in L.airhip_last_error()
+    pc = C.c_void_p()
+    assert L.airhip_pcair_create(C.byref(pc)) == 0
+    assert L.airhip_pcair_apply(pc, None, None) == -2                      # not set up
+    assert L.airhip_pcair_set_option(pc, b"poly_order", b"4") == 0
+    assert L.airhip_pcair_set_option(pc, b"-pc_air_a_drop", b"1e-3") == 0   # full option names accepted
+    assert L.airhip_pcair_destroy(C.byref(pc)) == 0 and not pc.value
+
+
+def _no_gpu():
+    n = C.c_int()
+    P.lib().airhip_device_count(C.byref(n))
+    return n.value == 0
+
+
+@pytest.mark.skipif(not _no_gpu(), reason="a GPU is visible")
+def test_solve_phase_fails_loudly_without_a_device():
+    A = P.HostMat.adv_diff_fd(dim=2, M=8, N=8)
+    with pytest.raises(P.AirhipError) as ei:
+        P.PCAIR().setup(A)
+    assert ei.value.code == -3 and "no CPU fallback" in str(ei.value)
+    with pytest.raises(P.AirhipError):
+        P.PCPFLAREINV().setup(A)
+    with pytest.raises(P.AirhipError):
+        P.DeviceMat(A)
+    # the host-side setup itself works without a device
+    pc = P.PCAIR().setup_host_only(A)
+    assert pc.num_levels >= 2
+
+
+def test_export_roundtrip_zero_copy_views():
+    A = P.HostMat.adv_diff_fd(dim=2, M=12, N=12)
+    pc = P.PCAIR().setup_host_only(A)
+    a = pc.export_level(0, copy=True); b = pc.export_level(0, copy=False)
+    assert np.array_equal(a["F"], b["F"]) and np.array_equal(a["Z"].val, b["Z"].val)
+    cx = pc.complexities()
+    assert cx["cycle"] > 0 and cx["cycle_alg_bytes"] == 0.0   # device bytes only after a device setup
