@@ -50,8 +50,9 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=2)
     ap.add_argument("--graph", type=int, default=0)
     ap.add_argument("--profile-kernels", type=int, default=1)
+    ap.add_argument("--variants", default="", help="diagnostic: comma list of SpMV kernel variants to time")
     ap.add_argument("--verbose", action="store_true")
-    ap.add_argument("--threads", type=int, default=32, help="host threads (256-core host / 8 GPUs)")
+    ap.add_argument("--threads", type=int, default=0, help="host threads for setup + CPU baseline (0: cores / ranks, capped at 32 - measured best on the GPU box)")
     args = ap.parse_args()
 
     import torch
@@ -76,7 +77,8 @@ def main():
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    threads = int(os.environ.get("AIRHIP_NUM_THREADS", max(1, min(args.threads, cores))))
+    want = args.threads if args.threads > 0 else min(32, max(1, cores // max(1, args.gpus)))
+    threads = int(os.environ.get("AIRHIP_NUM_THREADS", max(1, min(want, cores))))
     P.lib().airhip_set_num_threads(threads, None)
     log = (lambda *a: print(*a, file=sys.stderr, flush=True)) if args.verbose else (lambda *a: None)
 
@@ -144,6 +146,21 @@ def main():
             ms += r["solve_ms"]
         return ms
 
+    if args.variants:
+        for v in [int(t) for t in args.variants.split(",")]:
+            P.lib().airhip_debug_set_variant(v)
+            run_iterations(3)
+            pc.profile(True); pc.profile_reset()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            run_iterations(args.steps)
+            torch.cuda.synchronize(); w = time.perf_counter() - t0
+            stv = [s_ for s_ in pc.profile_stats() if s_["calls"] > 0]
+            pc.profile(False)
+            tot = sum(s_["total_ms"] for s_ in stv)
+            cyc = max(1, next((s_["calls"] for s_ in stv if s_["name"].startswith("restrict") and s_["level"] == 0), 1))
+            log(f"[variant {v}] {args.steps / w:8.2f} it/s  vcycle kernels {tot / cyc:8.3f} ms  "
+                f"{cx['cycle_alg_bytes'] / (tot / cyc * 1e-3) / 1e9:7.1f} GB/s")
+        P.lib().airhip_debug_set_variant(0)
     run_iterations(args.warmup)
     if args.profile_kernels:
         pc.profile(True)

@@ -37,6 +37,10 @@ int airhip_set_device(int device) {
   API_END
 }
 
+namespace airhip { extern int g_spmv_variant; }
+// kernel tuning knob used by the benchmarks (see device/spmv.hip); not part of the stable ABI
+extern "C" int airhip_debug_set_variant(int v) { airhip::g_spmv_variant = v; return 0; }
+
 int airhip_set_num_threads(int n, int* prev) {
   API_BEGIN
   if (prev) *prev = omp_get_max_threads();
@@ -630,7 +634,7 @@ int airhip_pcinv_destroy(airhip_pcinv* pc) {
 }
 
 // ------------------------------------------------------------------- device matrices
-struct airhip_mat_s { SellMat A; hipStream_t stream = nullptr; int64_t n = 0; std::unique_ptr<DevKSP> ksp; };
+struct airhip_mat_s { DevMat A; hipStream_t stream = nullptr; int64_t n = 0; std::unique_ptr<DevKSP> ksp; };
 
 int airhip_mat_create(const airhip_csr* A, airhip_mat* out) {
   API_BEGIN
@@ -640,7 +644,7 @@ int airhip_mat_create(const airhip_csr* A, airhip_mat* out) {
   auto* m = new airhip_mat_s;
   HIP_CHECK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
   Csr view; view_csr(A, view);
-  upload_sell(view, nullptr, nullptr, m->A, m->stream);
+  upload_mat(view, nullptr, nullptr, m->A, m->stream);
   m->n = A->m;
   *out = m;
   API_END
@@ -655,7 +659,7 @@ int airhip_mat_mult(airhip_mat A, const double* d_x, double* d_y) {
 }
 int airhip_mat_destroy(airhip_mat* A) {
   API_BEGIN
-  if (A && *A) { sell_free((*A)->A); if ((*A)->stream) (void)hipStreamDestroy((*A)->stream); delete *A; *A = nullptr; }
+  if (A && *A) { devmat_free((*A)->A); if ((*A)->stream) (void)hipStreamDestroy((*A)->stream); delete *A; *A = nullptr; }
   API_END
 }
 

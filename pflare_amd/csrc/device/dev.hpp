@@ -17,18 +17,21 @@
 
 namespace airhip {
 
-struct SellMat {
+// Row-block CSR: plain CSR (no padding, rows in vector order) plus a partition of the rows
+// into blocks of <= ~512 non-zeros.  One wavefront owns one block: it streams the block's
+// non-zeros with fully coalesced loads, stages the products a_ij * x_j in LDS and then every
+// lane sums the LDS segment of "its" rows in column order (CSR-stream); blocks dominated by
+// a long row fall back to a wave-wide reduction per row (CSR-vector).
+struct DevMat {
   int64_t m = 0, n = 0;          // rows, cols
-  int64_t nnz = 0;               // true non-zeros
-  int64_t padded = 0;            // stored entries (multiple of 64)
-  int64_t nslices = 0;
-  int T = 1;                     // lanes per row (power of two); a slice holds 64/T rows
-  int64_t* slice_ptr = nullptr;  // [nslices+1], entry offsets (multiples of 64)
-  int32_t* col = nullptr;        // [padded]
-  double* val = nullptr;         // [padded]
-  int32_t* rowidx = nullptr;     // [nslices*64/T] row stored in each slot (-1: empty); rows are
-                                 // sorted by length inside windows of 2048 rows (SELL-C-sigma)
-  bool valid() const { return slice_ptr != nullptr; }
+  int64_t nnz = 0;
+  int64_t nblocks = 0;
+  int32_t* blk_row = nullptr;    // [nblocks+1] first row of each block
+  int64_t* blk_p0 = nullptr;     // [nblocks+1] first non-zero of each block
+  uint32_t* roff = nullptr;      // [m] start of row r relative to its block's first non-zero
+  int32_t* col = nullptr;        // [nnz]
+  double* val = nullptr;         // [nnz]
+  bool valid() const { return blk_row != nullptr; }
   // algorithmic bytes of one SpMV with this operator: S(X) of SURVEY 8(d)
   double s_bytes() const { return 12.0 * nnz + 4.0 * (m + 1) + 8.0 * m + 8.0 * n; }
 };
@@ -44,13 +47,13 @@ struct SpmvEpi {
   double* y2 = nullptr; const double* w2 = nullptr; double delta = 0.0; int aux_out = 0;
 };
 
-void launch_spmv(const SellMat& A, const double* x, const SpmvEpi& e, hipStream_t s);
+void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t s);
 
 // Fused first stage of an F-point relaxation with a one-point prolongator:
 //   acc = (A_fc x_c)_i ; t4 = b_f_i - acc ; x0 = x_c[wcol_i] (0 if wcol_i < 0)
 //   diag mode (aff_d, minv != null):  x_f_i = x0 + minv_i * (t4 - aff_d_i * x0)
 //   split mode                     :  t4_out_i = t4 ; x_f_i = x0
-void launch_fc_first(const SellMat& A_fc, const int32_t* wcol, const double* b_f, const double* x_c,
+void launch_fc_first(const DevMat& A_fc, const int32_t* wcol, const double* b_f, const double* x_c,
                      const double* aff_d, const double* minv, double* t4_out, double* x_f, hipStream_t s);
 
 // vector kernels (n elements)
@@ -67,11 +70,11 @@ void launch_mdot(int64_t n, const double* w, const double* V, int64_t ld, int nv
 void launch_maxpy(int64_t n, double* w, const double* V, int64_t ld, int nv, const double* coef, hipStream_t s);
 int mdot_scratch_doubles(int nv);
 
-// CSR (device) -> SELL-64 conversion.  rowsrc (may be null): destination row r takes source
+// CSR (device) -> row-block CSR conversion.  rowsrc (may be null): destination row r takes source
 // row rowsrc[r]; colmap (may be null): column c becomes colmap[c].
-void sell_from_csr_device(int64_t m, int64_t n, const int64_t* d_rp, const int32_t* d_ci, const double* d_v,
-                          const int32_t* d_rowsrc, const int32_t* d_colmap, SellMat& out, hipStream_t s);
-void sell_free(SellMat& A);
+void devmat_from_csr_device(int64_t m, int64_t n, const int64_t* d_rp, const int32_t* d_ci, const double* d_v,
+                          const int32_t* d_rowsrc, const int32_t* d_colmap, DevMat& out, hipStream_t s);
+void devmat_free(DevMat& A);
 
 #define HIP_CHECK(expr)                                                                       \
   do {                                                                                        \

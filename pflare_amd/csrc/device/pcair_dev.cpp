@@ -10,12 +10,12 @@
 
 namespace airhip {
 
-void upload_sell(const Csr& A, const int32_t* d_rowsrc, const int32_t* d_colmap, SellMat& out, hipStream_t s) {
+void upload_mat(const Csr& A, const int32_t* d_rowsrc, const int32_t* d_colmap, DevMat& out, hipStream_t s) {
   DBuf<int64_t> rp; DBuf<int32_t> ci; DBuf<double> v;
   rp.upload(A.rp.data(), A.m + 1);
   ci.upload(A.ci.data(), A.nnz());
   v.upload(A.v.data(), A.nnz());
-  sell_from_csr_device(A.m, A.n, rp.p, ci.p, v.p, d_rowsrc, d_colmap, out, s);
+  devmat_from_csr_device(A.m, A.n, rp.p, ci.p, v.p, d_rowsrc, d_colmap, out, s);
 }
 
 double DevInv::alg_bytes() const {
@@ -31,7 +31,7 @@ DevPCAIR::~DevPCAIR() {
   if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
   for (auto e : event_pool_) (void)hipEventDestroy(e);
   for (auto& p : pending_) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
-  sell_free(A_perm_); sell_free(coarse_A_);
+  devmat_free(A_perm_); devmat_free(coarse_A_);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -74,7 +74,7 @@ void DevPCAIR::resolve_events() {
 }
 void DevPCAIR::reset_stats() { resolve_events(); for (auto& s : stats_) { s.calls = 0; s.ms = 0.0; } }
 
-void DevPCAIR::spmv(const SellMat& A, const double* x, const SpmvEpi& e, const char* name, int level, double bytes_override) {
+void DevPCAIR::spmv(const DevMat& A, const double* x, const SpmvEpi& e, const char* name, int level, double bytes_override) {
   int id = -1;
   if (profile_) { id = stat_id(name, level, bytes_override >= 0 ? bytes_override : A.s_bytes()); begin_kernel(id); }
   launch_spmv(A, x, e, stream_);
@@ -84,10 +84,10 @@ void DevPCAIR::spmv(const SellMat& A, const double* x, const SpmvEpi& e, const c
 // ---------------------------------------------------------------------------------------
 // upload
 // ---------------------------------------------------------------------------------------
-void DevPCAIR::upload_inv(const InvOp& h, DevInv& d, const SellMat* Aop, const double* host_diag_of_op) {
+void DevPCAIR::upload_inv(const InvOp& h, DevInv& d, const DevMat* Aop, const double* host_diag_of_op) {
   d.kind = h.kind; d.coeffs = h.coeffs; d.re = h.re; d.im = h.im;
   d.diag_scale = h.diag_scale; d.neumann = h.neumann; d.spmvs = h.spmvs;
-  if (h.kind == InvOp::ASSEMBLED) { d.n = h.mat.m; upload_sell(h.mat, nullptr, nullptr, d.mat, stream_); }
+  if (h.kind == InvOp::ASSEMBLED) { d.n = h.mat.m; upload_mat(h.mat, nullptr, nullptr, d.mat, stream_); }
   else if (h.kind == InvOp::DIAG) { d.n = h.d.size(); d.d.upload(h.d.data(), h.d.size()); }
   else if (h.kind == InvOp::HORNER || h.kind == InvOp::NEWTON) {
     d.Aop = Aop; d.n = Aop->m;
@@ -141,7 +141,7 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top) {
     std::vector<int32_t> ip = inverse(perm[0]);
     perm_.upload(perm[0].data(), n_);
     iperm_.upload(ip.data(), n_);
-    upload_sell(A_top, iperm_.p, perm_.p, A_perm_, stream_);
+    upload_mat(A_top, iperm_.p, perm_.p, A_perm_, stream_);
   }
 
   cycle_bytes_ = 0.0;
@@ -157,19 +157,19 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top) {
     pc.upload(perm[l + 1].data(), h.n_c);
     ipc.upload(ipn.data(), h.n_c);
 
-    upload_sell(h.A_fc, nullptr, pc.p, d.A_fc, stream_);           // rows F-order, cols permuted coarse
-    upload_sell(h.Z, ipc.p, nullptr, d.Z, stream_);                 // rows permuted coarse, cols F-order
+    upload_mat(h.A_fc, nullptr, pc.p, d.A_fc, stream_);           // rows F-order, cols permuted coarse
+    upload_mat(h.Z, ipc.p, nullptr, d.Z, stream_);                 // rows permuted coarse, cols F-order
     std::vector<double> affd_host;
     bool mf = (h.inv_ff.kind == InvOp::HORNER || h.inv_ff.kind == InvOp::NEWTON);
     if (h.aff_diag) {
       d.aff_d.upload(h.aff_d.data(), h.n_f);
       if (mf) {  // matrix-free polynomial over a diagonal operator: keep one code path
         Csr D = csr_from_diag(h.aff_d.data(), h.n_f);
-        upload_sell(D, nullptr, nullptr, d.A_ff, stream_);
+        upload_mat(D, nullptr, nullptr, d.A_ff, stream_);
       }
       affd_host.assign(h.aff_d.data(), h.aff_d.data() + h.n_f);
     } else {
-      upload_sell(h.A_ff, nullptr, nullptr, d.A_ff, stream_);
+      upload_mat(h.A_ff, nullptr, nullptr, d.A_ff, stream_);
       if (mf && h.inv_ff.diag_scale) { affd_host.resize(h.n_f); get_diagonal(h.A_ff, affd_host.data()); }
     }
     upload_inv(h.inv_ff, d.inv_ff, &d.A_ff, affd_host.empty() ? nullptr : affd_host.data());
@@ -178,15 +178,15 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top) {
       const int32_t* pn = perm[l + 1].data();
       for (int64_t i = 0; i < h.n_f; i++) wc[i] = h.wcol[i] >= 0 ? pn[h.wcol[i]] : -1;
       d.wcol.upload(wc.data(), h.n_f);
-    } else upload_sell(h.W, nullptr, pc.p, d.W, stream_);
+    } else upload_mat(h.W, nullptr, pc.p, d.W, stream_);
     d.t4.alloc(h.n_f); d.r.alloc(h.n_f);
     if (any_c_) {
-      upload_sell(h.A_cf, ipc.p, nullptr, d.A_cf, stream_);
-      upload_sell(h.A_cc, ipc.p, pc.p, d.A_cc, stream_);
+      upload_mat(h.A_cf, ipc.p, nullptr, d.A_cf, stream_);
+      upload_mat(h.A_cc, ipc.p, pc.p, d.A_cc, stream_);
       // inverse of A_cc lives in the permuted coarse numbering as well
       if (h.inv_cc.kind == InvOp::ASSEMBLED) {
         d.inv_cc.kind = InvOp::ASSEMBLED; d.inv_cc.n = h.n_c;
-        upload_sell(h.inv_cc.mat, ipc.p, pc.p, d.inv_cc.mat, stream_);
+        upload_mat(h.inv_cc.mat, ipc.p, pc.p, d.inv_cc.mat, stream_);
       } else if (h.inv_cc.kind == InvOp::DIAG) {
         std::vector<double> dd(h.n_c);
         for (int64_t j = 0; j < h.n_c; j++) dd[perm[l + 1][j]] = h.inv_cc.d[j];
@@ -218,7 +218,7 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top) {
   // coarse level
   {
     const bool mf = (H.coarse_inv.kind == InvOp::HORNER || H.coarse_inv.kind == InvOp::NEWTON);
-    if (mf || coarse_richardson_its_ > 0) upload_sell(H.coarse_A, nullptr, nullptr, coarse_A_, stream_);
+    if (mf || coarse_richardson_its_ > 0) upload_mat(H.coarse_A, nullptr, nullptr, coarse_A_, stream_);
     std::vector<double> dg;
     if (mf && H.coarse_inv.diag_scale) { dg.resize(H.coarse_A.m); get_diagonal(H.coarse_A, dg.data()); }
     upload_inv(H.coarse_inv, coarse_inv_, &coarse_A_, dg.empty() ? nullptr : dg.data());
@@ -239,7 +239,7 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top) {
 
 double DevPCAIR::storage_bytes() const {
   double b = 0;
-  auto sb = [&](const SellMat& m) { if (m.valid()) b += 12.0 * m.padded + 8.0 * (m.nslices + 1); };
+  auto sb = [&](const DevMat& m) { if (m.valid()) b += 12.0 * m.nnz + 4.0 * m.m + 12.0 * (m.nblocks + 1); };
   sb(A_perm_); sb(coarse_A_); sb(coarse_inv_.mat);
   for (auto& l : levels_) { sb(l->A_ff); sb(l->A_fc); sb(l->A_cf); sb(l->A_cc); sb(l->Z); sb(l->W); sb(l->inv_ff.mat); sb(l->inv_cc.mat); }
   return b;
@@ -263,7 +263,7 @@ void DevPCAIR::apply_inv(DevInv& I, const double* r, double* x, bool add, int lv
     if (profile_) end_kernel();
     return;
   }
-  const SellMat& A = *I.Aop;
+  const DevMat& A = *I.Aop;
   const double* rr = r;
   if (I.diag_scale) {   // MF_VEC_RHS = D^-1 x  (src/Gmres_Poly.F90:1406)
     launch_pointwise_mult(n, 1.0, I.dinv.p, r, 0.0, nullptr, I.rhs.p, stream_);

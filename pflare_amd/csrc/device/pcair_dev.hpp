@@ -23,20 +23,20 @@ struct DBuf {
 };
 
 // Upload a host CSR and convert it to SELL-64 on the device (rows/cols optionally permuted).
-void upload_sell(const Csr& A, const int32_t* d_rowsrc, const int32_t* d_colmap, SellMat& out, hipStream_t s);
+void upload_mat(const Csr& A, const int32_t* d_rowsrc, const int32_t* d_colmap, DevMat& out, hipStream_t s);
 
 struct DevInv {
   InvOp::Kind kind = InvOp::NONE;
   int64_t n = 0;
-  SellMat mat;                   // ASSEMBLED
+  DevMat mat;                   // ASSEMBLED
   DBuf<double> d;                // DIAG
   std::vector<double> coeffs, re, im;
   bool diag_scale = false, neumann = false;
   int spmvs = 0;
-  const SellMat* Aop = nullptr;  // operator of the matrix-free polynomial (not owned)
+  const DevMat* Aop = nullptr;  // operator of the matrix-free polynomial (not owned)
   DBuf<double> dinv;             // 1/diag(Aop) for the scaled variants
   DBuf<double> t1, t2, t3, rhs;  // matrix-free temporaries
-  ~DevInv() { sell_free(mat); }
+  ~DevInv() { devmat_free(mat); }
   // algorithmic bytes of one application (T(M) of SURVEY 8d)
   double alg_bytes() const;
 };
@@ -45,14 +45,14 @@ struct DevLevel {
   int64_t n = 0, n_f = 0, n_c = 0;
   bool aff_diag = false;
   DBuf<double> aff_d;
-  SellMat A_ff, A_fc, A_cf, A_cc, Z, W;
+  DevMat A_ff, A_fc, A_cf, A_cc, Z, W;
   bool one_point = true;
   DBuf<int32_t> wcol;
   DevInv inv_ff, inv_cc;
   int smooth_order[10] = {0};
   DBuf<double> t4, r, t4c, rc;
   int64_t nnz_A = 0;
-  ~DevLevel() { sell_free(A_ff); sell_free(A_fc); sell_free(A_cf); sell_free(A_cc); sell_free(Z); sell_free(W); }
+  ~DevLevel() { devmat_free(A_ff); devmat_free(A_fc); devmat_free(A_cf); devmat_free(A_cc); devmat_free(Z); devmat_free(W); }
 };
 
 struct KernelStat { std::string name; int level; double alg_bytes; int64_t calls = 0; double ms = 0.0; };
@@ -76,7 +76,7 @@ class DevPCAIR {
   void to_permuted(const double* nat, double* perm);
   void to_natural(const double* perm, double* nat);
 
-  const SellMat& A_perm() const { return A_perm_; }
+  const DevMat& A_perm() const { return A_perm_; }
   hipStream_t stream() const { return stream_; }
   double cycle_alg_bytes() const { return cycle_bytes_; }
   double storage_bytes() const;
@@ -89,7 +89,7 @@ class DevPCAIR {
   void set_use_graph(bool on) { want_graph_ = on; }
   std::vector<std::unique_ptr<DevLevel>> levels_;
   DevInv coarse_inv_;
-  SellMat coarse_A_;
+  DevMat coarse_A_;
   int coarse_richardson_its_ = 0;
   std::vector<int64_t> off_;     // off_[l]: start of the level-l vector inside the level-1 vector
 
@@ -99,11 +99,11 @@ class DevPCAIR {
   void f_smooths(DevLevel& L, int li, bool first, int its);
   void c_smooths(DevLevel& L, int li, bool first, int its);
   void apply_inv(DevInv& I, const double* r, double* x, bool add, int stat_level, const char* tag);
-  void spmv(const SellMat& A, const double* x, const SpmvEpi& e, const char* name, int level, double bytes_override = -1);
+  void spmv(const DevMat& A, const double* x, const SpmvEpi& e, const char* name, int level, double bytes_override = -1);
   int stat_id(const char* name, int level, double bytes);
   void begin_kernel(int stat);
   void end_kernel();
-  void upload_inv(const InvOp& h, DevInv& d, const SellMat* Aop, const double* host_diag_of_op);
+  void upload_inv(const InvOp& h, DevInv& d, const DevMat* Aop, const double* host_diag_of_op);
   double* bvec(int l) { return b_ptr_[l]; }
   double* xvec(int l) { return cx_.p + off_[l]; }
 
@@ -114,7 +114,7 @@ class DevPCAIR {
   std::vector<DBuf<double>> b_sep_;   // separate rhs per level when C smoothing keeps b_c alive
   std::vector<double*> b_ptr_;
   DBuf<int32_t> perm_, iperm_;    // natural -> hierarchical and back (level 1)
-  SellMat A_perm_;
+  DevMat A_perm_;
   DBuf<double> coarse_r_;
   double cycle_bytes_ = 0.0;
   // profiling
@@ -144,7 +144,7 @@ struct KspResult { int its = 0; int reason = 0; double rnorm = 0.0; double solve
 
 // Generic preconditioner callback in whatever ordering the operator uses.
 struct KspOperator {
-  const SellMat* A = nullptr;
+  const DevMat* A = nullptr;
   hipStream_t stream = nullptr;
   // z = M r ; null = identity
   std::function<void(const double*, double*)> pc;

@@ -1,0 +1,377 @@
+// Row-block CSR SpMV kernels (the dominant kernels of the AIR V-cycle) and the device-side
+// CSR -> row-block CSR conversion.
+//
+// Format and mapping (gfx950, wave64):
+//   * the matrix stays in plain CSR order (no padding; SELL-64 padded the AIR operators by
+//     1.75x, and length-sorted SELL-C-sigma destroyed the locality of the x gathers);
+//   * rows are partitioned into blocks of <= BLK_NNZ non-zeros (+ the tail of the last row);
+//     one WAVE owns one block: phase 1 streams the block's values / column indices with fully
+//     coalesced 512-B / 256-B wave loads, gathers x and stages the products in LDS (8 KB per
+//     wave); phase 2 lets lane l sum the LDS segment of row r0+l (+64, ...) in column order -
+//     the same summation order as a sequential CSR loop - and apply the fused epilogue, so the
+//     z / w / out vectors are read and written coalesced;
+//   * blocks whose non-zeros do not fit the LDS stage (a very long row) use a wave-wide
+//     reduction per row instead;
+//   * XCD-aware assignment: blocks b and b+8 of the grid share an XCD (observed round-robin
+//     dispatch; a speed assumption only), so each residue class of workgroups walks a contiguous
+//     range of row blocks and an XCD's private L2 sees a contiguous window of x.
+#include "dev.hpp"
+#include "kcommon.hpp"
+#include <stdexcept>
+
+namespace airhip {
+
+constexpr int BLK_NNZ = 512;       // target non-zeros per row block
+constexpr int LDS_CAP = 1024;      // products staged per wave (8 KB)
+constexpr int BLK_ROWS = 256;      // at most this many rows per block
+
+struct RbView {
+  int64_t m, nblocks;
+  const int32_t* blk_row;
+  const int64_t* blk_p0;
+  const uint32_t* roff;
+  const int32_t* col;
+  const double* val;
+};
+static RbView view_of(const DevMat& A) { return RbView{A.m, A.nblocks, A.blk_row, A.blk_p0, A.roff, A.col, A.val}; }
+
+struct BlockRange { int64_t first, last, stride; };
+
+// XCD-aware, grid-strided assignment of row blocks to waves (gridDim.x is a multiple of 8).
+__device__ __forceinline__ BlockRange my_blocks(int64_t nblocks) {
+  const int g = blockIdx.x & 7;
+  const int bi = blockIdx.x >> 3;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  BlockRange r;
+  const int64_t lo = nblocks * g / 8;
+  r.last = nblocks * (g + 1) / 8;
+  r.stride = (int64_t)(gridDim.x >> 3) * WAVES_PER_BLOCK;
+  r.first = lo + (int64_t)bi * WAVES_PER_BLOCK + wid;
+  return r;
+}
+
+static int grid_for_blocks(int64_t nblocks) {
+  int64_t blocks = (nblocks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+  if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
+  blocks = (blocks + 7) / 8 * 8;
+  if (blocks < 8) blocks = 8;
+  return (int)blocks;
+}
+
+// Calls epi(row, sum_j a_row,j x_j) once for every row of the matrix.
+template <class T, bool NT>
+__device__ __forceinline__ T ldg(const T* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p); else return *p;
+}
+
+template <int CAP, bool NT, int UNR, class Epi>
+__device__ __forceinline__ void rb_rows(const RbView& A, const double* __restrict__ x, double* __restrict__ lds, Epi epi) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const BlockRange br = my_blocks(A.nblocks);
+  for (int64_t b = br.first; b < br.last; b += br.stride) {
+    const int32_t r0 = __builtin_amdgcn_readfirstlane(A.blk_row[b]);
+    const int32_t r1 = __builtin_amdgcn_readfirstlane(A.blk_row[b + 1]);
+    const int64_t p0 = uniform64(A.blk_p0[b]);
+    const int64_t p1 = uniform64(A.blk_p0[b + 1]);
+    const int nb = (int)(p1 - p0);
+    const double* __restrict__ v = A.val + p0;
+    const int32_t* __restrict__ c = A.col + p0;
+    const int nr = r1 - r0;
+    if (nb <= 4 * nr) {
+      // very short rows (<= 4 non-zeros on average): one lane per row straight from global
+      // memory - the block's ~6 KB are shared by neighbouring lanes through L1, and the
+      // dependency chain is one round trip shorter than the LDS stage
+      for (int32_t r = r0 + lane; r < r1; r += WAVE) {
+        const int a = (int)A.roff[r];
+        const int e = (r + 1 < r1) ? (int)A.roff[r + 1] : nb;
+        double s = 0.0;
+        for (int j = a; j < e; j++) s += ldg<double, NT>(v + j) * x[ldg<int32_t, NT>(c + j)];
+        epi(r, s);
+      }
+    } else if (nb <= CAP) {
+      // phase 1: coalesced stream, products to LDS (UNR independent loads in flight per lane)
+      int k = lane;
+      for (; k + (UNR - 1) * WAVE < nb; k += UNR * WAVE) {
+        int32_t cc[UNR]; double vv[UNR], xx[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; u++) cc[u] = ldg<int32_t, NT>(c + k + u * WAVE);
+#pragma unroll
+        for (int u = 0; u < UNR; u++) vv[u] = ldg<double, NT>(v + k + u * WAVE);
+#pragma unroll
+        for (int u = 0; u < UNR; u++) xx[u] = x[cc[u]];
+#pragma unroll
+        for (int u = 0; u < UNR; u++) lds[k + u * WAVE] = vv[u] * xx[u];
+      }
+      for (; k < nb; k += WAVE) lds[k] = ldg<double, NT>(v + k) * x[ldg<int32_t, NT>(c + k)];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (nr > 16) {
+        // phase 2: one lane per row, column order
+        for (int32_t r = r0 + lane; r < r1; r += WAVE) {
+          const int a = (int)A.roff[r];
+          const int e = (r + 1 < r1) ? (int)A.roff[r + 1] : nb;
+          double s = 0.0;
+          for (int j = a; j < e; j++) s += lds[j];
+          epi(r, s);
+        }
+      } else {
+        // phase 2 for a few long rows: T = 64 / 2^ceil(log2 nr) lanes share a row
+        int T = WAVE;
+        while (WAVE / T < nr) T >>= 1;   // nr <= 16  ->  T >= 4
+        const int g = lane / T, t = lane - g * T;
+        const int32_t r = r0 + g;
+        double s = 0.0;
+        if (g < nr) {
+          const int a = (int)A.roff[r];
+          const int e = (r + 1 < r1) ? (int)A.roff[r + 1] : nb;
+          for (int j = a + t; j < e; j += T) s += lds[j];
+        }
+        for (int off = T >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
+        if (g < nr && t == 0) epi(r, s);
+      }
+      __builtin_amdgcn_wave_barrier();   // LDS is reused by the next block of this wave
+    } else {
+      // long rows: the whole wave reduces one row at a time
+      for (int32_t r = r0; r < r1; r++) {
+        const int a = (int)A.roff[r];
+        const int e = (r + 1 < r1) ? (int)A.roff[r + 1] : nb;
+        double s = 0.0;
+        for (int j = a + lane; j < e; j += WAVE) s = fma(ldg<double, NT>(v + j), x[ldg<int32_t, NT>(c + j)], s);
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
+        if (lane == 0) epi(r, s);
+      }
+    }
+  }
+}
+
+template <int CAP, bool NT, int UNR>
+__global__ __launch_bounds__(BLOCK) void k_rb_spmv(RbView A, const double* __restrict__ x, SpmvEpi e) {
+  __shared__ double lds_all[WAVES_PER_BLOCK][CAP];
+  double* lds = lds_all[threadIdx.x >> 6];
+  rb_rows<CAP, NT, UNR>(A, x, lds, [&](int32_t row, double acc) {
+    if (e.dscale) acc *= e.dscale[row];
+    double o = e.alpha * acc;
+    if (e.z) o += e.beta * e.z[row];
+    if (e.w) o += e.gamma * e.w[row];
+    e.out[row] = o;
+    if (e.y2) {
+      const double a = e.aux_out ? o : e.w2[row];
+      e.y2[row] += e.delta * a;
+    }
+  });
+}
+
+// tuning variant (bit 0: 640-entry LDS stage instead of 1024, bit 1: non-temporal matrix loads,
+// bit 2: 8 instead of 4 loads in flight); set through airhip_debug_set_variant
+int g_spmv_variant = 0;
+
+void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t s) {
+  if (A.m == 0) return;
+  const dim3 grid(grid_for_blocks(A.nblocks)), block(BLOCK);
+  const RbView v = view_of(A);
+#define RB_LAUNCH(CAP, NT, UNR) hipLaunchKernelGGL((k_rb_spmv<CAP, NT, UNR>), grid, block, 0, s, v, x, e)
+  switch (g_spmv_variant & 7) {
+    case 0: RB_LAUNCH(1024, false, 4); break;
+    case 1: RB_LAUNCH(640, false, 4); break;
+    case 2: RB_LAUNCH(1024, true, 4); break;
+    case 3: RB_LAUNCH(640, true, 4); break;
+    case 4: RB_LAUNCH(1024, false, 8); break;
+    case 5: RB_LAUNCH(640, false, 8); break;
+    case 6: RB_LAUNCH(1024, true, 8); break;
+    default: RB_LAUNCH(640, true, 8); break;
+  }
+#undef RB_LAUNCH
+}
+
+__global__ __launch_bounds__(BLOCK) void k_rb_fc_first(RbView A, const int32_t* __restrict__ wcol,
+                                                      const double* __restrict__ b_f, const double* __restrict__ x_c,
+                                                      const double* __restrict__ aff_d, const double* __restrict__ minv,
+                                                      double* __restrict__ t4_out, double* __restrict__ x_f) {
+  __shared__ double lds_all[WAVES_PER_BLOCK][LDS_CAP];
+  double* lds = lds_all[threadIdx.x >> 6];
+  rb_rows<LDS_CAP, false, 4>(A, x_c, lds, [&](int32_t row, double acc) {
+    const double t4 = b_f[row] + (-1.0) * acc;
+    const int32_t wc = wcol[row];
+    const double x0 = wc >= 0 ? x_c[wc] : 0.0;
+    if (aff_d) {
+      // one F smooth with diagonal A_ff and diagonal inverse (src/FC_Smooth.F90:541-559)
+      double t3 = aff_d[row] * x0;
+      t3 = t4 + (-1.0) * t3;
+      x_f[row] = x0 + minv[row] * t3;
+    } else {
+      t4_out[row] = t4;
+      x_f[row] = x0;
+    }
+  });
+}
+
+void launch_fc_first(const DevMat& A_fc, const int32_t* wcol, const double* b_f, const double* x_c,
+                     const double* aff_d, const double* minv, double* t4_out, double* x_f, hipStream_t s) {
+  if (A_fc.m == 0) return;
+  hipLaunchKernelGGL(k_rb_fc_first, dim3(grid_for_blocks(A_fc.nblocks)), dim3(BLOCK), 0, s, view_of(A_fc), wcol, b_f,
+                     x_c, aff_d, minv, t4_out, x_f);
+}
+
+// ---------------------------------------------------------------------------------------
+// CSR (device, any row order) -> row-block CSR (setup time)
+// ---------------------------------------------------------------------------------------
+constexpr int SCAN_CHUNK = 2048;   // elements per workgroup of the two-level scans
+
+__global__ __launch_bounds__(BLOCK) void k_row_len(int64_t m, const int64_t* __restrict__ rp, const int32_t* __restrict__ rowsrc,
+                                                  int64_t* __restrict__ len) {
+  const int64_t stride = (int64_t)gridDim.x * BLOCK;
+  for (int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x; r < m; r += stride) {
+    const int64_t src = rowsrc ? rowsrc[r] : r;
+    len[r] = rp[src + 1] - rp[src];
+  }
+}
+
+// chunk sums for a two-level exclusive scan
+__global__ __launch_bounds__(BLOCK) void k_chunk_sum(int64_t n, const int64_t* __restrict__ in, int64_t* __restrict__ sums) {
+  __shared__ int64_t red[BLOCK];
+  const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK;
+  int64_t s = 0;
+  for (int i = threadIdx.x; i < SCAN_CHUNK; i += BLOCK) { const int64_t k = base + i; if (k < n) s += in[k]; }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = BLOCK / 2; off > 0; off >>= 1) { if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off]; __syncthreads(); }
+  if (threadIdx.x == 0) sums[blockIdx.x] = red[0];
+}
+
+// out[k] = offs[chunk] + exclusive prefix inside the chunk; out[n] is written by the host
+__global__ __launch_bounds__(BLOCK) void k_chunk_scan(int64_t n, const int64_t* __restrict__ in, const int64_t* __restrict__ offs,
+                                                     int64_t* __restrict__ out) {
+  __shared__ int64_t tsum[BLOCK];
+  const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK;
+  constexpr int PER = SCAN_CHUNK / BLOCK;
+  // each thread owns PER consecutive elements
+  int64_t loc[PER]; int64_t s = 0;
+#pragma unroll
+  for (int j = 0; j < PER; j++) { const int64_t k = base + (int64_t)threadIdx.x * PER + j; loc[j] = k < n ? in[k] : 0; s += loc[j]; }
+  tsum[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { int64_t run = 0; for (int t = 0; t < BLOCK; t++) { int64_t c = tsum[t]; tsum[t] = run; run += c; } }
+  __syncthreads();
+  int64_t run = offs[blockIdx.x] + tsum[threadIdx.x];
+#pragma unroll
+  for (int j = 0; j < PER; j++) { const int64_t k = base + (int64_t)threadIdx.x * PER + j; if (k < n) out[k] = run; run += loc[j]; }
+}
+
+// exclusive scan of n int64 values on the device; returns the total
+static int64_t device_exclusive_scan(int64_t n, const int64_t* d_in, int64_t* d_out, hipStream_t s) {
+  if (n == 0) return 0;
+  const int64_t nchunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+  int64_t* d_sums = nullptr;
+  HIP_CHECK(hipMalloc(&d_sums, sizeof(int64_t) * (size_t)nchunks));
+  hipLaunchKernelGGL(k_chunk_sum, dim3((unsigned)nchunks), dim3(BLOCK), 0, s, n, d_in, d_sums);
+  std::vector<int64_t> h(nchunks);
+  HIP_CHECK(hipMemcpyAsync(h.data(), d_sums, sizeof(int64_t) * (size_t)nchunks, hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  int64_t run = 0;
+  for (int64_t i = 0; i < nchunks; i++) { int64_t c = h[i]; h[i] = run; run += c; }
+  HIP_CHECK(hipMemcpyAsync(d_sums, h.data(), sizeof(int64_t) * (size_t)nchunks, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_chunk_scan, dim3((unsigned)nchunks), dim3(BLOCK), 0, s, n, d_in, d_sums, d_out);
+  HIP_CHECK(hipStreamSynchronize(s));
+  (void)hipFree(d_sums);
+  return run;
+}
+
+// copy (and remap) the entries of every destination row; one wave per 64 consecutive entries
+// would need a row lookup, so rows are copied by lanes - setup only
+__global__ __launch_bounds__(BLOCK) void k_copy_rows(int64_t m, const int64_t* __restrict__ rp, const int32_t* __restrict__ ci,
+                                                    const double* __restrict__ v, const int32_t* __restrict__ rowsrc,
+                                                    const int32_t* __restrict__ colmap, const int64_t* __restrict__ nrp,
+                                                    int32_t* __restrict__ ocol, double* __restrict__ oval) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * BLOCK) >> 6;
+  // a wave copies one row at a time with coalesced accesses
+  for (int64_t r = wave; r < m; r += nwaves) {
+    const int64_t src = rowsrc ? rowsrc[r] : r;
+    const int64_t a = rp[src], len = rp[src + 1] - a, o = nrp[r];
+    for (int64_t k = lane; k < len; k += WAVE) {
+      int32_t c = ci[a + k];
+      if (colmap) c = colmap[c];
+      ocol[o + k] = c; oval[o + k] = v[a + k];
+    }
+  }
+}
+
+// flag[r] = 1 if row r starts a new block: its first non-zero lies in another BLK_NNZ bucket
+// than the previous row's, or BLK_ROWS rows have passed (runs of empty rows, e.g. Dirichlet
+// planes, must not pile up in one block)
+__global__ __launch_bounds__(BLOCK) void k_block_flags(int64_t m, const int64_t* __restrict__ nrp, int64_t* __restrict__ flag) {
+  const int64_t stride = (int64_t)gridDim.x * BLOCK;
+  for (int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x; r < m; r += stride)
+    flag[r] = (r % BLK_ROWS == 0 || (nrp[r] / BLK_NNZ) != (nrp[r - 1] / BLK_NNZ)) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_block_build(int64_t m, const int64_t* __restrict__ nrp, const int64_t* __restrict__ flag,
+                                                      const int64_t* __restrict__ blk_of, int32_t* __restrict__ blk_row,
+                                                      int64_t* __restrict__ blk_p0) {
+  const int64_t stride = (int64_t)gridDim.x * BLOCK;
+  for (int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x; r < m; r += stride)
+    if (flag[r]) { blk_row[blk_of[r]] = (int32_t)r; blk_p0[blk_of[r]] = nrp[r]; }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_row_offsets(int64_t m, const int64_t* __restrict__ nrp, const int64_t* __restrict__ flag,
+                                                      const int64_t* __restrict__ blk_of, const int64_t* __restrict__ blk_p0,
+                                                      uint32_t* __restrict__ roff) {
+  const int64_t stride = (int64_t)gridDim.x * BLOCK;
+  for (int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x; r < m; r += stride) {
+    const int64_t b = blk_of[r] + flag[r] - 1;   // exclusive scan of the flags: block of row r
+    roff[r] = (uint32_t)(nrp[r] - blk_p0[b]);
+  }
+}
+
+static int grid1d(int64_t n) {
+  int64_t b = (n + BLOCK - 1) / BLOCK;
+  if (b > MAX_BLOCKS) b = MAX_BLOCKS;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+void devmat_from_csr_device(int64_t m, int64_t n, const int64_t* d_rp, const int32_t* d_ci, const double* d_v,
+                            const int32_t* d_rowsrc, const int32_t* d_colmap, DevMat& out, hipStream_t s) {
+  devmat_free(out);
+  out.m = m; out.n = n;
+  if (m == 0) return;
+  if (m > 0x7fffffffll) throw std::runtime_error("matrix has too many rows for 32-bit row indices");
+  int64_t *d_len = nullptr, *d_nrp = nullptr, *d_flag = nullptr, *d_blk_of = nullptr;
+  HIP_CHECK(hipMalloc(&d_len, sizeof(int64_t) * (size_t)m));
+  HIP_CHECK(hipMalloc(&d_nrp, sizeof(int64_t) * (size_t)(m + 1)));
+  hipLaunchKernelGGL(k_row_len, dim3(grid1d(m)), dim3(BLOCK), 0, s, m, d_rp, d_rowsrc, d_len);
+  out.nnz = device_exclusive_scan(m, d_len, d_nrp, s);
+  HIP_CHECK(hipMemcpyAsync(d_nrp + m, &out.nnz, sizeof(int64_t), hipMemcpyHostToDevice, s));
+  HIP_CHECK(hipMalloc(&out.col, sizeof(int32_t) * (size_t)(out.nnz > 0 ? out.nnz : 1)));
+  HIP_CHECK(hipMalloc(&out.val, sizeof(double) * (size_t)(out.nnz > 0 ? out.nnz : 1)));
+  hipLaunchKernelGGL(k_copy_rows, dim3(MAX_BLOCKS), dim3(BLOCK), 0, s, m, d_rp, d_ci, d_v, d_rowsrc, d_colmap, d_nrp,
+                     out.col, out.val);
+  // row blocks
+  d_flag = d_len;   // reuse
+  HIP_CHECK(hipMalloc(&d_blk_of, sizeof(int64_t) * (size_t)m));
+  hipLaunchKernelGGL(k_block_flags, dim3(grid1d(m)), dim3(BLOCK), 0, s, m, d_nrp, d_flag);
+  out.nblocks = device_exclusive_scan(m, d_flag, d_blk_of, s);
+  HIP_CHECK(hipMalloc(&out.blk_row, sizeof(int32_t) * (size_t)(out.nblocks + 1)));
+  HIP_CHECK(hipMalloc(&out.blk_p0, sizeof(int64_t) * (size_t)(out.nblocks + 1)));
+  HIP_CHECK(hipMalloc(&out.roff, sizeof(uint32_t) * (size_t)m));
+  hipLaunchKernelGGL(k_block_build, dim3(grid1d(m)), dim3(BLOCK), 0, s, m, d_nrp, d_flag, d_blk_of, out.blk_row, out.blk_p0);
+  const int32_t m32 = (int32_t)m;
+  HIP_CHECK(hipMemcpyAsync(out.blk_row + out.nblocks, &m32, sizeof(int32_t), hipMemcpyHostToDevice, s));
+  HIP_CHECK(hipMemcpyAsync(out.blk_p0 + out.nblocks, &out.nnz, sizeof(int64_t), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_row_offsets, dim3(grid1d(m)), dim3(BLOCK), 0, s, m, d_nrp, d_flag, d_blk_of, out.blk_p0, out.roff);
+  HIP_CHECK(hipStreamSynchronize(s));
+  (void)hipFree(d_len); (void)hipFree(d_nrp); (void)hipFree(d_blk_of);
+}
+
+void devmat_free(DevMat& A) {
+  if (A.blk_row) (void)hipFree(A.blk_row);
+  if (A.blk_p0) (void)hipFree(A.blk_p0);
+  if (A.roff) (void)hipFree(A.roff);
+  if (A.col) (void)hipFree(A.col);
+  if (A.val) (void)hipFree(A.val);
+  A = DevMat();
+}
+
+}  // namespace airhip
