@@ -165,6 +165,8 @@ int airhip_pcair_profile_reset(airhip_pcair pc);
 int airhip_pcair_profile_count(airhip_pcair pc, int* n);
 int airhip_pcair_profile_get(airhip_pcair pc, int i, const char** name, int* level, double* alg_bytes,
                              int64_t* calls, double* total_ms);
+/* name of the HIP kernel function record i launches (the name a rocprofv3 kernel trace shows) */
+int airhip_pcair_profile_kernel(airhip_pcair pc, int i, const char** kernel);
 
 /* ------------------------------------------------------------------------ PCPFLAREINV */
 int airhip_pcinv_create(airhip_pcinv* pc);

@@ -40,7 +40,7 @@ DECLARED_SYMBOLS = [
     "airhip_pcair_level_get", "airhip_pcair_level_inv", "airhip_pcair_level_smooth_order",
     "airhip_pcair_coarse_get", "airhip_pcair_complexities", "airhip_pcair_setup_times",
     "airhip_pcair_release_host", "airhip_pcair_use_graph", "airhip_pcair_profile",
-    "airhip_pcair_profile_reset", "airhip_pcair_profile_count", "airhip_pcair_profile_get",
+    "airhip_pcair_profile_reset", "airhip_pcair_profile_count", "airhip_pcair_profile_get", "airhip_pcair_profile_kernel",
     "airhip_pcinv_create", "airhip_pcinv_set_option", "airhip_pcinv_setup", "airhip_pcinv_apply",
     "airhip_pcinv_sync", "airhip_pcinv_get_inv", "airhip_pcinv_destroy",
     "airhip_mat_create", "airhip_mat_mult", "airhip_mat_destroy",
@@ -104,6 +104,7 @@ def lib():
         "airhip_pcair_profile_reset": [vp],
         "airhip_pcair_profile_count": [vp, pint],
         "airhip_pcair_profile_get": [vp, C.c_int, C.POINTER(C.c_char_p), pint, pd, pi64, pd],
+        "airhip_pcair_profile_kernel": [vp, C.c_int, C.POINTER(C.c_char_p)],
         "airhip_pcinv_create": [pvp],
         "airhip_pcinv_set_option": [vp, C.c_char_p, C.c_char_p],
         "airhip_pcinv_setup": [vp, pcsr],

@@ -2,6 +2,8 @@
 #include "../../include/airhip.h"
 #include "host/air.hpp"
 #include "device/pcair_dev.hpp"
+#include "device/setup_accel.hpp"
+#include "device/spgemm.hpp"
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -96,6 +98,31 @@ int airhip_hostmat_get(airhip_hostmat A, airhip_csr* view) {
   expose_csr(A->A, view);
   API_END
 }
+// Test hook (not part of the stable ABI): C = filter(A*B) with the host or the device SpGEMM of
+// the setup; stats = {rows in the 1k-entry LDS bin, rows in the 4k-entry LDS bin, rows redone
+// with a global-memory table}.
+extern "C" int airhip_debug_spgemm(const airhip_csr* A, const airhip_csr* B, int drop, double tol, int lump, int negate,
+                                   int on_device, airhip_hostmat* out, int64_t* stats) {
+  API_BEGIN
+  REQUIRE(A && B && out && A->n == B->m, AIRHIP_ERR_ARG, "bad arguments");
+  Csr a, b; view_csr(A, a); view_csr(B, b);
+  SpgemmDrop d; d.enabled = drop != 0; d.tol = tol; d.lump = lump != 0; d.negate = negate != 0;
+  auto* h = new airhip_hostmat_s;
+  if (!on_device) h->A = spgemm(a, b, d);
+  else {
+    DCsr da = dcsr_upload(a.m, a.n, a.rp.data(), a.ci.data(), a.v.data());
+    DCsr db = dcsr_upload(b.m, b.n, b.rp.data(), b.ci.data(), b.v.data());
+    SpgemmStats st;
+    DCsr dc = dev_spgemm(da, db, d.enabled, d.tol, d.lump, d.negate, nullptr, &st);
+    h->A.m = dc.m; h->A.n = dc.n;
+    h->A.rp.alloc(dc.m + 1); h->A.ci.alloc(dc.nnz); h->A.v.alloc(dc.nnz);
+    dcsr_download(dc, h->A.rp.data(), h->A.ci.data(), h->A.v.data());
+    dcsr_free(da); dcsr_free(db); dcsr_free(dc);
+    if (stats) { stats[0] = st.rows_small; stats[1] = st.rows_big; stats[2] = st.rows_global; }
+  }
+  *out = h;
+  API_END
+}
 int airhip_hostmat_destroy(airhip_hostmat* A) {
   API_BEGIN
   if (A && *A) { delete *A; *A = nullptr; }
@@ -134,6 +161,9 @@ struct airhip_pcair_s {
   bool use_graph = false, profile = false;
   bool byo = false; int byo_levels = 0;
   double op_nnz_top = 0;
+  bool setup_on_device = true;    // sparse products of the setup as HIP SpGEMMs
+  int64_t setup_device_min_nnz = -1;
+  double accel_transfer_s = 0, accel_compute_s = 0;
 };
 
 int airhip_pcair_create(airhip_pcair* pc) {
@@ -189,6 +219,8 @@ int airhip_pcair_set_option(airhip_pcair pc, const char* name, const char* value
   else if (k == "print_stats_timings") o.print_stats_timings = parse_bool(v);
   else if (k == "mg_coarse_ksp_max_it" || k == "-mg_coarse_ksp_max_it") o.coarse_richardson_its = I();
   else if (k == "seed") o.seed = (uint64_t)std::atoll(v);
+  else if (k == "setup_on_device") pc->setup_on_device = parse_bool(v);
+  else if (k == "setup_device_min_nnz") pc->setup_device_min_nnz = std::atoll(v);
   else if (k == "processor_agglom" || k == "subcomm" || k == "coarsest_subcomm") { /* no-ops on one device */ }
   else if (k == "symmetric" || k == "z_type" || k == "cf_splitting_type" || k == "full_smoothing_up_and_down" ||
            k == "constrain_z" || k == "constrain_w" || k == "improve_z_its" || k == "improve_w_its" ||
@@ -223,7 +255,18 @@ int airhip_pcair_setup(airhip_pcair pc, const airhip_csr* A) {
   pc->dev.reset(); pc->H.reset();
   view_csr(A, pc->A_top);
   double t0 = now_s();
-  pc->H = setup_air(pc->A_top, pc->opt);
+  {
+    std::unique_ptr<SetupAccel> accel;
+    if (pc->setup_on_device) accel = make_device_setup_accel(nullptr, pc->setup_device_min_nnz);
+    pc->H = setup_air(pc->A_top, pc->opt, accel.get());
+    if (accel) {
+      pc->accel_transfer_s = accel->t_transfer; pc->accel_compute_s = accel->t_compute;
+      if (pc->opt.print_stats_timings) {
+        std::printf(" setup products on device: transfers %.2f s, SpGEMM %.2f s\n", accel->t_transfer, accel->t_compute);
+        std::fflush(stdout);
+      }
+    }
+  }
   pc->host_setup_s = now_s() - t0;
   pc->byo = false;
   finish_device(pc);
@@ -547,6 +590,15 @@ int airhip_pcair_profile_get(airhip_pcair pc, int i, const char** name, int* lev
   API_END
 }
 
+int airhip_pcair_profile_kernel(airhip_pcair pc, int i, const char** kernel) {
+  API_BEGIN
+  REQUIRE(pc && pc->dev && kernel, AIRHIP_ERR_STATE, "not set up");
+  const auto& st = pc->dev->stats();
+  REQUIRE(i >= 0 && i < (int)st.size(), AIRHIP_ERR_ARG, "index out of range");
+  *kernel = st[i].kernel;
+  API_END
+}
+
 // ------------------------------------------------------------------------ PCPFLAREINV
 // A PCPFLAREINV is a PCAIR hierarchy with no levels whose "coarse solver" is the
 // approximate inverse of the whole operator (PCApply_PFLAREINV_c = one MatMult with it).
@@ -689,6 +741,7 @@ int airhip_ksp_solve(const airhip_ksp_options* o, airhip_mat A, airhip_pcair pca
     dev.to_permuted(d_x, pc->kx.p);
     KspOperator op; op.A = &dev.A_perm(); op.stream = dev.stream();
     op.pc = [&dev](const double* in, double* out) { dev.apply_permuted(in, out); };
+    op.mult = [&dev](const double* x, const SpmvEpi& e) { dev.spmv(dev.A_perm(), x, e, "outer A*x (Krylov)", -1); };
     r = pc->ksp->solve(op, ko, pc->kb.p, pc->kx.p);
     dev.to_natural(pc->kx.p, d_x);
     HIP_CHECK(hipStreamSynchronize(dev.stream()));

@@ -53,10 +53,14 @@ KspResult DevKSP::solve(const KspOperator& op, const KspOptions& o, const double
   return r;
 }
 
+static void op_mult(const KspOperator& op, const double* x, const SpmvEpi& e) {
+  if (op.mult) op.mult(x, e); else launch_spmv(*op.A, x, e, op.stream);
+}
+
 // r = b - A x
 static void residual(const KspOperator& op, const double* b, const double* x, double* r) {
   SpmvEpi e; e.out = r; e.alpha = -1.0; e.z = b; e.beta = 1.0;
-  launch_spmv(*op.A, x, e, op.stream);
+  op_mult(op, x, e);
 }
 
 KspResult DevKSP::richardson(const KspOperator& op, const KspOptions& o, const double* b, double* x) {
@@ -134,8 +138,8 @@ KspResult DevKSP::gmres(const KspOperator& op, const KspOptions& o, const double
     bool hapend = false;
     while (!reason && it < m && its < o.max_it) {
       double* w = Vk(it + 1);
-      if (right) { apply_pc(Vk(it), t_.p); SpmvEpi e; e.out = w; launch_spmv(*op.A, t_.p, e, s); }
-      else { SpmvEpi e; e.out = t_.p; launch_spmv(*op.A, Vk(it), e, s); apply_pc(t_.p, w); }
+      if (right) { apply_pc(Vk(it), t_.p); SpmvEpi e; e.out = w; op_mult(op, t_.p, e); }
+      else { SpmvEpi e; e.out = t_.p; op_mult(op, Vk(it), e); apply_pc(t_.p, w); }
       // classical Gram-Schmidt: one multi-dot, one multi-axpy
       launch_mdot(n_, w, V_.p, n_, it + 1, scratch_.p, ddots_.p, s);
       HIP_CHECK(hipMemcpyAsync(lhh.data(), ddots_.p, sizeof(double) * (it + 1), hipMemcpyDeviceToHost, s));

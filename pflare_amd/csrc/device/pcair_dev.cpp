@@ -76,7 +76,7 @@ void DevPCAIR::reset_stats() { resolve_events(); for (auto& s : stats_) { s.call
 
 void DevPCAIR::spmv(const DevMat& A, const double* x, const SpmvEpi& e, const char* name, int level, double bytes_override) {
   int id = -1;
-  if (profile_) { id = stat_id(name, level, bytes_override >= 0 ? bytes_override : A.s_bytes()); begin_kernel(id); }
+  if (profile_) { id = stat_id(name, level, bytes_override >= 0 ? bytes_override : A.s_bytes()); stats_[id].kernel = "k_rb_spmv"; begin_kernel(id); }
   launch_spmv(A, x, e, stream_);
   if (profile_) end_kernel();
 }
@@ -258,7 +258,7 @@ void DevPCAIR::apply_inv(DevInv& I, const double* r, double* x, bool add, int lv
   }
   if (I.kind == InvOp::DIAG) {
     int id = -1;
-    if (profile_) { id = stat_id(tag, lvl, I.alg_bytes()); begin_kernel(id); }
+    if (profile_) { id = stat_id(tag, lvl, I.alg_bytes()); stats_[id].kernel = "k_pointwise_mult"; begin_kernel(id); }
     launch_pointwise_mult(n, 1.0, I.d.p, r, 1.0, add ? x : nullptr, x, stream_);
     if (profile_) end_kernel();
     return;
@@ -341,7 +341,7 @@ void DevPCAIR::f_smooths(DevLevel& L, int li, bool first, int its) {
     // and its inverse are diagonal and a single F smooth is requested)
     const bool full = diag_inv && its == 1;
     int id = -1;
-    if (profile_) { id = stat_id(full ? "fc_first_diag(A_fc+W)" : "fc_first(A_fc+W)", li, L.A_fc.s_bytes()); begin_kernel(id); }
+    if (profile_) { id = stat_id(full ? "fc_first_diag(A_fc+W)" : "fc_first(A_fc+W)", li, L.A_fc.s_bytes()); stats_[id].kernel = "k_rb_fc_first"; begin_kernel(id); }
     launch_fc_first(L.A_fc, L.wcol.p, b_f, x_c, full ? L.aff_d.p : nullptr, full ? L.inv_ff.d.p : nullptr, L.t4.p, x_f, stream_);
     if (profile_) end_kernel();
     if (full) return;

@@ -55,7 +55,9 @@ struct DevLevel {
   ~DevLevel() { devmat_free(A_ff); devmat_free(A_fc); devmat_free(A_cf); devmat_free(A_cc); devmat_free(Z); devmat_free(W); }
 };
 
-struct KernelStat { std::string name; int level; double alg_bytes; int64_t calls = 0; double ms = 0.0; };
+// one record per call site; `kernel` names the HIP kernel function the site launches (what a
+// rocprofv3 kernel trace aggregates by)
+struct KernelStat { std::string name; int level; double alg_bytes; int64_t calls = 0; double ms = 0.0; const char* kernel = ""; };
 
 struct PendingEvent { hipEvent_t a, b; int stat; };
 
@@ -93,13 +95,15 @@ class DevPCAIR {
   int coarse_richardson_its_ = 0;
   std::vector<int64_t> off_;     // off_[l]: start of the level-l vector inside the level-1 vector
 
+  // SpMV on the library stream, timed under (name, level) when profiling is on
+  void spmv(const DevMat& A, const double* x, const SpmvEpi& e, const char* name, int level, double bytes_override = -1);
+
  private:
   void vcycle();                                        // cb_ -> cx_
   void run_cycle();                                     // vcycle, through a HIP graph when enabled
   void f_smooths(DevLevel& L, int li, bool first, int its);
   void c_smooths(DevLevel& L, int li, bool first, int its);
   void apply_inv(DevInv& I, const double* r, double* x, bool add, int stat_level, const char* tag);
-  void spmv(const DevMat& A, const double* x, const SpmvEpi& e, const char* name, int level, double bytes_override = -1);
   int stat_id(const char* name, int level, double bytes);
   void begin_kernel(int stat);
   void end_kernel();
@@ -148,6 +152,8 @@ struct KspOperator {
   hipStream_t stream = nullptr;
   // z = M r ; null = identity
   std::function<void(const double*, double*)> pc;
+  // optional replacement of launch_spmv(*A, ...) (lets the owner time the outer operator product)
+  std::function<void(const double*, const SpmvEpi&)> mult;
 };
 
 class DevKSP {

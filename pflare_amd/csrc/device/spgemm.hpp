@@ -1,0 +1,29 @@
+// Device CSR container + SpGEMM with fused drop/lump used to accelerate the PCAIR setup
+// (the Z = -A_cf*M and R*A*P products, src/AIR_Operators_Setup.F90:784-795, 1008-1069).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace airhip {
+
+struct DCsr {
+  int64_t m = 0, n = 0, nnz = 0;
+  int64_t* rp = nullptr;
+  int32_t* ci = nullptr;
+  double* v = nullptr;
+};
+
+struct SpgemmStats { int64_t rows_small = 0, rows_big = 0, rows_global = 0; };
+
+void dcsr_free(DCsr& A);
+DCsr dcsr_upload(int64_t m, int64_t n, const int64_t* rp, const int32_t* ci, const double* v);
+void dcsr_download(const DCsr& d, int64_t* rp, int32_t* ci, double* v);
+
+// C = filter(A * B).  With drop_enabled: entries with |c_ij| < tol * max_j |c_ij| are removed
+// (the diagonal i==j is never removed; with lump the removed entries are added to it), negate
+// flips the sign of the product first.  Rows come out sorted by column; values are bit-identical
+// to the host spgemm (host/spops.cpp).
+DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, bool lump, bool negate, hipStream_t s,
+                SpgemmStats* stats = nullptr);
+
+}  // namespace airhip

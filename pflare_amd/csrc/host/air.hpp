@@ -95,7 +95,7 @@ void build_inverse(const OpView& A, int inverse_type, int poly_order, int sparsi
                    bool matrix_free, bool diag_scale, uint64_t seed, InvOp& op, InvOp* assembled_too);
 
 // Full setup.  A is consumed level by level (the caller's matrix is not modified).
-std::unique_ptr<Hierarchy> setup_air(const Csr& A, const AirOptions& o);
+std::unique_ptr<Hierarchy> setup_air(const Csr& A, const AirOptions& o, SetupAccel* accel = nullptr);
 
 // y = op(x) on the host (used by the auto-truncation test of the setup only)
 void host_apply_inv(const InvOp& op, const OpView& A, const double* x, double* y);

@@ -90,7 +90,7 @@ static void coarse_solver(const Csr& A, const AirOptions& o, InvOp& op) {
                 o.coarsest_matrix_free_polys, o.coarsest_diag_scale_polys, o.seed, op, nullptr);
 }
 
-std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o) {
+std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o, SetupAccel* accel) {
   auto H = std::make_unique<Hierarchy>();
   H->opt = o;
   H->timers.assign(8, 0.0);
@@ -111,12 +111,11 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o) {
       const uint64_t key = rng_key(o.seed + 7919);   // distinct stream from the polynomial RHS
 #pragma omp parallel for schedule(static)
       for (int64_t i = 0; i < n; i++) rnd[i] = uniform01(key, (uint64_t)i);
-      double nb = 0.0, nr = 0.0;
       OpView v; v.A = cur; v.n = n;
       host_apply_inv(cop, v, rnd.data(), sol.data());
       spmv(*cur, sol.data(), tmp.data());
-#pragma omp parallel for schedule(static) reduction(+ : nb, nr)
-      for (int64_t i = 0; i < n; i++) { nb += rnd[i] * rnd[i]; double d = tmp[i] - rnd[i]; nr += d * d; }
+      const double nb = det_sum(0, n, [&](int64_t i) { return rnd[i] * rnd[i]; });
+      const double nr = det_sum(0, n, [&](int64_t i) { const double d = tmp[i] - rnd[i]; return d * d; });
       if (std::sqrt(nr) / std::sqrt(nb) < o.auto_truncate_tol) { auto_truncated = true; H->coarse_inv = std::move(cop); }
       H->timers[7] += now_s() - t0;
     }
@@ -203,7 +202,7 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o) {
     t0 = now_s();
     {
       SpgemmDrop d; d.enabled = true; d.tol = o.r_drop; d.negate = true;
-      L.Z = spgemm(L.A_cf, *Mz, d);
+      L.Z = accel ? accel->spgemm(L.A_cf, *Mz, d) : spgemm(L.A_cf, *Mz, d);
     }
     Mz_store = Csr();
     inv_asm = InvOp();
@@ -215,12 +214,13 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o) {
     Csr coarse;
     {
       Csr P = build_P(L);
-      Csr AP = spgemm(*cur, P);
-      P = Csr();
       Csr R = build_R(L.Z, L.F, L.C, n);
       SpgemmDrop d; d.enabled = true; d.tol = o.a_drop; d.lump = o.a_lump;
-      coarse = spgemm(R, AP, d);      // drop / lump fused into the product (timer: RAP)
-      AP = Csr(); R = Csr();
+      if (accel) coarse = accel->rap(R, *cur, P, d);
+      else {
+        Csr AP = spgemm(*cur, P);
+        coarse = spgemm(R, AP, d);      // drop / lump fused into the product (timer: RAP)
+      }
       H->timers[5] += now_s() - t0;
     }
     if (!any_c) { /* A_cf is only needed again for C smoothing; keep it anyway for export */ }

@@ -101,6 +101,29 @@ inline void exclusive_scan(const int64_t* counts, int64_t m, int64_t* rp) {
   rp[m] = part[nt];
 }
 
+// Deterministic parallel sum of term(i), i in [lo, hi): fixed 8192-element blocks are summed
+// independently and the block partials are added in block order, so the result depends neither
+// on the thread count nor on scheduling (an OpenMP reduction clause combines the per-thread
+// partials in arrival order).  The setup must be reproducible bit for bit: 1-ulp changes of the
+// polynomial coefficients flip ties in the next level's CF splitting.
+template <class F>
+inline double det_sum(int64_t lo, int64_t hi, F term) {
+  const int64_t B = 8192;
+  const int64_t nb = hi > lo ? (hi - lo + B - 1) / B : 0;
+  if (nb <= 1) { double s = 0.0; for (int64_t i = lo; i < hi; i++) s += term(i); return s; }
+  std::vector<double> part((size_t)nb);
+#pragma omp parallel for schedule(static)
+  for (int64_t b = 0; b < nb; b++) {
+    const int64_t a = lo + b * B, e = std::min(hi, a + B);
+    double s = 0.0;
+    for (int64_t i = a; i < e; i++) s += term(i);
+    part[(size_t)b] = s;
+  }
+  double s = 0.0;
+  for (int64_t b = 0; b < nb; b++) s += part[(size_t)b];
+  return s;
+}
+
 // ---------------------------------------------------------------------------------------
 // Counter-based random numbers (documented replacement for the reference's Fortran
 // random_number streams, src/Gmres_Poly.F90:189-208, src/PMISR_Module.F90:207-222).

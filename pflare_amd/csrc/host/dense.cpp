@@ -216,9 +216,7 @@ Dense tall_qr_R(std::vector<Arr<double>>& cols, int64_t n) {
   Dense R(k, k);
   for (int j = 0; j < k && j < n; j++) {
     double* aj = cols[j].data();
-    double nrm2 = 0.0;
-#pragma omp parallel for schedule(static) reduction(+ : nrm2)
-    for (int64_t i = j; i < n; i++) nrm2 += aj[i] * aj[i];
+    const double nrm2 = det_sum(j, n, [&](int64_t i) { return aj[i] * aj[i]; });
     double nrm = std::sqrt(nrm2);
     for (int i = 0; i < j; i++) R(i, j) = aj[i];
     if (nrm == 0.0) { R(j, j) = 0.0; continue; }
@@ -230,9 +228,7 @@ Dense tall_qr_R(std::vector<Arr<double>>& cols, int64_t n) {
     if (vnorm2 == 0.0) continue;
     for (int c = j + 1; c < k; c++) {
       double* ac = cols[c].data();
-      double s = 0.0;
-#pragma omp parallel for schedule(static) reduction(+ : s)
-      for (int64_t i = j + 1; i < n; i++) s += aj[i] * ac[i];
+      double s = det_sum(j + 1, n, [&](int64_t i) { return aj[i] * ac[i]; });
       s += v0 * ac[j];
       s = 2.0 * s / vnorm2;
       ac[j] -= s * v0;

@@ -13,10 +13,7 @@ namespace airhip {
 // vector helpers
 // ---------------------------------------------------------------------------------------
 static double vdot(const double* a, const double* b, int64_t n) {
-  double s = 0.0;
-#pragma omp parallel for schedule(static) reduction(+ : s)
-  for (int64_t i = 0; i < n; i++) s += a[i] * b[i];
-  return s;
+  return det_sum(0, n, [&](int64_t i) { return a[i] * b[i]; });
 }
 static double vnorm(const double* a, int64_t n) { return std::sqrt(vdot(a, a, n)); }
 

@@ -42,6 +42,17 @@ void split_fc(const Csr& A, const int32_t* markers, const int32_t* newidx,
 struct SpgemmDrop { bool enabled = false; double tol = 0.0; bool lump = false; bool negate = false; };
 Csr spgemm(const Csr& A, const Csr& B, const SpgemmDrop& drop = SpgemmDrop());
 
+// Optional accelerator for the sparse products of the setup (implemented on the device in
+// device/setup_accel.cpp).  Results must be bit-identical to spgemm() above.
+struct SetupAccel {
+  virtual ~SetupAccel() = default;
+  virtual Csr spgemm(const Csr& A, const Csr& B, const SpgemmDrop& drop) = 0;
+  // filter(R * (A * P)); the implementation may keep the result resident and recognise it when
+  // it comes back as the A of the next level
+  virtual Csr rap(const Csr& R, const Csr& A, const Csr& P, const SpgemmDrop& drop) = 0;
+  double t_transfer = 0.0, t_compute = 0.0;
+};
+
 void spmv(const Csr& A, const double* x, double* y);
 // y = (A x) ./ d
 void spmv_dscale(const Csr& A, const double* d, const double* x, double* y);

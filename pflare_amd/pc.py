@@ -355,8 +355,10 @@ class PCAIR:
             name = C.c_char_p(); lvl = C.c_int(); by = C.c_double(); calls = C.c_int64(); ms = C.c_double()
             check(lib().airhip_pcair_profile_get(self._h, i, C.byref(name), C.byref(lvl), C.byref(by), C.byref(calls),
                                                  C.byref(ms)))
+            kern = C.c_char_p()
+            check(lib().airhip_pcair_profile_kernel(self._h, i, C.byref(kern)))
             out.append(dict(name=name.value.decode(), level=lvl.value, alg_bytes=by.value, calls=calls.value,
-                            total_ms=ms.value))
+                            total_ms=ms.value, kernel=(kern.value or b"").decode()))
         return out
 
     def __del__(self):

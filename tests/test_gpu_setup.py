@@ -1,0 +1,116 @@
+"""GPU parity of the setup products: the device SpGEMM with fused drop / lump (csrc/device/
+spgemm.hip) must be BIT-IDENTICAL to the host SpGEMM (csrc/host/spops.cpp), and a hierarchy
+built with the products on the device must be bit-identical to the host-only setup (which
+tests/test_host_setup.py checks against the oracle).  Exactness matters: the CF splitting
+of the next level flips on 1-ulp differences of the coarse operator."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+def _spgemm(P, A, B, drop=False, tol=0.0, lump=False, negate=False, on_device=True):
+    lib = P.lib()
+    fn = lib.airhip_debug_spgemm
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    a, b = P.as_csr(A), P.as_csr(B)
+    h = C.c_void_p()
+    stats = (C.c_int64 * 3)()
+    rc = fn(a.ref(), b.ref(), int(drop), float(tol), int(lump), int(negate), int(on_device), C.byref(h), stats)
+    assert rc == 0, P.lib().airhip_last_error().decode()
+    out = P.HostMat(h).csr()
+    return out, [int(s) for s in stats]
+
+
+def _rand(m, n, per_row, seed, diag=False):
+    rng = np.random.default_rng(seed)
+    rows = np.repeat(np.arange(m), per_row)
+    cols = rng.integers(0, n, size=m * per_row)
+    vals = rng.standard_normal(m * per_row) * 10.0 ** rng.integers(-4, 2, size=m * per_row)
+    A = sp.csr_matrix((vals, (rows, cols)), shape=(m, n))
+    if diag:
+        A = A + sp.eye(m, n, format="csr") * 3.0
+    A.sum_duplicates()
+    A.sort_indices()
+    return A.tocsr()
+
+
+def _same(c, d, what=""):
+    assert c.shape == d.shape, what
+    assert np.array_equal(c.rowptr, d.rowptr), what
+    assert np.array_equal(c.col, d.col), what
+    bad = np.flatnonzero(c.val != d.val)          # bitwise
+    assert bad.size == 0, (what, bad.size, c.val.size, bad[:5], c.val[bad[:5]], d.val[bad[:5]],
+                           float(np.max(np.abs(c.val[bad] - d.val[bad]))))
+
+
+SPGEMM_CASES = [
+    # m, k, n, nnz/row A, nnz/row B, expected path index with rows (0 small, 1 big, 2 global)
+    (500, 400, 600, 5, 6, 0),
+    (300, 300, 300, 40, 40, 1),
+    (64, 3000, 40000, 300, 30, 2),
+]
+
+
+@pytest.mark.parametrize("m,k,n,pa,pb,path", SPGEMM_CASES)
+@pytest.mark.parametrize("mode", ["plain", "drop", "drop_lump", "drop_negate"])
+def test_device_spgemm_bitwise(gpu, m, k, n, pa, pb, path, mode):
+    import pflare_amd as P
+    A = _rand(m, k, pa, 1)
+    B = _rand(k, n, pb, 2, diag=(k == n))
+    kw = dict(plain={}, drop=dict(drop=True, tol=1e-2), drop_lump=dict(drop=True, tol=5e-2, lump=True),
+              drop_negate=dict(drop=True, tol=1e-3, negate=True))[mode]
+    href, _ = _spgemm(P, A, B, on_device=False, **kw)
+    dev, stats = _spgemm(P, A, B, on_device=True, **kw)
+    assert stats[path] > 0, stats
+    _same(dev, href)
+    if mode == "plain":
+        ref = (A @ B).tocsr()
+        ref.sort_indices()
+        assert np.array_equal(ref.indptr, dev.rowptr) and np.array_equal(ref.indices, dev.col)
+        np.testing.assert_allclose(dev.val, ref.data, rtol=1e-12, atol=1e-12)
+
+
+def test_device_spgemm_empty_rows_and_diagonal_creation(gpu):
+    import pflare_amd as P
+    # rows without entries, and rows whose diagonal only exists through lumping
+    A = sp.csr_matrix(np.array([[0, 0, 0, 0], [1e-6, 0, 2.0, 0], [0, 0, 0, 0], [1.0, 1e-9, 0, 0.5]]))
+    B = sp.identity(4, format="csr")
+    for kw in (dict(drop=True, tol=1e-3, lump=True), dict(drop=True, tol=1e-3), {}):
+        href, _ = _spgemm(P, A, B, on_device=False, **kw)
+        dev, _ = _spgemm(P, A, B, on_device=True, **kw)
+        _same(dev, href)
+
+
+SETUP_CASES = {
+    "adv2d_60": (dict(dim=2, M=60, N=60), {}),
+    "adv3d_20_lump": (dict(dim=3, M=20, N=20, P=20), dict(a_lump=True)),
+    "diff2d_40": (dict(dim=2, M=40, N=40, u=0, v=0, alpha=1.0), {}),
+    "advdiff2d_50_order4": (dict(dim=2, M=50, N=50, alpha=0.1), dict(poly_order=4, inverse_sparsity_order=2)),
+    "adv2d_40_fcf": (dict(dim=2, M=40, N=40), dict(smooth_type="fcf", a_lump=True, a_drop=1e-5)),
+}
+
+
+@pytest.mark.parametrize("case", sorted(SETUP_CASES))
+def test_device_setup_equals_host_setup(gpu, case):
+    import pflare_amd as P
+    gen, opts = SETUP_CASES[case]
+    A = P.HostMat.adv_diff_fd(**gen)
+    pd = P.PCAIR(**opts)
+    pd.set_option("setup_device_min_nnz", 0)
+    pd.setup(A)
+    ph = P.PCAIR(**opts)
+    ph.setup_host_only(A)
+    assert pd.num_levels == ph.num_levels
+    for lv in range(pd.num_levels - 1):
+        d, h = pd.export_level(lv), ph.export_level(lv)
+        assert np.array_equal(d["F"], h["F"]) and np.array_equal(d["C"], h["C"])
+        for k in ("Z", "A_fc", "A_cf", "A_ff"):
+            if k in h:
+                _same(d[k], h[k], f"level {lv} {k}")
+    (Ad, _), (Ah, _) = pd.export_coarse(), ph.export_coarse()
+    _same(Ad, Ah, "coarse")

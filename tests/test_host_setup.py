@@ -188,3 +188,33 @@ def test_auto_truncation_and_options():
         P.PCAIR(smooth_type="fxc")
     with pytest.raises(P.AirhipError):
         P.PCAIR(z_type="lair")
+
+
+def test_host_setup_is_bitwise_reproducible_across_thread_counts():
+    """Reductions in the setup use fixed-block deterministic sums (csrc/host/common.hpp det_sum):
+    the hierarchy must not depend on the number of OpenMP threads or on scheduling."""
+    import ctypes as C
+    import pflare_amd as P
+    A = P.HostMat.adv_diff_fd(dim=2, M=70, N=70, alpha=0.05)
+    prev = C.c_int()
+    outs = []
+    try:
+        for nt in (1, 3, 8):
+            P.lib().airhip_set_num_threads(nt, C.byref(prev) if nt == 1 else None)
+            pc = P.PCAIR(a_lump=True)
+            pc.setup_host_only(A)
+            lv = [pc.export_level(i) for i in range(pc.num_levels - 1)]
+            outs.append((pc.num_levels, lv, pc.export_coarse()))
+    finally:
+        P.lib().airhip_set_num_threads(max(1, prev.value), None)
+    n0, l0, (c0, i0) = outs[0]
+    for n1, l1, (c1, i1) in outs[1:]:
+        assert n1 == n0
+        for a, b in zip(l0, l1):
+            for k in ("Z", "A_ff", "A_fc", "A_cf"):
+                if k in a:
+                    assert np.array_equal(a[k].rowptr, b[k].rowptr) and np.array_equal(a[k].col, b[k].col)
+                    assert np.array_equal(a[k].val, b[k].val), k
+            if "mat" in a["inv_ff"]:
+                assert np.array_equal(a["inv_ff"]["mat"].val, b["inv_ff"]["mat"].val)
+        assert np.array_equal(c0.val, c1.val)
