@@ -168,6 +168,46 @@ int airhip_pcair_profile_get(airhip_pcair pc, int i, const char** name, int* lev
 /* name of the HIP kernel function record i launches (the name a rocprofv3 kernel trace shows) */
 int airhip_pcair_profile_kernel(airhip_pcair pc, int i, const char** kernel);
 
+/* ---------------------------------------------------------------------- multi-GPU (8e)
+ * Row-block distribution, one process per GPU - the reference's MPIAIJ model (rank-owned rows,
+ * off-process columns fetched before each product; src/PMISR_Module.F90:174-180,
+ * src/Grid_Transfer.F90:656-668; coarse rows stay with their parent C point, :745-746).
+ * One rank builds the hierarchy (option "device_upload" = "0" keeps it on the host), cuts it
+ * with airhip_partition_*, and ships each rank its piece as an archive of named flat arrays
+ * (the transport is the caller's: torch.distributed in bench.py).  Every rank then calls
+ * airhip_pcair_load_distributed; apply / ksp_solve work on the rank's rows (natural order of
+ * its owned rows, ascending global index) and are collective. */
+typedef struct airhip_partition_s* airhip_partition;
+typedef struct airhip_archive_s* airhip_archive;
+typedef struct airhip_comm_s* airhip_comm;
+#define AIRHIP_I32 0
+#define AIRHIP_I64 1
+#define AIRHIP_F64 2
+/* owner[i] in [0,nranks): the rank owning fine row i.  A_top must stay valid until destroy. */
+int airhip_partition_create(airhip_pcair pc, const airhip_csr* A_top, int nranks, const int32_t* owner,
+                            airhip_partition* out);
+int airhip_partition_extract(airhip_partition p, int rank, airhip_archive* piece);
+int airhip_partition_destroy(airhip_partition* p);
+int airhip_archive_create(airhip_archive* out);
+/* adds a view of caller memory (must outlive the archive's use) */
+int airhip_archive_add(airhip_archive ar, const char* name, int dtype, const void* data, int64_t count);
+int airhip_archive_count(airhip_archive ar, int* n);
+int airhip_archive_item(airhip_archive ar, int i, const char** name, int* dtype, const void** data, int64_t* count);
+int airhip_archive_destroy(airhip_archive* ar);
+/* transports of the halo exchange: RCCL (device buffers, xGMI; unique id from rank 0, broadcast
+ * by the caller) or host-staged callbacks (MPI in a host application; several ranks per GPU). */
+typedef int (*airhip_exchange_fn)(void* user, int npeers, const int* peers, const double* send,
+                                  const int64_t* send_off, double* recv, const int64_t* recv_off);
+typedef int (*airhip_allreduce_fn)(void* user, double* vals, int n); /* in-place sum over ranks */
+int airhip_comm_rccl_unique_id(void* out128);
+int airhip_comm_create_rccl(int rank, int size, const void* unique_id128, airhip_comm* out);
+int airhip_comm_create_staged(int rank, int size, airhip_exchange_fn ex, airhip_allreduce_fn ar, void* user,
+                              airhip_comm* out);
+int airhip_comm_stats(airhip_comm c, int64_t* exchanges, int64_t* allreduces);
+int airhip_comm_destroy(airhip_comm* c);
+/* the communicator must outlive the PCAIR object */
+int airhip_pcair_load_distributed(airhip_pcair pc, airhip_archive piece, airhip_comm comm);
+
 /* ------------------------------------------------------------------------ PCPFLAREINV */
 int airhip_pcinv_create(airhip_pcinv* pc);
 /* names: "type" (power|arnoldi|newton|neumann|wjacobi|jacobi), "poly_order", "sparsity_order",

@@ -45,7 +45,15 @@ DECLARED_SYMBOLS = [
     "airhip_pcinv_sync", "airhip_pcinv_get_inv", "airhip_pcinv_destroy",
     "airhip_mat_create", "airhip_mat_mult", "airhip_mat_destroy",
     "airhip_ksp_default_options", "airhip_ksp_solve",
+    "airhip_partition_create", "airhip_partition_extract", "airhip_partition_destroy",
+    "airhip_archive_create", "airhip_archive_add", "airhip_archive_count", "airhip_archive_item",
+    "airhip_archive_destroy", "airhip_comm_rccl_unique_id", "airhip_comm_create_rccl",
+    "airhip_comm_create_staged", "airhip_comm_stats", "airhip_comm_destroy", "airhip_pcair_load_distributed",
 ]
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double),
+                          C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64))
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
 
 _lib = None
 
@@ -119,6 +127,20 @@ def lib():
         "airhip_ksp_default_options": [C.POINTER(airhip_ksp_options)],
         "airhip_ksp_solve": [C.POINTER(airhip_ksp_options), vp, vp, vp, vp, vp, C.POINTER(airhip_ksp_result), pd,
                              C.c_int, pint],
+        "airhip_partition_create": [vp, pcsr, C.c_int, pi32, pvp],
+        "airhip_partition_extract": [vp, C.c_int, pvp],
+        "airhip_partition_destroy": [pvp],
+        "airhip_archive_create": [pvp],
+        "airhip_archive_add": [vp, C.c_char_p, C.c_int, vp, C.c_int64],
+        "airhip_archive_count": [vp, pint],
+        "airhip_archive_item": [vp, C.c_int, C.POINTER(C.c_char_p), pint, pvp, pi64],
+        "airhip_archive_destroy": [pvp],
+        "airhip_comm_rccl_unique_id": [vp],
+        "airhip_comm_create_rccl": [C.c_int, C.c_int, vp, pvp],
+        "airhip_comm_create_staged": [C.c_int, C.c_int, EXCHANGE_FN, ALLREDUCE_FN, vp, pvp],
+        "airhip_comm_stats": [vp, pi64, pi64],
+        "airhip_comm_destroy": [pvp],
+        "airhip_pcair_load_distributed": [vp, vp, vp],
     }
     for name, args in sig.items():
         f = getattr(L, name)

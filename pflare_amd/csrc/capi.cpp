@@ -4,6 +4,8 @@
 #include "device/pcair_dev.hpp"
 #include "device/setup_accel.hpp"
 #include "device/spgemm.hpp"
+#include "device/comm.hpp"
+#include "host/dist.hpp"
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -163,6 +165,8 @@ struct airhip_pcair_s {
   double op_nnz_top = 0;
   bool setup_on_device = true;    // sparse products of the setup as HIP SpGEMMs
   int64_t setup_device_min_nnz = -1;
+  bool device_upload = true;      // false: keep the hierarchy on the host only (it will be partitioned)
+  std::unique_ptr<LocalHierarchy> local;   // distributed: this rank's piece (views into `piece`)
   double accel_transfer_s = 0, accel_compute_s = 0;
 };
 
@@ -221,6 +225,7 @@ int airhip_pcair_set_option(airhip_pcair pc, const char* name, const char* value
   else if (k == "seed") o.seed = (uint64_t)std::atoll(v);
   else if (k == "setup_on_device") pc->setup_on_device = parse_bool(v);
   else if (k == "setup_device_min_nnz") pc->setup_device_min_nnz = std::atoll(v);
+  else if (k == "device_upload") pc->device_upload = parse_bool(v);
   else if (k == "processor_agglom" || k == "subcomm" || k == "coarsest_subcomm") { /* no-ops on one device */ }
   else if (k == "symmetric" || k == "z_type" || k == "cf_splitting_type" || k == "full_smoothing_up_and_down" ||
            k == "constrain_z" || k == "constrain_w" || k == "improve_z_its" || k == "improve_w_its" ||
@@ -269,7 +274,8 @@ int airhip_pcair_setup(airhip_pcair pc, const airhip_csr* A) {
   }
   pc->host_setup_s = now_s() - t0;
   pc->byo = false;
-  finish_device(pc);
+  pc->op_nnz_top = (double)pc->A_top.nnz();
+  if (pc->device_upload) finish_device(pc);
   pc->A_top = Csr();   // drop the view of the caller's arrays
   API_END
 }
@@ -599,6 +605,126 @@ int airhip_pcair_profile_kernel(airhip_pcair pc, int i, const char** kernel) {
   API_END
 }
 
+// ------------------------------------------------------------------------ distribution
+struct airhip_archive_s { Archive ar; };
+struct airhip_partition_s { std::unique_ptr<Partitioner> p; Csr A_view; };
+struct airhip_comm_s { std::unique_ptr<Comm> c; };
+
+int airhip_partition_create(airhip_pcair pc, const airhip_csr* A_top, int nranks, const int32_t* owner, airhip_partition* out) {
+  API_BEGIN
+  REQUIRE(pc && pc->H && A_top && owner && out && nranks >= 1, AIRHIP_ERR_ARG, "partitioning needs a PCAIR with its host hierarchy");
+  REQUIRE(!pc->H->levels.empty() || true, AIRHIP_ERR_STATE, "");
+  auto* h = new airhip_partition_s;
+  view_csr(A_top, h->A_view);
+  try { h->p = std::make_unique<Partitioner>(*pc->H, h->A_view, nranks, owner); } catch (...) { delete h; throw; }
+  *out = h;
+  API_END
+}
+int airhip_partition_extract(airhip_partition p, int rank, airhip_archive* out) {
+  API_BEGIN
+  REQUIRE(p && out, AIRHIP_ERR_ARG, "null argument");
+  auto* a = new airhip_archive_s;
+  try { p->p->extract(rank, a->ar); } catch (...) { delete a; throw; }
+  *out = a;
+  API_END
+}
+int airhip_partition_destroy(airhip_partition* p) {
+  API_BEGIN
+  if (p && *p) { delete *p; *p = nullptr; }
+  API_END
+}
+int airhip_archive_create(airhip_archive* out) {
+  API_BEGIN
+  REQUIRE(out, AIRHIP_ERR_ARG, "null argument");
+  *out = new airhip_archive_s;
+  API_END
+}
+int airhip_archive_add(airhip_archive ar, const char* name, int dtype, const void* data, int64_t count) {
+  API_BEGIN
+  REQUIRE(ar && name && count >= 0 && dtype >= 0 && dtype <= 2, AIRHIP_ERR_ARG, "bad archive item");
+  ar->ar.add_view(name, dtype, data, count);
+  API_END
+}
+int airhip_archive_count(airhip_archive ar, int* n) {
+  API_BEGIN
+  REQUIRE(ar && n, AIRHIP_ERR_ARG, "null argument");
+  *n = (int)ar->ar.items.size();
+  API_END
+}
+int airhip_archive_item(airhip_archive ar, int i, const char** name, int* dtype, const void** data, int64_t* count) {
+  API_BEGIN
+  REQUIRE(ar && i >= 0 && i < (int)ar->ar.items.size(), AIRHIP_ERR_ARG, "index out of range");
+  const auto& it = ar->ar.items[i];
+  if (name) *name = it.name.c_str();
+  if (dtype) *dtype = it.dtype;
+  if (data) *data = it.ptr;
+  if (count) *count = it.count;
+  API_END
+}
+int airhip_archive_destroy(airhip_archive* ar) {
+  API_BEGIN
+  if (ar && *ar) { delete *ar; *ar = nullptr; }
+  API_END
+}
+
+int airhip_comm_rccl_unique_id(void* out128) {
+  API_BEGIN
+  REQUIRE(out128, AIRHIP_ERR_ARG, "null argument");
+  rccl_unique_id(out128);
+  API_END
+}
+int airhip_comm_create_rccl(int rank, int size, const void* unique_id128, airhip_comm* out) {
+  API_BEGIN
+  REQUIRE(out && unique_id128 && size >= 1 && rank >= 0 && rank < size, AIRHIP_ERR_ARG, "bad communicator arguments");
+  auto* c = new airhip_comm_s;
+  try { c->c = make_rccl_comm(rank, size, unique_id128); } catch (...) { delete c; throw; }
+  *out = c;
+  API_END
+}
+int airhip_comm_create_staged(int rank, int size, airhip_exchange_fn ex, airhip_allreduce_fn ar, void* user, airhip_comm* out) {
+  API_BEGIN
+  REQUIRE(out && ex && ar && size >= 1 && rank >= 0 && rank < size, AIRHIP_ERR_ARG, "bad communicator arguments");
+  auto* c = new airhip_comm_s;
+  c->c = make_staged_comm(rank, size, (exchange_cb)ex, (allreduce_cb)ar, user);
+  *out = c;
+  API_END
+}
+int airhip_comm_stats(airhip_comm c, int64_t* exchanges, int64_t* allreduces) {
+  API_BEGIN
+  REQUIRE(c, AIRHIP_ERR_ARG, "null argument");
+  if (exchanges) *exchanges = c->c->n_exchanges;
+  if (allreduces) *allreduces = c->c->n_allreduces;
+  API_END
+}
+int airhip_comm_destroy(airhip_comm* c) {
+  API_BEGIN
+  if (c && *c) { delete *c; *c = nullptr; }
+  API_END
+}
+
+// This rank's piece -> device.  The archive's arrays are only read during the call.
+int airhip_pcair_load_distributed(airhip_pcair pc, airhip_archive piece, airhip_comm comm) {
+  API_BEGIN
+  REQUIRE(pc && piece && comm, AIRHIP_ERR_ARG, "null argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    g_err = "no HIP device: the PCAIR solve phase has no CPU fallback"; return AIRHIP_ERR_HIP;
+  }
+  pc->dev.reset(); pc->H.reset(); pc->ksp.reset(); pc->kb.release(); pc->kx.release();
+  auto loc = std::make_unique<LocalHierarchy>();
+  load_local(piece->ar, *loc);
+  REQUIRE(loc->nranks == comm->c->size && loc->rank == comm->c->rank, AIRHIP_ERR_ARG, "piece does not belong to this rank");
+  double t0 = now_s();
+  pc->dev = std::make_unique<DevPCAIR>();
+  pc->dev->upload(loc->H, loc->A_top, loc.get(), comm->c.get());
+  pc->dev->set_use_graph(false);
+  pc->dev->set_profile(pc->profile);
+  pc->upload_s = now_s() - t0;
+  pc->op_nnz_top = (double)loc->A_top.nnz();
+  pc->byo = false;
+  API_END
+}
+
 // ------------------------------------------------------------------------ PCPFLAREINV
 // A PCPFLAREINV is a PCAIR hierarchy with no levels whose "coarse solver" is the
 // approximate inverse of the whole operator (PCApply_PFLAREINV_c = one MatMult with it).
@@ -739,7 +865,7 @@ int airhip_ksp_solve(const airhip_ksp_options* o, airhip_mat A, airhip_pcair pca
     if (!pc->ksp) { pc->ksp = std::make_unique<DevKSP>(n); pc->kb.alloc(n); pc->kx.alloc(n); }
     dev.to_permuted(d_b, pc->kb.p);
     dev.to_permuted(d_x, pc->kx.p);
-    KspOperator op; op.A = &dev.A_perm(); op.stream = dev.stream();
+    KspOperator op; op.A = &dev.A_perm(); op.stream = dev.stream(); op.comm = dev.comm();
     op.pc = [&dev](const double* in, double* out) { dev.apply_permuted(in, out); };
     op.mult = [&dev](const double* x, const SpmvEpi& e) { dev.spmv(dev.A_perm(), x, e, "outer A*x (Krylov)", -1); };
     r = pc->ksp->solve(op, ko, pc->kb.p, pc->kx.p);

@@ -23,7 +23,9 @@ namespace airhip {
 // lane sums the LDS segment of "its" rows in column order (CSR-stream); blocks dominated by
 // a long row fall back to a wave-wide reduction per row (CSR-vector).
 struct DevMat {
-  int64_t m = 0, n = 0;          // rows, cols
+  int64_t m = 0, n = 0;          // rows, cols (n includes the ghost columns of a distributed operand)
+  int64_t n_ghost = 0;           // distributed operand: columns [n - n_ghost, n) are ghost values
+  struct HaloPlan* halo = nullptr;   // how to obtain them (not owned)
   int64_t nnz = 0;
   int64_t nblocks = 0;
   int32_t* blk_row = nullptr;    // [nblocks+1] first row of each block
@@ -47,14 +49,16 @@ struct SpmvEpi {
   double* y2 = nullptr; const double* w2 = nullptr; double delta = 0.0; int aux_out = 0;
 };
 
-void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t s);
+// x_ghost: the received ghost values of a distributed operand (A.n_ghost entries), else null
+void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t s, const double* x_ghost = nullptr);
 
 // Fused first stage of an F-point relaxation with a one-point prolongator:
 //   acc = (A_fc x_c)_i ; t4 = b_f_i - acc ; x0 = x_c[wcol_i] (0 if wcol_i < 0)
 //   diag mode (aff_d, minv != null):  x_f_i = x0 + minv_i * (t4 - aff_d_i * x0)
 //   split mode                     :  t4_out_i = t4 ; x_f_i = x0
 void launch_fc_first(const DevMat& A_fc, const int32_t* wcol, const double* b_f, const double* x_c,
-                     const double* aff_d, const double* minv, double* t4_out, double* x_f, hipStream_t s);
+                     const double* aff_d, const double* minv, double* t4_out, double* x_f, hipStream_t s,
+                     const double* x_ghost = nullptr);
 
 // vector kernels (n elements)
 void launch_axpby(int64_t n, double a, const double* x, double b, const double* y, double* out, hipStream_t s);  // out = a x + b y
@@ -73,7 +77,8 @@ int mdot_scratch_doubles(int nv);
 // CSR (device) -> row-block CSR conversion.  rowsrc (may be null): destination row r takes source
 // row rowsrc[r]; colmap (may be null): column c becomes colmap[c].
 void devmat_from_csr_device(int64_t m, int64_t n, const int64_t* d_rp, const int32_t* d_ci, const double* d_v,
-                          const int32_t* d_rowsrc, const int32_t* d_colmap, DevMat& out, hipStream_t s);
+                          const int32_t* d_rowsrc, const int32_t* d_colmap, DevMat& out, hipStream_t s,
+                          int64_t n_ghost = 0);   // the last n_ghost columns are not remapped
 void devmat_free(DevMat& A);
 
 #define HIP_CHECK(expr)                                                                       \

@@ -31,17 +31,24 @@ DevKSP::DevKSP(int64_t n) : n_(n) {
   ddots_.alloc(64); dcoef_.alloc(64);
 }
 
+// dots of the local parts land in ddots_; summed over the ranks when distributed
+void DevKSP::fetch_dots(double* host, int n, hipStream_t s) {
+  if (comm_ && comm_->size > 1) { comm_->allreduce_sum(ddots_.p, host, n, s); return; }
+  HIP_CHECK(hipMemcpyAsync(host, ddots_.p, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+}
+
 double DevKSP::norm2(const double* v, hipStream_t s) {
   launch_mdot(n_, v, v, 0, 1, scratch_.p, ddots_.p, s);
   double h = 0.0;
-  HIP_CHECK(hipMemcpyAsync(&h, ddots_.p, sizeof(double), hipMemcpyDeviceToHost, s));
-  HIP_CHECK(hipStreamSynchronize(s));
+  fetch_dots(&h, 1, s);
   return std::sqrt(h);
 }
 
 KspResult DevKSP::solve(const KspOperator& op, const KspOptions& o, const double* d_b, double* d_x) {
   hipEvent_t e0, e1;
   HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+  comm_ = op.comm;
   HIP_CHECK(hipStreamSynchronize(op.stream));
   HIP_CHECK(hipEventRecord(e0, op.stream));
   KspResult r = (o.type == 0) ? richardson(op, o, d_b, d_x) : gmres(op, o, d_b, d_x);
@@ -142,8 +149,7 @@ KspResult DevKSP::gmres(const KspOperator& op, const KspOptions& o, const double
       else { SpmvEpi e; e.out = t_.p; op_mult(op, Vk(it), e); apply_pc(t_.p, w); }
       // classical Gram-Schmidt: one multi-dot, one multi-axpy
       launch_mdot(n_, w, V_.p, n_, it + 1, scratch_.p, ddots_.p, s);
-      HIP_CHECK(hipMemcpyAsync(lhh.data(), ddots_.p, sizeof(double) * (it + 1), hipMemcpyDeviceToHost, s));
-      HIP_CHECK(hipStreamSynchronize(s));
+      fetch_dots(lhh.data(), it + 1, s);
       for (int j = 0; j <= it; j++) { H(j, it) = lhh[j]; nrs[j] = -lhh[j]; }
       HIP_CHECK(hipMemcpyAsync(dcoef_.p, nrs.data(), sizeof(double) * (it + 1), hipMemcpyHostToDevice, s));
       launch_maxpy(n_, w, V_.p, n_, it + 1, dcoef_.p, s);

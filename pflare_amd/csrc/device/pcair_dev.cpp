@@ -10,12 +10,12 @@
 
 namespace airhip {
 
-void upload_mat(const Csr& A, const int32_t* d_rowsrc, const int32_t* d_colmap, DevMat& out, hipStream_t s) {
+void upload_mat(const Csr& A, const int32_t* d_rowsrc, const int32_t* d_colmap, DevMat& out, hipStream_t s, int64_t n_ghost) {
   DBuf<int64_t> rp; DBuf<int32_t> ci; DBuf<double> v;
   rp.upload(A.rp.data(), A.m + 1);
   ci.upload(A.ci.data(), A.nnz());
   v.upload(A.v.data(), A.nnz());
-  devmat_from_csr_device(A.m, A.n, rp.p, ci.p, v.p, d_rowsrc, d_colmap, out, s);
+  devmat_from_csr_device(A.m, A.n, rp.p, ci.p, v.p, d_rowsrc, d_colmap, out, s, n_ghost);
 }
 
 double DevInv::alg_bytes() const {
@@ -77,17 +77,53 @@ void DevPCAIR::reset_stats() { resolve_events(); for (auto& s : stats_) { s.call
 void DevPCAIR::spmv(const DevMat& A, const double* x, const SpmvEpi& e, const char* name, int level, double bytes_override) {
   int id = -1;
   if (profile_) { id = stat_id(name, level, bytes_override >= 0 ? bytes_override : A.s_bytes()); stats_[id].kernel = "k_rb_spmv"; begin_kernel(id); }
-  launch_spmv(A, x, e, stream_);
+  const double* xg = halo_update(A, x);
+  if (profile_ && id >= 0 && A.halo) begin_kernel(id);   // time the product, not the exchange
+  launch_spmv(A, x, e, stream_, xg);
   if (profile_) end_kernel();
+}
+
+// ---------------------------------------------------------------------------------------
+// distributed operands
+// ---------------------------------------------------------------------------------------
+void DevPCAIR::attach_halo(DevMat& M, const HaloHost* h, const int32_t* host_colmap) {
+  if (!h || !comm_ || !M.valid()) return;
+  auto p = std::make_unique<HaloPlan>();
+  p->peers.assign(h->peers.begin(), h->peers.end());
+  p->send_off = h->send_off; p->recv_off = h->recv_off;
+  if (p->send_off.empty()) { p->send_off.push_back(0); p->recv_off.push_back(0); }
+  p->n_send = p->send_off.back(); p->n_ghost = h->n_ghost;
+  std::vector<int32_t> idx((size_t)p->n_send);
+  for (int64_t i = 0; i < p->n_send; i++) idx[i] = host_colmap ? host_colmap[h->send_idx[i]] : h->send_idx[i];
+  HIP_CHECK(hipMalloc(&p->send_idx, sizeof(int32_t) * (size_t)std::max<int64_t>(p->n_send, 1)));
+  HIP_CHECK(hipMalloc(&p->sendbuf, sizeof(double) * (size_t)std::max<int64_t>(p->n_send, 1)));
+  HIP_CHECK(hipMalloc(&p->recvbuf, sizeof(double) * (size_t)std::max<int64_t>(p->n_ghost, 1)));
+  if (p->n_send) HIP_CHECK(hipMemcpy(p->send_idx, idx.data(), sizeof(int32_t) * (size_t)p->n_send, hipMemcpyHostToDevice));
+  M.halo = p.get();
+  plans_.push_back(std::move(p));
+}
+
+// Every rank calls this for the same operand in the same order (the cycle is SPMD), also when it
+// has nothing to send or receive itself.
+const double* DevPCAIR::halo_update(const DevMat& A, const double* x) {
+  if (!A.halo) return nullptr;
+  HaloPlan& p = *A.halo;
+  if (p.n_send) launch_gather(p.n_send, p.send_idx, x, p.sendbuf, stream_);
+  comm_->exchange(p, stream_);
+  return p.recvbuf;
 }
 
 // ---------------------------------------------------------------------------------------
 // upload
 // ---------------------------------------------------------------------------------------
-void DevPCAIR::upload_inv(const InvOp& h, DevInv& d, const DevMat* Aop, const double* host_diag_of_op) {
+void DevPCAIR::upload_inv(const InvOp& h, DevInv& d, const DevMat* Aop, const double* host_diag_of_op, const HaloHost* halo) {
   d.kind = h.kind; d.coeffs = h.coeffs; d.re = h.re; d.im = h.im;
   d.diag_scale = h.diag_scale; d.neumann = h.neumann; d.spmvs = h.spmvs;
-  if (h.kind == InvOp::ASSEMBLED) { d.n = h.mat.m; upload_mat(h.mat, nullptr, nullptr, d.mat, stream_); }
+  if (h.kind == InvOp::ASSEMBLED) {
+    d.n = h.mat.m;
+    upload_mat(h.mat, nullptr, nullptr, d.mat, stream_, halo ? halo->n_ghost : 0);
+    attach_halo(d.mat, halo, nullptr);
+  }
   else if (h.kind == InvOp::DIAG) { d.n = h.d.size(); d.d.upload(h.d.data(), h.d.size()); }
   else if (h.kind == InvOp::HORNER || h.kind == InvOp::NEWTON) {
     d.Aop = Aop; d.n = Aop->m;
@@ -101,8 +137,12 @@ void DevPCAIR::upload_inv(const InvOp& h, DevInv& d, const DevMat* Aop, const do
   }
 }
 
-void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top) {
+void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy* dist, Comm* comm) {
   const int L = H.no_levels();
+  comm_ = dist ? comm : nullptr;
+  if (dist && !comm) throw std::runtime_error("a distributed hierarchy needs a communicator");
+  plans_.clear();
+  auto ng = [&](const HaloHost* h) -> int64_t { return (dist && h) ? h->n_ghost : 0; };
   n_ = A_top.m;
   any_c_ = H.opt.any_c_smooths();
   coarse_richardson_its_ = H.opt.coarse_richardson_its;
@@ -141,7 +181,8 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top) {
     std::vector<int32_t> ip = inverse(perm[0]);
     perm_.upload(perm[0].data(), n_);
     iperm_.upload(ip.data(), n_);
-    upload_mat(A_top, iperm_.p, perm_.p, A_perm_, stream_);
+    upload_mat(A_top, iperm_.p, perm_.p, A_perm_, stream_, ng(dist ? &dist->h_top : nullptr));
+    attach_halo(A_perm_, dist ? &dist->h_top : nullptr, perm[0].data());
   }
 
   cycle_bytes_ = 0.0;
@@ -157,8 +198,11 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top) {
     pc.upload(perm[l + 1].data(), h.n_c);
     ipc.upload(ipn.data(), h.n_c);
 
-    upload_mat(h.A_fc, nullptr, pc.p, d.A_fc, stream_);           // rows F-order, cols permuted coarse
-    upload_mat(h.Z, ipc.p, nullptr, d.Z, stream_);                 // rows permuted coarse, cols F-order
+    const LevelHalos* hl = dist ? &dist->halos[l] : nullptr;
+    upload_mat(h.A_fc, nullptr, pc.p, d.A_fc, stream_, ng(hl ? &hl->A_fc : nullptr));   // rows F-order, cols permuted coarse
+    attach_halo(d.A_fc, hl ? &hl->A_fc : nullptr, perm[l + 1].data());
+    upload_mat(h.Z, ipc.p, nullptr, d.Z, stream_, ng(hl ? &hl->Z : nullptr));           // rows permuted coarse, cols F-order
+    attach_halo(d.Z, hl ? &hl->Z : nullptr, nullptr);
     std::vector<double> affd_host;
     bool mf = (h.inv_ff.kind == InvOp::HORNER || h.inv_ff.kind == InvOp::NEWTON);
     if (h.aff_diag) {
@@ -169,24 +213,31 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top) {
       }
       affd_host.assign(h.aff_d.data(), h.aff_d.data() + h.n_f);
     } else {
-      upload_mat(h.A_ff, nullptr, nullptr, d.A_ff, stream_);
+      upload_mat(h.A_ff, nullptr, nullptr, d.A_ff, stream_, ng(hl ? &hl->A_ff : nullptr));
+      attach_halo(d.A_ff, hl ? &hl->A_ff : nullptr, nullptr);
       if (mf && h.inv_ff.diag_scale) { affd_host.resize(h.n_f); get_diagonal(h.A_ff, affd_host.data()); }
     }
-    upload_inv(h.inv_ff, d.inv_ff, &d.A_ff, affd_host.empty() ? nullptr : affd_host.data());
+    upload_inv(h.inv_ff, d.inv_ff, &d.A_ff, affd_host.empty() ? nullptr : affd_host.data(), hl ? &hl->M_ff : nullptr);
     if (h.one_point) {
       std::vector<int32_t> wc(h.n_f);
       const int32_t* pn = perm[l + 1].data();
       for (int64_t i = 0; i < h.n_f; i++) wc[i] = h.wcol[i] >= 0 ? pn[h.wcol[i]] : -1;
       d.wcol.upload(wc.data(), h.n_f);
-    } else upload_mat(h.W, nullptr, pc.p, d.W, stream_);
+    } else {
+      upload_mat(h.W, nullptr, pc.p, d.W, stream_, ng(hl ? &hl->W : nullptr));
+      attach_halo(d.W, hl ? &hl->W : nullptr, perm[l + 1].data());
+    }
     d.t4.alloc(h.n_f); d.r.alloc(h.n_f);
     if (any_c_) {
-      upload_mat(h.A_cf, ipc.p, nullptr, d.A_cf, stream_);
-      upload_mat(h.A_cc, ipc.p, pc.p, d.A_cc, stream_);
+      upload_mat(h.A_cf, ipc.p, nullptr, d.A_cf, stream_, ng(hl ? &hl->A_cf : nullptr));
+      attach_halo(d.A_cf, hl ? &hl->A_cf : nullptr, nullptr);
+      upload_mat(h.A_cc, ipc.p, pc.p, d.A_cc, stream_, ng(hl ? &hl->A_cc : nullptr));
+      attach_halo(d.A_cc, hl ? &hl->A_cc : nullptr, perm[l + 1].data());
       // inverse of A_cc lives in the permuted coarse numbering as well
       if (h.inv_cc.kind == InvOp::ASSEMBLED) {
         d.inv_cc.kind = InvOp::ASSEMBLED; d.inv_cc.n = h.n_c;
-        upload_mat(h.inv_cc.mat, ipc.p, pc.p, d.inv_cc.mat, stream_);
+        upload_mat(h.inv_cc.mat, ipc.p, pc.p, d.inv_cc.mat, stream_, ng(hl ? &hl->M_cc : nullptr));
+        attach_halo(d.inv_cc.mat, hl ? &hl->M_cc : nullptr, perm[l + 1].data());
       } else if (h.inv_cc.kind == InvOp::DIAG) {
         std::vector<double> dd(h.n_c);
         for (int64_t j = 0; j < h.n_c; j++) dd[perm[l + 1][j]] = h.inv_cc.d[j];
@@ -218,10 +269,13 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top) {
   // coarse level
   {
     const bool mf = (H.coarse_inv.kind == InvOp::HORNER || H.coarse_inv.kind == InvOp::NEWTON);
-    if (mf || coarse_richardson_its_ > 0) upload_mat(H.coarse_A, nullptr, nullptr, coarse_A_, stream_);
+    if (mf || coarse_richardson_its_ > 0) {
+      upload_mat(H.coarse_A, nullptr, nullptr, coarse_A_, stream_, ng(dist ? &dist->h_coarse_A : nullptr));
+      attach_halo(coarse_A_, dist ? &dist->h_coarse_A : nullptr, nullptr);
+    }
     std::vector<double> dg;
     if (mf && H.coarse_inv.diag_scale) { dg.resize(H.coarse_A.m); get_diagonal(H.coarse_A, dg.data()); }
-    upload_inv(H.coarse_inv, coarse_inv_, &coarse_A_, dg.empty() ? nullptr : dg.data());
+    upload_inv(H.coarse_inv, coarse_inv_, &coarse_A_, dg.empty() ? nullptr : dg.data(), dist ? &dist->h_coarse_M : nullptr);
     coarse_inv_.n = H.coarse_A.m;
     if (coarse_richardson_its_ > 0) coarse_r_.alloc(H.coarse_A.m);
     cycle_bytes_ += coarse_inv_.alg_bytes();
@@ -342,7 +396,9 @@ void DevPCAIR::f_smooths(DevLevel& L, int li, bool first, int its) {
     const bool full = diag_inv && its == 1;
     int id = -1;
     if (profile_) { id = stat_id(full ? "fc_first_diag(A_fc+W)" : "fc_first(A_fc+W)", li, L.A_fc.s_bytes()); stats_[id].kernel = "k_rb_fc_first"; begin_kernel(id); }
-    launch_fc_first(L.A_fc, L.wcol.p, b_f, x_c, full ? L.aff_d.p : nullptr, full ? L.inv_ff.d.p : nullptr, L.t4.p, x_f, stream_);
+    const double* xg = halo_update(L.A_fc, x_c);
+    if (profile_ && L.A_fc.halo) begin_kernel(id);
+    launch_fc_first(L.A_fc, L.wcol.p, b_f, x_c, full ? L.aff_d.p : nullptr, full ? L.inv_ff.d.p : nullptr, L.t4.p, x_f, stream_, xg);
     if (profile_) end_kernel();
     if (full) return;
   } else {
@@ -365,7 +421,10 @@ void DevPCAIR::c_smooths(DevLevel& L, int li, bool first, int its) {
   double* x_f = xvec(li); double* x_c = x_f + L.n_f;
   const double* b_c = bvec(li) + L.n_f;
   if (first) {   // prolongation has not been applied yet
-    if (L.one_point) launch_gather(L.n_f, L.wcol.p, x_c, x_f, stream_);   // wcol < 0 -> 0 (no W entry)
+    if (L.one_point) {
+      if (L.A_fc.halo) throw std::runtime_error("a distributed cycle that starts with C smoothing needs a general W");
+      launch_gather(L.n_f, L.wcol.p, x_c, x_f, stream_);   // wcol < 0 -> 0 (no W entry)
+    }
     else { SpmvEpi e; e.out = x_f; spmv(L.W, x_c, e, "prolong(W)", li); }
   }
   SpmvEpi e; e.out = L.t4c.p; e.alpha = -1.0; e.z = b_c; e.beta = 1.0;
@@ -416,7 +475,7 @@ void DevPCAIR::vcycle() {
 }
 
 void DevPCAIR::run_cycle() {
-  if (want_graph_ && !profile_) {
+  if (want_graph_ && !profile_ && !comm_) {
     if (!graph_exec_) {
       hipGraph_t g;
       HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));

@@ -1,7 +1,9 @@
 // Device-resident PCAIR hierarchy, the V-cycle driver and the outer Krylov solvers.
 #pragma once
 #include "dev.hpp"
+#include "comm.hpp"
 #include "../host/air.hpp"
+#include "../host/dist.hpp"
 #include <map>
 #include <functional>
 #include <memory>
@@ -23,7 +25,7 @@ struct DBuf {
 };
 
 // Upload a host CSR and convert it to SELL-64 on the device (rows/cols optionally permuted).
-void upload_mat(const Csr& A, const int32_t* d_rowsrc, const int32_t* d_colmap, DevMat& out, hipStream_t s);
+void upload_mat(const Csr& A, const int32_t* d_rowsrc, const int32_t* d_colmap, DevMat& out, hipStream_t s, int64_t n_ghost = 0);
 
 struct DevInv {
   InvOp::Kind kind = InvOp::NONE;
@@ -66,7 +68,9 @@ class DevPCAIR {
   DevPCAIR();
   ~DevPCAIR();
   // Build the device hierarchy from a host hierarchy; A_top is the fine operator (natural order).
-  void upload(const Hierarchy& H, const Csr& A_top);
+  // dist / comm: this rank's piece of a row-block distributed hierarchy and its transport.
+  void upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy* dist = nullptr, Comm* comm = nullptr);
+  Comm* comm() const { return comm_; }
   int64_t n() const { return n_; }
   int no_levels() const { return (int)levels_.size() + 1; }
 
@@ -107,7 +111,12 @@ class DevPCAIR {
   int stat_id(const char* name, int level, double bytes);
   void begin_kernel(int stat);
   void end_kernel();
-  void upload_inv(const InvOp& h, DevInv& d, const DevMat* Aop, const double* host_diag_of_op);
+  void upload_inv(const InvOp& h, DevInv& d, const DevMat* Aop, const double* host_diag_of_op, const HaloHost* halo = nullptr);
+  // distributed operands: halo plan creation and the exchange in front of a product
+  void attach_halo(DevMat& M, const HaloHost* h, const int32_t* host_colmap);
+  const double* halo_update(const DevMat& A, const double* x);
+  Comm* comm_ = nullptr;
+  std::vector<std::unique_ptr<HaloPlan>> plans_;
   double* bvec(int l) { return b_ptr_[l]; }
   double* xvec(int l) { return cx_.p + off_[l]; }
 
@@ -152,8 +161,10 @@ struct KspOperator {
   hipStream_t stream = nullptr;
   // z = M r ; null = identity
   std::function<void(const double*, double*)> pc;
-  // optional replacement of launch_spmv(*A, ...) (lets the owner time the outer operator product)
+  // optional replacement of launch_spmv(*A, ...) (lets the owner time the outer operator product;
+  // mandatory for a distributed operator, whose product needs a halo exchange)
   std::function<void(const double*, const SpmvEpi&)> mult;
+  Comm* comm = nullptr;         // distributed: dots and norms are summed over the ranks
 };
 
 class DevKSP {
@@ -163,6 +174,8 @@ class DevKSP {
   KspResult solve(const KspOperator& op, const KspOptions& o, const double* d_b, double* d_x);
  private:
   double norm2(const double* v, hipStream_t s);
+  void fetch_dots(double* host, int n, hipStream_t s);
+  Comm* comm_ = nullptr;
   KspResult richardson(const KspOperator& op, const KspOptions& o, const double* b, double* x);
   KspResult gmres(const KspOperator& op, const KspOptions& o, const double* b, double* x);
   int64_t n_;

@@ -58,14 +58,24 @@ static int grid_for_blocks(int64_t nblocks) {
   return (int)blocks;
 }
 
+// Input vector of an SpMV.  Single device: DIST = false, plain x[c].  Row-block distributed
+// (one rank per GPU): columns < nl index the rank's own segment, columns >= nl the ghost values
+// received from the neighbours (xg is pre-shifted by -nl).
+template <bool DIST> struct XVec {
+  const double* __restrict__ x; const double* __restrict__ xg; int32_t nl;
+  __device__ __forceinline__ double operator[](int32_t c) const {
+    if constexpr (DIST) return c < nl ? x[c] : xg[c]; else return x[c];
+  }
+};
+
 // Calls epi(row, sum_j a_row,j x_j) once for every row of the matrix.
 template <class T, bool NT>
 __device__ __forceinline__ T ldg(const T* p) {
   if constexpr (NT) return __builtin_nontemporal_load(p); else return *p;
 }
 
-template <int CAP, bool NT, int UNR, class Epi>
-__device__ __forceinline__ void rb_rows(const RbView& A, const double* __restrict__ x, double* __restrict__ lds, Epi epi) {
+template <int CAP, bool NT, int UNR, bool DIST, class Epi>
+__device__ __forceinline__ void rb_rows(const RbView& A, const XVec<DIST> x, double* __restrict__ lds, Epi epi) {
   const int lane = threadIdx.x & (WAVE - 1);
   const BlockRange br = my_blocks(A.nblocks);
   for (int64_t b = br.first; b < br.last; b += br.stride) {
@@ -145,11 +155,11 @@ __device__ __forceinline__ void rb_rows(const RbView& A, const double* __restric
   }
 }
 
-template <int CAP, bool NT, int UNR>
-__global__ __launch_bounds__(BLOCK) void k_rb_spmv(RbView A, const double* __restrict__ x, SpmvEpi e) {
+template <int CAP, bool NT, int UNR, bool DIST>
+__global__ __launch_bounds__(BLOCK) void k_rb_spmv(RbView A, XVec<DIST> x, SpmvEpi e) {
   __shared__ double lds_all[WAVES_PER_BLOCK][CAP];
   double* lds = lds_all[threadIdx.x >> 6];
-  rb_rows<CAP, NT, UNR>(A, x, lds, [&](int32_t row, double acc) {
+  rb_rows<CAP, NT, UNR, DIST>(A, x, lds, [&](int32_t row, double acc) {
     if (e.dscale) acc *= e.dscale[row];
     double o = e.alpha * acc;
     if (e.z) o += e.beta * e.z[row];
@@ -166,11 +176,20 @@ __global__ __launch_bounds__(BLOCK) void k_rb_spmv(RbView A, const double* __res
 // bit 2: 8 instead of 4 loads in flight); set through airhip_debug_set_variant
 int g_spmv_variant = 0;
 
-void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t s) {
+void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t s, const double* x_ghost) {
   if (A.m == 0) return;
   const dim3 grid(grid_for_blocks(A.nblocks)), block(BLOCK);
   const RbView v = view_of(A);
-#define RB_LAUNCH(CAP, NT, UNR) hipLaunchKernelGGL((k_rb_spmv<CAP, NT, UNR>), grid, block, 0, s, v, x, e)
+  if (A.n_ghost > 0) {
+    // distributed operand: ghost columns start at A.n - A.n_ghost
+    if (!x_ghost) throw std::runtime_error("launch_spmv: distributed operand without ghost values");
+    const int32_t nl = (int32_t)(A.n - A.n_ghost);
+    const XVec<true> xv{x, x_ghost - nl, nl};
+    hipLaunchKernelGGL((k_rb_spmv<1024, false, 4, true>), grid, block, 0, s, v, xv, e);
+    return;
+  }
+  const XVec<false> xv{x, nullptr, 0};
+#define RB_LAUNCH(CAP, NT, UNR) hipLaunchKernelGGL((k_rb_spmv<CAP, NT, UNR, false>), grid, block, 0, s, v, xv, e)
   switch (g_spmv_variant & 7) {
     case 0: RB_LAUNCH(1024, false, 4); break;
     case 1: RB_LAUNCH(640, false, 4); break;
@@ -184,13 +203,14 @@ void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t
 #undef RB_LAUNCH
 }
 
+template <bool DIST>
 __global__ __launch_bounds__(BLOCK) void k_rb_fc_first(RbView A, const int32_t* __restrict__ wcol,
-                                                      const double* __restrict__ b_f, const double* __restrict__ x_c,
+                                                      const double* __restrict__ b_f, XVec<DIST> x_c,
                                                       const double* __restrict__ aff_d, const double* __restrict__ minv,
                                                       double* __restrict__ t4_out, double* __restrict__ x_f) {
   __shared__ double lds_all[WAVES_PER_BLOCK][LDS_CAP];
   double* lds = lds_all[threadIdx.x >> 6];
-  rb_rows<LDS_CAP, false, 4>(A, x_c, lds, [&](int32_t row, double acc) {
+  rb_rows<LDS_CAP, false, 4, DIST>(A, x_c, lds, [&](int32_t row, double acc) {
     const double t4 = b_f[row] + (-1.0) * acc;
     const int32_t wc = wcol[row];
     const double x0 = wc >= 0 ? x_c[wc] : 0.0;
@@ -207,10 +227,19 @@ __global__ __launch_bounds__(BLOCK) void k_rb_fc_first(RbView A, const int32_t* 
 }
 
 void launch_fc_first(const DevMat& A_fc, const int32_t* wcol, const double* b_f, const double* x_c,
-                     const double* aff_d, const double* minv, double* t4_out, double* x_f, hipStream_t s) {
+                     const double* aff_d, const double* minv, double* t4_out, double* x_f, hipStream_t s,
+                     const double* x_ghost) {
   if (A_fc.m == 0) return;
-  hipLaunchKernelGGL(k_rb_fc_first, dim3(grid_for_blocks(A_fc.nblocks)), dim3(BLOCK), 0, s, view_of(A_fc), wcol, b_f,
-                     x_c, aff_d, minv, t4_out, x_f);
+  const dim3 grid(grid_for_blocks(A_fc.nblocks)), block(BLOCK);
+  if (A_fc.n_ghost > 0) {
+    if (!x_ghost) throw std::runtime_error("launch_fc_first: distributed operand without ghost values");
+    const int32_t nl = (int32_t)(A_fc.n - A_fc.n_ghost);
+    const XVec<true> xv{x_c, x_ghost - nl, nl};
+    hipLaunchKernelGGL(k_rb_fc_first<true>, grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
+  } else {
+    const XVec<false> xv{x_c, nullptr, 0};
+    hipLaunchKernelGGL(k_rb_fc_first<false>, grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -281,7 +310,8 @@ static int64_t device_exclusive_scan(int64_t n, const int64_t* d_in, int64_t* d_
 // would need a row lookup, so rows are copied by lanes - setup only
 __global__ __launch_bounds__(BLOCK) void k_copy_rows(int64_t m, const int64_t* __restrict__ rp, const int32_t* __restrict__ ci,
                                                     const double* __restrict__ v, const int32_t* __restrict__ rowsrc,
-                                                    const int32_t* __restrict__ colmap, const int64_t* __restrict__ nrp,
+                                                    const int32_t* __restrict__ colmap, int32_t n_mapped,
+                                                    const int64_t* __restrict__ nrp,
                                                     int32_t* __restrict__ ocol, double* __restrict__ oval) {
   const int lane = threadIdx.x & (WAVE - 1);
   const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
@@ -292,7 +322,7 @@ __global__ __launch_bounds__(BLOCK) void k_copy_rows(int64_t m, const int64_t* _
     const int64_t a = rp[src], len = rp[src + 1] - a, o = nrp[r];
     for (int64_t k = lane; k < len; k += WAVE) {
       int32_t c = ci[a + k];
-      if (colmap) c = colmap[c];
+      if (colmap && c < n_mapped) c = colmap[c];   // columns >= n_mapped (ghosts) keep their index
       ocol[o + k] = c; oval[o + k] = v[a + k];
     }
   }
@@ -333,9 +363,9 @@ static int grid1d(int64_t n) {
 }
 
 void devmat_from_csr_device(int64_t m, int64_t n, const int64_t* d_rp, const int32_t* d_ci, const double* d_v,
-                            const int32_t* d_rowsrc, const int32_t* d_colmap, DevMat& out, hipStream_t s) {
+                            const int32_t* d_rowsrc, const int32_t* d_colmap, DevMat& out, hipStream_t s, int64_t n_ghost) {
   devmat_free(out);
-  out.m = m; out.n = n;
+  out.m = m; out.n = n; out.n_ghost = n_ghost;
   if (m == 0) return;
   if (m > 0x7fffffffll) throw std::runtime_error("matrix has too many rows for 32-bit row indices");
   int64_t *d_len = nullptr, *d_nrp = nullptr, *d_flag = nullptr, *d_blk_of = nullptr;
@@ -346,8 +376,8 @@ void devmat_from_csr_device(int64_t m, int64_t n, const int64_t* d_rp, const int
   HIP_CHECK(hipMemcpyAsync(d_nrp + m, &out.nnz, sizeof(int64_t), hipMemcpyHostToDevice, s));
   HIP_CHECK(hipMalloc(&out.col, sizeof(int32_t) * (size_t)(out.nnz > 0 ? out.nnz : 1)));
   HIP_CHECK(hipMalloc(&out.val, sizeof(double) * (size_t)(out.nnz > 0 ? out.nnz : 1)));
-  hipLaunchKernelGGL(k_copy_rows, dim3(MAX_BLOCKS), dim3(BLOCK), 0, s, m, d_rp, d_ci, d_v, d_rowsrc, d_colmap, d_nrp,
-                     out.col, out.val);
+  hipLaunchKernelGGL(k_copy_rows, dim3(MAX_BLOCKS), dim3(BLOCK), 0, s, m, d_rp, d_ci, d_v, d_rowsrc, d_colmap,
+                     (int32_t)(n - n_ghost), d_nrp, out.col, out.val);
   // row blocks
   d_flag = d_len;   // reuse
   HIP_CHECK(hipMalloc(&d_blk_of, sizeof(int64_t) * (size_t)m));
