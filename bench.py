@@ -61,16 +61,27 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the PCAIR solve phase has no CPU fallback")
+    # rehearsal mode for a one-GPU box: AIRHIP_BENCH_COMM=staged runs all ranks on device 0 over gloo
+    # with the host-staged halo transport (RCCL refuses two ranks on one device)
+    staged = os.environ.get("AIRHIP_BENCH_COMM", "rccl") == "staged"
+    if staged:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        from pflare_amd import dist_bench
-        dist_bench.run(args, rank, world, local_rank)
-        return
-
     import pflare_amd as P
     P.lib().airhip_set_device(local_rank)
+    dist = meta = None
+    if world > 1:
+        # one process per GPU (torch.distributed.run): RCCL for the bulk data and the halo exchange,
+        # a gloo group for small host-side metadata.  Rank 0 builds the hierarchy, so the others wait
+        # for minutes: generous timeouts.
+        import datetime
+        import torch.distributed as dist
+        if staged:
+            dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=90))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank),
+                                    timeout=datetime.timedelta(minutes=90))
+            meta = dist.new_group(backend="gloo", timeout=datetime.timedelta(minutes=90))
     # host threads for the setup phase and the CPU baseline: this rank's share of the host
     cores = os.cpu_count() or 1
     try:
@@ -80,26 +91,55 @@ def main():
     want = args.threads if args.threads > 0 else min(32, max(1, cores // max(1, args.gpus)))
     threads = int(os.environ.get("AIRHIP_NUM_THREADS", max(1, min(want, cores))))
     P.lib().airhip_set_num_threads(threads, None)
-    log = (lambda *a: print(*a, file=sys.stderr, flush=True)) if args.verbose else (lambda *a: None)
+    log = (lambda *a: print(*a, file=sys.stderr, flush=True)) if (args.verbose and rank == 0) else (lambda *a: None)
 
     M = args.size
-    t0 = time.time()
-    hm = P.HostMat.adv_diff_fd(dim=3, M=M, N=M, P=M)
-    n = hm.shape[0]
-    nnzA = hm.nnz
-    log(f"[bench] operator {M}^3: n={n} nnz={nnzA} generated in {time.time()-t0:.1f}s")
     opts = dict(RECIPES[args.recipe])
     if args.max_levels:
         opts["max_levels"] = args.max_levels
-    pc = P.PCAIR(**opts)
-    if args.verbose:
-        pc.set_option("print_stats_timings", True)   # per-level progress lines (keeps long setups audible)
-    t0 = time.time()
-    pc.setup(hm)
-    t_setup = time.time() - t0
-    st = pc.setup_times()
-    cx = pc.complexities()
-    log(f"[bench] setup {t_setup:.1f}s (host {st['host_setup_s']:.1f}s, upload {st['upload_s']:.1f}s) levels={pc.num_levels} {cx}")
+    n = M ** 3
+    hm = pc = None
+    info = None
+    if rank == 0:
+        t0 = time.time()
+        hm = P.HostMat.adv_diff_fd(dim=3, M=M, N=M, P=M)
+        nnzA = hm.nnz
+        log(f"[bench] operator {M}^3: n={n} nnz={nnzA} generated in {time.time()-t0:.1f}s")
+        pc = P.PCAIR(**opts)
+        if world > 1:
+            pc.set_option("device_upload", False)     # the hierarchy is cut and shipped below
+        if args.verbose:
+            pc.set_option("print_stats_timings", True)   # per-level progress lines (keeps long setups audible)
+        t0 = time.time()
+        pc.setup(hm)
+        t_setup = time.time() - t0
+        st = pc.setup_times()
+        cx = pc.complexities()
+        log(f"[bench] setup {t_setup:.1f}s (host {st['host_setup_s']:.1f}s, upload {st['upload_s']:.1f}s) levels={pc.num_levels} {cx}")
+        info = dict(nnzA=nnzA, t_setup=t_setup, st=st, cx=cx, levels=pc.num_levels)
+    parallelism = "single GPU"
+    comm = None
+    if world > 1:
+        from pflare_amd import dist as D
+        px, py, pz = D.box_dims(world, (M, M, M))
+        parallelism = (f"row-block: {px}x{py}x{pz} boxes of the {M}^3 grid, one rank per GPU, hierarchy built on rank 0 "
+                       f"and cut; RCCL halo exchange per sparse product, all-reduce for Krylov dots")
+        comm = D.StagedComm() if staged else D.RcclComm()
+        t0 = time.time()
+        owner = D.box_owner(M, M, M, world) if rank == 0 else None
+        pcl, gid = D.distribute(pc, hm, owner, comm, src=0, meta_group=meta, bulk_group=None, bulk_on_gpu=not staged, log=log)
+        box = [info]
+        dist.broadcast_object_list(box, src=0, group=meta)
+        info = box[0]
+        info["t_distribute"] = time.time() - t0
+        log(f"[bench] partition + ship + upload: {info['t_distribute']:.1f}s")
+        if rank == 0:
+            pc.release_host()
+        pc = pcl
+        hm = None
+        n = int(gid.size)
+        args.no_cpu_baseline = True      # the CPU leg belongs to rank 0 at N=1
+    nnzA, t_setup, st, cx = info["nnzA"], info["t_setup"], info["st"], info["cx"]
 
     ksp_kw = dict(ksp_type="gmres", pc_side="right", rtol=1e-10, atol=1e-50)
 
@@ -120,8 +160,14 @@ def main():
                          f"(oracle/air_oracle.c), {dt:.1f}s"}
         del ch
         log(f"[bench] cpu baseline: {cpu}")
-    pc.release_host()
-    del hm
+    if world == 1:
+        pc.release_host()
+    hm = None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
 
     b = torch.zeros(n, dtype=torch.float64, device="cuda")
     x = torch.ones(n, dtype=torch.float64, device="cuda")
@@ -165,13 +211,26 @@ def main():
     if args.profile_kernels:
         pc.profile(True)
         pc.profile_reset()
-    torch.cuda.synchronize()
+    barrier()
     t0 = time.perf_counter()
     ms_dev = run_iterations(args.steps)
-    torch.cuda.synchronize()
+    barrier()
     wall = time.perf_counter() - t0
+    if world > 1:      # MAX over ranks
+        tw = torch.tensor([wall], dtype=torch.float64, device="cpu" if staged else "cuda")
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        wall = float(tw.item())
     stats = pc.profile_stats() if args.profile_kernels else []
     pc.profile(False)
+    if world > 1:
+        info["comm"] = comm.stats()
+        cab = torch.tensor([pc.cycle_alg_bytes()], dtype=torch.float64, device="cpu" if staged else "cuda")
+        dist.all_reduce(cab)
+        cx = dict(cx); cx["cycle_alg_bytes"] = float(cab.item())
+        if rank != 0:
+            dist.barrier()
+            dist.destroy_process_group()
+            return
 
     value = args.steps / wall
     roofline = None
@@ -209,12 +268,13 @@ def main():
                     f"{s['alg_bytes']/(a*1e-3)/1e9:8.1f} GB/s")
     out = {
         "metric": "KSP iterations/sec (right-preconditioned GMRES(30) + PCAIR V-cycle)",
-        "value": value, "unit": "iterations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"3D upwind advection (tests/adv_diff_fd.c) {M}^3 = {n} DoF, nnz(A)={nnzA}, b=0, x0=1, "
+        "config": {"workload": f"3D upwind advection (tests/adv_diff_fd.c) {M}^3 = {M ** 3} DoF, nnz(A)={nnzA}, b=0, x0=1, "
                                f"GMRES(30) right PC rtol 1e-10, PCAIR recipe '{args.recipe}' {opts}",
-                   "levels": pc.num_levels, "iterations_to_rtol_1e-10": res0["its"],
+                   "parallelism": parallelism,
+                   "levels": info["levels"], "iterations_to_rtol_1e-10": res0["its"],
                    "converged_reason": res0["reason_name"], "converged_solve_ms": res0["solve_ms"],
                    "cycle_complexity": cx["cycle"], "operator_complexity": cx["operator"],
                    "storage_complexity": cx["storage"], "cycle_alg_bytes": cx["cycle_alg_bytes"],
@@ -222,7 +282,16 @@ def main():
                    "device_ms_of_timed_solves": ms_dev, "hip_graph": bool(args.graph)},
         "roofline": roofline, "cpu_baseline": cpu,
     }
-    print(json.dumps(out))
+    if world > 1:
+        out["config"]["distribute_s"] = info["t_distribute"]
+        out["config"]["halo_exchanges_rank0"] = info["comm"]["exchanges"]
+        out["config"]["allreduces_rank0"] = info["comm"]["allreduces"]
+        if out["roofline"] is not None:
+            out["roofline"]["note"] = "kernel timings of rank 0"
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

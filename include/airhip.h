@@ -153,6 +153,8 @@ int airhip_pcair_coarse_get(airhip_pcair pc, airhip_csr* A_coarse);
  * the algorithmic bytes of one V-cycle */
 int airhip_pcair_complexities(airhip_pcair pc, double* grid, double* op, double* cycle, double* storage,
                               double* cycle_alg_bytes);
+/* algorithmic bytes of one V-cycle on this device (this rank's share when distributed) */
+int airhip_pcair_cycle_alg_bytes(airhip_pcair pc, double* bytes);
 int airhip_pcair_setup_times(airhip_pcair pc, double* host_setup_s, double* upload_s);
 /* free the host copy of the hierarchy (export functions then fail with AIRHIP_ERR_STATE) */
 int airhip_pcair_release_host(airhip_pcair pc);

@@ -543,6 +543,12 @@ int airhip_pcair_complexities(airhip_pcair pc, double* grid, double* op, double*
   API_END
 }
 
+int airhip_pcair_cycle_alg_bytes(airhip_pcair pc, double* bytes) {
+  API_BEGIN
+  REQUIRE(pc && pc->dev && bytes, AIRHIP_ERR_STATE, "not set up on a device");
+  *bytes = pc->dev->cycle_alg_bytes();
+  API_END
+}
 int airhip_pcair_setup_times(airhip_pcair pc, double* host_setup_s, double* upload_s) {
   API_BEGIN
   REQUIRE(pc, AIRHIP_ERR_ARG, "null argument");

@@ -22,8 +22,8 @@ struct StagedComm final : Comm {
   double* hs = nullptr; double* hr = nullptr; int64_t cap_s = 0, cap_r = 0;   // pinned staging
   ~StagedComm() override { if (hs) (void)hipHostFree(hs); if (hr) (void)hipHostFree(hr); }
   void ensure(int64_t ns, int64_t nr) {
-    if (ns > cap_s) { if (hs) (void)hipHostFree(hs); cap_s = ns + ns / 2 + 64; HIP_CHECK(hipHostMalloc(&hs, sizeof(double) * (size_t)cap_s)); }
-    if (nr > cap_r) { if (hr) (void)hipHostFree(hr); cap_r = nr + nr / 2 + 64; HIP_CHECK(hipHostMalloc(&hr, sizeof(double) * (size_t)cap_r)); }
+    if (ns > cap_s || !hs) { if (hs) (void)hipHostFree(hs); cap_s = ns + ns / 2 + 64; HIP_CHECK(hipHostMalloc(&hs, sizeof(double) * (size_t)cap_s)); }
+    if (nr > cap_r || !hr) { if (hr) (void)hipHostFree(hr); cap_r = nr + nr / 2 + 64; HIP_CHECK(hipHostMalloc(&hr, sizeof(double) * (size_t)cap_r)); }
   }
   void exchange(const HaloPlan& p, hipStream_t s) override {
     n_exchanges++;

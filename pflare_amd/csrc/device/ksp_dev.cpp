@@ -33,7 +33,7 @@ DevKSP::DevKSP(int64_t n) : n_(n) {
 
 // dots of the local parts land in ddots_; summed over the ranks when distributed
 void DevKSP::fetch_dots(double* host, int n, hipStream_t s) {
-  if (comm_ && comm_->size > 1) { comm_->allreduce_sum(ddots_.p, host, n, s); return; }
+  if (comm_) { comm_->allreduce_sum(ddots_.p, host, n, s); return; }
   HIP_CHECK(hipMemcpyAsync(host, ddots_.p, sizeof(double) * n, hipMemcpyDeviceToHost, s));
   HIP_CHECK(hipStreamSynchronize(s));
 }

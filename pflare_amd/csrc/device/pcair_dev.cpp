@@ -87,7 +87,7 @@ void DevPCAIR::spmv(const DevMat& A, const double* x, const SpmvEpi& e, const ch
 // distributed operands
 // ---------------------------------------------------------------------------------------
 void DevPCAIR::attach_halo(DevMat& M, const HaloHost* h, const int32_t* host_colmap) {
-  if (!h || !comm_ || !M.valid()) return;
+  if (!h || !comm_) return;   // also for an operand without local rows: its owner still serves the neighbours
   auto p = std::make_unique<HaloPlan>();
   p->peers.assign(h->peers.begin(), h->peers.end());
   p->send_off = h->send_off; p->recv_off = h->recv_off;
@@ -221,7 +221,8 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
     if (h.one_point) {
       std::vector<int32_t> wc(h.n_f);
       const int32_t* pn = perm[l + 1].data();
-      for (int64_t i = 0; i < h.n_f; i++) wc[i] = h.wcol[i] >= 0 ? pn[h.wcol[i]] : -1;
+      // distributed: columns >= n_c are ghost columns of A_fc and keep their index
+      for (int64_t i = 0; i < h.n_f; i++) { const int32_t c = h.wcol[i]; wc[i] = c < 0 ? -1 : (c < h.n_c ? pn[c] : c); }
       d.wcol.upload(wc.data(), h.n_f);
     } else {
       upload_mat(h.W, nullptr, pc.p, d.W, stream_, ng(hl ? &hl->W : nullptr));

@@ -375,8 +375,18 @@ bool get_csr(const Archive& ar, const std::string& name, Csr& A, HaloHost& h) {
   h.recv_off.assign((const int64_t*)ro.ptr, (const int64_t*)ro.ptr + ro.count);
   h.send_idx.view((const int32_t*)si.ptr, si.count);
   if ((int64_t)h.send_off.size() != pe.count + 1 || (int64_t)h.recv_off.size() != pe.count + 1 ||
-      h.send_off.back() != si.count || h.recv_off.back() != h.n_ghost)
+      h.send_off.back() != si.count || h.recv_off.back() != h.n_ghost || h.n_ghost > A.n)
     throw std::runtime_error("archive: inconsistent halo plan " + name);
+  // the device kernels index with these numbers: validate them on the host
+  {
+    const int64_t nnz = ci.count, ncol = A.n, nloc = A.n - h.n_ghost;
+    if (A.rp[0] != 0 || A.rp[A.m] != nnz) throw std::runtime_error("archive: bad row pointers in " + name);
+    int64_t bad = 0;
+#pragma omp parallel for schedule(static) reduction(+ : bad)
+    for (int64_t k = 0; k < nnz; k++) bad += (A.ci[k] < 0 || A.ci[k] >= ncol) ? 1 : 0;
+    for (int64_t k = 0; k < si.count; k++) bad += (h.send_idx[k] < 0 || h.send_idx[k] >= nloc) ? 1 : 0;
+    if (bad) throw std::runtime_error("archive: column / send index out of range in " + name);
+  }
   return true;
 }
 void get_inv(const Archive& ar, const std::string& name, InvOp& I, HaloHost& h) {
@@ -426,7 +436,15 @@ void load_local(const Archive& ar, LocalHierarchy& out) {
     get_csr(ar, p + ".A_cc", Lv.A_cc, H.A_cc);
     if (!get_csr(ar, p + ".Z", Lv.Z, H.Z)) throw std::runtime_error("archive: missing " + p + ".Z");
     get_csr(ar, p + ".W", Lv.W, H.W);
-    if (Lv.one_point) { const auto& w = need(ar, p + ".wcol", Archive::I32); Lv.wcol.view((const int32_t*)w.ptr, w.count); }
+    if (Lv.one_point) {
+      const auto& w = need(ar, p + ".wcol", Archive::I32);
+      Lv.wcol.view((const int32_t*)w.ptr, w.count);
+      if (w.count != Lv.n_f) throw std::runtime_error("archive: wcol size mismatch in " + p);
+      for (int64_t i = 0; i < w.count; i++)
+        if (Lv.wcol[i] >= Lv.A_fc.n) throw std::runtime_error("archive: wcol out of range in " + p);
+    }
+    if (Lv.F.size() != Lv.n_f || Lv.C.size() != Lv.n_c || Lv.n_f + Lv.n_c != Lv.n || Lv.A_fc.m != Lv.n_f || Lv.Z.m != Lv.n_c)
+      throw std::runtime_error("archive: level size mismatch in " + p);
     get_inv(ar, p + ".inv_ff", Lv.inv_ff, H.M_ff);
     get_inv(ar, p + ".inv_cc", Lv.inv_cc, H.M_cc);
     out.H.levels.push_back(std::move(Lp));

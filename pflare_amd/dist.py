@@ -163,8 +163,8 @@ class StagedComm:
             if npeers == 0:
                 return 0
             ns, nr = send_off[npeers], recv_off[npeers]
-            sb = torch.from_numpy(np.ctypeslib.as_array(send, shape=(max(ns, 1),)))
-            rb = torch.from_numpy(np.ctypeslib.as_array(recv, shape=(max(nr, 1),)))
+            sb = torch.from_numpy(np.ctypeslib.as_array(send, shape=(ns,))) if ns else None
+            rb = torch.from_numpy(np.ctypeslib.as_array(recv, shape=(nr,))) if nr else None
             ops = []
             for k in range(npeers):
                 p = self._global(peers[k])

@@ -330,6 +330,11 @@ class PCAIR:
         check(lib().airhip_pcair_complexities(self._h, C.byref(g), C.byref(o), C.byref(cy), C.byref(st), C.byref(by)))
         return dict(grid=g.value, operator=o.value, cycle=cy.value, storage=st.value, cycle_alg_bytes=by.value)
 
+    def cycle_alg_bytes(self):
+        b = C.c_double()
+        check(lib().airhip_pcair_cycle_alg_bytes(self._h, C.byref(b)))
+        return b.value
+
     def setup_times(self):
         a, b = C.c_double(), C.c_double()
         check(lib().airhip_pcair_setup_times(self._h, C.byref(a), C.byref(b)))
