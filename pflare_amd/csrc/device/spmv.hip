@@ -18,6 +18,7 @@
 #include "dev.hpp"
 #include "kcommon.hpp"
 #include <stdexcept>
+#include <cstdlib>
 
 namespace airhip {
 
@@ -26,14 +27,14 @@ constexpr int LDS_CAP = 1024;      // products staged per wave (8 KB)
 constexpr int BLK_ROWS = 256;      // at most this many rows per block
 
 struct RbView {
-  int64_t m, nblocks;
+  int64_t m, nblocks, nnz;
   const int32_t* blk_row;
   const int64_t* blk_p0;
   const uint32_t* roff;
   const int32_t* col;
   const double* val;
 };
-static RbView view_of(const DevMat& A) { return RbView{A.m, A.nblocks, A.blk_row, A.blk_p0, A.roff, A.col, A.val}; }
+static RbView view_of(const DevMat& A) { return RbView{A.m, A.nblocks, A.nnz, A.blk_row, A.blk_p0, A.roff, A.col, A.val}; }
 
 struct BlockRange { int64_t first, last, stride; };
 
@@ -50,9 +51,12 @@ __device__ __forceinline__ BlockRange my_blocks(int64_t nblocks) {
   return r;
 }
 
+extern int g_spmv_variant;
 static int grid_for_blocks(int64_t nblocks) {
   int64_t blocks = (nblocks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-  if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
+  // diagnostic: bits 16..23 of the variant override the grid cap in units of 64 workgroups
+  const int64_t cap = ((g_spmv_variant >> 16) & 0xff) ? (int64_t)((g_spmv_variant >> 16) & 0xff) * 64 : MAX_BLOCKS;
+  if (blocks > cap) blocks = cap;
   blocks = (blocks + 7) / 8 * 8;
   if (blocks < 8) blocks = 8;
   return (int)blocks;
@@ -74,8 +78,15 @@ __device__ __forceinline__ T ldg(const T* p) {
   if constexpr (NT) return __builtin_nontemporal_load(p); else return *p;
 }
 
-template <int CAP, bool NT, int UNR, bool DIST, class Epi>
-__device__ __forceinline__ void rb_rows(const RbView& A, const XVec<DIST> x, double* __restrict__ lds, Epi epi) {
+// diagnostic only (airhip_debug_set_variant(8)): every gather hits the same 8 KB of x - shows how
+// much of the kernel time is the x-vector gather
+struct XVecNoGather {
+  const double* __restrict__ x;
+  __device__ __forceinline__ double operator[](int32_t c) const { return x[c & 1023]; }
+};
+
+template <int CAP, bool NT, int UNR, class X, class Epi>
+__device__ __forceinline__ void rb_rows(const RbView& A, const X x, double* __restrict__ lds, Epi epi) {
   const int lane = threadIdx.x & (WAVE - 1);
   const BlockRange br = my_blocks(A.nblocks);
   for (int64_t b = br.first; b < br.last; b += br.stride) {
@@ -155,11 +166,120 @@ __device__ __forceinline__ void rb_rows(const RbView& A, const XVec<DIST> x, dou
   }
 }
 
-template <int CAP, bool NT, int UNR, bool DIST>
-__global__ __launch_bounds__(BLOCK) void k_rb_spmv(RbView A, XVec<DIST> x, SpmvEpi e) {
+// Software-pipelined variant: while the products of block i are staged and reduced, the first 512
+// (column, value) pairs and the row offsets of block i+1 are already in flight, and the descriptor
+// of block i+2 is being fetched - a wave keeps HBM requests outstanding during its LDS phases
+// instead of alternating between "load" and "reduce".  All blocks with <= CAP non-zeros take
+// the LDS path (no scalar mode); loads of a partially filled block are clamped, not predicated,
+// so the issue order stays branch-free.  Requires A.nnz > 0.
+template <int CAP, class X, class Epi>
+__device__ __forceinline__ void rb_rows_pipe(const RbView& A, const X x, double* __restrict__ lds, Epi epi) {
+  constexpr int PF = 8;                         // prefetched loads per lane: 8 x 64 = 512 entries
+  constexpr int RC = BLK_ROWS / WAVE;           // row-offset registers per lane (rows per block <= 256)
+  const int lane = threadIdx.x & (WAVE - 1);
+  const BlockRange br = my_blocks(A.nblocks);
+  if (br.first >= br.last) return;
+  const int64_t last_nz = A.nnz - 1;
+  const int32_t last_row = (int32_t)(A.m - 1);
+  // block descriptors travel through the scalar cache (s_load, lgkmcnt): waiting for them does
+  // not drain the vector-memory queue that holds the prefetched non-zeros
+  // (issue and wait live in ONE asm statement: the compiler must never see the destination
+  // registers between the two)
+  auto desc = [&](int64_t b, int32_t& r0, int32_t& r1, int64_t& p0, int64_t& p1) {
+    uint64_t rr, q0, q1;
+    const int32_t* pr = A.blk_row + b; const int64_t* pp = A.blk_p0 + b;
+    asm volatile("s_load_dwordx2 %0, %3, 0x0\n\ts_load_dwordx2 %1, %4, 0x0\n\ts_load_dwordx2 %2, %4, 0x8\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(rr), "=&s"(q0), "=&s"(q1) : "s"(pr), "s"(pp) : "memory");
+    r0 = (int32_t)(rr & 0xffffffffull); r1 = (int32_t)(rr >> 32); p0 = (int64_t)q0; p1 = (int64_t)q1;
+  };
+  int32_t pc[PF]; double pv[PF]; uint32_t pro[RC];
+  auto prefetch = [&](int32_t r0, int64_t p0) {
+#pragma unroll
+    for (int u = 0; u < PF; u++) {
+      const int64_t k = min(p0 + lane + u * WAVE, last_nz);
+      pc[u] = A.col[k]; pv[u] = A.val[k];
+    }
+#pragma unroll
+    for (int j = 0; j < RC; j++) pro[j] = A.roff[min(r0 + lane + j * WAVE, last_row)];
+  };
+  int32_t r0, r1, r0n = 0, r1n = 0, r0t = 0, r1t = 0;
+  int64_t p0, p1, p0n = 0, p1n = 0, p0t = 0, p1t = 0;
+  desc(br.first, r0, r1, p0, p1);
+  if (br.first + br.stride < br.last) desc(br.first + br.stride, r0n, r1n, p0n, p1n);
+  prefetch(r0, p0);
+  for (int64_t b = br.first; b < br.last; b += br.stride) {
+    const int nb = (int)(p1 - p0);
+    const int nr = r1 - r0;
+    const double* __restrict__ v = A.val + p0;
+    const int32_t* __restrict__ c = A.col + p0;
+    // current block's prefetched data -> gathers
+    double cv[PF], xx[PF]; uint32_t ro[RC];
+#pragma unroll
+    for (int u = 0; u < PF; u++) { cv[u] = pv[u]; xx[u] = x[pc[u]]; }
+#pragma unroll
+    for (int j = 0; j < RC; j++) ro[j] = pro[j];
+    // next block's data and the descriptor after it
+    const bool have_next = b + br.stride < br.last;
+    if (have_next) prefetch(r0n, p0n);
+    if (b + 2 * br.stride < br.last) desc(b + 2 * br.stride, r0t, r1t, p0t, p1t);   // waits on lgkmcnt only
+    if (nb <= CAP) {
+#pragma unroll
+      for (int u = 0; u < PF; u++) { const int k = lane + u * WAVE; if (k < nb) lds[k] = cv[u] * xx[u]; }
+      for (int k = lane + PF * WAVE; k < nb; k += WAVE) lds[k] = v[k] * x[c[k]];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (nr > 16) {
+#pragma unroll
+        for (int j = 0; j < RC; j++) {
+          const int32_t r = r0 + lane + j * WAVE;
+          // end of the row = start of the next one (next lane, or lane 0 of the next register)
+          uint32_t e = __shfl_down(ro[j], 1, WAVE);
+          const uint32_t e0 = __shfl(j + 1 < RC ? ro[j + 1 < RC ? j + 1 : j] : 0u, 0, WAVE);
+          if (lane == WAVE - 1) e = e0;
+          if (r < r1) {
+            const int a = (int)ro[j];
+            const int ee = (r + 1 < r1) ? (int)e : nb;
+            double s = 0.0;
+            for (int q = a; q < ee; q++) s += lds[q];
+            epi(r, s);
+          }
+        }
+      } else {
+        int T = WAVE;
+        while (WAVE / T < nr) T >>= 1;
+        const int g = lane / T, t = lane - g * T;
+        const int a = (int)__shfl(ro[0], g, WAVE);
+        const int en = (int)__shfl(ro[0], g + 1 < WAVE ? g + 1 : g, WAVE);
+        double s = 0.0;
+        if (g < nr) {
+          const int e = (g + 1 < nr) ? en : nb;
+          for (int q = a + t; q < e; q += T) s += lds[q];
+        }
+        for (int off = T >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
+        if (g < nr && t == 0) epi(r0 + g, s);
+      }
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      for (int32_t r = r0; r < r1; r++) {
+        const int a = (int)A.roff[r];
+        const int e = (r + 1 < r1) ? (int)A.roff[r + 1] : nb;
+        double s = 0.0;
+        for (int q = a + lane; q < e; q += WAVE) s = fma(v[q], x[c[q]], s);
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
+        if (lane == 0) epi(r, s);
+      }
+    }
+    r0 = r0n; r1 = r1n; p0 = p0n; p1 = p1n;
+    r0n = r0t; r1n = r1t; p0n = p0t; p1n = p1t;
+  }
+}
+
+template <int CAP, class X>
+__global__ __launch_bounds__(BLOCK) void k_rb_spmv_pipe(RbView A, X x, SpmvEpi e) {
   __shared__ double lds_all[WAVES_PER_BLOCK][CAP];
   double* lds = lds_all[threadIdx.x >> 6];
-  rb_rows<CAP, NT, UNR, DIST>(A, x, lds, [&](int32_t row, double acc) {
+  rb_rows_pipe<CAP>(A, x, lds, [&](int32_t row, double acc) {
     if (e.dscale) acc *= e.dscale[row];
     double o = e.alpha * acc;
     if (e.z) o += e.beta * e.z[row];
@@ -172,9 +292,199 @@ __global__ __launch_bounds__(BLOCK) void k_rb_spmv(RbView A, XVec<DIST> x, SpmvE
   });
 }
 
+template <int CAP, bool NT, int UNR, class X>
+__global__ __launch_bounds__(BLOCK) void k_rb_spmv(RbView A, X x, SpmvEpi e) {
+  __shared__ double lds_all[WAVES_PER_BLOCK][CAP];
+  double* lds = lds_all[threadIdx.x >> 6];
+  rb_rows<CAP, NT, UNR>(A, x, lds, [&](int32_t row, double acc) {
+    if (e.dscale) acc *= e.dscale[row];
+    double o = e.alpha * acc;
+    if (e.z) o += e.beta * e.z[row];
+    if (e.w) o += e.gamma * e.w[row];
+    e.out[row] = o;
+    if (e.y2) {
+      const double a = e.aux_out ? o : e.w2[row];
+      e.y2[row] += e.delta * a;
+    }
+  });
+}
+
+// ---------------------------------------------------------------------------------------
+// v2 of the row-block kernel: every global load a block needs is issued up front - descriptor
+// through the scalar cache (s_load: waiting for it does not drain the vector-memory queue), then in
+// one burst the first 512 (column, value) pairs, the row offsets and the epilogue operands of the
+// first 64 rows - so a block costs two vector-memory round trips (non-zeros, x gather) instead of
+// four or five.  Loads of a partially filled block are clamped, not predicated.  Requires nnz > 0.
+// EpiT: struct with  Pre pre(row) const;  Pre shfl(Pre, src_lane) const;  void post(row, acc, Pre) const.
+// ---------------------------------------------------------------------------------------
+template <int CAP, class X, class EpiT>
+__device__ __forceinline__ void rb_rows2(const RbView& A, const X x, double* __restrict__ lds, const EpiT epi) {
+  constexpr int PF = 8;
+  constexpr int RC = BLK_ROWS / WAVE;
+  using Pre = typename EpiT::Pre;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const BlockRange br = my_blocks(A.nblocks);
+  const int64_t last_nz = A.nnz - 1;
+  const int32_t last_row = (int32_t)(A.m - 1);
+  for (int64_t b = br.first; b < br.last; b += br.stride) {
+    int32_t r0, r1; int64_t p0, p1;
+    {
+      uint64_t rr, q0, q1;
+      const int32_t* pr = A.blk_row + b; const int64_t* pp = A.blk_p0 + b;
+      asm volatile("s_load_dwordx2 %0, %3, 0x0\n\ts_load_dwordx2 %1, %4, 0x0\n\ts_load_dwordx2 %2, %4, 0x8\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&s"(rr), "=&s"(q0), "=&s"(q1) : "s"(pr), "s"(pp) : "memory");
+      r0 = (int32_t)(rr & 0xffffffffull); r1 = (int32_t)(rr >> 32); p0 = (int64_t)q0; p1 = (int64_t)q1;
+    }
+    const int nb = (int)(p1 - p0);
+    const int nr = r1 - r0;
+    const double* __restrict__ v = A.val + p0;
+    const int32_t* __restrict__ c = A.col + p0;
+    if (nb <= CAP) {
+      int32_t cc[PF]; double vv[PF], xx[PF]; uint32_t ro[RC];
+#pragma unroll
+      for (int u = 0; u < PF; u++) cc[u] = A.col[min(p0 + lane + u * WAVE, last_nz)];
+#pragma unroll
+      for (int u = 0; u < PF; u++) vv[u] = A.val[min(p0 + lane + u * WAVE, last_nz)];
+#pragma unroll
+      for (int j = 0; j < RC; j++) ro[j] = A.roff[min(r0 + lane + j * WAVE, last_row)];
+      const Pre pre0 = epi.pre(min(r0 + lane, last_row));
+#pragma unroll
+      for (int u = 0; u < PF; u++) xx[u] = x[cc[u]];
+#pragma unroll
+      for (int u = 0; u < PF; u++) { const int k = lane + u * WAVE; if (k < nb) lds[k] = vv[u] * xx[u]; }
+      for (int k = lane + PF * WAVE; k < nb; k += WAVE) lds[k] = v[k] * x[c[k]];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (nr > 16) {
+#pragma unroll
+        for (int j = 0; j < RC; j++) {
+          const int32_t r = r0 + lane + j * WAVE;
+          uint32_t e = __shfl_down(ro[j], 1, WAVE);
+          const uint32_t e0 = __shfl(ro[j + 1 < RC ? j + 1 : j], 0, WAVE);
+          if (lane == WAVE - 1) e = e0;
+          if (r < r1) {
+            const int a = (int)ro[j];
+            const int ee = (r + 1 < r1) ? (int)e : nb;
+            double s = 0.0;
+            for (int q = a; q < ee; q++) s += lds[q];
+            if (j == 0) epi.post(r, s, pre0); else epi.post(r, s, epi.pre(r));
+          }
+        }
+      } else {
+        int T = WAVE;
+        while (WAVE / T < nr) T >>= 1;
+        const int g = lane / T, t = lane - g * T;
+        const int a = (int)__shfl(ro[0], g, WAVE);
+        const int en = (int)__shfl(ro[0], g + 1 < WAVE ? g + 1 : g, WAVE);
+        const Pre pg = epi.shfl(pre0, g);
+        double s = 0.0;
+        if (g < nr) {
+          const int e = (g + 1 < nr) ? en : nb;
+          for (int q = a + t; q < e; q += T) s += lds[q];
+        }
+        for (int off = T >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
+        if (g < nr && t == 0) epi.post(r0 + g, s, pg);
+      }
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      for (int32_t r = r0; r < r1; r++) {
+        const int a = (int)A.roff[r];
+        const int e = (r + 1 < r1) ? (int)A.roff[r + 1] : nb;
+        double s = 0.0;
+        for (int q = a + lane; q < e; q += WAVE) s = fma(v[q], x[c[q]], s);
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
+        if (lane == 0) epi.post(r, s, epi.pre(r));
+      }
+    }
+  }
+}
+
+struct SpmvEpi2 {
+  SpmvEpi e;
+  struct Pre { double z, w, ds; };
+  __device__ __forceinline__ Pre pre(int32_t row) const {
+    Pre p;
+    p.z = e.z ? e.z[row] : 0.0;
+    p.w = e.w ? e.w[row] : 0.0;
+    p.ds = e.dscale ? e.dscale[row] : 1.0;
+    return p;
+  }
+  __device__ __forceinline__ Pre shfl(const Pre& p, int src) const {
+    Pre q; q.z = __shfl(p.z, src, WAVE); q.w = __shfl(p.w, src, WAVE); q.ds = __shfl(p.ds, src, WAVE); return q;
+  }
+  __device__ __forceinline__ void post(int32_t row, double acc, const Pre& p) const {
+    if (e.dscale) acc *= p.ds;
+    double o = e.alpha * acc;
+    if (e.z) o += e.beta * p.z;
+    if (e.w) o += e.gamma * p.w;
+    e.out[row] = o;
+    if (e.y2) {
+      const double a = e.aux_out ? o : e.w2[row];
+      e.y2[row] += e.delta * a;
+    }
+  }
+};
+
+template <int CAP, class X>
+__global__ __launch_bounds__(BLOCK) void k_rb_spmv2(RbView A, X x, SpmvEpi e) {
+  __shared__ double lds_all[WAVES_PER_BLOCK][CAP];
+  rb_rows2<CAP>(A, x, lds_all[threadIdx.x >> 6], SpmvEpi2{e});
+}
+
+// diagnostics (airhip_debug_set_variant 32 / 64): MODE 1 streams the non-zeros and the gathered x
+// and keeps a running sum only (no LDS, one store per block); MODE 2 also stages the products in
+// LDS but skips the per-row reduction.  Wrong results by construction - timing only.
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void k_rb_stream_dbg(RbView A, const double* __restrict__ x, double* __restrict__ out) {
+  __shared__ double lds_all[WAVES_PER_BLOCK][1024];
+  double* lds = lds_all[threadIdx.x >> 6];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const BlockRange br = my_blocks(A.nblocks);
+  for (int64_t b = br.first; b < br.last; b += br.stride) {
+    const int32_t r0 = __builtin_amdgcn_readfirstlane(A.blk_row[b]);
+    const int64_t p0 = uniform64(A.blk_p0[b]);
+    const int64_t p1 = uniform64(A.blk_p0[b + 1]);
+    const int nb = (int)(p1 - p0);
+    const double* __restrict__ v = A.val + p0;
+    const int32_t* __restrict__ c = A.col + p0;
+    double s = 0.0;
+    int k = lane;
+    for (; k + 3 * WAVE < nb; k += 4 * WAVE) {
+      int32_t cc[4]; double vv[4], xx[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) cc[u] = c[k + u * WAVE];
+#pragma unroll
+      for (int u = 0; u < 4; u++) vv[u] = v[k + u * WAVE];
+#pragma unroll
+      for (int u = 0; u < 4; u++) xx[u] = x[cc[u]];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { if (MODE == 2 && k + u * WAVE < 1024) lds[k + u * WAVE] = vv[u] * xx[u]; s += vv[u] * xx[u]; }
+    }
+    for (; k < nb; k += WAVE) s += v[k] * x[c[k]];
+    if (MODE == 2) { __builtin_amdgcn_wave_barrier(); s += lds[lane]; __builtin_amdgcn_wave_barrier(); }
+    if (s == 123.456) out[r0] = s;      // practically never: keeps the loads alive
+    else if (lane == 0) out[r0] = s;
+  }
+}
+
+// diagnostics 256 / 512: flat grid-stride stream over the non-zeros (no row structure at all),
+// without / with the x gather - the ceiling any SpMV organisation of these arrays can reach
+template <bool GATHER>
+__global__ __launch_bounds__(BLOCK) void k_flat_stream_dbg(int64_t nnz, const int32_t* __restrict__ col, const double* __restrict__ val,
+                                                           const double* __restrict__ x, double* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * BLOCK;
+  double s = 0.0;
+  for (int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x; k < nnz; k += stride) {
+    const int32_t c = col[k];
+    s += val[k] * (GATHER ? x[c] : (double)c);
+  }
+  if (s == 123.456) out[0] = s;
+}
+
 // tuning variant (bit 0: 640-entry LDS stage instead of 1024, bit 1: non-temporal matrix loads,
 // bit 2: 8 instead of 4 loads in flight); set through airhip_debug_set_variant
-int g_spmv_variant = 0;
+int g_spmv_variant = std::getenv("AIRHIP_SPMV_VARIANT") ? std::atoi(std::getenv("AIRHIP_SPMV_VARIANT")) : 0;
 
 void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t s, const double* x_ghost) {
   if (A.m == 0) return;
@@ -185,11 +495,30 @@ void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t
     if (!x_ghost) throw std::runtime_error("launch_spmv: distributed operand without ghost values");
     const int32_t nl = (int32_t)(A.n - A.n_ghost);
     const XVec<true> xv{x, x_ghost - nl, nl};
-    hipLaunchKernelGGL((k_rb_spmv<1024, false, 4, true>), grid, block, 0, s, v, xv, e);
+    hipLaunchKernelGGL((k_rb_spmv<1024, false, 4, XVec<true>>), grid, block, 0, s, v, xv, e);
+    return;
+  }
+  if ((g_spmv_variant & 16) && A.nnz > 0) {
+    const XVec<false> xp{x, nullptr, 0};
+    hipLaunchKernelGGL((k_rb_spmv_pipe<1024, XVec<false>>), grid, block, 0, s, v, xp, e);
+    return;
+  }
+  if (g_spmv_variant & 256) { hipLaunchKernelGGL(k_flat_stream_dbg<false>, dim3(2048), block, 0, s, A.nnz, A.col, A.val, x, e.out); return; }
+  if (g_spmv_variant & 512) { hipLaunchKernelGGL(k_flat_stream_dbg<true>, dim3(2048), block, 0, s, A.nnz, A.col, A.val, x, e.out); return; }
+  if ((g_spmv_variant & 128) && A.nnz > 0) {
+    const XVec<false> xp{x, nullptr, 0};
+    hipLaunchKernelGGL((k_rb_spmv2<1024, XVec<false>>), grid, block, 0, s, v, xp, e);
+    return;
+  }
+  if (g_spmv_variant & 32) { hipLaunchKernelGGL(k_rb_stream_dbg<1>, grid, block, 0, s, v, x, e.out); return; }
+  if (g_spmv_variant & 64) { hipLaunchKernelGGL(k_rb_stream_dbg<2>, grid, block, 0, s, v, x, e.out); return; }
+  if (g_spmv_variant & 8) {
+    const XVecNoGather xd{x};
+    hipLaunchKernelGGL((k_rb_spmv<1024, false, 4, XVecNoGather>), grid, block, 0, s, v, xd, e);
     return;
   }
   const XVec<false> xv{x, nullptr, 0};
-#define RB_LAUNCH(CAP, NT, UNR) hipLaunchKernelGGL((k_rb_spmv<CAP, NT, UNR, false>), grid, block, 0, s, v, xv, e)
+#define RB_LAUNCH(CAP, NT, UNR) hipLaunchKernelGGL((k_rb_spmv<CAP, NT, UNR, XVec<false>>), grid, block, 0, s, v, xv, e)
   switch (g_spmv_variant & 7) {
     case 0: RB_LAUNCH(1024, false, 4); break;
     case 1: RB_LAUNCH(640, false, 4); break;
@@ -210,7 +539,7 @@ __global__ __launch_bounds__(BLOCK) void k_rb_fc_first(RbView A, const int32_t* 
                                                       double* __restrict__ t4_out, double* __restrict__ x_f) {
   __shared__ double lds_all[WAVES_PER_BLOCK][LDS_CAP];
   double* lds = lds_all[threadIdx.x >> 6];
-  rb_rows<LDS_CAP, false, 4, DIST>(A, x_c, lds, [&](int32_t row, double acc) {
+  rb_rows<LDS_CAP, false, 4>(A, x_c, lds, [&](int32_t row, double acc) {
     const double t4 = b_f[row] + (-1.0) * acc;
     const int32_t wc = wcol[row];
     const double x0 = wc >= 0 ? x_c[wc] : 0.0;
