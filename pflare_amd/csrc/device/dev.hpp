@@ -33,6 +33,13 @@ struct DevMat {
   uint32_t* roff = nullptr;      // [m] start of row r relative to its block's first non-zero
   int32_t* col = nullptr;        // [nnz]
   double* val = nullptr;         // [nnz]
+  // tiles: consecutive row blocks (~2k non-zeros) whose distinct columns are staged in LDS by the
+  // workgroup that owns the tile; entries address the staged copy through a 16-bit local index
+  int64_t ntiles = 0, n_ucol = 0;
+  int32_t* tile_blk = nullptr;   // [ntiles+1] first block of each tile
+  int64_t* tile_u0 = nullptr;    // [ntiles+1] offset of the tile's sorted distinct columns in ucol (empty: direct tile)
+  int32_t* ucol = nullptr;       // [n_ucol]
+  uint16_t* lidx = nullptr;      // [nnz] position of the entry's column in its tile's list
   bool valid() const { return blk_row != nullptr; }
   // algorithmic bytes of one SpMV with this operator: S(X) of SURVEY 8(d)
   double s_bytes() const { return 12.0 * nnz + 4.0 * (m + 1) + 8.0 * m + 8.0 * n; }

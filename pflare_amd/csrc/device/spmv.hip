@@ -17,24 +17,11 @@
 //     range of row blocks and an XCD's private L2 sees a contiguous window of x.
 #include "dev.hpp"
 #include "kcommon.hpp"
+#include "rb.hpp"
 #include <stdexcept>
 #include <cstdlib>
 
 namespace airhip {
-
-constexpr int BLK_NNZ = 512;       // target non-zeros per row block
-constexpr int LDS_CAP = 1024;      // products staged per wave (8 KB)
-constexpr int BLK_ROWS = 256;      // at most this many rows per block
-
-struct RbView {
-  int64_t m, nblocks, nnz;
-  const int32_t* blk_row;
-  const int64_t* blk_p0;
-  const uint32_t* roff;
-  const int32_t* col;
-  const double* val;
-};
-static RbView view_of(const DevMat& A) { return RbView{A.m, A.nblocks, A.nnz, A.blk_row, A.blk_p0, A.roff, A.col, A.val}; }
 
 struct BlockRange { int64_t first, last, stride; };
 
@@ -61,16 +48,6 @@ static int grid_for_blocks(int64_t nblocks) {
   if (blocks < 8) blocks = 8;
   return (int)blocks;
 }
-
-// Input vector of an SpMV.  Single device: DIST = false, plain x[c].  Row-block distributed
-// (one rank per GPU): columns < nl index the rank's own segment, columns >= nl the ghost values
-// received from the neighbours (xg is pre-shifted by -nl).
-template <bool DIST> struct XVec {
-  const double* __restrict__ x; const double* __restrict__ xg; int32_t nl;
-  __device__ __forceinline__ double operator[](int32_t c) const {
-    if constexpr (DIST) return c < nl ? x[c] : xg[c]; else return x[c];
-  }
-};
 
 // Calls epi(row, sum_j a_row,j x_j) once for every row of the matrix.
 template <class T, bool NT>
@@ -470,14 +447,22 @@ __global__ __launch_bounds__(BLOCK) void k_rb_stream_dbg(RbView A, const double*
 
 // diagnostics 256 / 512: flat grid-stride stream over the non-zeros (no row structure at all),
 // without / with the x gather - the ceiling any SpMV organisation of these arrays can reach
-template <bool GATHER>
-__global__ __launch_bounds__(BLOCK) void k_flat_stream_dbg(int64_t nnz, const int32_t* __restrict__ col, const double* __restrict__ val,
-                                                           const double* __restrict__ x, double* __restrict__ out) {
+// GATHER: 0 none, 1 x[col], 2 x[(col of lane 0 rounded down to 64) + lane] (same traffic pattern
+// into x but 4 lines per wave instruction instead of 20-33)
+template <int GATHER>
+__global__ __launch_bounds__(BLOCK) void k_flat_stream_dbg(int64_t nnz, int64_t nx, const int32_t* __restrict__ col,
+                                                           const double* __restrict__ val, const double* __restrict__ x,
+                                                           double* __restrict__ out) {
   const int64_t stride = (int64_t)gridDim.x * BLOCK;
+  const int lane = threadIdx.x & 63;
   double s = 0.0;
   for (int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x; k < nnz; k += stride) {
     const int32_t c = col[k];
-    s += val[k] * (GATHER ? x[c] : (double)c);
+    double xv;
+    if (GATHER == 0) xv = (double)c;
+    else if (GATHER == 1) xv = x[c];
+    else { int64_t c0 = (__shfl(c, 0, 64) & ~63) + lane; if (c0 >= nx) c0 = lane; xv = x[c0]; }
+    s += val[k] * xv;
   }
   if (s == 123.456) out[0] = s;
 }
@@ -488,6 +473,7 @@ int g_spmv_variant = std::getenv("AIRHIP_SPMV_VARIANT") ? std::atoi(std::getenv(
 
 void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t s, const double* x_ghost) {
   if (A.m == 0) return;
+  if (g_spmv_variant == 0 && launch_spmv_tiled(A, x, e, s, x_ghost)) return;
   const dim3 grid(grid_for_blocks(A.nblocks)), block(BLOCK);
   const RbView v = view_of(A);
   if (A.n_ghost > 0) {
@@ -503,8 +489,9 @@ void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t
     hipLaunchKernelGGL((k_rb_spmv_pipe<1024, XVec<false>>), grid, block, 0, s, v, xp, e);
     return;
   }
-  if (g_spmv_variant & 256) { hipLaunchKernelGGL(k_flat_stream_dbg<false>, dim3(2048), block, 0, s, A.nnz, A.col, A.val, x, e.out); return; }
-  if (g_spmv_variant & 512) { hipLaunchKernelGGL(k_flat_stream_dbg<true>, dim3(2048), block, 0, s, A.nnz, A.col, A.val, x, e.out); return; }
+  if (g_spmv_variant & 256) { hipLaunchKernelGGL(k_flat_stream_dbg<0>, dim3(2048), block, 0, s, A.nnz, A.n, A.col, A.val, x, e.out); return; }
+  if (g_spmv_variant & 512) { hipLaunchKernelGGL(k_flat_stream_dbg<1>, dim3(2048), block, 0, s, A.nnz, A.n, A.col, A.val, x, e.out); return; }
+  if (g_spmv_variant & 1024) { hipLaunchKernelGGL(k_flat_stream_dbg<2>, dim3(2048), block, 0, s, A.nnz, A.n, A.col, A.val, x, e.out); return; }
   if ((g_spmv_variant & 128) && A.nnz > 0) {
     const XVec<false> xp{x, nullptr, 0};
     hipLaunchKernelGGL((k_rb_spmv2<1024, XVec<false>>), grid, block, 0, s, v, xp, e);
@@ -559,6 +546,7 @@ void launch_fc_first(const DevMat& A_fc, const int32_t* wcol, const double* b_f,
                      const double* aff_d, const double* minv, double* t4_out, double* x_f, hipStream_t s,
                      const double* x_ghost) {
   if (A_fc.m == 0) return;
+  if (g_spmv_variant == 0 && launch_fc_first_tiled(A_fc, wcol, b_f, x_c, aff_d, minv, t4_out, x_f, s, x_ghost)) return;
   const dim3 grid(grid_for_blocks(A_fc.nblocks)), block(BLOCK);
   if (A_fc.n_ghost > 0) {
     if (!x_ghost) throw std::runtime_error("launch_fc_first: distributed operand without ghost values");
@@ -617,7 +605,7 @@ __global__ __launch_bounds__(BLOCK) void k_chunk_scan(int64_t n, const int64_t* 
 }
 
 // exclusive scan of n int64 values on the device; returns the total
-static int64_t device_exclusive_scan(int64_t n, const int64_t* d_in, int64_t* d_out, hipStream_t s) {
+int64_t device_exclusive_scan(int64_t n, const int64_t* d_in, int64_t* d_out, hipStream_t s) {
   if (n == 0) return 0;
   const int64_t nchunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
   int64_t* d_sums = nullptr;
@@ -660,10 +648,10 @@ __global__ __launch_bounds__(BLOCK) void k_copy_rows(int64_t m, const int64_t* _
 // flag[r] = 1 if row r starts a new block: its first non-zero lies in another BLK_NNZ bucket
 // than the previous row's, or BLK_ROWS rows have passed (runs of empty rows, e.g. Dirichlet
 // planes, must not pile up in one block)
-__global__ __launch_bounds__(BLOCK) void k_block_flags(int64_t m, const int64_t* __restrict__ nrp, int64_t* __restrict__ flag) {
+__global__ __launch_bounds__(BLOCK) void k_block_flags(int64_t m, int blk_nnz, const int64_t* __restrict__ nrp, int64_t* __restrict__ flag) {
   const int64_t stride = (int64_t)gridDim.x * BLOCK;
   for (int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x; r < m; r += stride)
-    flag[r] = (r % BLK_ROWS == 0 || (nrp[r] / BLK_NNZ) != (nrp[r - 1] / BLK_NNZ)) ? 1 : 0;
+    flag[r] = (r % BLK_ROWS == 0 || (nrp[r] / blk_nnz) != (nrp[r - 1] / blk_nnz)) ? 1 : 0;
 }
 
 __global__ __launch_bounds__(BLOCK) void k_block_build(int64_t m, const int64_t* __restrict__ nrp, const int64_t* __restrict__ flag,
@@ -710,7 +698,7 @@ void devmat_from_csr_device(int64_t m, int64_t n, const int64_t* d_rp, const int
   // row blocks
   d_flag = d_len;   // reuse
   HIP_CHECK(hipMalloc(&d_blk_of, sizeof(int64_t) * (size_t)m));
-  hipLaunchKernelGGL(k_block_flags, dim3(grid1d(m)), dim3(BLOCK), 0, s, m, d_nrp, d_flag);
+  hipLaunchKernelGGL(k_block_flags, dim3(grid1d(m)), dim3(BLOCK), 0, s, m, tiles_enabled() ? BLK_NNZ_TILED : BLK_NNZ, d_nrp, d_flag);
   out.nblocks = device_exclusive_scan(m, d_flag, d_blk_of, s);
   HIP_CHECK(hipMalloc(&out.blk_row, sizeof(int32_t) * (size_t)(out.nblocks + 1)));
   HIP_CHECK(hipMalloc(&out.blk_p0, sizeof(int64_t) * (size_t)(out.nblocks + 1)));
@@ -722,6 +710,7 @@ void devmat_from_csr_device(int64_t m, int64_t n, const int64_t* d_rp, const int
   hipLaunchKernelGGL(k_row_offsets, dim3(grid1d(m)), dim3(BLOCK), 0, s, m, d_nrp, d_flag, d_blk_of, out.blk_p0, out.roff);
   HIP_CHECK(hipStreamSynchronize(s));
   (void)hipFree(d_len); (void)hipFree(d_nrp); (void)hipFree(d_blk_of);
+  if (tiles_enabled()) devmat_build_tiles(out, s);
 }
 
 void devmat_free(DevMat& A) {
@@ -730,6 +719,10 @@ void devmat_free(DevMat& A) {
   if (A.roff) (void)hipFree(A.roff);
   if (A.col) (void)hipFree(A.col);
   if (A.val) (void)hipFree(A.val);
+  if (A.tile_blk) (void)hipFree(A.tile_blk);
+  if (A.tile_u0) (void)hipFree(A.tile_u0);
+  if (A.ucol) (void)hipFree(A.ucol);
+  if (A.lidx) (void)hipFree(A.lidx);
   A = DevMat();
 }
 
