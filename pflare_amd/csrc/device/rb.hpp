@@ -22,8 +22,9 @@ struct RbView {
   const uint32_t* roff;
   const int32_t* col;
   const double* val;
+  const uint16_t* slot;   // column-sorted blocks: position of the entry in row-major order inside its block
 };
-inline RbView view_of(const DevMat& A) { return RbView{A.m, A.nblocks, A.nnz, A.blk_row, A.blk_p0, A.roff, A.col, A.val}; }
+inline RbView view_of(const DevMat& A) { return RbView{A.m, A.nblocks, A.nnz, A.blk_row, A.blk_p0, A.roff, A.col, A.val, A.slot}; }
 
 // Input vector of an SpMV.  Single device: DIST = false, plain x[c].  Row-block distributed
 // (one rank per GPU): columns < nl index the rank's own segment, columns >= nl the ghost values

@@ -19,6 +19,7 @@
 #include "kcommon.hpp"
 #include "rb.hpp"
 #include <stdexcept>
+#include <algorithm>
 #include <cstdlib>
 
 namespace airhip {
@@ -62,7 +63,7 @@ struct XVecNoGather {
   __device__ __forceinline__ double operator[](int32_t c) const { return x[c & 1023]; }
 };
 
-template <int CAP, bool NT, int UNR, class X, class Epi>
+template <int CAP, bool NT, int UNR, bool SORTED, class X, class Epi>
 __device__ __forceinline__ void rb_rows(const RbView& A, const X x, double* __restrict__ lds, Epi epi) {
   const int lane = threadIdx.x & (WAVE - 1);
   const BlockRange br = my_blocks(A.nblocks);
@@ -74,6 +75,7 @@ __device__ __forceinline__ void rb_rows(const RbView& A, const X x, double* __re
     const int nb = (int)(p1 - p0);
     const double* __restrict__ v = A.val + p0;
     const int32_t* __restrict__ c = A.col + p0;
+    const uint16_t* __restrict__ sl = A.slot + p0;
     const int nr = r1 - r0;
     if (nb <= 4 * nr) {
       // very short rows (<= 4 non-zeros on average): one lane per row straight from global
@@ -90,17 +92,19 @@ __device__ __forceinline__ void rb_rows(const RbView& A, const X x, double* __re
       // phase 1: coalesced stream, products to LDS (UNR independent loads in flight per lane)
       int k = lane;
       for (; k + (UNR - 1) * WAVE < nb; k += UNR * WAVE) {
-        int32_t cc[UNR]; double vv[UNR], xx[UNR];
+        int32_t cc[UNR]; double vv[UNR], xx[UNR]; int ss[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; u++) cc[u] = ldg<int32_t, NT>(c + k + u * WAVE);
 #pragma unroll
         for (int u = 0; u < UNR; u++) vv[u] = ldg<double, NT>(v + k + u * WAVE);
 #pragma unroll
+        for (int u = 0; u < UNR; u++) ss[u] = SORTED ? (int)sl[k + u * WAVE] : k + u * WAVE;
+#pragma unroll
         for (int u = 0; u < UNR; u++) xx[u] = x[cc[u]];
 #pragma unroll
-        for (int u = 0; u < UNR; u++) lds[k + u * WAVE] = vv[u] * xx[u];
+        for (int u = 0; u < UNR; u++) lds[ss[u]] = vv[u] * xx[u];
       }
-      for (; k < nb; k += WAVE) lds[k] = ldg<double, NT>(v + k) * x[ldg<int32_t, NT>(c + k)];
+      for (; k < nb; k += WAVE) lds[SORTED ? (int)sl[k] : k] = ldg<double, NT>(v + k) * x[ldg<int32_t, NT>(c + k)];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -269,11 +273,11 @@ __global__ __launch_bounds__(BLOCK) void k_rb_spmv_pipe(RbView A, X x, SpmvEpi e
   });
 }
 
-template <int CAP, bool NT, int UNR, class X>
+template <int CAP, bool NT, int UNR, bool SORTED, class X>
 __global__ __launch_bounds__(BLOCK) void k_rb_spmv(RbView A, X x, SpmvEpi e) {
   __shared__ double lds_all[WAVES_PER_BLOCK][CAP];
   double* lds = lds_all[threadIdx.x >> 6];
-  rb_rows<CAP, NT, UNR>(A, x, lds, [&](int32_t row, double acc) {
+  rb_rows<CAP, NT, UNR, SORTED>(A, x, lds, [&](int32_t row, double acc) {
     if (e.dscale) acc *= e.dscale[row];
     double o = e.alpha * acc;
     if (e.z) o += e.beta * e.z[row];
@@ -481,10 +485,11 @@ void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t
     if (!x_ghost) throw std::runtime_error("launch_spmv: distributed operand without ghost values");
     const int32_t nl = (int32_t)(A.n - A.n_ghost);
     const XVec<true> xv{x, x_ghost - nl, nl};
-    hipLaunchKernelGGL((k_rb_spmv<1024, false, 4, XVec<true>>), grid, block, 0, s, v, xv, e);
+    if (A.slot) hipLaunchKernelGGL((k_rb_spmv<1024, false, 4, true, XVec<true>>), grid, block, 0, s, v, xv, e);
+    else hipLaunchKernelGGL((k_rb_spmv<1024, false, 4, false, XVec<true>>), grid, block, 0, s, v, xv, e);
     return;
   }
-  if ((g_spmv_variant & 16) && A.nnz > 0) {
+  if ((g_spmv_variant & 16) && A.nnz > 0 && !A.slot) {
     const XVec<false> xp{x, nullptr, 0};
     hipLaunchKernelGGL((k_rb_spmv_pipe<1024, XVec<false>>), grid, block, 0, s, v, xp, e);
     return;
@@ -492,7 +497,7 @@ void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t
   if (g_spmv_variant & 256) { hipLaunchKernelGGL(k_flat_stream_dbg<0>, dim3(2048), block, 0, s, A.nnz, A.n, A.col, A.val, x, e.out); return; }
   if (g_spmv_variant & 512) { hipLaunchKernelGGL(k_flat_stream_dbg<1>, dim3(2048), block, 0, s, A.nnz, A.n, A.col, A.val, x, e.out); return; }
   if (g_spmv_variant & 1024) { hipLaunchKernelGGL(k_flat_stream_dbg<2>, dim3(2048), block, 0, s, A.nnz, A.n, A.col, A.val, x, e.out); return; }
-  if ((g_spmv_variant & 128) && A.nnz > 0) {
+  if ((g_spmv_variant & 128) && A.nnz > 0 && !A.slot) {
     const XVec<false> xp{x, nullptr, 0};
     hipLaunchKernelGGL((k_rb_spmv2<1024, XVec<false>>), grid, block, 0, s, v, xp, e);
     return;
@@ -501,11 +506,15 @@ void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t
   if (g_spmv_variant & 64) { hipLaunchKernelGGL(k_rb_stream_dbg<2>, grid, block, 0, s, v, x, e.out); return; }
   if (g_spmv_variant & 8) {
     const XVecNoGather xd{x};
-    hipLaunchKernelGGL((k_rb_spmv<1024, false, 4, XVecNoGather>), grid, block, 0, s, v, xd, e);
+    hipLaunchKernelGGL((k_rb_spmv<1024, false, 4, false, XVecNoGather>), grid, block, 0, s, v, xd, e);
     return;
   }
   const XVec<false> xv{x, nullptr, 0};
-#define RB_LAUNCH(CAP, NT, UNR) hipLaunchKernelGGL((k_rb_spmv<CAP, NT, UNR, XVec<false>>), grid, block, 0, s, v, xv, e)
+  if (A.slot) {   // column-sorted blocks: the production kernel
+    hipLaunchKernelGGL((k_rb_spmv<1024, false, 4, true, XVec<false>>), grid, block, 0, s, v, xv, e);
+    return;
+  }
+#define RB_LAUNCH(CAP, NT, UNR) hipLaunchKernelGGL((k_rb_spmv<CAP, NT, UNR, false, XVec<false>>), grid, block, 0, s, v, xv, e)
   switch (g_spmv_variant & 7) {
     case 0: RB_LAUNCH(1024, false, 4); break;
     case 1: RB_LAUNCH(640, false, 4); break;
@@ -519,14 +528,14 @@ void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t
 #undef RB_LAUNCH
 }
 
-template <bool DIST>
+template <bool DIST, bool SORTED>
 __global__ __launch_bounds__(BLOCK) void k_rb_fc_first(RbView A, const int32_t* __restrict__ wcol,
                                                       const double* __restrict__ b_f, XVec<DIST> x_c,
                                                       const double* __restrict__ aff_d, const double* __restrict__ minv,
                                                       double* __restrict__ t4_out, double* __restrict__ x_f) {
   __shared__ double lds_all[WAVES_PER_BLOCK][LDS_CAP];
   double* lds = lds_all[threadIdx.x >> 6];
-  rb_rows<LDS_CAP, false, 4>(A, x_c, lds, [&](int32_t row, double acc) {
+  rb_rows<LDS_CAP, false, 4, SORTED>(A, x_c, lds, [&](int32_t row, double acc) {
     const double t4 = b_f[row] + (-1.0) * acc;
     const int32_t wc = wcol[row];
     const double x0 = wc >= 0 ? x_c[wc] : 0.0;
@@ -552,10 +561,12 @@ void launch_fc_first(const DevMat& A_fc, const int32_t* wcol, const double* b_f,
     if (!x_ghost) throw std::runtime_error("launch_fc_first: distributed operand without ghost values");
     const int32_t nl = (int32_t)(A_fc.n - A_fc.n_ghost);
     const XVec<true> xv{x_c, x_ghost - nl, nl};
-    hipLaunchKernelGGL(k_rb_fc_first<true>, grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
+    if (A_fc.slot) hipLaunchKernelGGL((k_rb_fc_first<true, true>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
+    else hipLaunchKernelGGL((k_rb_fc_first<true, false>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
   } else {
     const XVec<false> xv{x_c, nullptr, 0};
-    hipLaunchKernelGGL(k_rb_fc_first<false>, grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
+    if (A_fc.slot) hipLaunchKernelGGL((k_rb_fc_first<false, true>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
+    else hipLaunchKernelGGL((k_rb_fc_first<false, false>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
   }
 }
 
@@ -672,6 +683,58 @@ __global__ __launch_bounds__(BLOCK) void k_row_offsets(int64_t m, const int64_t*
   }
 }
 
+// Column-sort the entries of every block that takes the LDS path (4*rows < nnz <= LDS_CAP); other
+// blocks are copied through with slot = identity.  One wave per block, bitonic sort of
+// (column << 16 | position) keys in LDS.
+__global__ __launch_bounds__(BLOCK) void k_block_sort(int64_t nblocks, const int32_t* __restrict__ blk_row, const int64_t* __restrict__ blk_p0,
+                                                     const int32_t* __restrict__ col, const double* __restrict__ val,
+                                                     int32_t* __restrict__ ocol, double* __restrict__ oval, uint16_t* __restrict__ slot) {
+  __shared__ unsigned long long keys_all[WAVES_PER_BLOCK][LDS_CAP];
+  unsigned long long* keys = keys_all[threadIdx.x >> 6];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * BLOCK) >> 6;
+  for (int64_t b = wave; b < nblocks; b += nwaves) {
+    const int64_t p0 = blk_p0[b], p1 = blk_p0[b + 1];
+    const int nb = (int)(p1 - p0);
+    const int nr = blk_row[b + 1] - blk_row[b];
+    if (p1 - p0 > LDS_CAP || nb <= 4 * nr) {
+      for (int64_t k = p0 + lane; k < p1; k += WAVE) { ocol[k] = col[k]; oval[k] = val[k]; slot[k] = (uint16_t)((k - p0) & 0xffff); }
+      continue;
+    }
+    int P2 = WAVE; while (P2 < nb) P2 <<= 1;
+    for (int i = lane; i < P2; i += WAVE)
+      keys[i] = i < nb ? (((unsigned long long)(uint32_t)col[p0 + i]) << 16) | (unsigned long long)i : ~0ull;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int size = 2; size <= P2; size <<= 1)
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int i = lane; i < P2 / 2; i += WAVE) {
+          const int a = 2 * i - (i & (stride - 1));
+          const int bb = a + stride;
+          const bool asc = (a & size) == 0;
+          const unsigned long long ka = keys[a], kb = keys[bb];
+          if ((ka > kb) == asc) { keys[a] = kb; keys[bb] = ka; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    for (int i = lane; i < nb; i += WAVE) {
+      const unsigned long long k = keys[i];
+      const int pos = (int)(k & 0xffffull);
+      ocol[p0 + i] = (int32_t)(k >> 16);
+      oval[p0 + i] = val[p0 + pos];
+      slot[p0 + i] = (uint16_t)pos;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+static bool sort_blocks_enabled() {
+  static const bool on = !(std::getenv("AIRHIP_NO_BLOCK_SORT") && std::atoi(std::getenv("AIRHIP_NO_BLOCK_SORT")) != 0);
+  return on;
+}
+
 static int grid1d(int64_t n) {
   int64_t b = (n + BLOCK - 1) / BLOCK;
   if (b > MAX_BLOCKS) b = MAX_BLOCKS;
@@ -710,6 +773,18 @@ void devmat_from_csr_device(int64_t m, int64_t n, const int64_t* d_rp, const int
   hipLaunchKernelGGL(k_row_offsets, dim3(grid1d(m)), dim3(BLOCK), 0, s, m, d_nrp, d_flag, d_blk_of, out.blk_p0, out.roff);
   HIP_CHECK(hipStreamSynchronize(s));
   (void)hipFree(d_len); (void)hipFree(d_nrp); (void)hipFree(d_blk_of);
+  if (sort_blocks_enabled() && !tiles_enabled() && out.nnz > 0) {
+    int32_t* ncol = nullptr; double* nval = nullptr;
+    HIP_CHECK(hipMalloc(&ncol, sizeof(int32_t) * (size_t)out.nnz));
+    HIP_CHECK(hipMalloc(&nval, sizeof(double) * (size_t)out.nnz));
+    HIP_CHECK(hipMalloc(&out.slot, sizeof(uint16_t) * (size_t)out.nnz));
+    const int g = (int)std::min<int64_t>((out.nblocks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 4096);
+    hipLaunchKernelGGL(k_block_sort, dim3(g < 1 ? 1 : g), dim3(BLOCK), 0, s, out.nblocks, out.blk_row, out.blk_p0, out.col, out.val, ncol, nval,
+                       out.slot);
+    HIP_CHECK(hipStreamSynchronize(s));
+    (void)hipFree(out.col); (void)hipFree(out.val);
+    out.col = ncol; out.val = nval;
+  }
   if (tiles_enabled()) devmat_build_tiles(out, s);
 }
 
@@ -719,6 +794,7 @@ void devmat_free(DevMat& A) {
   if (A.roff) (void)hipFree(A.roff);
   if (A.col) (void)hipFree(A.col);
   if (A.val) (void)hipFree(A.val);
+  if (A.slot) (void)hipFree(A.slot);
   if (A.tile_blk) (void)hipFree(A.tile_blk);
   if (A.tile_u0) (void)hipFree(A.tile_u0);
   if (A.ucol) (void)hipFree(A.ucol);

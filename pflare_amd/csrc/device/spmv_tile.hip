@@ -22,11 +22,11 @@
 
 namespace airhip {
 
-// AIRHIP_TILE_MODE: 0 = untiled kernels, 1 = one tile per row block, staged by the wave that owns the
-// block (no workgroup barriers; default), 2 = one tile per ~2k non-zeros, staged by the workgroup
+// AIRHIP_TILE_MODE: 0 = untiled kernels with column-sorted blocks (default), 1 = one tile per row block, staged by the wave that owns the
+// block (no workgroup barriers), 2 = one tile per ~2k non-zeros, staged by the workgroup
 static int tile_mode() {
   static const int m = std::getenv("AIRHIP_TILE_MODE") ? std::atoi(std::getenv("AIRHIP_TILE_MODE"))
-                       : ((std::getenv("AIRHIP_NO_TILES") && std::atoi(std::getenv("AIRHIP_NO_TILES")) != 0) ? 0 : 1);
+                       : 0;
   return m;
 }
 bool tiles_enabled() { return tile_mode() != 0; }
