@@ -138,8 +138,17 @@ __device__ __forceinline__ void rb_rows(const RbView& A, const X x, double* __re
       for (int32_t r = r0; r < r1; r++) {
         const int a = (int)A.roff[r];
         const int e = (r + 1 < r1) ? (int)A.roff[r + 1] : nb;
-        double s = 0.0;
-        for (int j = a + lane; j < e; j += WAVE) s = fma(ldg<double, NT>(v + j), x[ldg<int32_t, NT>(c + j)], s);
+        // four independent (column, value, x) chains in flight per lane
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int j = a + lane;
+        for (; j + 3 * WAVE < e; j += 4 * WAVE) {
+          const int32_t c0 = c[j], c1 = c[j + WAVE], c2 = c[j + 2 * WAVE], c3 = c[j + 3 * WAVE];
+          const double v0 = v[j], v1 = v[j + WAVE], v2 = v[j + 2 * WAVE], v3 = v[j + 3 * WAVE];
+          const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+          s0 = fma(v0, x0, s0); s1 = fma(v1, x1, s1); s2 = fma(v2, x2, s2); s3 = fma(v3, x3, s3);
+        }
+        for (; j < e; j += WAVE) s0 = fma(v[j], x[c[j]], s0);
+        double s = (s0 + s1) + (s2 + s3);
         for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
         if (lane == 0) epi(r, s);
       }
@@ -473,6 +482,14 @@ __global__ __launch_bounds__(BLOCK) void k_flat_stream_dbg(int64_t nnz, int64_t 
 
 // tuning variant (bit 0: 640-entry LDS stage instead of 1024, bit 1: non-temporal matrix loads,
 // bit 2: 8 instead of 4 loads in flight); set through airhip_debug_set_variant
+// AIRHIP_BLK=256: blocks of <= 255 + row length non-zeros with a 512-entry LDS stage (4 KB per wave ->
+// twice the resident waves; rows longer than ~256 take the wave-per-row path).  Default 512 / 1024.
+static int blk_from_env() {
+  const char* e = std::getenv("AIRHIP_BLK");
+  const int v = e ? std::atoi(e) : BLK_NNZ;
+  return (v == 256 || v == 1024) ? v : BLK_NNZ;
+}
+int g_blk_nnz = blk_from_env();
 int g_spmv_variant = std::getenv("AIRHIP_SPMV_VARIANT") ? std::atoi(std::getenv("AIRHIP_SPMV_VARIANT")) : 0;
 
 void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t s, const double* x_ghost) {
@@ -511,7 +528,9 @@ void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t
   }
   const XVec<false> xv{x, nullptr, 0};
   if (A.slot) {   // column-sorted blocks: the production kernel
-    hipLaunchKernelGGL((k_rb_spmv<1024, false, 4, true, XVec<false>>), grid, block, 0, s, v, xv, e);
+    if (g_blk_nnz == 256) hipLaunchKernelGGL((k_rb_spmv<512, false, 4, true, XVec<false>>), grid, block, 0, s, v, xv, e);
+    else if (g_blk_nnz == 1024) hipLaunchKernelGGL((k_rb_spmv<2048, false, 8, true, XVec<false>>), grid, block, 0, s, v, xv, e);
+    else hipLaunchKernelGGL((k_rb_spmv<1024, false, 4, true, XVec<false>>), grid, block, 0, s, v, xv, e);
     return;
   }
 #define RB_LAUNCH(CAP, NT, UNR) hipLaunchKernelGGL((k_rb_spmv<CAP, NT, UNR, false, XVec<false>>), grid, block, 0, s, v, xv, e)
@@ -528,14 +547,14 @@ void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t
 #undef RB_LAUNCH
 }
 
-template <bool DIST, bool SORTED>
+template <bool DIST, bool SORTED, int CAP>
 __global__ __launch_bounds__(BLOCK) void k_rb_fc_first(RbView A, const int32_t* __restrict__ wcol,
                                                       const double* __restrict__ b_f, XVec<DIST> x_c,
                                                       const double* __restrict__ aff_d, const double* __restrict__ minv,
                                                       double* __restrict__ t4_out, double* __restrict__ x_f) {
-  __shared__ double lds_all[WAVES_PER_BLOCK][LDS_CAP];
+  __shared__ double lds_all[WAVES_PER_BLOCK][CAP];
   double* lds = lds_all[threadIdx.x >> 6];
-  rb_rows<LDS_CAP, false, 4, SORTED>(A, x_c, lds, [&](int32_t row, double acc) {
+  rb_rows<CAP, false, 4, SORTED>(A, x_c, lds, [&](int32_t row, double acc) {
     const double t4 = b_f[row] + (-1.0) * acc;
     const int32_t wc = wcol[row];
     const double x0 = wc >= 0 ? x_c[wc] : 0.0;
@@ -561,12 +580,14 @@ void launch_fc_first(const DevMat& A_fc, const int32_t* wcol, const double* b_f,
     if (!x_ghost) throw std::runtime_error("launch_fc_first: distributed operand without ghost values");
     const int32_t nl = (int32_t)(A_fc.n - A_fc.n_ghost);
     const XVec<true> xv{x_c, x_ghost - nl, nl};
-    if (A_fc.slot) hipLaunchKernelGGL((k_rb_fc_first<true, true>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
-    else hipLaunchKernelGGL((k_rb_fc_first<true, false>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
+    if (A_fc.slot) hipLaunchKernelGGL((k_rb_fc_first<true, true, 1024>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
+    else hipLaunchKernelGGL((k_rb_fc_first<true, false, 1024>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
   } else {
     const XVec<false> xv{x_c, nullptr, 0};
-    if (A_fc.slot) hipLaunchKernelGGL((k_rb_fc_first<false, true>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
-    else hipLaunchKernelGGL((k_rb_fc_first<false, false>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
+    if (A_fc.slot && g_blk_nnz == 256) hipLaunchKernelGGL((k_rb_fc_first<false, true, 512>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
+    else if (A_fc.slot && g_blk_nnz == 1024) hipLaunchKernelGGL((k_rb_fc_first<false, true, 2048>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
+    else if (A_fc.slot) hipLaunchKernelGGL((k_rb_fc_first<false, true, 1024>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
+    else hipLaunchKernelGGL((k_rb_fc_first<false, false, 1024>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
   }
 }
 
@@ -688,8 +709,9 @@ __global__ __launch_bounds__(BLOCK) void k_row_offsets(int64_t m, const int64_t*
 // (column << 16 | position) keys in LDS.
 __global__ __launch_bounds__(BLOCK) void k_block_sort(int64_t nblocks, const int32_t* __restrict__ blk_row, const int64_t* __restrict__ blk_p0,
                                                      const int32_t* __restrict__ col, const double* __restrict__ val,
-                                                     int32_t* __restrict__ ocol, double* __restrict__ oval, uint16_t* __restrict__ slot) {
-  __shared__ unsigned long long keys_all[WAVES_PER_BLOCK][LDS_CAP];
+                                                     int32_t* __restrict__ ocol, double* __restrict__ oval, uint16_t* __restrict__ slot,
+                                                     int cap) {
+  __shared__ unsigned long long keys_all[WAVES_PER_BLOCK][2 * LDS_CAP];
   unsigned long long* keys = keys_all[threadIdx.x >> 6];
   const int lane = threadIdx.x & (WAVE - 1);
   const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
@@ -698,7 +720,7 @@ __global__ __launch_bounds__(BLOCK) void k_block_sort(int64_t nblocks, const int
     const int64_t p0 = blk_p0[b], p1 = blk_p0[b + 1];
     const int nb = (int)(p1 - p0);
     const int nr = blk_row[b + 1] - blk_row[b];
-    if (p1 - p0 > LDS_CAP || nb <= 4 * nr) {
+    if (p1 - p0 > cap || nb <= 4 * nr) {
       for (int64_t k = p0 + lane; k < p1; k += WAVE) { ocol[k] = col[k]; oval[k] = val[k]; slot[k] = (uint16_t)((k - p0) & 0xffff); }
       continue;
     }
@@ -761,7 +783,7 @@ void devmat_from_csr_device(int64_t m, int64_t n, const int64_t* d_rp, const int
   // row blocks
   d_flag = d_len;   // reuse
   HIP_CHECK(hipMalloc(&d_blk_of, sizeof(int64_t) * (size_t)m));
-  hipLaunchKernelGGL(k_block_flags, dim3(grid1d(m)), dim3(BLOCK), 0, s, m, tiles_enabled() ? BLK_NNZ_TILED : BLK_NNZ, d_nrp, d_flag);
+  hipLaunchKernelGGL(k_block_flags, dim3(grid1d(m)), dim3(BLOCK), 0, s, m, tiles_enabled() ? BLK_NNZ_TILED : g_blk_nnz, d_nrp, d_flag);
   out.nblocks = device_exclusive_scan(m, d_flag, d_blk_of, s);
   HIP_CHECK(hipMalloc(&out.blk_row, sizeof(int32_t) * (size_t)(out.nblocks + 1)));
   HIP_CHECK(hipMalloc(&out.blk_p0, sizeof(int64_t) * (size_t)(out.nblocks + 1)));
@@ -780,7 +802,7 @@ void devmat_from_csr_device(int64_t m, int64_t n, const int64_t* d_rp, const int
     HIP_CHECK(hipMalloc(&out.slot, sizeof(uint16_t) * (size_t)out.nnz));
     const int g = (int)std::min<int64_t>((out.nblocks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 4096);
     hipLaunchKernelGGL(k_block_sort, dim3(g < 1 ? 1 : g), dim3(BLOCK), 0, s, out.nblocks, out.blk_row, out.blk_p0, out.col, out.val, ncol, nval,
-                       out.slot);
+                       out.slot, g_blk_nnz == 256 ? 512 : (g_blk_nnz == 1024 ? 2 * LDS_CAP : LDS_CAP));
     HIP_CHECK(hipStreamSynchronize(s));
     (void)hipFree(out.col); (void)hipFree(out.val);
     out.col = ncol; out.val = nval;
