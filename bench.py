@@ -248,8 +248,19 @@ def main():
         tot_ms = sum(s["total_ms"] for s in live)
         site = max((s for s in live if s["kernel"] == kname), key=lambda s: s["total_ms"])
         site_avg = site["total_ms"] / site["calls"]
+        # HBM bytes per launch of that kernel from the PMC counters (FETCH_SIZE + WRITE_SIZE, separate
+        # rocprofv3 --pmc passes of this same command, corrected as MI355X_MICROARCH.md prescribes;
+        # recorded in profiles/pmc_traffic.json by tools/pmc_traffic.py) - null if not measured
+        traffic = traffic_src = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                ent = json.load(f).get(f"{kname}@{M}")
+            if ent and world == 1:
+                traffic, traffic_src = ent["bytes_per_launch"], ent["source"]
+        except Exception:
+            pass
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                     "kernel": kname, "avg_launch_ms": avg_ms,
                     "alg_bytes_per_launch": dom["bytes"] / dom["calls"], "calls": dom["calls"],
                     "share_of_profiled_kernel_time": dom["total_ms"] / tot_ms,
