@@ -330,9 +330,11 @@ __device__ __forceinline__ void rb_rows2(const RbView& A, const X x, double* __r
     const double* __restrict__ v = A.val + p0;
     const int32_t* __restrict__ c = A.col + p0;
     if (nb <= CAP) {
-      int32_t cc[PF]; double vv[PF], xx[PF]; uint32_t ro[RC];
+      int32_t cc[PF]; double vv[PF], xx[PF]; uint32_t ro[RC]; int ss[PF];
 #pragma unroll
       for (int u = 0; u < PF; u++) cc[u] = A.col[min(p0 + lane + u * WAVE, last_nz)];
+#pragma unroll
+      for (int u = 0; u < PF; u++) ss[u] = A.slot ? (int)A.slot[min(p0 + lane + u * WAVE, last_nz)] : lane + u * WAVE;
 #pragma unroll
       for (int u = 0; u < PF; u++) vv[u] = A.val[min(p0 + lane + u * WAVE, last_nz)];
 #pragma unroll
@@ -341,8 +343,8 @@ __device__ __forceinline__ void rb_rows2(const RbView& A, const X x, double* __r
 #pragma unroll
       for (int u = 0; u < PF; u++) xx[u] = x[cc[u]];
 #pragma unroll
-      for (int u = 0; u < PF; u++) { const int k = lane + u * WAVE; if (k < nb) lds[k] = vv[u] * xx[u]; }
-      for (int k = lane + PF * WAVE; k < nb; k += WAVE) lds[k] = v[k] * x[c[k]];
+      for (int u = 0; u < PF; u++) { const int k = lane + u * WAVE; if (k < nb) lds[ss[u]] = vv[u] * xx[u]; }
+      for (int k = lane + PF * WAVE; k < nb; k += WAVE) lds[A.slot ? (int)A.slot[p0 + k] : k] = v[k] * x[c[k]];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -514,7 +516,7 @@ void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t
   if (g_spmv_variant & 256) { hipLaunchKernelGGL(k_flat_stream_dbg<0>, dim3(2048), block, 0, s, A.nnz, A.n, A.col, A.val, x, e.out); return; }
   if (g_spmv_variant & 512) { hipLaunchKernelGGL(k_flat_stream_dbg<1>, dim3(2048), block, 0, s, A.nnz, A.n, A.col, A.val, x, e.out); return; }
   if (g_spmv_variant & 1024) { hipLaunchKernelGGL(k_flat_stream_dbg<2>, dim3(2048), block, 0, s, A.nnz, A.n, A.col, A.val, x, e.out); return; }
-  if ((g_spmv_variant & 128) && A.nnz > 0 && !A.slot) {
+  if ((g_spmv_variant & 128) && A.nnz > 0) {
     const XVec<false> xp{x, nullptr, 0};
     hipLaunchKernelGGL((k_rb_spmv2<1024, XVec<false>>), grid, block, 0, s, v, xp, e);
     return;
