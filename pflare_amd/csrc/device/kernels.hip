@@ -130,12 +130,15 @@ __global__ __launch_bounds__(BLOCK) void k_mdot_partial(int64_t n, const double*
   }
 }
 
-__global__ void k_mdot_final(int nblocks, int nv, const double* __restrict__ partial, double* __restrict__ dots) {
-  const int k = threadIdx.x;
-  if (k < nv) {
+// second stage: one wave per dot product, lanes stride over the block partials, fixed-order wave
+// reduction (deterministic)
+__global__ __launch_bounds__(BLOCK) void k_mdot_final(int nblocks, int nv, const double* __restrict__ partial, double* __restrict__ dots) {
+  const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x >> 6;
+  for (int k = wid; k < nv; k += WAVES_PER_BLOCK) {
     double v = 0.0;
-    for (int b = 0; b < nblocks; b++) v += partial[(int64_t)b * nv + k];
-    dots[k] = v;
+    for (int b = lane; b < nblocks; b += WAVE) v += partial[(int64_t)b * nv + k];
+    v = wave_sum(v);
+    if (lane == 0) dots[k] = v;
   }
 }
 
@@ -151,7 +154,7 @@ void launch_mdot(int64_t n, const double* w, const double* V, int64_t ld, int nv
     else if (rem >= 2) { hipLaunchKernelGGL(k_mdot_partial<2>, dim3(blocks), dim3(BLOCK), 0, s, n, w, V, ld, scratch, nv, k0); k0 += 2; }
     else { hipLaunchKernelGGL(k_mdot_partial<1>, dim3(blocks), dim3(BLOCK), 0, s, n, w, V, ld, scratch, nv, k0); k0 += 1; }
   }
-  hipLaunchKernelGGL(k_mdot_final, dim3(1), dim3(64), 0, s, blocks, nv, scratch, dots);
+  hipLaunchKernelGGL(k_mdot_final, dim3(1), dim3(BLOCK), 0, s, blocks, nv, scratch, dots);
 }
 
 template <int K>
