@@ -52,6 +52,10 @@ def main():
     ap.add_argument("--profile-kernels", type=int, default=1)
     ap.add_argument("--variants", default="", help="diagnostic: comma list of SpMV kernel variants to time")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--hint-brick", type=int, default=16,
+                    help="locality hint for the device layout: grid points grouped in BxBxB bricks (0: none); the "
+                         "operator keeps the reference numbering")
+    ap.add_argument("--brick", type=int, default=0, help="diagnostic: renumber the grid in BxBxB bricks before the setup (locality experiment; not the reference numbering)")
     ap.add_argument("--threads", type=int, default=0, help="host threads for setup + CPU baseline (0: cores / ranks, capped at 32 - measured best on the GPU box)")
     args = ap.parse_args()
 
@@ -105,7 +109,33 @@ def main():
         hm = P.HostMat.adv_diff_fd(dim=3, M=M, N=M, P=M)
         nnzA = hm.nnz
         log(f"[bench] operator {M}^3: n={n} nnz={nnzA} generated in {time.time()-t0:.1f}s")
+        if args.brick:
+            import numpy as np
+            import scipy.sparse as sp
+            B = args.brick
+            i, j, k = np.meshgrid(np.arange(M), np.arange(M), np.arange(M), indexing="ij")   # natural id = (k*M + j)*M + i
+            nat = ((k * M + j) * M + i).ravel()
+            nb = (M + B - 1) // B
+            key = ((((k // B) * nb + (j // B)) * nb + (i // B)) * B ** 3 + ((k % B) * B + (j % B)) * B + (i % B)).ravel()
+            order = nat[np.argsort(key, kind="stable")]          # new position -> natural id
+            a = hm.csr()
+            A = sp.csr_matrix((a.val, a.col, a.rowptr), shape=a.shape)
+            A = A[order][:, order].tocsr(); A.sort_indices()
+            hm = P.CsrArrays(A.indptr, A.indices, A.data, A.shape)
+            log(f"[bench] renumbered in {B}^3 bricks")
         pc = P.PCAIR(**opts)
+        if args.hint_brick > 0 and not args.brick:
+            # what a DM would tell the preconditioner: the brick of each grid point.  Only the device
+            # layout uses it (airhip_pcair_set_ordering_hint); operator and hierarchy are the reference's.
+            import numpy as np
+            B = args.hint_brick
+            nbk = (M + B - 1) // B
+            ax = np.arange(M, dtype=np.int64)
+            bi, li = ax // B, ax % B
+            key = ((bi[:, None, None] * nbk + bi[None, :, None]) * nbk + bi[None, None, :]) * B ** 3 \
+                + (li[:, None, None] * B + li[None, :, None]) * B + li[None, None, :]      # [k, j, i]
+            pc.set_ordering_hint(key.reshape(-1))
+            del key
         if world > 1:
             pc.set_option("device_upload", False)     # the hierarchy is cut and shipped below
         if args.verbose:
@@ -285,6 +315,7 @@ def main():
         "config": {"workload": f"3D upwind advection (tests/adv_diff_fd.c) {M}^3 = {M ** 3} DoF, nnz(A)={nnzA}, b=0, x0=1, "
                                f"GMRES(30) right PC rtol 1e-10, PCAIR recipe '{args.recipe}' {opts}",
                    "parallelism": parallelism,
+                   "layout_hint": (f"{args.hint_brick}^3 bricks" if args.hint_brick > 0 and not args.brick else "none"),
                    "levels": info["levels"], "iterations_to_rtol_1e-10": res0["its"],
                    "converged_reason": res0["reason_name"], "converged_solve_ms": res0["solve_ms"],
                    "cycle_complexity": cx["cycle"], "operator_complexity": cx["operator"],

@@ -111,6 +111,12 @@ int airhip_pcair_create(airhip_pcair* pc);
  * e.g. ("a_drop","1e-3"), ("inverse_type","power"), ("smooth_type","ff"), ("a_lump","1").
  * Also accepted: ("mg_coarse_ksp_max_it","10") for -mg_coarse_ksp_type richardson. */
 int airhip_pcair_set_option(airhip_pcair pc, const char* name, const char* value);
+/* Optional locality hint for the DEVICE LAYOUT: key[i] for every row i of the operator (e.g. a brick
+ * or Morton index of the grid point a DM would know).  Rows with close keys are stored close together
+ * on every level (coarse rows inherit the key of their parent C point), which shortens the reach of the
+ * x gathers.  The hierarchy, the numbering of the caller's vectors and the results are unaffected.
+ * Call before setup / finalize / partition_create. */
+int airhip_pcair_set_ordering_hint(airhip_pcair pc, const int64_t* key, int64_t n);
 /* Full setup from the operator: host hierarchy construction + device upload. */
 int airhip_pcair_setup(airhip_pcair pc, const airhip_csr* A);
 

@@ -34,7 +34,7 @@ DECLARED_SYMBOLS = [
     "airhip_last_error", "airhip_version", "airhip_device_count", "airhip_set_device", "airhip_set_num_threads",
     "airhip_gen_adv_1d", "airhip_gen_adv_diff_fd", "airhip_hostmat_from_csr", "airhip_hostmat_get",
     "airhip_hostmat_destroy",
-    "airhip_pcair_create", "airhip_pcair_set_option", "airhip_pcair_setup", "airhip_pcair_begin_levels",
+    "airhip_pcair_create", "airhip_pcair_set_option", "airhip_pcair_set_ordering_hint", "airhip_pcair_setup", "airhip_pcair_begin_levels",
     "airhip_pcair_set_level", "airhip_pcair_set_coarse", "airhip_pcair_finalize", "airhip_pcair_apply",
     "airhip_pcair_sync", "airhip_pcair_destroy", "airhip_pcair_num_levels", "airhip_pcair_level_sizes",
     "airhip_pcair_level_get", "airhip_pcair_level_inv", "airhip_pcair_level_smooth_order",
@@ -88,6 +88,7 @@ def lib():
         "airhip_hostmat_destroy": [pvp],
         "airhip_pcair_create": [pvp],
         "airhip_pcair_set_option": [vp, C.c_char_p, C.c_char_p],
+        "airhip_pcair_set_ordering_hint": [vp, pi64, C.c_int64],
         "airhip_pcair_setup": [vp, pcsr],
         "airhip_pcair_setup_host_only": [vp, pcsr],
         "airhip_pcair_begin_levels": [vp, C.c_int, pcsr],

@@ -166,7 +166,7 @@ struct airhip_pcair_s {
   bool setup_on_device = true;    // sparse products of the setup as HIP SpGEMMs
   int64_t setup_device_min_nnz = -1;
   bool device_upload = true;      // false: keep the hierarchy on the host only (it will be partitioned)
-  std::unique_ptr<LocalHierarchy> local;   // distributed: this rank's piece (views into `piece`)
+  std::vector<int64_t> hint;      // optional locality keys of the fine rows (device layout only)
   double accel_transfer_s = 0, accel_compute_s = 0;
 };
 
@@ -241,6 +241,10 @@ int airhip_pcair_set_option(airhip_pcair pc, const char* name, const char* value
 static void finish_device(airhip_pcair pc) {
   double t0 = now_s();
   pc->dev = std::make_unique<DevPCAIR>();
+  if (!pc->hint.empty()) {
+    if ((int64_t)pc->hint.size() != pc->A_top.m) throw std::runtime_error("ordering hint: one key per row of the operator is required");
+    pc->dev->set_ordering_hint(pc->hint.data(), (int64_t)pc->hint.size());
+  }
   pc->dev->upload(*pc->H, pc->A_top);
   pc->dev->set_use_graph(pc->use_graph);
   pc->dev->set_profile(pc->profile);
@@ -543,6 +547,12 @@ int airhip_pcair_complexities(airhip_pcair pc, double* grid, double* op, double*
   API_END
 }
 
+int airhip_pcair_set_ordering_hint(airhip_pcair pc, const int64_t* key, int64_t n) {
+  API_BEGIN
+  REQUIRE(pc && (key || n == 0) && n >= 0, AIRHIP_ERR_ARG, "bad ordering hint");
+  pc->hint.assign(key, key + n);
+  API_END
+}
 int airhip_pcair_cycle_alg_bytes(airhip_pcair pc, double* bytes) {
   API_BEGIN
   REQUIRE(pc && pc->dev && bytes, AIRHIP_ERR_STATE, "not set up on a device");
@@ -622,7 +632,9 @@ int airhip_partition_create(airhip_pcair pc, const airhip_csr* A_top, int nranks
   REQUIRE(!pc->H->levels.empty() || true, AIRHIP_ERR_STATE, "");
   auto* h = new airhip_partition_s;
   view_csr(A_top, h->A_view);
-  try { h->p = std::make_unique<Partitioner>(*pc->H, h->A_view, nranks, owner); } catch (...) { delete h; throw; }
+  REQUIRE(pc->hint.empty() || (int64_t)pc->hint.size() == A_top->m, AIRHIP_ERR_ARG, "ordering hint: one key per row of the operator is required");
+  try { h->p = std::make_unique<Partitioner>(*pc->H, h->A_view, nranks, owner, pc->hint.empty() ? nullptr : pc->hint.data()); }
+  catch (...) { delete h; throw; }
   *out = h;
   API_END
 }
@@ -722,6 +734,7 @@ int airhip_pcair_load_distributed(airhip_pcair pc, airhip_archive piece, airhip_
   REQUIRE(loc->nranks == comm->c->size && loc->rank == comm->c->rank, AIRHIP_ERR_ARG, "piece does not belong to this rank");
   double t0 = now_s();
   pc->dev = std::make_unique<DevPCAIR>();
+  if (loc->hint.size() > 0) pc->dev->set_ordering_hint(loc->hint.data(), loc->hint.size());
   pc->dev->upload(loc->H, loc->A_top, loc.get(), comm->c.get());
   pc->dev->set_use_graph(false);
   pc->dev->set_profile(pc->profile);

@@ -6,6 +6,7 @@
 // src/FC_Smooth.F90:421-640; petsc_horner src/Gmres_Poly.F90:1418-1484; petsc_newton
 // src/Gmres_Poly_Newton.F90:763-875; Neumann shell src/Neumann_Poly.F90:19-55.
 #include "pcair_dev.hpp"
+#include <parallel/algorithm>
 #include <cstdio>
 
 namespace airhip {
@@ -116,15 +117,25 @@ const double* DevPCAIR::halo_update(const DevMat& A, const double* x) {
 // ---------------------------------------------------------------------------------------
 // upload
 // ---------------------------------------------------------------------------------------
-void DevPCAIR::upload_inv(const InvOp& h, DevInv& d, const DevMat* Aop, const double* host_diag_of_op, const HaloHost* halo) {
+// d_rowsrc / d_colmap / pos_host: placement of the operator's index space on the device (null = identity);
+// host_diag_of_op is already in device order
+void DevPCAIR::upload_inv(const InvOp& h, DevInv& d, const DevMat* Aop, const double* host_diag_of_op, const HaloHost* halo,
+                          const int32_t* d_rowsrc, const int32_t* d_colmap, const int32_t* pos_host) {
   d.kind = h.kind; d.coeffs = h.coeffs; d.re = h.re; d.im = h.im;
   d.diag_scale = h.diag_scale; d.neumann = h.neumann; d.spmvs = h.spmvs;
   if (h.kind == InvOp::ASSEMBLED) {
     d.n = h.mat.m;
-    upload_mat(h.mat, nullptr, nullptr, d.mat, stream_, halo ? halo->n_ghost : 0);
-    attach_halo(d.mat, halo, nullptr);
+    upload_mat(h.mat, d_rowsrc, d_colmap, d.mat, stream_, halo ? halo->n_ghost : 0);
+    attach_halo(d.mat, halo, pos_host);
   }
-  else if (h.kind == InvOp::DIAG) { d.n = h.d.size(); d.d.upload(h.d.data(), h.d.size()); }
+  else if (h.kind == InvOp::DIAG) {
+    d.n = h.d.size();
+    if (pos_host) {
+      std::vector<double> dd(d.n);
+      for (int64_t i = 0; i < d.n; i++) dd[pos_host[i]] = h.d[i];
+      d.d.upload(dd.data(), d.n);
+    } else d.d.upload(h.d.data(), h.d.size());
+  }
   else if (h.kind == InvOp::HORNER || h.kind == InvOp::NEWTON) {
     d.Aop = Aop; d.n = Aop->m;
     d.t1.alloc(d.n); d.t2.alloc(d.n); d.t3.alloc(d.n);
@@ -150,20 +161,52 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
   off_.assign(L, 0);
   for (int l = 0; l + 1 < L; l++) off_[l + 1] = off_[l] + H.levels[l]->n_f;
 
+  // Optional locality keys (hint_): rows with close keys are stored close together.  The key of a
+  // coarse row is the key of its parent C point, so every level inherits the top-level locality.
+  // fpos[l][i] = position of the level's i-th F point inside the F block (empty = identity).
+  const bool use_key = !hint_.empty();
+  if (use_key && (int64_t)hint_.size() != n_) throw std::runtime_error("ordering hint has the wrong length");
+  std::vector<std::vector<int32_t>> fpos(L > 0 ? L - 1 : 0);
+  std::vector<int32_t> cpos;       // coarsest level: natural index -> position (empty = identity)
+  if (use_key) {
+    auto rank_by = [](const std::vector<int64_t>& k) {
+      const int64_t n = (int64_t)k.size();
+      std::vector<int32_t> ord(n), pos(n);
+#pragma omp parallel for schedule(static)
+      for (int64_t i = 0; i < n; i++) ord[i] = (int32_t)i;
+      __gnu_parallel::stable_sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) { return k[a] < k[b]; });
+#pragma omp parallel for schedule(static)
+      for (int64_t r = 0; r < n; r++) pos[ord[r]] = (int32_t)r;
+      return pos;
+    };
+    std::vector<int64_t> key(hint_), nxt, kf;
+    for (int l = 0; l + 1 < L; l++) {
+      const Level& Lv = *H.levels[l];
+      kf.resize(Lv.n_f); nxt.resize(Lv.n_c);
+#pragma omp parallel for schedule(static)
+      for (int64_t i = 0; i < Lv.n_f; i++) kf[i] = key[Lv.F[i]];
+#pragma omp parallel for schedule(static)
+      for (int64_t j = 0; j < Lv.n_c; j++) nxt[j] = key[Lv.C[j]];
+      fpos[l] = rank_by(kf);
+      key.swap(nxt);
+    }
+    cpos = rank_by(key);
+  }
   // hierarchical permutations, coarsest level first: perm[l][i] = position of natural
   // index i of level l inside the level-l vector [F_l | level l+1 ...]
   std::vector<std::vector<int32_t>> perm(L);
   {
     const int64_t nL = H.coarse_A.m;
     perm[L - 1].resize(nL);
-    for (int64_t i = 0; i < nL; i++) perm[L - 1][i] = (int32_t)i;
+    for (int64_t i = 0; i < nL; i++) perm[L - 1][i] = use_key ? cpos[i] : (int32_t)i;
     for (int l = L - 2; l >= 0; l--) {
       const Level& Lv = *H.levels[l];
       perm[l].resize(Lv.n);
       int32_t* p = perm[l].data();
       const int32_t* pn = perm[l + 1].data();
+      const int32_t* fp = use_key ? fpos[l].data() : nullptr;
 #pragma omp parallel for schedule(static)
-      for (int64_t i = 0; i < Lv.n_f; i++) p[Lv.F[i]] = (int32_t)i;
+      for (int64_t i = 0; i < Lv.n_f; i++) p[Lv.F[i]] = fp ? fp[i] : (int32_t)i;
 #pragma omp parallel for schedule(static)
       for (int64_t j = 0; j < Lv.n_c; j++) p[Lv.C[j]] = (int32_t)(Lv.n_f + pn[j]);
     }
@@ -198,40 +241,60 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
     pc.upload(perm[l + 1].data(), h.n_c);
     ipc.upload(ipn.data(), h.n_c);
 
+    // placement of the F points inside the F block (identity without locality keys)
+    DBuf<int32_t> fpd, ifpd;
+    const int32_t* fph = nullptr;     // host: F index -> position
+    if (use_key) {
+      std::vector<int32_t> ifp = inverse(fpos[l]);
+      fpd.upload(fpos[l].data(), h.n_f);
+      ifpd.upload(ifp.data(), h.n_f);
+      fph = fpos[l].data();
+    }
+    const int32_t* Frow = use_key ? ifpd.p : nullptr;   // device row r takes host F row Frow[r]
+    const int32_t* Fcol = use_key ? fpd.p : nullptr;    // host F column c becomes Fcol[c]
+    auto fperm_vec = [&](const double* v) {             // host F-indexed vector -> device order
+      std::vector<double> o(h.n_f);
+      for (int64_t i = 0; i < h.n_f; i++) o[fph ? fph[i] : i] = v[i];
+      return o;
+    };
+
     const LevelHalos* hl = dist ? &dist->halos[l] : nullptr;
-    upload_mat(h.A_fc, nullptr, pc.p, d.A_fc, stream_, ng(hl ? &hl->A_fc : nullptr));   // rows F-order, cols permuted coarse
+    upload_mat(h.A_fc, Frow, pc.p, d.A_fc, stream_, ng(hl ? &hl->A_fc : nullptr));   // rows F block, cols permuted coarse
     attach_halo(d.A_fc, hl ? &hl->A_fc : nullptr, perm[l + 1].data());
-    upload_mat(h.Z, ipc.p, nullptr, d.Z, stream_, ng(hl ? &hl->Z : nullptr));           // rows permuted coarse, cols F-order
-    attach_halo(d.Z, hl ? &hl->Z : nullptr, nullptr);
+    upload_mat(h.Z, ipc.p, Fcol, d.Z, stream_, ng(hl ? &hl->Z : nullptr));           // rows permuted coarse, cols F block
+    attach_halo(d.Z, hl ? &hl->Z : nullptr, fph);
     std::vector<double> affd_host;
     bool mf = (h.inv_ff.kind == InvOp::HORNER || h.inv_ff.kind == InvOp::NEWTON);
     if (h.aff_diag) {
-      d.aff_d.upload(h.aff_d.data(), h.n_f);
+      affd_host = fperm_vec(h.aff_d.data());
+      d.aff_d.upload(affd_host.data(), h.n_f);
       if (mf) {  // matrix-free polynomial over a diagonal operator: keep one code path
-        Csr D = csr_from_diag(h.aff_d.data(), h.n_f);
+        Csr D = csr_from_diag(affd_host.data(), h.n_f);
         upload_mat(D, nullptr, nullptr, d.A_ff, stream_);
       }
-      affd_host.assign(h.aff_d.data(), h.aff_d.data() + h.n_f);
     } else {
-      upload_mat(h.A_ff, nullptr, nullptr, d.A_ff, stream_, ng(hl ? &hl->A_ff : nullptr));
-      attach_halo(d.A_ff, hl ? &hl->A_ff : nullptr, nullptr);
-      if (mf && h.inv_ff.diag_scale) { affd_host.resize(h.n_f); get_diagonal(h.A_ff, affd_host.data()); }
+      upload_mat(h.A_ff, Frow, Fcol, d.A_ff, stream_, ng(hl ? &hl->A_ff : nullptr));
+      attach_halo(d.A_ff, hl ? &hl->A_ff : nullptr, fph);
+      if (mf && h.inv_ff.diag_scale) {
+        std::vector<double> nat(h.n_f); get_diagonal(h.A_ff, nat.data());
+        affd_host = fperm_vec(nat.data());
+      }
     }
-    upload_inv(h.inv_ff, d.inv_ff, &d.A_ff, affd_host.empty() ? nullptr : affd_host.data(), hl ? &hl->M_ff : nullptr);
+    upload_inv(h.inv_ff, d.inv_ff, &d.A_ff, affd_host.empty() ? nullptr : affd_host.data(), hl ? &hl->M_ff : nullptr, Frow, Fcol, fph);
     if (h.one_point) {
       std::vector<int32_t> wc(h.n_f);
       const int32_t* pn = perm[l + 1].data();
       // distributed: columns >= n_c are ghost columns of A_fc and keep their index
-      for (int64_t i = 0; i < h.n_f; i++) { const int32_t c = h.wcol[i]; wc[i] = c < 0 ? -1 : (c < h.n_c ? pn[c] : c); }
+      for (int64_t i = 0; i < h.n_f; i++) { const int32_t c = h.wcol[i]; wc[fph ? fph[i] : i] = c < 0 ? -1 : (c < h.n_c ? pn[c] : c); }
       d.wcol.upload(wc.data(), h.n_f);
     } else {
-      upload_mat(h.W, nullptr, pc.p, d.W, stream_, ng(hl ? &hl->W : nullptr));
+      upload_mat(h.W, Frow, pc.p, d.W, stream_, ng(hl ? &hl->W : nullptr));
       attach_halo(d.W, hl ? &hl->W : nullptr, perm[l + 1].data());
     }
     d.t4.alloc(h.n_f); d.r.alloc(h.n_f);
     if (any_c_) {
-      upload_mat(h.A_cf, ipc.p, nullptr, d.A_cf, stream_, ng(hl ? &hl->A_cf : nullptr));
-      attach_halo(d.A_cf, hl ? &hl->A_cf : nullptr, nullptr);
+      upload_mat(h.A_cf, ipc.p, Fcol, d.A_cf, stream_, ng(hl ? &hl->A_cf : nullptr));
+      attach_halo(d.A_cf, hl ? &hl->A_cf : nullptr, fph);
       upload_mat(h.A_cc, ipc.p, pc.p, d.A_cc, stream_, ng(hl ? &hl->A_cc : nullptr));
       attach_halo(d.A_cc, hl ? &hl->A_cc : nullptr, perm[l + 1].data());
       // inverse of A_cc lives in the permuted coarse numbering as well
@@ -270,13 +333,26 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
   // coarse level
   {
     const bool mf = (H.coarse_inv.kind == InvOp::HORNER || H.coarse_inv.kind == InvOp::NEWTON);
+    const int64_t nL = H.coarse_A.m;
+    DBuf<int32_t> cpd, icpd;
+    const int32_t* cph = nullptr;
+    if (use_key) {
+      std::vector<int32_t> icp = inverse(perm[L - 1]);
+      cpd.upload(perm[L - 1].data(), nL); icpd.upload(icp.data(), nL);
+      cph = perm[L - 1].data();
+    }
     if (mf || coarse_richardson_its_ > 0) {
-      upload_mat(H.coarse_A, nullptr, nullptr, coarse_A_, stream_, ng(dist ? &dist->h_coarse_A : nullptr));
-      attach_halo(coarse_A_, dist ? &dist->h_coarse_A : nullptr, nullptr);
+      upload_mat(H.coarse_A, use_key ? icpd.p : nullptr, use_key ? cpd.p : nullptr, coarse_A_, stream_, ng(dist ? &dist->h_coarse_A : nullptr));
+      attach_halo(coarse_A_, dist ? &dist->h_coarse_A : nullptr, cph);
     }
     std::vector<double> dg;
-    if (mf && H.coarse_inv.diag_scale) { dg.resize(H.coarse_A.m); get_diagonal(H.coarse_A, dg.data()); }
-    upload_inv(H.coarse_inv, coarse_inv_, &coarse_A_, dg.empty() ? nullptr : dg.data(), dist ? &dist->h_coarse_M : nullptr);
+    if (mf && H.coarse_inv.diag_scale) {
+      std::vector<double> nat(nL); get_diagonal(H.coarse_A, nat.data());
+      dg.resize(nL);
+      for (int64_t i = 0; i < nL; i++) dg[cph ? cph[i] : i] = nat[i];
+    }
+    upload_inv(H.coarse_inv, coarse_inv_, &coarse_A_, dg.empty() ? nullptr : dg.data(), dist ? &dist->h_coarse_M : nullptr,
+               use_key ? icpd.p : nullptr, use_key ? cpd.p : nullptr, cph);
     coarse_inv_.n = H.coarse_A.m;
     if (coarse_richardson_its_ > 0) coarse_r_.alloc(H.coarse_A.m);
     cycle_bytes_ += coarse_inv_.alg_bytes();

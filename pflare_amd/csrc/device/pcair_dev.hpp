@@ -71,6 +71,9 @@ class DevPCAIR {
   // dist / comm: this rank's piece of a row-block distributed hierarchy and its transport.
   void upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy* dist = nullptr, Comm* comm = nullptr);
   Comm* comm() const { return comm_; }
+  // Locality keys of the fine rows (e.g. a brick / Morton index of the grid point): rows with close
+  // keys are stored close together on every level.  Affects the device layout only; call before upload.
+  void set_ordering_hint(const int64_t* key, int64_t n) { hint_.assign(key, key + n); }
   int64_t n() const { return n_; }
   int no_levels() const { return (int)levels_.size() + 1; }
 
@@ -111,7 +114,9 @@ class DevPCAIR {
   int stat_id(const char* name, int level, double bytes);
   void begin_kernel(int stat);
   void end_kernel();
-  void upload_inv(const InvOp& h, DevInv& d, const DevMat* Aop, const double* host_diag_of_op, const HaloHost* halo = nullptr);
+  void upload_inv(const InvOp& h, DevInv& d, const DevMat* Aop, const double* host_diag_of_op, const HaloHost* halo = nullptr,
+                  const int32_t* d_rowsrc = nullptr, const int32_t* d_colmap = nullptr, const int32_t* pos_host = nullptr);
+  std::vector<int64_t> hint_;    // optional locality keys of the fine rows (see set_ordering_hint)
   // distributed operands: halo plan creation and the exchange in front of a product
   void attach_halo(DevMat& M, const HaloHost* h, const int32_t* host_colmap);
   const double* halo_update(const DevMat& A, const double* x);

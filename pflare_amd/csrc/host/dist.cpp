@@ -195,6 +195,7 @@ void put_inv_meta(Archive& ar, const std::string& name, const InvOp& I) {
 struct Partitioner::Impl {
   const Hierarchy* G = nullptr;
   const Csr* A_top = nullptr;
+  const int64_t* hint = nullptr;
   int N = 1;
   std::vector<Space> full, fsp;        // full[l]: level l rows; fsp[l]: F points of level l (C points = full[l+1])
   struct LevelOps { OpRef A_ff, A_fc, A_cf, A_cc, Z, W, M_ff, M_cc; };
@@ -205,9 +206,9 @@ struct Partitioner::Impl {
 
 Partitioner::~Partitioner() = default;
 
-Partitioner::Partitioner(const Hierarchy& G, const Csr& A_top, int nranks, const int32_t* owner) : impl_(new Impl) {
+Partitioner::Partitioner(const Hierarchy& G, const Csr& A_top, int nranks, const int32_t* owner, const int64_t* hint) : impl_(new Impl) {
   Impl& I = *impl_;
-  I.G = &G; I.A_top = &A_top; I.N = nranks;
+  I.G = &G; I.A_top = &A_top; I.N = nranks; I.hint = hint;
   const int L = G.no_levels();
   I.full.resize(L); I.fsp.resize(L > 0 ? L - 1 : 0);
   I.full[0].own.assign(owner, owner + A_top.m);
@@ -270,6 +271,12 @@ void Partitioner::extract(int rank, Archive& ar) const {
     for (int i = 0; i < 10; i++) meta[6 + i] = G.opt.smooth_order[i];
     ar.add_copy("meta", Archive::I64, meta, 16);
     ar.add_copy("gid", Archive::I32, I.full[0].members[rank].data(), I.full[0].count(rank));
+    if (I.hint) {
+      const auto& mem = I.full[0].members[rank];
+      std::vector<int64_t> k(mem.size());
+      for (size_t q = 0; q < mem.size(); q++) k[q] = I.hint[mem[q]];
+      ar.add_copy("hint", Archive::I64, k.data(), (int64_t)k.size());
+    }
   }
   emit("top.A", I.top);
   for (int l = 0; l + 1 < L; l++) {
@@ -415,6 +422,11 @@ void load_local(const Archive& ar, LocalHierarchy& out) {
   for (int i = 0; i < 10; i++) out.H.opt.smooth_order[i] = (int)s[6 + i];
   const auto& gid = need(ar, "gid", Archive::I32);
   out.gid.view((const int32_t*)gid.ptr, gid.count);
+  out.hint = Arr<int64_t>();
+  if (const Archive::Item* hk = ar.find("hint")) {
+    if (hk->dtype != Archive::I64 || hk->count != gid.count) throw std::runtime_error("archive: bad ordering hint");
+    out.hint.view((const int64_t*)hk->ptr, hk->count);
+  }
   if (!get_csr(ar, "top.A", out.A_top, out.h_top)) throw std::runtime_error("archive: missing top.A");
   out.halos.clear();
   out.halos.resize(L > 0 ? L - 1 : 0);

@@ -36,6 +36,7 @@ struct LocalHierarchy {
   int rank = 0, nranks = 1;
   int64_t n_global = 0;
   Arr<int32_t> gid;                           // global (natural) index of each local fine row, ascending
+  Arr<int64_t> hint;                          // optional locality keys of the local fine rows
 };
 
 // Named flat arrays (the wire format of a LocalHierarchy)
@@ -52,7 +53,7 @@ struct Archive {
 // Cuts a global hierarchy.  owner[i] in [0, nranks) for every fine row i.
 class Partitioner {
  public:
-  Partitioner(const Hierarchy& G, const Csr& A_top, int nranks, const int32_t* owner);
+  Partitioner(const Hierarchy& G, const Csr& A_top, int nranks, const int32_t* owner, const int64_t* hint = nullptr);
   ~Partitioner();
   void extract(int rank, Archive& out) const;
  private:

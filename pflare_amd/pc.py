@@ -194,6 +194,11 @@ class PCAIR:
         check(lib().airhip_pcair_set_option(self._h, name.encode(), repr(value).encode() if isinstance(value, float)
                                             else str(value).encode()))
 
+    def set_ordering_hint(self, key):
+        """Locality keys of the operator's rows (device layout only; see include/airhip.h)."""
+        k = np.ascontiguousarray(key, dtype=np.int64)
+        check(lib().airhip_pcair_set_ordering_hint(self._h, k.ctypes.data_as(C.POINTER(C.c_int64)), k.size))
+
     # -- setup
     def setup(self, A):
         self._A = as_csr(A)

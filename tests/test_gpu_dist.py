@@ -47,6 +47,8 @@ def _worker(rank, world, port, case, out):
             owner = (D.box_owner(gen["M"], gen["N"], gen.get("P", 1), world) if kind != "block"
                      else D.block_owner(n, world))
             pcg = P.PCAIR(device_upload=False, **opts)
+            if case == "adv3d_24_lump":      # also exercise the locality hint through the partitioner
+                pcg.set_ordering_hint(np.random.default_rng(9).permutation(n))
             pcg.setup(A)
         comm = D.StagedComm()
         pc, gid = D.distribute(pcg, A, owner, comm)

@@ -164,3 +164,27 @@ def test_pcpflareinv_apply(torch_mod, itype, mf, order):
     y = torch.empty(n, dtype=torch.float64, device="cuda")
     pc.apply(dev(torch, x), y)
     assert relerr(y.cpu().numpy(), R.apply_inv(op, x)) <= 4e-11
+
+
+@pytest.mark.parametrize("case", ["adv3d_12_lump", "adv2d_30_newton_coarse", "adv2d_16_fcf", "diff2d_12_diagscale"])
+def test_ordering_hint_changes_layout_not_results(torch_mod, case):
+    """airhip_pcair_set_ordering_hint: any key vector (here a random shuffle, the worst case) must leave
+    PCApply and the Krylov iteration counts unchanged - it only moves rows around inside the device."""
+    torch = torch_mod
+    import pflare_amd as P
+    gen, opts = CASES[case]
+    A = P.HostMat.adv_diff_fd(**gen)
+    n = A.shape[0]
+    x = dev(torch, lcg_vector(n))
+    pc0 = P.PCAIR(**opts).setup(A)
+    z0 = torch.empty_like(x); pc0.apply(x, z0)
+    pc1 = P.PCAIR(**opts)
+    pc1.set_ordering_hint(np.random.default_rng(5).permutation(n))
+    pc1.setup(A)
+    z1 = torch.empty_like(x); pc1.apply(x, z1)
+    assert relerr(z1.cpu().numpy(), z0.cpu().numpy()) <= 1e-12
+    ksp = P.KSP("gmres", pc_side="right", rtol=1e-10, atol=1e-50)
+    b = torch.zeros_like(x)
+    x0 = torch.ones_like(x); r0 = ksp.solve(b, x0, pc=pc0)
+    x1 = torch.ones_like(x); r1 = ksp.solve(b, x1, pc=pc1)
+    assert r0["its"] == r1["its"] and r0["reason"] == r1["reason"]
