@@ -53,8 +53,8 @@ def main():
     ap.add_argument("--variants", default="", help="diagnostic: comma list of SpMV kernel variants to time")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--hint-brick", type=int, default=16,
-                    help="locality hint for the device layout: grid points grouped in BxBxB bricks (0: none); the "
-                         "operator keeps the reference numbering")
+                    help="locality hint for the device layout: grid points grouped in BxBxB bricks (0: none, -1: Morton "
+                         "order of the bricks of size 4); the operator keeps the reference numbering")
     ap.add_argument("--brick", type=int, default=0, help="diagnostic: renumber the grid in BxBxB bricks before the setup (locality experiment; not the reference numbering)")
     ap.add_argument("--threads", type=int, default=0, help="host threads for setup + CPU baseline (0: cores / ranks, capped at 32 - measured best on the GPU box)")
     args = ap.parse_args()
@@ -124,6 +124,19 @@ def main():
             hm = P.CsrArrays(A.indptr, A.indices, A.data, A.shape)
             log(f"[bench] renumbered in {B}^3 bricks")
         pc = P.PCAIR(**opts)
+        if args.hint_brick == -1 and not args.brick:
+            import numpy as np
+            ax = np.arange(M, dtype=np.int64)
+
+            def spread(v):          # interleave the bits of v with two zero bits
+                r = np.zeros_like(v)
+                for bit in range(10):
+                    r |= ((v >> bit) & 1) << (3 * bit)
+                return r
+            sx = spread(ax)
+            key = (sx[:, None, None] << 2) | (sx[None, :, None] << 1) | sx[None, None, :]     # [k, j, i]
+            pc.set_ordering_hint(key.reshape(-1))
+            del key
         if args.hint_brick > 0 and not args.brick:
             # what a DM would tell the preconditioner: the brick of each grid point.  Only the device
             # layout uses it (airhip_pcair_set_ordering_hint); operator and hierarchy are the reference's.
@@ -315,7 +328,7 @@ def main():
         "config": {"workload": f"3D upwind advection (tests/adv_diff_fd.c) {M}^3 = {M ** 3} DoF, nnz(A)={nnzA}, b=0, x0=1, "
                                f"GMRES(30) right PC rtol 1e-10, PCAIR recipe '{args.recipe}' {opts}",
                    "parallelism": parallelism,
-                   "layout_hint": (f"{args.hint_brick}^3 bricks" if args.hint_brick > 0 and not args.brick else "none"),
+                   "layout_hint": ("morton" if args.hint_brick == -1 else f"{args.hint_brick}^3 bricks" if args.hint_brick > 0 and not args.brick else "none"),
                    "levels": info["levels"], "iterations_to_rtol_1e-10": res0["its"],
                    "converged_reason": res0["reason_name"], "converged_solve_ms": res0["solve_ms"],
                    "cycle_complexity": cx["cycle"], "operator_complexity": cx["operator"],

@@ -2,19 +2,24 @@
 // CSR -> row-block CSR conversion.
 //
 // Format and mapping (gfx950, wave64):
-//   * the matrix stays in plain CSR order (no padding; SELL-64 padded the AIR operators by
-//     1.75x, and length-sorted SELL-C-sigma destroyed the locality of the x gathers);
-//   * rows are partitioned into blocks of <= BLK_NNZ non-zeros (+ the tail of the last row);
-//     one WAVE owns one block: phase 1 streams the block's values / column indices with fully
-//     coalesced 512-B / 256-B wave loads, gathers x and stages the products in LDS (8 KB per
-//     wave); phase 2 lets lane l sum the LDS segment of row r0+l (+64, ...) in column order -
-//     the same summation order as a sequential CSR loop - and apply the fused epilogue, so the
-//     z / w / out vectors are read and written coalesced;
-//   * blocks whose non-zeros do not fit the LDS stage (a very long row) use a wave-wide
-//     reduction per row instead;
+//   * the matrix stays in CSR row order (no padding; SELL-64 padded the AIR operators by 1.75x, and
+//     length-sorted SELL-C-sigma destroyed the locality of the x gathers);
+//   * rows are partitioned into blocks of <= BLK_NNZ non-zeros (+ the tail of the last row, at most
+//     BLK_ROWS rows); one WAVE owns one block: phase 1 streams the block's values / column indices
+//     with coalesced wave loads, gathers x and stages the products in LDS (8 KB per wave);
+//     phase 2 lets lane l sum the LDS segment of row r0+l (+64, ...) in column order - the same
+//     summation order as a sequential CSR loop - and apply the fused epilogue, so the z / w / out
+//     vectors are read and written coalesced;
+//   * inside a block that takes the LDS path the (column, value) pairs are stored SORTED BY COLUMN
+//     and a 16-bit slot gives the row-major position where the product is staged: neighbouring
+//     lanes gather neighbouring x entries (the gather is bound by distinct cache lines per wave
+//     instruction, profiles/r01_spmv_experiments.md); results are unchanged bit for bit;
+//   * blocks with <= 4 non-zeros per row on average skip the LDS stage (one lane per row); a block
+//     holding a row longer than the LDS stage uses a wave-wide reduction per row;
 //   * XCD-aware assignment: blocks b and b+8 of the grid share an XCD (observed round-robin
 //     dispatch; a speed assumption only), so each residue class of workgroups walks a contiguous
 //     range of row blocks and an XCD's private L2 sees a contiguous window of x.
+// Kernels suffixed _dbg are timing-only diagnostics selected through airhip_debug_set_variant.
 #include "dev.hpp"
 #include "kcommon.hpp"
 #include "rb.hpp"
@@ -156,132 +161,6 @@ __device__ __forceinline__ void rb_rows(const RbView& A, const X x, double* __re
   }
 }
 
-// Software-pipelined variant: while the products of block i are staged and reduced, the first 512
-// (column, value) pairs and the row offsets of block i+1 are already in flight, and the descriptor
-// of block i+2 is being fetched - a wave keeps HBM requests outstanding during its LDS phases
-// instead of alternating between "load" and "reduce".  All blocks with <= CAP non-zeros take
-// the LDS path (no scalar mode); loads of a partially filled block are clamped, not predicated,
-// so the issue order stays branch-free.  Requires A.nnz > 0.
-template <int CAP, class X, class Epi>
-__device__ __forceinline__ void rb_rows_pipe(const RbView& A, const X x, double* __restrict__ lds, Epi epi) {
-  constexpr int PF = 8;                         // prefetched loads per lane: 8 x 64 = 512 entries
-  constexpr int RC = BLK_ROWS / WAVE;           // row-offset registers per lane (rows per block <= 256)
-  const int lane = threadIdx.x & (WAVE - 1);
-  const BlockRange br = my_blocks(A.nblocks);
-  if (br.first >= br.last) return;
-  const int64_t last_nz = A.nnz - 1;
-  const int32_t last_row = (int32_t)(A.m - 1);
-  // block descriptors travel through the scalar cache (s_load, lgkmcnt): waiting for them does
-  // not drain the vector-memory queue that holds the prefetched non-zeros
-  // (issue and wait live in ONE asm statement: the compiler must never see the destination
-  // registers between the two)
-  auto desc = [&](int64_t b, int32_t& r0, int32_t& r1, int64_t& p0, int64_t& p1) {
-    uint64_t rr, q0, q1;
-    const int32_t* pr = A.blk_row + b; const int64_t* pp = A.blk_p0 + b;
-    asm volatile("s_load_dwordx2 %0, %3, 0x0\n\ts_load_dwordx2 %1, %4, 0x0\n\ts_load_dwordx2 %2, %4, 0x8\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&s"(rr), "=&s"(q0), "=&s"(q1) : "s"(pr), "s"(pp) : "memory");
-    r0 = (int32_t)(rr & 0xffffffffull); r1 = (int32_t)(rr >> 32); p0 = (int64_t)q0; p1 = (int64_t)q1;
-  };
-  int32_t pc[PF]; double pv[PF]; uint32_t pro[RC];
-  auto prefetch = [&](int32_t r0, int64_t p0) {
-#pragma unroll
-    for (int u = 0; u < PF; u++) {
-      const int64_t k = min(p0 + lane + u * WAVE, last_nz);
-      pc[u] = A.col[k]; pv[u] = A.val[k];
-    }
-#pragma unroll
-    for (int j = 0; j < RC; j++) pro[j] = A.roff[min(r0 + lane + j * WAVE, last_row)];
-  };
-  int32_t r0, r1, r0n = 0, r1n = 0, r0t = 0, r1t = 0;
-  int64_t p0, p1, p0n = 0, p1n = 0, p0t = 0, p1t = 0;
-  desc(br.first, r0, r1, p0, p1);
-  if (br.first + br.stride < br.last) desc(br.first + br.stride, r0n, r1n, p0n, p1n);
-  prefetch(r0, p0);
-  for (int64_t b = br.first; b < br.last; b += br.stride) {
-    const int nb = (int)(p1 - p0);
-    const int nr = r1 - r0;
-    const double* __restrict__ v = A.val + p0;
-    const int32_t* __restrict__ c = A.col + p0;
-    // current block's prefetched data -> gathers
-    double cv[PF], xx[PF]; uint32_t ro[RC];
-#pragma unroll
-    for (int u = 0; u < PF; u++) { cv[u] = pv[u]; xx[u] = x[pc[u]]; }
-#pragma unroll
-    for (int j = 0; j < RC; j++) ro[j] = pro[j];
-    // next block's data and the descriptor after it
-    const bool have_next = b + br.stride < br.last;
-    if (have_next) prefetch(r0n, p0n);
-    if (b + 2 * br.stride < br.last) desc(b + 2 * br.stride, r0t, r1t, p0t, p1t);   // waits on lgkmcnt only
-    if (nb <= CAP) {
-#pragma unroll
-      for (int u = 0; u < PF; u++) { const int k = lane + u * WAVE; if (k < nb) lds[k] = cv[u] * xx[u]; }
-      for (int k = lane + PF * WAVE; k < nb; k += WAVE) lds[k] = v[k] * x[c[k]];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (nr > 16) {
-#pragma unroll
-        for (int j = 0; j < RC; j++) {
-          const int32_t r = r0 + lane + j * WAVE;
-          // end of the row = start of the next one (next lane, or lane 0 of the next register)
-          uint32_t e = __shfl_down(ro[j], 1, WAVE);
-          const uint32_t e0 = __shfl(j + 1 < RC ? ro[j + 1 < RC ? j + 1 : j] : 0u, 0, WAVE);
-          if (lane == WAVE - 1) e = e0;
-          if (r < r1) {
-            const int a = (int)ro[j];
-            const int ee = (r + 1 < r1) ? (int)e : nb;
-            double s = 0.0;
-            for (int q = a; q < ee; q++) s += lds[q];
-            epi(r, s);
-          }
-        }
-      } else {
-        int T = WAVE;
-        while (WAVE / T < nr) T >>= 1;
-        const int g = lane / T, t = lane - g * T;
-        const int a = (int)__shfl(ro[0], g, WAVE);
-        const int en = (int)__shfl(ro[0], g + 1 < WAVE ? g + 1 : g, WAVE);
-        double s = 0.0;
-        if (g < nr) {
-          const int e = (g + 1 < nr) ? en : nb;
-          for (int q = a + t; q < e; q += T) s += lds[q];
-        }
-        for (int off = T >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
-        if (g < nr && t == 0) epi(r0 + g, s);
-      }
-      __builtin_amdgcn_wave_barrier();
-    } else {
-      for (int32_t r = r0; r < r1; r++) {
-        const int a = (int)A.roff[r];
-        const int e = (r + 1 < r1) ? (int)A.roff[r + 1] : nb;
-        double s = 0.0;
-        for (int q = a + lane; q < e; q += WAVE) s = fma(v[q], x[c[q]], s);
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
-        if (lane == 0) epi(r, s);
-      }
-    }
-    r0 = r0n; r1 = r1n; p0 = p0n; p1 = p1n;
-    r0n = r0t; r1n = r1t; p0n = p0t; p1n = p1t;
-  }
-}
-
-template <int CAP, class X>
-__global__ __launch_bounds__(BLOCK) void k_rb_spmv_pipe(RbView A, X x, SpmvEpi e) {
-  __shared__ double lds_all[WAVES_PER_BLOCK][CAP];
-  double* lds = lds_all[threadIdx.x >> 6];
-  rb_rows_pipe<CAP>(A, x, lds, [&](int32_t row, double acc) {
-    if (e.dscale) acc *= e.dscale[row];
-    double o = e.alpha * acc;
-    if (e.z) o += e.beta * e.z[row];
-    if (e.w) o += e.gamma * e.w[row];
-    e.out[row] = o;
-    if (e.y2) {
-      const double a = e.aux_out ? o : e.w2[row];
-      e.y2[row] += e.delta * a;
-    }
-  });
-}
-
 template <int CAP, bool NT, int UNR, bool SORTED, class X>
 __global__ __launch_bounds__(BLOCK) void k_rb_spmv(RbView A, X x, SpmvEpi e) {
   __shared__ double lds_all[WAVES_PER_BLOCK][CAP];
@@ -297,131 +176,6 @@ __global__ __launch_bounds__(BLOCK) void k_rb_spmv(RbView A, X x, SpmvEpi e) {
       e.y2[row] += e.delta * a;
     }
   });
-}
-
-// ---------------------------------------------------------------------------------------
-// v2 of the row-block kernel: every global load a block needs is issued up front - descriptor
-// through the scalar cache (s_load: waiting for it does not drain the vector-memory queue), then in
-// one burst the first 512 (column, value) pairs, the row offsets and the epilogue operands of the
-// first 64 rows - so a block costs two vector-memory round trips (non-zeros, x gather) instead of
-// four or five.  Loads of a partially filled block are clamped, not predicated.  Requires nnz > 0.
-// EpiT: struct with  Pre pre(row) const;  Pre shfl(Pre, src_lane) const;  void post(row, acc, Pre) const.
-// ---------------------------------------------------------------------------------------
-template <int CAP, class X, class EpiT>
-__device__ __forceinline__ void rb_rows2(const RbView& A, const X x, double* __restrict__ lds, const EpiT epi) {
-  constexpr int PF = 8;
-  constexpr int RC = BLK_ROWS / WAVE;
-  using Pre = typename EpiT::Pre;
-  const int lane = threadIdx.x & (WAVE - 1);
-  const BlockRange br = my_blocks(A.nblocks);
-  const int64_t last_nz = A.nnz - 1;
-  const int32_t last_row = (int32_t)(A.m - 1);
-  for (int64_t b = br.first; b < br.last; b += br.stride) {
-    int32_t r0, r1; int64_t p0, p1;
-    {
-      uint64_t rr, q0, q1;
-      const int32_t* pr = A.blk_row + b; const int64_t* pp = A.blk_p0 + b;
-      asm volatile("s_load_dwordx2 %0, %3, 0x0\n\ts_load_dwordx2 %1, %4, 0x0\n\ts_load_dwordx2 %2, %4, 0x8\n\ts_waitcnt lgkmcnt(0)"
-                   : "=&s"(rr), "=&s"(q0), "=&s"(q1) : "s"(pr), "s"(pp) : "memory");
-      r0 = (int32_t)(rr & 0xffffffffull); r1 = (int32_t)(rr >> 32); p0 = (int64_t)q0; p1 = (int64_t)q1;
-    }
-    const int nb = (int)(p1 - p0);
-    const int nr = r1 - r0;
-    const double* __restrict__ v = A.val + p0;
-    const int32_t* __restrict__ c = A.col + p0;
-    if (nb <= CAP) {
-      int32_t cc[PF]; double vv[PF], xx[PF]; uint32_t ro[RC]; int ss[PF];
-#pragma unroll
-      for (int u = 0; u < PF; u++) cc[u] = A.col[min(p0 + lane + u * WAVE, last_nz)];
-#pragma unroll
-      for (int u = 0; u < PF; u++) ss[u] = A.slot ? (int)A.slot[min(p0 + lane + u * WAVE, last_nz)] : lane + u * WAVE;
-#pragma unroll
-      for (int u = 0; u < PF; u++) vv[u] = A.val[min(p0 + lane + u * WAVE, last_nz)];
-#pragma unroll
-      for (int j = 0; j < RC; j++) ro[j] = A.roff[min(r0 + lane + j * WAVE, last_row)];
-      const Pre pre0 = epi.pre(min(r0 + lane, last_row));
-#pragma unroll
-      for (int u = 0; u < PF; u++) xx[u] = x[cc[u]];
-#pragma unroll
-      for (int u = 0; u < PF; u++) { const int k = lane + u * WAVE; if (k < nb) lds[ss[u]] = vv[u] * xx[u]; }
-      for (int k = lane + PF * WAVE; k < nb; k += WAVE) lds[A.slot ? (int)A.slot[p0 + k] : k] = v[k] * x[c[k]];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (nr > 16) {
-#pragma unroll
-        for (int j = 0; j < RC; j++) {
-          const int32_t r = r0 + lane + j * WAVE;
-          uint32_t e = __shfl_down(ro[j], 1, WAVE);
-          const uint32_t e0 = __shfl(ro[j + 1 < RC ? j + 1 : j], 0, WAVE);
-          if (lane == WAVE - 1) e = e0;
-          if (r < r1) {
-            const int a = (int)ro[j];
-            const int ee = (r + 1 < r1) ? (int)e : nb;
-            double s = 0.0;
-            for (int q = a; q < ee; q++) s += lds[q];
-            if (j == 0) epi.post(r, s, pre0); else epi.post(r, s, epi.pre(r));
-          }
-        }
-      } else {
-        int T = WAVE;
-        while (WAVE / T < nr) T >>= 1;
-        const int g = lane / T, t = lane - g * T;
-        const int a = (int)__shfl(ro[0], g, WAVE);
-        const int en = (int)__shfl(ro[0], g + 1 < WAVE ? g + 1 : g, WAVE);
-        const Pre pg = epi.shfl(pre0, g);
-        double s = 0.0;
-        if (g < nr) {
-          const int e = (g + 1 < nr) ? en : nb;
-          for (int q = a + t; q < e; q += T) s += lds[q];
-        }
-        for (int off = T >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
-        if (g < nr && t == 0) epi.post(r0 + g, s, pg);
-      }
-      __builtin_amdgcn_wave_barrier();
-    } else {
-      for (int32_t r = r0; r < r1; r++) {
-        const int a = (int)A.roff[r];
-        const int e = (r + 1 < r1) ? (int)A.roff[r + 1] : nb;
-        double s = 0.0;
-        for (int q = a + lane; q < e; q += WAVE) s = fma(v[q], x[c[q]], s);
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
-        if (lane == 0) epi.post(r, s, epi.pre(r));
-      }
-    }
-  }
-}
-
-struct SpmvEpi2 {
-  SpmvEpi e;
-  struct Pre { double z, w, ds; };
-  __device__ __forceinline__ Pre pre(int32_t row) const {
-    Pre p;
-    p.z = e.z ? e.z[row] : 0.0;
-    p.w = e.w ? e.w[row] : 0.0;
-    p.ds = e.dscale ? e.dscale[row] : 1.0;
-    return p;
-  }
-  __device__ __forceinline__ Pre shfl(const Pre& p, int src) const {
-    Pre q; q.z = __shfl(p.z, src, WAVE); q.w = __shfl(p.w, src, WAVE); q.ds = __shfl(p.ds, src, WAVE); return q;
-  }
-  __device__ __forceinline__ void post(int32_t row, double acc, const Pre& p) const {
-    if (e.dscale) acc *= p.ds;
-    double o = e.alpha * acc;
-    if (e.z) o += e.beta * p.z;
-    if (e.w) o += e.gamma * p.w;
-    e.out[row] = o;
-    if (e.y2) {
-      const double a = e.aux_out ? o : e.w2[row];
-      e.y2[row] += e.delta * a;
-    }
-  }
-};
-
-template <int CAP, class X>
-__global__ __launch_bounds__(BLOCK) void k_rb_spmv2(RbView A, X x, SpmvEpi e) {
-  __shared__ double lds_all[WAVES_PER_BLOCK][CAP];
-  rb_rows2<CAP>(A, x, lds_all[threadIdx.x >> 6], SpmvEpi2{e});
 }
 
 // diagnostics (airhip_debug_set_variant 32 / 64): MODE 1 streams the non-zeros and the gathered x
@@ -508,21 +262,6 @@ void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t
     else hipLaunchKernelGGL((k_rb_spmv<1024, false, 4, false, XVec<true>>), grid, block, 0, s, v, xv, e);
     return;
   }
-  if ((g_spmv_variant & 16) && A.nnz > 0 && !A.slot) {
-    const XVec<false> xp{x, nullptr, 0};
-    hipLaunchKernelGGL((k_rb_spmv_pipe<1024, XVec<false>>), grid, block, 0, s, v, xp, e);
-    return;
-  }
-  if (g_spmv_variant & 256) { hipLaunchKernelGGL(k_flat_stream_dbg<0>, dim3(2048), block, 0, s, A.nnz, A.n, A.col, A.val, x, e.out); return; }
-  if (g_spmv_variant & 512) { hipLaunchKernelGGL(k_flat_stream_dbg<1>, dim3(2048), block, 0, s, A.nnz, A.n, A.col, A.val, x, e.out); return; }
-  if (g_spmv_variant & 1024) { hipLaunchKernelGGL(k_flat_stream_dbg<2>, dim3(2048), block, 0, s, A.nnz, A.n, A.col, A.val, x, e.out); return; }
-  if ((g_spmv_variant & 128) && A.nnz > 0) {
-    const XVec<false> xp{x, nullptr, 0};
-    hipLaunchKernelGGL((k_rb_spmv2<1024, XVec<false>>), grid, block, 0, s, v, xp, e);
-    return;
-  }
-  if (g_spmv_variant & 32) { hipLaunchKernelGGL(k_rb_stream_dbg<1>, grid, block, 0, s, v, x, e.out); return; }
-  if (g_spmv_variant & 64) { hipLaunchKernelGGL(k_rb_stream_dbg<2>, grid, block, 0, s, v, x, e.out); return; }
   if (g_spmv_variant & 8) {
     const XVecNoGather xd{x};
     hipLaunchKernelGGL((k_rb_spmv<1024, false, 4, false, XVecNoGather>), grid, block, 0, s, v, xd, e);
