@@ -566,6 +566,13 @@ void DevPCAIR::run_cycle() {
 }
 
 void DevPCAIR::apply_permuted(const double* r, double* z) {
+  if (r != z && !(want_graph_ && !profile_ && !comm_)) {
+    b0_ = r; xbase_ = z;          // r is preserved, z receives the cycle's output directly
+    run_cycle();
+    return;
+  }
+  // captured graph (fixed addresses) or aliased arguments: go through the internal buffers
+  b0_ = cb_.p; xbase_ = cx_.p;
   HIP_CHECK(hipMemcpyAsync(cb_.p, r, sizeof(double) * (size_t)n_, hipMemcpyDeviceToDevice, stream_));
   run_cycle();
   HIP_CHECK(hipMemcpyAsync(z, cx_.p, sizeof(double) * (size_t)n_, hipMemcpyDeviceToDevice, stream_));
@@ -575,6 +582,7 @@ void DevPCAIR::to_permuted(const double* nat, double* perm) { launch_gather(n_, 
 void DevPCAIR::to_natural(const double* perm, double* nat) { launch_gather(n_, perm_.p, perm, nat, stream_); }
 
 void DevPCAIR::apply_natural(const double* d_x, double* d_y) {
+  b0_ = cb_.p; xbase_ = cx_.p;
   launch_gather(n_, iperm_.p, d_x, cb_.p, stream_);
   run_cycle();
   launch_gather(n_, perm_.p, cx_.p, d_y, stream_);

@@ -122,8 +122,12 @@ class DevPCAIR {
   const double* halo_update(const DevMat& A, const double* x);
   Comm* comm_ = nullptr;
   std::vector<std::unique_ptr<HaloPlan>> plans_;
-  double* bvec(int l) { return b_ptr_[l]; }
-  double* xvec(int l) { return cx_.p + off_[l]; }
+  // level-0 rhs is only read and the solution of every level is a suffix of one buffer: PCApply in
+  // hierarchical ordering therefore works straight on the caller's vectors (no copies)
+  double* bvec(int l) { return l == 0 ? const_cast<double*>(b0_) : b_ptr_[l]; }
+  double* xvec(int l) { return xbase_ + off_[l]; }
+  const double* b0_ = nullptr;
+  double* xbase_ = nullptr;
 
   int64_t n_ = 0;
   hipStream_t stream_ = nullptr;

@@ -2,6 +2,7 @@
 #pragma once
 #include "dev.hpp"
 #include "kcommon.hpp"
+#include <cstdlib>
 
 namespace airhip {
 
@@ -23,8 +24,17 @@ struct RbView {
   const int32_t* col;
   const double* val;
   const uint16_t* slot;   // column-sorted blocks: position of the entry in row-major order inside its block
+  int scalar_t;           // blocks with nnz <= scalar_t * rows skip the LDS stage (one lane per row)
 };
-inline RbView view_of(const DevMat& A) { return RbView{A.m, A.nblocks, A.nnz, A.blk_row, A.blk_p0, A.roff, A.col, A.val, A.slot}; }
+// AIRHIP_SCALAR_T (default 0 = never): average row length up to which a block is handled one lane per row
+// straight from global memory (was faster before the blocks were column-sorted; now the LDS path wins by 4 %)
+inline int scalar_threshold() {
+  static const int t = std::getenv("AIRHIP_SCALAR_T") ? std::atoi(std::getenv("AIRHIP_SCALAR_T")) : 0;
+  return t;
+}
+inline RbView view_of(const DevMat& A) {
+  return RbView{A.m, A.nblocks, A.nnz, A.blk_row, A.blk_p0, A.roff, A.col, A.val, A.slot, scalar_threshold()};
+}
 
 // Input vector of an SpMV.  Single device: DIST = false, plain x[c].  Row-block distributed
 // (one rank per GPU): columns < nl index the rank's own segment, columns >= nl the ghost values

@@ -82,7 +82,7 @@ __device__ __forceinline__ void rb_rows(const RbView& A, const X x, double* __re
     const int32_t* __restrict__ c = A.col + p0;
     const uint16_t* __restrict__ sl = A.slot + p0;
     const int nr = r1 - r0;
-    if (nb <= 4 * nr) {
+    if (nb <= A.scalar_t * nr) {
       // very short rows (<= 4 non-zeros on average): one lane per row straight from global
       // memory - the block's ~6 KB are shared by neighbouring lanes through L1, and the
       // dependency chain is one round trip shorter than the LDS stage
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(BLOCK) void k_row_offsets(int64_t m, const int64_t*
 __global__ __launch_bounds__(BLOCK) void k_block_sort(int64_t nblocks, const int32_t* __restrict__ blk_row, const int64_t* __restrict__ blk_p0,
                                                      const int32_t* __restrict__ col, const double* __restrict__ val,
                                                      int32_t* __restrict__ ocol, double* __restrict__ oval, uint16_t* __restrict__ slot,
-                                                     int cap) {
+                                                     int cap, int scalar_t) {
   __shared__ unsigned long long keys_all[WAVES_PER_BLOCK][2 * LDS_CAP];
   unsigned long long* keys = keys_all[threadIdx.x >> 6];
   const int lane = threadIdx.x & (WAVE - 1);
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(BLOCK) void k_block_sort(int64_t nblocks, const int
     const int64_t p0 = blk_p0[b], p1 = blk_p0[b + 1];
     const int nb = (int)(p1 - p0);
     const int nr = blk_row[b + 1] - blk_row[b];
-    if (p1 - p0 > cap || nb <= 4 * nr) {
+    if (p1 - p0 > cap || nb <= scalar_t * nr) {
       for (int64_t k = p0 + lane; k < p1; k += WAVE) { ocol[k] = col[k]; oval[k] = val[k]; slot[k] = (uint16_t)((k - p0) & 0xffff); }
       continue;
     }
@@ -543,7 +543,7 @@ void devmat_from_csr_device(int64_t m, int64_t n, const int64_t* d_rp, const int
     HIP_CHECK(hipMalloc(&out.slot, sizeof(uint16_t) * (size_t)out.nnz));
     const int g = (int)std::min<int64_t>((out.nblocks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 4096);
     hipLaunchKernelGGL(k_block_sort, dim3(g < 1 ? 1 : g), dim3(BLOCK), 0, s, out.nblocks, out.blk_row, out.blk_p0, out.col, out.val, ncol, nval,
-                       out.slot, g_blk_nnz == 256 ? 512 : (g_blk_nnz == 1024 ? 2 * LDS_CAP : LDS_CAP));
+                       out.slot, g_blk_nnz == 256 ? 512 : (g_blk_nnz == 1024 ? 2 * LDS_CAP : LDS_CAP), scalar_threshold());
     HIP_CHECK(hipStreamSynchronize(s));
     (void)hipFree(out.col); (void)hipFree(out.val);
     out.col = ncol; out.val = nval;
