@@ -246,6 +246,8 @@ static int blk_from_env() {
   return (v == 256 || v == 1024) ? v : BLK_NNZ;
 }
 int g_blk_nnz = blk_from_env();
+// AIRHIP_CAP=768: 6-KB LDS stage per wave (6 instead of 5 workgroups per CU) with 512-nnz blocks
+static int g_cap768 = (std::getenv("AIRHIP_CAP") && std::atoi(std::getenv("AIRHIP_CAP")) == 768) ? 1 : 0;
 int g_spmv_variant = std::getenv("AIRHIP_SPMV_VARIANT") ? std::atoi(std::getenv("AIRHIP_SPMV_VARIANT")) : 0;
 
 void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t s, const double* x_ghost) {
@@ -271,6 +273,7 @@ void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t
   if (A.slot) {   // column-sorted blocks: the production kernel
     if (g_blk_nnz == 256) hipLaunchKernelGGL((k_rb_spmv<512, false, 4, true, XVec<false>>), grid, block, 0, s, v, xv, e);
     else if (g_blk_nnz == 1024) hipLaunchKernelGGL((k_rb_spmv<2048, false, 8, true, XVec<false>>), grid, block, 0, s, v, xv, e);
+    else if (g_cap768) hipLaunchKernelGGL((k_rb_spmv<768, false, 4, true, XVec<false>>), grid, block, 0, s, v, xv, e);
     else hipLaunchKernelGGL((k_rb_spmv<1024, false, 4, true, XVec<false>>), grid, block, 0, s, v, xv, e);
     return;
   }
@@ -326,6 +329,7 @@ void launch_fc_first(const DevMat& A_fc, const int32_t* wcol, const double* b_f,
   } else {
     const XVec<false> xv{x_c, nullptr, 0};
     if (A_fc.slot && g_blk_nnz == 256) hipLaunchKernelGGL((k_rb_fc_first<false, true, 512>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
+    else if (A_fc.slot && g_cap768) hipLaunchKernelGGL((k_rb_fc_first<false, true, 768>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
     else if (A_fc.slot && g_blk_nnz == 1024) hipLaunchKernelGGL((k_rb_fc_first<false, true, 2048>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
     else if (A_fc.slot) hipLaunchKernelGGL((k_rb_fc_first<false, true, 1024>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
     else hipLaunchKernelGGL((k_rb_fc_first<false, false, 1024>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
@@ -543,7 +547,7 @@ void devmat_from_csr_device(int64_t m, int64_t n, const int64_t* d_rp, const int
     HIP_CHECK(hipMalloc(&out.slot, sizeof(uint16_t) * (size_t)out.nnz));
     const int g = (int)std::min<int64_t>((out.nblocks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 4096);
     hipLaunchKernelGGL(k_block_sort, dim3(g < 1 ? 1 : g), dim3(BLOCK), 0, s, out.nblocks, out.blk_row, out.blk_p0, out.col, out.val, ncol, nval,
-                       out.slot, g_blk_nnz == 256 ? 512 : (g_blk_nnz == 1024 ? 2 * LDS_CAP : LDS_CAP), scalar_threshold());
+                       out.slot, g_blk_nnz == 256 ? 512 : (g_blk_nnz == 1024 ? 2 * LDS_CAP : (g_cap768 ? 768 : LDS_CAP)), scalar_threshold());
     HIP_CHECK(hipStreamSynchronize(s));
     (void)hipFree(out.col); (void)hipFree(out.val);
     out.col = ncol; out.val = nval;

@@ -93,15 +93,15 @@ def _worker(rank, world, port, case, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", sorted(CASES))
-def test_two_ranks_match_single_gpu(gpu, case, tmp_path):
+@pytest.mark.parametrize("case,world", [(c, 2) for c in sorted(CASES)] + [("adv3d_24_lump", 4)])
+def test_ranks_match_single_gpu(gpu, case, world, tmp_path):
     import torch.multiprocessing as mp
     out = str(tmp_path / "r.txt")
-    mp.spawn(_worker, args=(2, _free_port(), case, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), case, out), nprocs=world, join=True)
     r = eval(open(out).read())
     assert r["verr"] <= 1e-10, r
-    assert r["its"] == [r["its_single"]] * 2, r
-    assert r["reasons"] == [r["reason_single"]] * 2, r
+    assert r["its"] == [r["its_single"]] * world, r
+    assert r["reasons"] == [r["reason_single"]] * world, r
     assert r["xerr"] <= 1e-8, r
     assert r["stats"]["exchanges"] > 0 and r["stats"]["allreduces"] > 0
 
