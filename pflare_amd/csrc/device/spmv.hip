@@ -103,7 +103,7 @@ __device__ __forceinline__ void rb_rows(const RbView& A, const X x, double* __re
 #pragma unroll
         for (int u = 0; u < UNR; u++) vv[u] = ldg<double, NT>(v + k + u * WAVE);
 #pragma unroll
-        for (int u = 0; u < UNR; u++) ss[u] = SORTED ? (int)sl[k + u * WAVE] : k + u * WAVE;
+        for (int u = 0; u < UNR; u++) ss[u] = SORTED ? (int)ldg<uint16_t, NT>(sl + k + u * WAVE) : k + u * WAVE;
 #pragma unroll
         for (int u = 0; u < UNR; u++) xx[u] = x[cc[u]];
 #pragma unroll
@@ -247,6 +247,8 @@ static int blk_from_env() {
 }
 int g_blk_nnz = blk_from_env();
 // AIRHIP_CAP=768: 6-KB LDS stage per wave (6 instead of 5 workgroups per CU) with 512-nnz blocks
+// AIRHIP_NT=1: non-temporal loads for the matrix stream (keeps L2 / Infinity Cache for the x vector)
+static int g_nt = (std::getenv("AIRHIP_NT") && std::atoi(std::getenv("AIRHIP_NT")) != 0) ? 1 : 0;
 static int g_cap768 = (std::getenv("AIRHIP_CAP") && std::atoi(std::getenv("AIRHIP_CAP")) == 768) ? 1 : 0;
 int g_spmv_variant = std::getenv("AIRHIP_SPMV_VARIANT") ? std::atoi(std::getenv("AIRHIP_SPMV_VARIANT")) : 0;
 
@@ -274,6 +276,7 @@ void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t
     if (g_blk_nnz == 256) hipLaunchKernelGGL((k_rb_spmv<512, false, 4, true, XVec<false>>), grid, block, 0, s, v, xv, e);
     else if (g_blk_nnz == 1024) hipLaunchKernelGGL((k_rb_spmv<2048, false, 8, true, XVec<false>>), grid, block, 0, s, v, xv, e);
     else if (g_cap768) hipLaunchKernelGGL((k_rb_spmv<768, false, 4, true, XVec<false>>), grid, block, 0, s, v, xv, e);
+    else if (g_nt) hipLaunchKernelGGL((k_rb_spmv<1024, true, 4, true, XVec<false>>), grid, block, 0, s, v, xv, e);
     else hipLaunchKernelGGL((k_rb_spmv<1024, false, 4, true, XVec<false>>), grid, block, 0, s, v, xv, e);
     return;
   }
