@@ -289,8 +289,9 @@ def generate_sabs(A, strong_threshold, symmetrize):
     return S
 
 
-def pmisr(S, seed=1):
-    """src/PMISR_Module.F90:121-671 (serial; synchronous Luby rounds, smallest measure -> F)."""
+def pmisr(S, seed=1, max_luby_steps=-1):
+    """src/PMISR_Module.F90:121-671 (serial; synchronous Luby rounds, smallest measure -> F;
+    after max_luby_steps > 0 rounds whatever is undecided becomes C)."""
     n = S.shape[0]
     indptr, indices = S.indptr, S.indices
     measure = uniform(seed, 0, n) + np.diff(indptr)
@@ -301,7 +302,11 @@ def pmisr(S, seed=1):
     markers[lonely] = F_POINT
     ei = _rows_of(S)
     ej = indices
+    loops = 0
     while not assigned.all():
+        if max_luby_steps > 0 and loops == max_luby_steps:
+            break
+        loops += 1
         live = ~assigned[ei] & ~assigned[ej]
         li, lj = ei[live], ej[live]
         worse = (measure[li] > measure[lj]) | ((measure[li] == measure[lj]) & (li > lj))
@@ -373,10 +378,10 @@ def ddc(A, markers, fraction_swap):
 
 
 def compute_cf_splitting(A, strong_threshold=0.5, ddc_its=1, ddc_fraction=_f32(0.1),
-                         symmetric=False, seed=1):
+                         symmetric=False, seed=1, max_luby_steps=-1):
     """src/CF_Splitting.F90:235-392 for CF_PMISR_DDC."""
     S = generate_sabs(A, strong_threshold, not symmetric)
-    markers = pmisr(S, seed)
+    markers = pmisr(S, seed, max_luby_steps)
     if strong_threshold != 0.0:
         for _ in range(ddc_its):
             markers = ddc(A, markers, ddc_fraction)
@@ -989,6 +994,7 @@ class AirOptions:
     strong_threshold: float = 0.5
     ddc_its: int = 1
     ddc_fraction: float = _f32(0.1)
+    max_luby_steps: int = -1
     smooth_type: str = "ff"
     diag_scale_polys: bool = False
     matrix_free_polys: bool = False
@@ -1142,7 +1148,7 @@ def setup_air(A, o: AirOptions) -> Hierarchy:
                 H.coarse_inv = cop
         if not auto_truncated:
             F, C = compute_cf_splitting(cur, o.strong_threshold, o.ddc_its, o.ddc_fraction,
-                                        o.symmetric, o.seed)
+                                        o.symmetric, o.seed, o.max_luby_steps)
             n_f, n_c = F.size, C.size
         else:
             n_f = n_c = 0

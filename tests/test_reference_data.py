@@ -1,0 +1,116 @@
+"""The reference's own load tests (tests/Makefile:85-166, `run_tests_load_serial`) on the reference's
+own data files (copied as fixtures to tests/golden/reference_data/): tests/ex12f.F90 / tests/ex6.c read
+the matrix and the right-hand side from the file and require KSPSolve to converge within -ksp_max_it
+(GMRES(30), left preconditioning, rtol 1e-5, zero initial guess).  The oracle must meet every bound
+(CPU); the product must meet them too (GPU, through the C ABI)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import air_ref as R
+from pflare_amd.petscio import load_mat_vec
+
+DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_data")
+
+POWER = dict(a_drop=1e-3, inverse_type="power")
+EXACT = dict(strong_threshold=0.0, a_drop=0.0, r_drop=0.0, inverse_type="jacobi")
+
+# (Makefile line, file, PCAIR options, ksp kwargs, bound)
+AIR_CASES = [
+    ("89 default", "mat_stream_2364", {}, {}, 5),
+    ("91 a_drop power", "mat_stream_2364", POWER, {}, 5),
+    ("93 fcf", "mat_stream_2364", dict(POWER, smooth_type="fcf"), {}, 5),
+    ("95 matrix-free", "mat_stream_2364", dict(POWER, matrix_free_polys=True), {}, 5),
+    ("131-135 exact, arnoldi-18 coarse", "mat_stream_2364",
+     dict(EXACT, mg_coarse_ksp_max_it=5, max_levels=30, coarsest_poly_order=18, coarsest_matrix_free_polys=True,
+          coarsest_inverse_type="arnoldi"), dict(ksp="richardson", norm="unpreconditioned"), 1),
+    ("140-143 exact, newton-60 coarse", "mat_stream_2364",
+     dict(EXACT, max_levels=10, coarsest_poly_order=60, coarsest_matrix_free_polys=True, coarsest_inverse_type="newton",
+          max_luby_steps=3), dict(ksp="richardson", norm="unpreconditioned"), 1),
+    ("157 indefinite power", "e05r0100_petsc", POWER, dict(b_in_f=False), 26),
+]
+# Not run: tests/Makefile:159,162,164 and :120 need the ASSEMBLED Newton-basis inverse (build_gmres_polynomial_newton_inverse
+# with fixed sparsity), which is outside this build's scope (matrix-free Newton only);
+# :147 needs -mg_coarse_pc_type lu; :199-205 (1138_bus) is stored as a symmetric half.
+INV_CASES = [
+    ("116 pflareinv default", {}, 21),
+    ("118 pflareinv power", dict(type="power"), 21),
+    ("124 pflareinv newton matrix-free", dict(type="newton", matrix_free=True), 13),
+]
+
+_INV = dict(power=R.INV_POWER, arnoldi=R.INV_ARNOLDI, newton=R.INV_NEWTON, jacobi=R.INV_JACOBI)
+
+
+def _problem(fname, b_in_f=True):
+    A, b = load_mat_vec(os.path.join(DATA, fname))
+    n = A.shape[0]
+    if b_in_f:
+        assert b is not None and b.size == n
+        return A, b, np.zeros(n)
+    # tests/ex6.c:148-152: random initial guess, zero right-hand side
+    return A, np.zeros(n), np.random.default_rng(0).random(n)
+
+
+def _oracle_opts(o):
+    o = dict(o)
+    for k in ("inverse_type", "coarsest_inverse_type"):
+        if k in o:
+            o[k] = _INV[o[k]]
+    if "mg_coarse_ksp_max_it" in o:
+        o["coarse_richardson_its"] = o.pop("mg_coarse_ksp_max_it")
+    return R.AirOptions(**o)
+
+
+@pytest.mark.parametrize("label,fname,opts,kw,bound", AIR_CASES, ids=[c[0] for c in AIR_CASES])
+def test_oracle_meets_reference_load_test_bounds(label, fname, opts, kw, bound):
+    kw = dict(kw)
+    A, b, x0 = _problem(fname, kw.pop("b_in_f", True))
+    H = R.setup_air(A, _oracle_opts(opts))
+    pc = lambda r: R.vcycle(H, r)
+    if kw.get("ksp") == "richardson":
+        x, its, reason, rn = R.ksp_richardson(A, pc, b, x0, rtol=1e-5, max_it=bound, norm_type=kw["norm"])
+    else:
+        x, its, reason, rn = R.ksp_gmres(A, pc, b, x0, rtol=1e-5, max_it=bound, pc_side="left")
+    assert reason > 0 and its <= bound, (label, its, reason)
+
+
+@pytest.mark.parametrize("label,opts,bound", INV_CASES, ids=[c[0] for c in INV_CASES])
+def test_oracle_pflareinv_meets_reference_bounds(label, opts, bound):
+    A, b, x0 = _problem("mat_stream_2364")
+    op = R.pcpflareinv_setup(A, inverse_type=_INV[opts.get("type", "arnoldi")], matrix_free=opts.get("matrix_free", False))
+    x, its, reason, rn = R.ksp_gmres(A, lambda r: R.apply_inv(op, r), b, x0, rtol=1e-5, max_it=bound, pc_side="left")
+    assert reason > 0 and its <= bound, (label, its, reason)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("label,fname,opts,kw,bound", AIR_CASES, ids=[c[0] for c in AIR_CASES])
+def test_product_meets_reference_load_test_bounds(gpu, label, fname, opts, kw, bound):
+    import torch
+    import pflare_amd as P
+    kw = dict(kw)
+    A, b, x0 = _problem(fname, kw.pop("b_in_f", True))
+    pc = P.PCAIR(**opts).setup(A)
+    if kw.get("ksp") == "richardson":
+        ksp = P.KSP("richardson", norm_type=kw["norm"], rtol=1e-5, max_it=bound)
+    else:
+        ksp = P.KSP("gmres", pc_side="left", rtol=1e-5, max_it=bound)
+    bd = torch.from_numpy(b).cuda(); xd = torch.from_numpy(x0.copy()).cuda()
+    res = ksp.solve(bd, xd, pc=pc)
+    assert res["reason"] > 0 and res["its"] <= bound, (label, res)
+    # true residual of the returned iterate
+    r = b - A @ xd.cpu().numpy()
+    assert np.linalg.norm(r) <= 1e-3 * max(np.linalg.norm(b - A @ x0), 1e-300)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("label,opts,bound", INV_CASES, ids=[c[0] for c in INV_CASES])
+def test_product_pflareinv_meets_reference_bounds(gpu, label, opts, bound):
+    import torch
+    import pflare_amd as P
+    A, b, x0 = _problem("mat_stream_2364")
+    pc = P.PCPFLAREINV(**opts).setup(A)
+    ksp = P.KSP("gmres", pc_side="left", rtol=1e-5, max_it=bound)
+    bd = torch.from_numpy(b).cuda(); xd = torch.from_numpy(x0.copy()).cuda()
+    res = ksp.solve(bd, xd, pc=pc, A=P.DeviceMat(A))
+    assert res["reason"] > 0 and res["its"] <= bound, (label, res)
