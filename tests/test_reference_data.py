@@ -32,11 +32,18 @@ AIR_CASES = [
 ]
 # Not run: tests/Makefile:159,162,164 and :120 need the ASSEMBLED Newton-basis inverse (build_gmres_polynomial_newton_inverse
 # with fixed sparsity), which is outside this build's scope (matrix-free Newton only);
-# :147 needs -mg_coarse_pc_type lu; :199-205 (1138_bus) is stored as a symmetric half.
+# :147 needs -mg_coarse_pc_type lu; :201,205 are the assembled variants of the 1138_bus cases.
 INV_CASES = [
     ("116 pflareinv default", {}, 21),
     ("118 pflareinv power", dict(type="power"), 21),
     ("124 pflareinv newton matrix-free", dict(type="newton", matrix_free=True), 13),
+]
+
+# tests/Makefile:199,203: the file stores the upper triangle of 1138_bus; MatLoad into AIJ keeps exactly that
+# (a triangular operator).  -ksp_norm_type unpreconditioned selects right preconditioning for GMRES.
+BUS_CASES = [
+    ("199 1138_bus newton-60 matrix-free", dict(type="newton", poly_order=60, matrix_free=True), 6),
+    ("203 1138_bus newton-120 matrix-free", dict(type="newton", poly_order=120, matrix_free=True), 5),
 ]
 
 _INV = dict(power=R.INV_POWER, arnoldi=R.INV_ARNOLDI, newton=R.INV_NEWTON, jacobi=R.INV_JACOBI)
@@ -81,6 +88,27 @@ def test_oracle_pflareinv_meets_reference_bounds(label, opts, bound):
     op = R.pcpflareinv_setup(A, inverse_type=_INV[opts.get("type", "arnoldi")], matrix_free=opts.get("matrix_free", False))
     x, its, reason, rn = R.ksp_gmres(A, lambda r: R.apply_inv(op, r), b, x0, rtol=1e-5, max_it=bound, pc_side="left")
     assert reason > 0 and its <= bound, (label, its, reason)
+
+
+@pytest.mark.parametrize("label,opts,bound", BUS_CASES, ids=[c[0] for c in BUS_CASES])
+def test_oracle_high_order_newton_on_1138_bus(label, opts, bound):
+    A, b, x0 = _problem("1138_bus", b_in_f=False)
+    op = R.pcpflareinv_setup(A, inverse_type=R.INV_NEWTON, poly_order=opts["poly_order"], matrix_free=True)
+    x, its, reason, rn = R.ksp_gmres(A, lambda r: R.apply_inv(op, r), b, x0, rtol=1e-5, max_it=bound, pc_side="right")
+    assert reason > 0 and its <= bound, (label, its, reason)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("label,opts,bound", BUS_CASES, ids=[c[0] for c in BUS_CASES])
+def test_product_high_order_newton_on_1138_bus(gpu, label, opts, bound):
+    import torch
+    import pflare_amd as P
+    A, b, x0 = _problem("1138_bus", b_in_f=False)
+    pc = P.PCPFLAREINV(**opts).setup(A)
+    ksp = P.KSP("gmres", pc_side="right", rtol=1e-5, max_it=bound)
+    bd = torch.from_numpy(b).cuda(); xd = torch.from_numpy(x0.copy()).cuda()
+    res = ksp.solve(bd, xd, pc=pc, A=P.DeviceMat(A))
+    assert res["reason"] > 0 and res["its"] <= bound, (label, res)
 
 
 @pytest.mark.gpu
