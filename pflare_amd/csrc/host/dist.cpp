@@ -241,7 +241,9 @@ Partitioner::Partitioner(const Hierarchy& G, const Csr& A_top, int nranks, const
     const Space& F = I.fsp[l]; const Space& C = I.full[l + 1];
     auto& o = I.ops[l];
     o.A_ff = mk(Lv.A_ff, F, F); o.A_fc = mk(Lv.A_fc, F, C);
-    o.A_cf = mk(Lv.A_cf, C, F); o.A_cc = mk(Lv.A_cc, C, C);
+    static const Csr none;
+    const bool any_c = G.opt.any_c_smooths();
+    o.A_cf = mk(any_c ? Lv.A_cf : none, C, F); o.A_cc = mk(any_c ? Lv.A_cc : none, C, C);
     o.Z = mk(Lv.Z, C, F); o.W = mk(Lv.W, F, C);
     o.M_ff = mk(Lv.inv_ff.mat, F, F); o.M_cc = mk(Lv.inv_cc.mat, C, C);
   }
@@ -322,8 +324,10 @@ void Partitioner::extract(int rank, Archive& ar) const {
       put_halo(ar, p + ".A_fc", h);
       if (Lv.one_point) ar.add_copy(p + ".wcol", Archive::I32, wc.data(), nf);
     }
-    emit(p + ".A_cf", I.ops[l].A_cf);
-    emit(p + ".A_cc", I.ops[l].A_cc);
+    if (G.opt.any_c_smooths()) {     // only the C-point relaxation reads these
+      emit(p + ".A_cf", I.ops[l].A_cf);
+      emit(p + ".A_cc", I.ops[l].A_cc);
+    }
     emit(p + ".Z", I.ops[l].Z);
     emit(p + ".W", I.ops[l].W);
     auto inv = [&](const std::string& nm, const InvOp& Iv, const OpRef& mat, const Space& Sp) {
