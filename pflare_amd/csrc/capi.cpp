@@ -281,6 +281,16 @@ int airhip_pcair_setup(airhip_pcair pc, const airhip_csr* A) {
   pc->op_nnz_top = (double)pc->A_top.nnz();
   if (pc->device_upload) finish_device(pc);
   pc->A_top = Csr();   // drop the view of the caller's arrays
+  if (pc->opt.print_stats_timings) {
+    // print_stats (src/AIR_MG_Stats.F90:386-416); the format tools/parse_pflare_output.py reads
+    double g = 0, o = 0, c = 0, st = 0, by = 0;
+    if (airhip_pcair_complexities(pc, &g, &o, &c, &st, &by) == 0) {
+      std::printf(" ~~~~~~~~~~~~\n Grid complexity            : %.15g\n Operator complexity        : %.15g\n"
+                  " Cycle complexity           : %.15g\n Storage complexity         : %.15g\n"
+                  " Reuse storage complexity   : %.15g\n ~~~~~~~~~~~~\n", g, o, c, st, 0.0);
+      std::fflush(stdout);
+    }
+  }
   API_END
 }
 

@@ -99,6 +99,7 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o, SetupAc
   const bool any_c = o.any_c_smooths();
   bool auto_truncated = false;
   const double t_setup = now_s();
+  if (o.print_stats_timings) std::printf(" Timers are cumulative\n");     // src/AIR_MG_Setup.F90:130
 
   for (int our_level = 1; our_level < o.max_levels; our_level++) {
     const int64_t n = cur->m;
@@ -228,9 +229,12 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o, SetupAc
       std::printf(" ~~~~~~~~~~~~ Level %d\n Global rows %lld Global F-points %lld Global C-points %lld  (nnz %lld, A_ff %s, t=%.2fs)\n",
                   our_level, (long long)n, (long long)n_f, (long long)n_c, (long long)L.nnz_A,
                   L.aff_diag ? "diagonal" : "sparse", now_s() - t_setup);
-    if (o.print_stats_timings)
-      std::printf("   cumulative: coarsen %.2f extract %.2f inverse %.2f prolong %.2f restrict %.2f RAP %.2f drop %.2f truncate %.2f\n",
-                  H->timers[0], H->timers[1], H->timers[2], H->timers[3], H->timers[4], H->timers[5], H->timers[6], H->timers[7]);
+    if (o.print_stats_timings)   // labels of print_timers() (src/Timers.F90:30-46): tools/parse_pflare_output.py reads them
+      std::printf(" coarsen time     : %.6f\n extract time     : %.6f\n proc agglom time : %.6f\n inverse time     : %.6f\n"
+                  " restrict time    : %.6f\n prolong time     : %.6f\n constrain time   : %.6f\n rap time         : %.6f\n"
+                  " identity time    : %.6f\n drop time        : %.6f\n truncate time    : %.6f\n",
+                  H->timers[0], H->timers[1], 0.0, H->timers[2], H->timers[4], H->timers[3], 0.0, H->timers[5], 0.0, H->timers[6],
+                  H->timers[7]);
     if (o.print_stats_timings) std::fflush(stdout);
     H->levels.push_back(std::move(Lp));
     owned = std::move(coarse);
@@ -252,7 +256,7 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o, SetupAc
     H->timers[2] += now_s() - t0;
   }
   if (o.print_stats_timings)
-    std::printf(" ~~~~~~~~~~~~ Coarse grid %d\n Global rows %lld\n Total cumulative setup time : %.3f\n",
+    std::printf(" ~~~~~~~~~~~~ Coarse grid %d\n Global rows %lld\n ~~~~~~~~~~~~\n Total cumulative setup time : %.3f\n ~~~~~~~~~~~~\n",
                 H->no_levels(), (long long)H->coarse_A.m, now_s() - t_setup);
   return H;
 }

@@ -70,3 +70,25 @@ def test_export_roundtrip_zero_copy_views():
     assert np.array_equal(a["F"], b["F"]) and np.array_equal(a["Z"].val, b["Z"].val)
     cx = pc.complexities()
     assert cx["cycle"] > 0 and cx["cycle_alg_bytes"] == 0.0   # device bytes only after a device setup
+
+
+def test_print_stats_timings_output_has_the_reference_labels():
+    """-pc_air_print_stats_timings: the per-level block and the timer labels of the reference
+    (src/AIR_MG_Setup.F90:324-325,1220-1225, src/Timers.F90:30-46) so that its tools/parse_pflare_output.py
+    reads our output (checked by hand against that script; here: the same regular expressions)."""
+    import re
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import pflare_amd as P\n"
+            "A = P.HostMat.adv_diff_fd(dim=2, M=30, N=30)\n"
+            "P.PCAIR(print_stats_timings=True).setup_host_only(A)\n") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout
+    levels = re.findall(r"~~~~~~~~~~~~ Level\s+(\d+)", out)
+    assert levels and levels[0] == "1"
+    assert re.search(r"Global rows\s+900\s+Global F-points\s+(\d+)\s+Global C-points\s+(\d+)", out)
+    for label in ("coarsen time", "extract time", "proc agglom time", "inverse time", "restrict time", "prolong time",
+                  "constrain time", "rap time", "identity time", "drop time", "truncate time"):
+        assert len(re.findall(r"\b" + re.escape(label) + r"\s*:\s*(\S+)", out)) == len(levels), label
+    assert re.search(r"~~~~~~~~~~~~ Coarse grid\s+(\d+)", out)
+    assert re.search(r"Total cumulative setup time\s*:\s*(\S+)", out)
