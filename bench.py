@@ -316,7 +316,7 @@ def main():
         roofline["vcycle_alg_GBs"] = cx["cycle_alg_bytes"] / (vc_ms / cycles * 1e-3) / 1e9
         roofline["vcycle_kernel_ms"] = vc_ms / cycles
         if args.verbose:
-            for s in sorted(live, key=lambda s: -s["total_ms"])[:14]:
+            for s in sorted(live, key=lambda s: -s["total_ms"])[:60]:
                 a = s["total_ms"] / s["calls"]
                 log(f"   {s['name']:28s} L{s['level']+1:<2d} calls={s['calls']:4d} avg={a:8.3f} ms  "
                     f"{s['alg_bytes']/(a*1e-3)/1e9:8.1f} GB/s")

@@ -639,7 +639,6 @@ struct airhip_comm_s { std::unique_ptr<Comm> c; };
 int airhip_partition_create(airhip_pcair pc, const airhip_csr* A_top, int nranks, const int32_t* owner, airhip_partition* out) {
   API_BEGIN
   REQUIRE(pc && pc->H && A_top && owner && out && nranks >= 1, AIRHIP_ERR_ARG, "partitioning needs a PCAIR with its host hierarchy");
-  REQUIRE(!pc->H->levels.empty() || true, AIRHIP_ERR_STATE, "");
   auto* h = new airhip_partition_s;
   view_csr(A_top, h->A_view);
   REQUIRE(pc->hint.empty() || (int64_t)pc->hint.size() == A_top->m, AIRHIP_ERR_ARG, "ordering hint: one key per row of the operator is required");
