@@ -36,7 +36,8 @@ struct DevMat {
   // Blocks that take the LDS path store their entries sorted by COLUMN (neighbouring lanes then
   // gather neighbouring x entries: a 64-lane gather touches ~7 instead of ~25 cache lines) and
   // slot[k] gives the entry's row-major position inside the block, where its product is staged.
-  uint16_t* slot = nullptr;      // [nnz] or null (unsorted)
+  uint16_t* slot = nullptr;      // [nnz] or null (unsorted, or packed)
+  bool packed = false;           // operators with <= 2^22 columns: slot lives in bits 22..31 of col (12 B/nnz again)
   // tiles: consecutive row blocks (~2k non-zeros) whose distinct columns are staged in LDS by the
   // workgroup that owns the tile; entries address the staged copy through a 16-bit local index
   int64_t ntiles = 0, n_ucol = 0;

@@ -19,7 +19,9 @@
 //   * XCD-aware assignment: blocks b and b+8 of the grid share an XCD (observed round-robin
 //     dispatch; a speed assumption only), so each residue class of workgroups walks a contiguous
 //     range of row blocks and an XCD's private L2 sees a contiguous window of x.
-// Kernels suffixed _dbg are timing-only diagnostics selected through airhip_debug_set_variant.
+// airhip_debug_set_variant selects timing variants (LDS stage size, non-temporal loads, unroll depth, a
+// no-far-gather diagnostic); the flat-stream diagnostics of profiles/r01_spmv_experiments.md were removed
+// after the measurements.
 #include "dev.hpp"
 #include "kcommon.hpp"
 #include "rb.hpp"
@@ -68,7 +70,9 @@ struct XVecNoGather {
   __device__ __forceinline__ double operator[](int32_t c) const { return x[c & 1023]; }
 };
 
-template <int CAP, bool NT, int UNR, bool SORTED, class X, class Epi>
+// SORTED: 0 = row-major blocks, 1 = column-sorted blocks + 16-bit slot array, 2 = column-sorted blocks with
+// the slot packed into the upper 10 bits of the column word (operators with <= 2^22 columns: 12 B/nnz again)
+template <int CAP, bool NT, int UNR, int SORTED, class X, class Epi>
 __device__ __forceinline__ void rb_rows(const RbView& A, const X x, double* __restrict__ lds, Epi epi) {
   const int lane = threadIdx.x & (WAVE - 1);
   const BlockRange br = my_blocks(A.nblocks);
@@ -82,6 +86,7 @@ __device__ __forceinline__ void rb_rows(const RbView& A, const X x, double* __re
     const int32_t* __restrict__ c = A.col + p0;
     const uint16_t* __restrict__ sl = A.slot + p0;
     const int nr = r1 - r0;
+    constexpr int32_t CMASK = SORTED == 2 ? 0x3fffff : -1;
     if (nb <= A.scalar_t * nr) {
       // very short rows (<= 4 non-zeros on average): one lane per row straight from global
       // memory - the block's ~6 KB are shared by neighbouring lanes through L1, and the
@@ -90,7 +95,7 @@ __device__ __forceinline__ void rb_rows(const RbView& A, const X x, double* __re
         const int a = (int)A.roff[r];
         const int e = (r + 1 < r1) ? (int)A.roff[r + 1] : nb;
         double s = 0.0;
-        for (int j = a; j < e; j++) s += ldg<double, NT>(v + j) * x[ldg<int32_t, NT>(c + j)];
+        for (int j = a; j < e; j++) s += ldg<double, NT>(v + j) * x[ldg<int32_t, NT>(c + j) & CMASK];
         epi(r, s);
       }
     } else if (nb <= CAP) {
@@ -103,13 +108,17 @@ __device__ __forceinline__ void rb_rows(const RbView& A, const X x, double* __re
 #pragma unroll
         for (int u = 0; u < UNR; u++) vv[u] = ldg<double, NT>(v + k + u * WAVE);
 #pragma unroll
-        for (int u = 0; u < UNR; u++) ss[u] = SORTED ? (int)ldg<uint16_t, NT>(sl + k + u * WAVE) : k + u * WAVE;
+        for (int u = 0; u < UNR; u++)
+          ss[u] = SORTED == 2 ? (int)((uint32_t)cc[u] >> 22) : SORTED == 1 ? (int)ldg<uint16_t, NT>(sl + k + u * WAVE) : k + u * WAVE;
 #pragma unroll
-        for (int u = 0; u < UNR; u++) xx[u] = x[cc[u]];
+        for (int u = 0; u < UNR; u++) xx[u] = x[cc[u] & CMASK];
 #pragma unroll
         for (int u = 0; u < UNR; u++) lds[ss[u]] = vv[u] * xx[u];
       }
-      for (; k < nb; k += WAVE) lds[SORTED ? (int)sl[k] : k] = ldg<double, NT>(v + k) * x[ldg<int32_t, NT>(c + k)];
+      for (; k < nb; k += WAVE) {
+        const int32_t cw = ldg<int32_t, NT>(c + k);
+        lds[SORTED == 2 ? (int)((uint32_t)cw >> 22) : SORTED == 1 ? (int)sl[k] : k] = ldg<double, NT>(v + k) * x[cw & CMASK];
+      }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -147,12 +156,12 @@ __device__ __forceinline__ void rb_rows(const RbView& A, const X x, double* __re
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
         int j = a + lane;
         for (; j + 3 * WAVE < e; j += 4 * WAVE) {
-          const int32_t c0 = c[j], c1 = c[j + WAVE], c2 = c[j + 2 * WAVE], c3 = c[j + 3 * WAVE];
+          const int32_t c0 = c[j] & CMASK, c1 = c[j + WAVE] & CMASK, c2 = c[j + 2 * WAVE] & CMASK, c3 = c[j + 3 * WAVE] & CMASK;
           const double v0 = v[j], v1 = v[j + WAVE], v2 = v[j + 2 * WAVE], v3 = v[j + 3 * WAVE];
           const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
           s0 = fma(v0, x0, s0); s1 = fma(v1, x1, s1); s2 = fma(v2, x2, s2); s3 = fma(v3, x3, s3);
         }
-        for (; j < e; j += WAVE) s0 = fma(v[j], x[c[j]], s0);
+        for (; j < e; j += WAVE) s0 = fma(v[j], x[c[j] & CMASK], s0);
         double s = (s0 + s1) + (s2 + s3);
         for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
         if (lane == 0) epi(r, s);
@@ -161,7 +170,7 @@ __device__ __forceinline__ void rb_rows(const RbView& A, const X x, double* __re
   }
 }
 
-template <int CAP, bool NT, int UNR, bool SORTED, class X>
+template <int CAP, bool NT, int UNR, int SORTED, class X>
 __global__ __launch_bounds__(BLOCK) void k_rb_spmv(RbView A, X x, SpmvEpi e) {
   __shared__ double lds_all[WAVES_PER_BLOCK][CAP];
   double* lds = lds_all[threadIdx.x >> 6];
@@ -176,64 +185,6 @@ __global__ __launch_bounds__(BLOCK) void k_rb_spmv(RbView A, X x, SpmvEpi e) {
       e.y2[row] += e.delta * a;
     }
   });
-}
-
-// diagnostics (airhip_debug_set_variant 32 / 64): MODE 1 streams the non-zeros and the gathered x
-// and keeps a running sum only (no LDS, one store per block); MODE 2 also stages the products in
-// LDS but skips the per-row reduction.  Wrong results by construction - timing only.
-template <int MODE>
-__global__ __launch_bounds__(BLOCK) void k_rb_stream_dbg(RbView A, const double* __restrict__ x, double* __restrict__ out) {
-  __shared__ double lds_all[WAVES_PER_BLOCK][1024];
-  double* lds = lds_all[threadIdx.x >> 6];
-  const int lane = threadIdx.x & (WAVE - 1);
-  const BlockRange br = my_blocks(A.nblocks);
-  for (int64_t b = br.first; b < br.last; b += br.stride) {
-    const int32_t r0 = __builtin_amdgcn_readfirstlane(A.blk_row[b]);
-    const int64_t p0 = uniform64(A.blk_p0[b]);
-    const int64_t p1 = uniform64(A.blk_p0[b + 1]);
-    const int nb = (int)(p1 - p0);
-    const double* __restrict__ v = A.val + p0;
-    const int32_t* __restrict__ c = A.col + p0;
-    double s = 0.0;
-    int k = lane;
-    for (; k + 3 * WAVE < nb; k += 4 * WAVE) {
-      int32_t cc[4]; double vv[4], xx[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) cc[u] = c[k + u * WAVE];
-#pragma unroll
-      for (int u = 0; u < 4; u++) vv[u] = v[k + u * WAVE];
-#pragma unroll
-      for (int u = 0; u < 4; u++) xx[u] = x[cc[u]];
-#pragma unroll
-      for (int u = 0; u < 4; u++) { if (MODE == 2 && k + u * WAVE < 1024) lds[k + u * WAVE] = vv[u] * xx[u]; s += vv[u] * xx[u]; }
-    }
-    for (; k < nb; k += WAVE) s += v[k] * x[c[k]];
-    if (MODE == 2) { __builtin_amdgcn_wave_barrier(); s += lds[lane]; __builtin_amdgcn_wave_barrier(); }
-    if (s == 123.456) out[r0] = s;      // practically never: keeps the loads alive
-    else if (lane == 0) out[r0] = s;
-  }
-}
-
-// diagnostics 256 / 512: flat grid-stride stream over the non-zeros (no row structure at all),
-// without / with the x gather - the ceiling any SpMV organisation of these arrays can reach
-// GATHER: 0 none, 1 x[col], 2 x[(col of lane 0 rounded down to 64) + lane] (same traffic pattern
-// into x but 4 lines per wave instruction instead of 20-33)
-template <int GATHER>
-__global__ __launch_bounds__(BLOCK) void k_flat_stream_dbg(int64_t nnz, int64_t nx, const int32_t* __restrict__ col,
-                                                           const double* __restrict__ val, const double* __restrict__ x,
-                                                           double* __restrict__ out) {
-  const int64_t stride = (int64_t)gridDim.x * BLOCK;
-  const int lane = threadIdx.x & 63;
-  double s = 0.0;
-  for (int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x; k < nnz; k += stride) {
-    const int32_t c = col[k];
-    double xv;
-    if (GATHER == 0) xv = (double)c;
-    else if (GATHER == 1) xv = x[c];
-    else { int64_t c0 = (__shfl(c, 0, 64) & ~63) + lane; if (c0 >= nx) c0 = lane; xv = x[c0]; }
-    s += val[k] * xv;
-  }
-  if (s == 123.456) out[0] = s;
 }
 
 // tuning variant (bit 0: 640-entry LDS stage instead of 1024, bit 1: non-temporal matrix loads,
@@ -262,25 +213,31 @@ void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t
     if (!x_ghost) throw std::runtime_error("launch_spmv: distributed operand without ghost values");
     const int32_t nl = (int32_t)(A.n - A.n_ghost);
     const XVec<true> xv{x, x_ghost - nl, nl};
-    if (A.slot) hipLaunchKernelGGL((k_rb_spmv<1024, false, 4, true, XVec<true>>), grid, block, 0, s, v, xv, e);
-    else hipLaunchKernelGGL((k_rb_spmv<1024, false, 4, false, XVec<true>>), grid, block, 0, s, v, xv, e);
+    if (A.packed) hipLaunchKernelGGL((k_rb_spmv<1024, false, 4, 2, XVec<true>>), grid, block, 0, s, v, xv, e);
+    else if (A.slot) hipLaunchKernelGGL((k_rb_spmv<1024, false, 4, 1, XVec<true>>), grid, block, 0, s, v, xv, e);
+    else hipLaunchKernelGGL((k_rb_spmv<1024, false, 4, 0, XVec<true>>), grid, block, 0, s, v, xv, e);
+    return;
+  }
+  if (A.packed) {
+    if (g_spmv_variant) throw std::runtime_error("kernel variants are not available for packed operators (set AIRHIP_NO_PACK=1)");
+    hipLaunchKernelGGL((k_rb_spmv<1024, false, 4, 2, XVec<false>>), grid, block, 0, s, v, XVec<false>{x, nullptr, 0}, e);
     return;
   }
   if (g_spmv_variant & 8) {
     const XVecNoGather xd{x};
-    hipLaunchKernelGGL((k_rb_spmv<1024, false, 4, false, XVecNoGather>), grid, block, 0, s, v, xd, e);
+    hipLaunchKernelGGL((k_rb_spmv<1024, false, 4, 0, XVecNoGather>), grid, block, 0, s, v, xd, e);
     return;
   }
   const XVec<false> xv{x, nullptr, 0};
   if (A.slot) {   // column-sorted blocks: the production kernel
-    if (g_blk_nnz == 256) hipLaunchKernelGGL((k_rb_spmv<512, false, 4, true, XVec<false>>), grid, block, 0, s, v, xv, e);
-    else if (g_blk_nnz == 1024) hipLaunchKernelGGL((k_rb_spmv<2048, false, 8, true, XVec<false>>), grid, block, 0, s, v, xv, e);
-    else if (g_cap768) hipLaunchKernelGGL((k_rb_spmv<768, false, 4, true, XVec<false>>), grid, block, 0, s, v, xv, e);
-    else if (g_nt) hipLaunchKernelGGL((k_rb_spmv<1024, true, 4, true, XVec<false>>), grid, block, 0, s, v, xv, e);
-    else hipLaunchKernelGGL((k_rb_spmv<1024, false, 4, true, XVec<false>>), grid, block, 0, s, v, xv, e);
+    if (g_blk_nnz == 256) hipLaunchKernelGGL((k_rb_spmv<512, false, 4, 1, XVec<false>>), grid, block, 0, s, v, xv, e);
+    else if (g_blk_nnz == 1024) hipLaunchKernelGGL((k_rb_spmv<2048, false, 8, 1, XVec<false>>), grid, block, 0, s, v, xv, e);
+    else if (g_cap768) hipLaunchKernelGGL((k_rb_spmv<768, false, 4, 1, XVec<false>>), grid, block, 0, s, v, xv, e);
+    else if (g_nt) hipLaunchKernelGGL((k_rb_spmv<1024, true, 4, 1, XVec<false>>), grid, block, 0, s, v, xv, e);
+    else hipLaunchKernelGGL((k_rb_spmv<1024, false, 4, 1, XVec<false>>), grid, block, 0, s, v, xv, e);
     return;
   }
-#define RB_LAUNCH(CAP, NT, UNR) hipLaunchKernelGGL((k_rb_spmv<CAP, NT, UNR, false, XVec<false>>), grid, block, 0, s, v, xv, e)
+#define RB_LAUNCH(CAP, NT, UNR) hipLaunchKernelGGL((k_rb_spmv<CAP, NT, UNR, 0, XVec<false>>), grid, block, 0, s, v, xv, e)
   switch (g_spmv_variant & 7) {
     case 0: RB_LAUNCH(1024, false, 4); break;
     case 1: RB_LAUNCH(640, false, 4); break;
@@ -294,7 +251,7 @@ void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t
 #undef RB_LAUNCH
 }
 
-template <bool DIST, bool SORTED, int CAP>
+template <bool DIST, int SORTED, int CAP>
 __global__ __launch_bounds__(BLOCK) void k_rb_fc_first(RbView A, const int32_t* __restrict__ wcol,
                                                       const double* __restrict__ b_f, XVec<DIST> x_c,
                                                       const double* __restrict__ aff_d, const double* __restrict__ minv,
@@ -327,15 +284,17 @@ void launch_fc_first(const DevMat& A_fc, const int32_t* wcol, const double* b_f,
     if (!x_ghost) throw std::runtime_error("launch_fc_first: distributed operand without ghost values");
     const int32_t nl = (int32_t)(A_fc.n - A_fc.n_ghost);
     const XVec<true> xv{x_c, x_ghost - nl, nl};
-    if (A_fc.slot) hipLaunchKernelGGL((k_rb_fc_first<true, true, 1024>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
-    else hipLaunchKernelGGL((k_rb_fc_first<true, false, 1024>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
+    if (A_fc.packed) hipLaunchKernelGGL((k_rb_fc_first<true, 2, 1024>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
+    else if (A_fc.slot) hipLaunchKernelGGL((k_rb_fc_first<true, 1, 1024>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
+    else hipLaunchKernelGGL((k_rb_fc_first<true, 0, 1024>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
   } else {
     const XVec<false> xv{x_c, nullptr, 0};
-    if (A_fc.slot && g_blk_nnz == 256) hipLaunchKernelGGL((k_rb_fc_first<false, true, 512>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
-    else if (A_fc.slot && g_cap768) hipLaunchKernelGGL((k_rb_fc_first<false, true, 768>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
-    else if (A_fc.slot && g_blk_nnz == 1024) hipLaunchKernelGGL((k_rb_fc_first<false, true, 2048>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
-    else if (A_fc.slot) hipLaunchKernelGGL((k_rb_fc_first<false, true, 1024>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
-    else hipLaunchKernelGGL((k_rb_fc_first<false, false, 1024>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
+    if (A_fc.packed) hipLaunchKernelGGL((k_rb_fc_first<false, 2, 1024>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
+    else if (A_fc.slot && g_blk_nnz == 256) hipLaunchKernelGGL((k_rb_fc_first<false, 1, 512>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
+    else if (A_fc.slot && g_cap768) hipLaunchKernelGGL((k_rb_fc_first<false, 1, 768>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
+    else if (A_fc.slot && g_blk_nnz == 1024) hipLaunchKernelGGL((k_rb_fc_first<false, 1, 2048>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
+    else if (A_fc.slot) hipLaunchKernelGGL((k_rb_fc_first<false, 1, 1024>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
+    else hipLaunchKernelGGL((k_rb_fc_first<false, 0, 1024>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
   }
 }
 
@@ -500,6 +459,29 @@ __global__ __launch_bounds__(BLOCK) void k_block_sort(int64_t nblocks, const int
   }
 }
 
+// col |= slot << 22 for the entries of column-sorted blocks (operators with <= 2^22 columns)
+__global__ __launch_bounds__(BLOCK) void k_pack_slot(int64_t nnz, int32_t* __restrict__ col, const uint16_t* __restrict__ slot) {
+  const int64_t stride = (int64_t)gridDim.x * BLOCK;
+  for (int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x; k < nnz; k += stride)
+    col[k] = (int32_t)((uint32_t)col[k] | ((uint32_t)slot[k] << 22));
+}
+
+// blocks that were not sorted (longer than the LDS stage) keep slot = 0: their slot is never read
+__global__ __launch_bounds__(BLOCK) void k_pack_unsorted_zero(int64_t nblocks, const int64_t* __restrict__ blk_p0, uint16_t* __restrict__ slot, int cap) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * BLOCK) >> 6;
+  for (int64_t b = wave; b < nblocks; b += nwaves) {
+    const int64_t p0 = blk_p0[b], p1 = blk_p0[b + 1];
+    if (p1 - p0 > cap) for (int64_t k = p0 + lane; k < p1; k += WAVE) slot[k] = 0;
+  }
+}
+
+static bool pack_enabled() {
+  static const bool on = !(std::getenv("AIRHIP_NO_PACK") && std::atoi(std::getenv("AIRHIP_NO_PACK")) != 0);
+  return on;
+}
+
 static bool sort_blocks_enabled() {
   static const bool on = !(std::getenv("AIRHIP_NO_BLOCK_SORT") && std::atoi(std::getenv("AIRHIP_NO_BLOCK_SORT")) != 0);
   return on;
@@ -554,6 +536,14 @@ void devmat_from_csr_device(int64_t m, int64_t n, const int64_t* d_rp, const int
     HIP_CHECK(hipStreamSynchronize(s));
     (void)hipFree(out.col); (void)hipFree(out.val);
     out.col = ncol; out.val = nval;
+    // unsorted blocks carry slot = position, which may exceed 10 bits: only default-shaped blocks are packed
+    if (pack_enabled() && out.n <= (1 << 22) && g_blk_nnz == BLK_NNZ && !g_cap768 && scalar_threshold() == 0) {
+      hipLaunchKernelGGL(k_pack_unsorted_zero, dim3(g < 1 ? 1 : g), dim3(BLOCK), 0, s, out.nblocks, out.blk_p0, out.slot, (int)LDS_CAP);
+      hipLaunchKernelGGL(k_pack_slot, dim3(grid1d(out.nnz)), dim3(BLOCK), 0, s, out.nnz, out.col, out.slot);
+      HIP_CHECK(hipStreamSynchronize(s));
+      (void)hipFree(out.slot); out.slot = nullptr;
+      out.packed = true;
+    }
   }
   if (tiles_enabled()) devmat_build_tiles(out, s);
 }
