@@ -55,8 +55,6 @@ def main():
     ap.add_argument("--hint-brick", type=int, default=16,
                     help="locality hint for the device layout: grid points grouped in BxBxB bricks (0: none, -1: Morton "
                          "order of the bricks of size 4); the operator keeps the reference numbering")
-    ap.add_argument("--no-auto-layout", action="store_true", help="without a hint: keep the natural row order inside every level "
-                                                                 "(default: cluster rows by their coarsest-level ancestor)")
     ap.add_argument("--brick", type=int, default=0, help="diagnostic: renumber the grid in BxBxB bricks before the setup (locality experiment; not the reference numbering)")
     ap.add_argument("--threads", type=int, default=0, help="host threads for setup + CPU baseline (0: cores / ranks, capped at 32 - measured best on the GPU box)")
     args = ap.parse_args()
@@ -126,8 +124,6 @@ def main():
             hm = P.CsrArrays(A.indptr, A.indices, A.data, A.shape)
             log(f"[bench] renumbered in {B}^3 bricks")
         pc = P.PCAIR(**opts)
-        if args.no_auto_layout:
-            pc.set_option("auto_layout", False)
         if args.hint_brick == -1 and not args.brick:
             import numpy as np
             ax = np.arange(M, dtype=np.int64)
@@ -332,8 +328,7 @@ def main():
         "config": {"workload": f"3D upwind advection (tests/adv_diff_fd.c) {M}^3 = {M ** 3} DoF, nnz(A)={nnzA}, b=0, x0=1, "
                                f"GMRES(30) right PC rtol 1e-10, PCAIR recipe '{args.recipe}' {opts}",
                    "parallelism": parallelism,
-                   "layout_hint": ("morton" if args.hint_brick == -1 else f"{args.hint_brick}^3 bricks" if args.hint_brick > 0 and not args.brick
-                                   else "none (natural order)" if args.no_auto_layout else "none (automatic: hierarchy ancestors)"),
+                   "layout_hint": ("morton" if args.hint_brick == -1 else f"{args.hint_brick}^3 bricks" if args.hint_brick > 0 and not args.brick else "none"),
                    "levels": info["levels"], "iterations_to_rtol_1e-10": res0["its"],
                    "converged_reason": res0["reason_name"], "converged_solve_ms": res0["solve_ms"],
                    "cycle_complexity": cx["cycle"], "operator_complexity": cx["operator"],

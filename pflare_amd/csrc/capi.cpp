@@ -167,7 +167,6 @@ struct airhip_pcair_s {
   int64_t setup_device_min_nnz = -1;
   bool device_upload = true;      // false: keep the hierarchy on the host only (it will be partitioned)
   std::vector<int64_t> hint;      // optional locality keys of the fine rows (device layout only)
-  bool auto_layout = true;        // without a hint: cluster the rows by their coarsest-level ancestor
   double accel_transfer_s = 0, accel_compute_s = 0;
 };
 
@@ -227,7 +226,7 @@ int airhip_pcair_set_option(airhip_pcair pc, const char* name, const char* value
   else if (k == "setup_on_device") pc->setup_on_device = parse_bool(v);
   else if (k == "setup_device_min_nnz") pc->setup_device_min_nnz = std::atoll(v);
   else if (k == "device_upload") pc->device_upload = parse_bool(v);
-  else if (k == "auto_layout") pc->auto_layout = parse_bool(v);
+
   else if (k == "processor_agglom" || k == "subcomm" || k == "coarsest_subcomm") { /* no-ops on one device */ }
   else if (k == "symmetric" || k == "z_type" || k == "cf_splitting_type" || k == "full_smoothing_up_and_down" ||
            k == "constrain_z" || k == "constrain_w" || k == "improve_z_its" || k == "improve_w_its" ||
@@ -246,9 +245,6 @@ static void finish_device(airhip_pcair pc) {
   if (!pc->hint.empty()) {
     if ((int64_t)pc->hint.size() != pc->A_top.m) throw std::runtime_error("ordering hint: one key per row of the operator is required");
     pc->dev->set_ordering_hint(pc->hint.data(), (int64_t)pc->hint.size());
-  } else if (pc->auto_layout && pc->H->no_levels() > 1) {
-    const std::vector<int64_t> keys = auto_locality_keys(*pc->H);
-    pc->dev->set_ordering_hint(keys.data(), (int64_t)keys.size());
   }
   pc->dev->upload(*pc->H, pc->A_top);
   pc->dev->set_use_graph(pc->use_graph);
@@ -647,7 +643,6 @@ int airhip_partition_create(airhip_pcair pc, const airhip_csr* A_top, int nranks
   auto* h = new airhip_partition_s;
   view_csr(A_top, h->A_view);
   REQUIRE(pc->hint.empty() || (int64_t)pc->hint.size() == A_top->m, AIRHIP_ERR_ARG, "ordering hint: one key per row of the operator is required");
-  if (pc->hint.empty() && pc->auto_layout && pc->H->no_levels() > 1) pc->hint = auto_locality_keys(*pc->H);
   try { h->p = std::make_unique<Partitioner>(*pc->H, h->A_view, nranks, owner, pc->hint.empty() ? nullptr : pc->hint.data()); }
   catch (...) { delete h; throw; }
   *out = h;

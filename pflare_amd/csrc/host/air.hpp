@@ -97,12 +97,6 @@ void build_inverse(const OpView& A, int inverse_type, int poly_order, int sparsi
 // Full setup.  A is consumed level by level (the caller's matrix is not modified).
 std::unique_ptr<Hierarchy> setup_air(const Csr& A, const AirOptions& o, SetupAccel* accel = nullptr);
 
-// Locality keys for the device layout derived from the hierarchy itself: key[i] = index of fine row i's
-// ancestor on the coarsest level (C points map to themselves, F points to the coarse point their
-// prolongation weight is largest on), i.e. the rows are clustered the way AIR aggregated them.
-// Rows without an ancestor (no coarse neighbour, e.g. Dirichlet rows) get the largest key.
-std::vector<int64_t> auto_locality_keys(const Hierarchy& H);
-
 // y = op(x) on the host (used by the auto-truncation test of the setup only)
 void host_apply_inv(const InvOp& op, const OpView& A, const double* x, double* y);
 

@@ -261,36 +261,4 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o, SetupAc
   return H;
 }
 
-std::vector<int64_t> auto_locality_keys(const Hierarchy& H) {
-  const int L = H.no_levels();
-  const int64_t n0 = L > 1 ? H.levels[0]->n : H.coarse_A.m;
-  std::vector<int64_t> anc((size_t)n0);
-#pragma omp parallel for schedule(static)
-  for (int64_t i = 0; i < n0; i++) anc[i] = i;
-  std::vector<int32_t> par;
-  for (int l = 0; l + 1 < L; l++) {
-    const Level& Lv = *H.levels[l];
-    par.assign((size_t)Lv.n, -1);
-#pragma omp parallel for schedule(static)
-    for (int64_t j = 0; j < Lv.n_c; j++) par[Lv.C[j]] = (int32_t)j;
-#pragma omp parallel for schedule(static)
-    for (int64_t i = 0; i < Lv.n_f; i++) {
-      int32_t p = -1;
-      if (Lv.one_point) p = Lv.wcol[i];
-      else {
-        double best = -1.0;
-        for (int64_t k = Lv.W.rp[i]; k < Lv.W.rp[i + 1]; k++)
-          if (std::fabs(Lv.W.v[k]) > best) { best = std::fabs(Lv.W.v[k]); p = Lv.W.ci[k]; }
-      }
-      par[Lv.F[i]] = (p >= 0 && p < Lv.n_c) ? p : -1;   // a ghost parent (distributed piece) counts as none
-    }
-#pragma omp parallel for schedule(static)
-    for (int64_t i = 0; i < n0; i++) if (anc[i] >= 0) anc[i] = par[anc[i]];
-  }
-  const int64_t big = (int64_t)1 << 40;
-#pragma omp parallel for schedule(static)
-  for (int64_t i = 0; i < n0; i++) if (anc[i] < 0) anc[i] = big;
-  return anc;
-}
-
 }  // namespace airhip
