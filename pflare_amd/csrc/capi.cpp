@@ -439,11 +439,19 @@ int airhip_pcair_level_sizes(airhip_pcair pc, int level, int64_t* n, int64_t* n_
   const int L = pc->H->no_levels();
   REQUIRE(level >= 0 && level < L, AIRHIP_ERR_ARG, "level out of range");
   if (level == L - 1) {
-    if (n) *n = pc->H->coarse_A.m; if (n_f) *n_f = 0; if (n_c) *n_c = 0; if (aff_diag) *aff_diag = 0; if (one_point) *one_point = 0;
+    if (n) *n = pc->H->coarse_A.m;
+    if (n_f) *n_f = 0;
+    if (n_c) *n_c = 0;
+    if (aff_diag) *aff_diag = 0;
+    if (one_point) *one_point = 0;
     if (nnz_A) *nnz_A = pc->H->coarse_A.nnz();
   } else {
     const Level& lv = *pc->H->levels[level];
-    if (n) *n = lv.n; if (n_f) *n_f = lv.n_f; if (n_c) *n_c = lv.n_c; if (aff_diag) *aff_diag = lv.aff_diag; if (one_point) *one_point = lv.one_point;
+    if (n) *n = lv.n;
+    if (n_f) *n_f = lv.n_f;
+    if (n_c) *n_c = lv.n_c;
+    if (aff_diag) *aff_diag = lv.aff_diag;
+    if (one_point) *one_point = lv.one_point;
     if (nnz_A) *nnz_A = lv.nnz_A;
   }
   API_END
