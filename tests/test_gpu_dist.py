@@ -148,3 +148,57 @@ def test_rccl_transport_loads_and_reduces(gpu, tmp_path):
     r = eval(open(out).read())
     assert r["its"] == r["its_single"] and r["diff"] <= 1e-12, r
     assert r["stats"]["allreduces"] > 0
+
+
+def _refdata_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import pflare_amd as P
+    from pflare_amd import dist as D
+    from pflare_amd.petscio import load_mat_vec
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        A, b = load_mat_vec(os.path.join(ROOT, "tests", "golden", "reference_data", "mat_stream_2364"))
+        n = A.shape[0]
+        pcg = owner = Ag = None
+        if rank == 0:
+            Ag = A
+            owner = D.block_owner(n, world)
+            pcg = P.PCAIR(device_upload=False, a_drop=1e-3, inverse_type="power", matrix_free_polys=True)
+            pcg.setup(A)
+        comm = D.StagedComm()
+        pc, gid = D.distribute(pcg, Ag, owner, comm)
+        ksp = P.KSP("gmres", pc_side="left", rtol=1e-5, max_it=5)
+        bd = torch.from_numpy(b[gid]).cuda(); xd = torch.zeros_like(bd)
+        res = ksp.solve(bd, xd, pc=pc)
+        if rank == 0:
+            got = [(gid, xd.cpu().numpy(), res["its"], res["reason"])]
+            for r in range(1, world):
+                box = [None]; dist.recv_object_list(box, src=r); got.append(box[0])
+            x = np.empty(n)
+            for g, xx, *_ in got:
+                x[g] = xx
+            rel = float(np.linalg.norm(b - A @ x) / np.linalg.norm(b))
+            with open(out, "w") as f:
+                f.write(repr(dict(its=[g[2] for g in got], reasons=[g[3] for g in got], rel=rel)))
+        else:
+            dist.send_object_list([(gid, xd.cpu().numpy(), res["its"], res["reason"])], dst=0)
+        dist.barrier()
+        comm.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_reference_parallel_load_test_two_ranks(gpu, tmp_path):
+    """tests/Makefile:217-218 (`$(MPIEXEC) -n 2 ./ex6 -f data/mat_stream_2364 -pc_air_a_drop 1e-3
+    -pc_air_inverse_type power -pc_air_matrix_free_polys -ksp_max_it 5`): the distributed product must converge
+    within the reference's bound (row-block ownership instead of the reference's graph partition)."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "r.txt")
+    mp.spawn(_refdata_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r = eval(open(out).read())
+    assert all(x > 0 for x in r["reasons"]) and max(r["its"]) <= 5 and len(set(r["its"])) == 1, r
+    assert r["rel"] <= 1e-3, r
