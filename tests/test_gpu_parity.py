@@ -42,6 +42,11 @@ CASES = {
     "diff2d_16_neumann_mf": (dict(dim=2, M=16, N=16, u=0, v=0, alpha=1.0),
                              dict(inverse_type="neumann", a_drop=1e-3, matrix_free_polys=True)),
     "adv2d_30_mf": (dict(dim=2, M=30, N=30), dict(matrix_free_polys=True)),
+    # BASELINE config 5 (SURVEY 8d substitute): anisotropic 3D FD diffusion, Neumann-polynomial smoother
+    "aniso3d_14_neumann": (dict(dim=3, M=14, N=14, P=14, u=0, v=0, w=0, alpha=1.0, L_z=0.01),
+                           dict(inverse_type="neumann", a_drop=1e-3)),
+    "aniso3d_14_neumann_mf": (dict(dim=3, M=14, N=14, P=14, u=0, v=0, w=0, alpha=1.0, L_z=0.01),
+                              dict(inverse_type="neumann", a_drop=1e-3, matrix_free_polys=True)),
     "adv2d_30_newton_coarse": (dict(dim=2, M=30, N=30),
                                dict(coarsest_inverse_type="newton", coarsest_poly_order=10,
                                     coarsest_matrix_free_polys=True, inverse_type="power", a_drop=1e-3,
