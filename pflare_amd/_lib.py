@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libairhip.so")
+# AIRHIP_LIB: alternative build of the same library (e.g. a sanitizer build of the host code)
+LIB_PATH = os.environ.get("AIRHIP_LIB") or os.path.join(_HERE, "libairhip.so")
 
 
 class airhip_csr(C.Structure):
