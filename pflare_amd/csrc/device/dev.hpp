@@ -45,6 +45,10 @@ struct DevMat {
   int64_t* tile_u0 = nullptr;    // [ntiles+1] offset of the tile's sorted distinct columns in ucol (empty: direct tile)
   int32_t* ucol = nullptr;       // [n_ucol]
   uint16_t* lidx = nullptr;      // [nnz] position of the entry's column in its tile's list
+  // distributed operand: the row blocks that touch no ghost column (interior) / at least one (boundary);
+  // the interior blocks run while the neighbour exchange is in flight
+  int32_t* list_int = nullptr; int32_t* list_bnd = nullptr;
+  int64_t n_int = 0, n_bnd = 0;
   bool valid() const { return blk_row != nullptr; }
   // algorithmic bytes of one SpMV with this operator: S(X) of SURVEY 8(d)
   double s_bytes() const { return 12.0 * nnz + 4.0 * (m + 1) + 8.0 * m + 8.0 * n; }
@@ -62,7 +66,9 @@ struct SpmvEpi {
 };
 
 // x_ghost: the received ghost values of a distributed operand (A.n_ghost entries), else null
-void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t s, const double* x_ghost = nullptr);
+// blk_list / nlist: restrict the launch to these row blocks (null = all)
+void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t s, const double* x_ghost = nullptr,
+                 const int32_t* blk_list = nullptr, int64_t nlist = 0);
 
 // Fused first stage of an F-point relaxation with a one-point prolongator:
 //   acc = (A_fc x_c)_i ; t4 = b_f_i - acc ; x0 = x_c[wcol_i] (0 if wcol_i < 0)
@@ -70,7 +76,9 @@ void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t
 //   split mode                     :  t4_out_i = t4 ; x_f_i = x0
 void launch_fc_first(const DevMat& A_fc, const int32_t* wcol, const double* b_f, const double* x_c,
                      const double* aff_d, const double* minv, double* t4_out, double* x_f, hipStream_t s,
-                     const double* x_ghost = nullptr);
+                     const double* x_ghost = nullptr, const int32_t* blk_list = nullptr, int64_t nlist = 0);
+// host flags (one per row block): does the block reference a ghost column?
+void devmat_boundary_flags(const DevMat& A, std::vector<uint8_t>& flags, hipStream_t s);
 
 // vector kernels (n elements)
 void launch_axpby(int64_t n, double a, const double* x, double b, const double* y, double* out, hipStream_t s);  // out = a x + b y

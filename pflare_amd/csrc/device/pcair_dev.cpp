@@ -26,7 +26,14 @@ double DevInv::alg_bytes() const {
   return 0.0;
 }
 
-DevPCAIR::DevPCAIR() { HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking)); }
+DevPCAIR::DevPCAIR() {
+  HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  HIP_CHECK(hipStreamCreateWithFlags(&comm_stream_, hipStreamNonBlocking));
+  HIP_CHECK(hipEventCreateWithFlags(&ev_pack_, hipEventDisableTiming));
+  HIP_CHECK(hipEventCreateWithFlags(&ev_recv_, hipEventDisableTiming));
+  if (const char* e = std::getenv("AIRHIP_OVERLAP")) overlap_ = std::atoi(e) != 0;
+  if (const char* e = std::getenv("AIRHIP_OVERLAP_MIN_BLOCKS")) overlap_min_blocks_ = std::atoll(e);
+}
 
 DevPCAIR::~DevPCAIR() {
   if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
@@ -34,6 +41,9 @@ DevPCAIR::~DevPCAIR() {
   for (auto& p : pending_) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   devmat_free(A_perm_); devmat_free(coarse_A_);
   if (stream_) (void)hipStreamDestroy(stream_);
+  if (comm_stream_) (void)hipStreamDestroy(comm_stream_);
+  if (ev_pack_) (void)hipEventDestroy(ev_pack_);
+  if (ev_recv_) (void)hipEventDestroy(ev_recv_);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -77,12 +87,37 @@ void DevPCAIR::reset_stats() { resolve_events(); for (auto& s : stats_) { s.call
 
 void DevPCAIR::spmv(const DevMat& A, const double* x, const SpmvEpi& e, const char* name, int level, double bytes_override) {
   int id = -1;
-  if (profile_) { id = stat_id(name, level, bytes_override >= 0 ? bytes_override : A.s_bytes()); stats_[id].kernel = "k_rb_spmv"; begin_kernel(id); }
+  if (profile_) { id = stat_id(name, level, bytes_override >= 0 ? bytes_override : A.s_bytes()); stats_[id].kernel = "k_rb_spmv"; }
+  if (begin_exchange(A, x)) {
+    if (profile_) begin_kernel(id);
+    launch_spmv(A, x, e, stream_, A.halo->recvbuf, A.list_int, A.n_int);   // rows that read no ghost value
+    wait_exchange();
+    launch_spmv(A, x, e, stream_, A.halo->recvbuf, A.list_bnd, A.n_bnd);
+    if (profile_) end_kernel();
+    return;
+  }
   const double* xg = halo_update(A, x);
-  if (profile_ && id >= 0 && A.halo) begin_kernel(id);   // time the product, not the exchange
+  if (profile_) begin_kernel(id);      // times the product, not the exchange
   launch_spmv(A, x, e, stream_, xg);
   if (profile_) end_kernel();
 }
+
+// Starts the neighbour exchange of a distributed operand on the communication stream.  Ordering: the
+// pack kernel runs on the compute stream after everything that produced x; the exchange waits for it;
+// the boundary launch waits for the exchange (wait_exchange); the NEXT pack is queued behind that
+// boundary launch on the compute stream, so a plan's buffers are never rewritten while still in use.
+bool DevPCAIR::begin_exchange(const DevMat& A, const double* x) {
+  // worth it only when the interior part runs longer than an exchange takes (~20 us ~ 50 MB of matrix)
+  if (!A.halo || !overlap_ || !A.list_int || A.n_int < overlap_min_blocks_) return false;
+  HaloPlan& p = *A.halo;
+  if (p.n_send) launch_gather(p.n_send, p.send_idx, x, p.sendbuf, stream_);
+  HIP_CHECK(hipEventRecord(ev_pack_, stream_));
+  HIP_CHECK(hipStreamWaitEvent(comm_stream_, ev_pack_, 0));
+  comm_->exchange(p, comm_stream_);
+  HIP_CHECK(hipEventRecord(ev_recv_, comm_stream_));
+  return true;
+}
+void DevPCAIR::wait_exchange() { HIP_CHECK(hipStreamWaitEvent(stream_, ev_recv_, 0)); }
 
 // ---------------------------------------------------------------------------------------
 // distributed operands
@@ -102,6 +137,17 @@ void DevPCAIR::attach_halo(DevMat& M, const HaloHost* h, const int32_t* host_col
   if (p->n_send) HIP_CHECK(hipMemcpy(p->send_idx, idx.data(), sizeof(int32_t) * (size_t)p->n_send, hipMemcpyHostToDevice));
   M.halo = p.get();
   plans_.push_back(std::move(p));
+  if (overlap_ && M.valid() && M.n_ghost > 0) {
+    std::vector<uint8_t> fl;
+    devmat_boundary_flags(M, fl, stream_);
+    std::vector<int32_t> li, lb;
+    for (int64_t b = 0; b < M.nblocks; b++) (fl[b] ? lb : li).push_back((int32_t)b);
+    M.n_int = (int64_t)li.size(); M.n_bnd = (int64_t)lb.size();
+    HIP_CHECK(hipMalloc(&M.list_int, sizeof(int32_t) * std::max<size_t>(li.size(), 1)));
+    HIP_CHECK(hipMalloc(&M.list_bnd, sizeof(int32_t) * std::max<size_t>(lb.size(), 1)));
+    if (!li.empty()) HIP_CHECK(hipMemcpy(M.list_int, li.data(), sizeof(int32_t) * li.size(), hipMemcpyHostToDevice));
+    if (!lb.empty()) HIP_CHECK(hipMemcpy(M.list_bnd, lb.data(), sizeof(int32_t) * lb.size(), hipMemcpyHostToDevice));
+  }
 }
 
 // Every rank calls this for the same operand in the same order (the cycle is SPMD), also when it
@@ -472,10 +518,18 @@ void DevPCAIR::f_smooths(DevLevel& L, int li, bool first, int its) {
     // and its inverse are diagonal and a single F smooth is requested)
     const bool full = diag_inv && its == 1;
     int id = -1;
-    if (profile_) { id = stat_id(full ? "fc_first_diag(A_fc+W)" : "fc_first(A_fc+W)", li, L.A_fc.s_bytes()); stats_[id].kernel = "k_rb_fc_first"; begin_kernel(id); }
-    const double* xg = halo_update(L.A_fc, x_c);
-    if (profile_ && L.A_fc.halo) begin_kernel(id);
-    launch_fc_first(L.A_fc, L.wcol.p, b_f, x_c, full ? L.aff_d.p : nullptr, full ? L.inv_ff.d.p : nullptr, L.t4.p, x_f, stream_, xg);
+    if (profile_) { id = stat_id(full ? "fc_first_diag(A_fc+W)" : "fc_first(A_fc+W)", li, L.A_fc.s_bytes()); stats_[id].kernel = "k_rb_fc_first"; }
+    const double* ad = full ? L.aff_d.p : nullptr; const double* mi = full ? L.inv_ff.d.p : nullptr;
+    if (begin_exchange(L.A_fc, x_c)) {
+      if (profile_) begin_kernel(id);
+      launch_fc_first(L.A_fc, L.wcol.p, b_f, x_c, ad, mi, L.t4.p, x_f, stream_, L.A_fc.halo->recvbuf, L.A_fc.list_int, L.A_fc.n_int);
+      wait_exchange();
+      launch_fc_first(L.A_fc, L.wcol.p, b_f, x_c, ad, mi, L.t4.p, x_f, stream_, L.A_fc.halo->recvbuf, L.A_fc.list_bnd, L.A_fc.n_bnd);
+    } else {
+      const double* xg = halo_update(L.A_fc, x_c);
+      if (profile_) begin_kernel(id);
+      launch_fc_first(L.A_fc, L.wcol.p, b_f, x_c, ad, mi, L.t4.p, x_f, stream_, xg);
+    }
     if (profile_) end_kernel();
     if (full) return;
   } else {

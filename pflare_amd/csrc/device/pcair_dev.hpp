@@ -122,6 +122,15 @@ class DevPCAIR {
   const double* halo_update(const DevMat& A, const double* x);
   Comm* comm_ = nullptr;
   std::vector<std::unique_ptr<HaloPlan>> plans_;
+  // exchange / compute overlap (opt-in, AIRHIP_OVERLAP=1: validated for correctness with the staged transport,
+  // not yet measured under RCCL): the exchange runs on its own stream while the interior row blocks (no ghost
+  // column) are processed; the boundary blocks follow once the ghosts have arrived
+  bool overlap_ = false;
+  int64_t overlap_min_blocks_ = 8192;   // interior row blocks (x 512 non-zeros) below which the plain path is used
+  hipStream_t comm_stream_ = nullptr;
+  hipEvent_t ev_pack_ = nullptr, ev_recv_ = nullptr;
+  bool begin_exchange(const DevMat& A, const double* x);   // true: split launch (interior, wait_exchange, boundary)
+  void wait_exchange();
   // level-0 rhs is only read and the solution of every level is a suffix of one buffer: PCApply in
   // hierarchical ordering therefore works straight on the caller's vectors (no copies)
   double* bvec(int l) { return l == 0 ? const_cast<double*>(b0_) : b_ptr_[l]; }

@@ -25,6 +25,8 @@ struct RbView {
   const double* val;
   const uint16_t* slot;   // column-sorted blocks: position of the entry in row-major order inside its block
   int scalar_t;           // blocks with nnz <= scalar_t * rows skip the LDS stage (one lane per row)
+  const int32_t* blk_list;   // optional: process only these blocks (interior / boundary split of a distributed operand)
+  int64_t nlist;
 };
 // AIRHIP_SCALAR_T (default 0 = never): average row length up to which a block is handled one lane per row
 // straight from global memory (was faster before the blocks were column-sorted; now the LDS path wins by 4 %)
@@ -33,7 +35,7 @@ inline int scalar_threshold() {
   return t;
 }
 inline RbView view_of(const DevMat& A) {
-  return RbView{A.m, A.nblocks, A.nnz, A.blk_row, A.blk_p0, A.roff, A.col, A.val, A.slot, scalar_threshold()};
+  return RbView{A.m, A.nblocks, A.nnz, A.blk_row, A.blk_p0, A.roff, A.col, A.val, A.slot, scalar_threshold(), nullptr, 0};
 }
 
 // Input vector of an SpMV.  Single device: DIST = false, plain x[c].  Row-block distributed

@@ -26,6 +26,7 @@
 #include "kcommon.hpp"
 #include "rb.hpp"
 #include <stdexcept>
+#include <vector>
 #include <algorithm>
 #include <cstdlib>
 
@@ -75,8 +76,9 @@ struct XVecNoGather {
 template <int CAP, bool NT, int UNR, int SORTED, class X, class Epi>
 __device__ __forceinline__ void rb_rows(const RbView& A, const X x, double* __restrict__ lds, Epi epi) {
   const int lane = threadIdx.x & (WAVE - 1);
-  const BlockRange br = my_blocks(A.nblocks);
-  for (int64_t b = br.first; b < br.last; b += br.stride) {
+  const BlockRange br = my_blocks(A.blk_list ? A.nlist : A.nblocks);
+  for (int64_t bi = br.first; bi < br.last; bi += br.stride) {
+    const int64_t b = A.blk_list ? (int64_t)__builtin_amdgcn_readfirstlane(A.blk_list[bi]) : bi;
     const int32_t r0 = __builtin_amdgcn_readfirstlane(A.blk_row[b]);
     const int32_t r1 = __builtin_amdgcn_readfirstlane(A.blk_row[b + 1]);
     const int64_t p0 = uniform64(A.blk_p0[b]);
@@ -203,11 +205,13 @@ static int g_nt = (std::getenv("AIRHIP_NT") && std::atoi(std::getenv("AIRHIP_NT"
 static int g_cap768 = (std::getenv("AIRHIP_CAP") && std::atoi(std::getenv("AIRHIP_CAP")) == 768) ? 1 : 0;
 int g_spmv_variant = std::getenv("AIRHIP_SPMV_VARIANT") ? std::atoi(std::getenv("AIRHIP_SPMV_VARIANT")) : 0;
 
-void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t s, const double* x_ghost) {
-  if (A.m == 0) return;
-  if (g_spmv_variant == 0 && launch_spmv_tiled(A, x, e, s, x_ghost)) return;
-  const dim3 grid(grid_for_blocks(A.nblocks)), block(BLOCK);
-  const RbView v = view_of(A);
+void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t s, const double* x_ghost,
+                 const int32_t* blk_list, int64_t nlist) {
+  if (A.m == 0 || (blk_list && nlist == 0)) return;
+  if (!blk_list && g_spmv_variant == 0 && launch_spmv_tiled(A, x, e, s, x_ghost)) return;
+  const dim3 grid(grid_for_blocks(blk_list ? nlist : A.nblocks)), block(BLOCK);
+  RbView v = view_of(A);
+  v.blk_list = blk_list; v.nlist = nlist;
   if (A.n_ghost > 0) {
     // distributed operand: ghost columns start at A.n - A.n_ghost
     if (!x_ghost) throw std::runtime_error("launch_spmv: distributed operand without ghost values");
@@ -276,25 +280,27 @@ __global__ __launch_bounds__(BLOCK) void k_rb_fc_first(RbView A, const int32_t* 
 
 void launch_fc_first(const DevMat& A_fc, const int32_t* wcol, const double* b_f, const double* x_c,
                      const double* aff_d, const double* minv, double* t4_out, double* x_f, hipStream_t s,
-                     const double* x_ghost) {
-  if (A_fc.m == 0) return;
-  if (g_spmv_variant == 0 && launch_fc_first_tiled(A_fc, wcol, b_f, x_c, aff_d, minv, t4_out, x_f, s, x_ghost)) return;
-  const dim3 grid(grid_for_blocks(A_fc.nblocks)), block(BLOCK);
+                     const double* x_ghost, const int32_t* blk_list, int64_t nlist) {
+  if (A_fc.m == 0 || (blk_list && nlist == 0)) return;
+  if (!blk_list && g_spmv_variant == 0 && launch_fc_first_tiled(A_fc, wcol, b_f, x_c, aff_d, minv, t4_out, x_f, s, x_ghost)) return;
+  const dim3 grid(grid_for_blocks(blk_list ? nlist : A_fc.nblocks)), block(BLOCK);
+  RbView vfc = view_of(A_fc);
+  vfc.blk_list = blk_list; vfc.nlist = nlist;
   if (A_fc.n_ghost > 0) {
     if (!x_ghost) throw std::runtime_error("launch_fc_first: distributed operand without ghost values");
     const int32_t nl = (int32_t)(A_fc.n - A_fc.n_ghost);
     const XVec<true> xv{x_c, x_ghost - nl, nl};
-    if (A_fc.packed) hipLaunchKernelGGL((k_rb_fc_first<true, 2, 1024>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
-    else if (A_fc.slot) hipLaunchKernelGGL((k_rb_fc_first<true, 1, 1024>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
-    else hipLaunchKernelGGL((k_rb_fc_first<true, 0, 1024>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
+    if (A_fc.packed) hipLaunchKernelGGL((k_rb_fc_first<true, 2, 1024>), grid, block, 0, s, vfc, wcol, b_f, xv, aff_d, minv, t4_out, x_f);
+    else if (A_fc.slot) hipLaunchKernelGGL((k_rb_fc_first<true, 1, 1024>), grid, block, 0, s, vfc, wcol, b_f, xv, aff_d, minv, t4_out, x_f);
+    else hipLaunchKernelGGL((k_rb_fc_first<true, 0, 1024>), grid, block, 0, s, vfc, wcol, b_f, xv, aff_d, minv, t4_out, x_f);
   } else {
     const XVec<false> xv{x_c, nullptr, 0};
-    if (A_fc.packed) hipLaunchKernelGGL((k_rb_fc_first<false, 2, 1024>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
-    else if (A_fc.slot && g_blk_nnz == 256) hipLaunchKernelGGL((k_rb_fc_first<false, 1, 512>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
-    else if (A_fc.slot && g_cap768) hipLaunchKernelGGL((k_rb_fc_first<false, 1, 768>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
-    else if (A_fc.slot && g_blk_nnz == 1024) hipLaunchKernelGGL((k_rb_fc_first<false, 1, 2048>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
-    else if (A_fc.slot) hipLaunchKernelGGL((k_rb_fc_first<false, 1, 1024>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
-    else hipLaunchKernelGGL((k_rb_fc_first<false, 0, 1024>), grid, block, 0, s, view_of(A_fc), wcol, b_f, xv, aff_d, minv, t4_out, x_f);
+    if (A_fc.packed) hipLaunchKernelGGL((k_rb_fc_first<false, 2, 1024>), grid, block, 0, s, vfc, wcol, b_f, xv, aff_d, minv, t4_out, x_f);
+    else if (A_fc.slot && g_blk_nnz == 256) hipLaunchKernelGGL((k_rb_fc_first<false, 1, 512>), grid, block, 0, s, vfc, wcol, b_f, xv, aff_d, minv, t4_out, x_f);
+    else if (A_fc.slot && g_cap768) hipLaunchKernelGGL((k_rb_fc_first<false, 1, 768>), grid, block, 0, s, vfc, wcol, b_f, xv, aff_d, minv, t4_out, x_f);
+    else if (A_fc.slot && g_blk_nnz == 1024) hipLaunchKernelGGL((k_rb_fc_first<false, 1, 2048>), grid, block, 0, s, vfc, wcol, b_f, xv, aff_d, minv, t4_out, x_f);
+    else if (A_fc.slot) hipLaunchKernelGGL((k_rb_fc_first<false, 1, 1024>), grid, block, 0, s, vfc, wcol, b_f, xv, aff_d, minv, t4_out, x_f);
+    else hipLaunchKernelGGL((k_rb_fc_first<false, 0, 1024>), grid, block, 0, s, vfc, wcol, b_f, xv, aff_d, minv, t4_out, x_f);
   }
 }
 
@@ -482,6 +488,34 @@ static bool pack_enabled() {
   return on;
 }
 
+// flag[b] = 1 if block b references a ghost column (column >= n_local); one wave per block
+__global__ __launch_bounds__(BLOCK) void k_boundary_flags(int64_t nblocks, const int64_t* __restrict__ blk_p0, const int32_t* __restrict__ col,
+                                                         int32_t n_local, int32_t cmask, uint8_t* __restrict__ flag) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * BLOCK) >> 6;
+  for (int64_t b = wave; b < nblocks; b += nwaves) {
+    bool any = false;
+    for (int64_t k = blk_p0[b] + lane; k < blk_p0[b + 1]; k += WAVE) any |= (col[k] & cmask) >= n_local;
+    if (__any(any) && lane == 0) flag[b] = 1;
+  }
+}
+
+void devmat_boundary_flags(const DevMat& A, std::vector<uint8_t>& flags, hipStream_t s) {
+  flags.assign((size_t)A.nblocks, 0);
+  if (A.nblocks == 0 || A.n_ghost == 0) return;
+  uint8_t* d = nullptr;
+  HIP_CHECK(hipMalloc(&d, (size_t)A.nblocks));
+  HIP_CHECK(hipMemsetAsync(d, 0, (size_t)A.nblocks, s));
+  const int g = (int)std::min<int64_t>((A.nblocks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 4096);
+  // packed operators keep the column in the low 22 bits of the word (unsorted blocks: upper bits are zero)
+  hipLaunchKernelGGL(k_boundary_flags, dim3(g < 1 ? 1 : g), dim3(BLOCK), 0, s, A.nblocks, A.blk_p0, A.col, (int32_t)(A.n - A.n_ghost),
+                     A.packed ? 0x3fffff : -1, d);
+  HIP_CHECK(hipMemcpyAsync(flags.data(), d, (size_t)A.nblocks, hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  (void)hipFree(d);
+}
+
 static bool sort_blocks_enabled() {
   static const bool on = !(std::getenv("AIRHIP_NO_BLOCK_SORT") && std::atoi(std::getenv("AIRHIP_NO_BLOCK_SORT")) != 0);
   return on;
@@ -555,6 +589,8 @@ void devmat_free(DevMat& A) {
   if (A.col) (void)hipFree(A.col);
   if (A.val) (void)hipFree(A.val);
   if (A.slot) (void)hipFree(A.slot);
+  if (A.list_int) (void)hipFree(A.list_int);
+  if (A.list_bnd) (void)hipFree(A.list_bnd);
   if (A.tile_blk) (void)hipFree(A.tile_blk);
   if (A.tile_u0) (void)hipFree(A.tile_u0);
   if (A.ucol) (void)hipFree(A.ucol);

@@ -29,6 +29,9 @@ def _free_port():
 
 def _worker(rank, world, port, case, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    if case == "adv3d_24_lump":      # exercise the opt-in interior / boundary split (exchange overlap) as well
+        os.environ["AIRHIP_OVERLAP"] = "1"
+        os.environ["AIRHIP_OVERLAP_MIN_BLOCKS"] = "4"
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
