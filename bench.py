@@ -74,12 +74,17 @@ def main():
     import pflare_amd as P
     P.lib().airhip_set_device(local_rank)
     dist = meta = None
-    if world > 1:
+    # AIRHIP_BENCH_FORCE_DIST=1: run the distributed code path (RCCL communicator, partition, shipping,
+    # collective timing) even with a single rank - a rehearsal of everything but the peer traffic
+    dist_mode = world > 1 or os.environ.get("AIRHIP_BENCH_FORCE_DIST", "0") == "1"
+    if dist_mode:
         # one process per GPU (torch.distributed.run): RCCL for the bulk data and the halo exchange,
         # a gloo group for small host-side metadata.  Rank 0 builds the hierarchy, so the others wait
         # for minutes: generous timeouts.
         import datetime
         import torch.distributed as dist
+        for k_, v_ in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29577"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(k_, v_)
         if staged:
             dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=90))
         else:
@@ -149,7 +154,7 @@ def main():
                 + (li[:, None, None] * B + li[None, :, None]) * B + li[None, None, :]      # [k, j, i]
             pc.set_ordering_hint(key.reshape(-1))
             del key
-        if world > 1:
+        if dist_mode:
             pc.set_option("device_upload", False)     # the hierarchy is cut and shipped below
         if args.verbose:
             pc.set_option("print_stats_timings", True)   # per-level progress lines (keeps long setups audible)
@@ -162,7 +167,7 @@ def main():
         info = dict(nnzA=nnzA, t_setup=t_setup, st=st, cx=cx, levels=pc.num_levels)
     parallelism = "single GPU"
     comm = None
-    if world > 1:
+    if dist_mode:
         from pflare_amd import dist as D
         px, py, pz = D.box_dims(world, (M, M, M))
         parallelism = (f"row-block: {px}x{py}x{pz} boxes of the {M}^3 grid, one rank per GPU, hierarchy built on rank 0 "
@@ -203,12 +208,12 @@ def main():
                          f"(oracle/air_oracle.c), {dt:.1f}s"}
         del ch
         log(f"[bench] cpu baseline: {cpu}")
-    if world == 1:
+    if not dist_mode:
         pc.release_host()
     hm = None
 
     def barrier():
-        if world > 1:
+        if dist_mode:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -259,13 +264,13 @@ def main():
     ms_dev = run_iterations(args.steps)
     barrier()
     wall = time.perf_counter() - t0
-    if world > 1:      # MAX over ranks
+    if dist_mode:      # MAX over ranks
         tw = torch.tensor([wall], dtype=torch.float64, device="cpu" if staged else "cuda")
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
     stats = pc.profile_stats() if args.profile_kernels else []
     pc.profile(False)
-    if world > 1:
+    if dist_mode:
         info["comm"] = comm.stats()
         cab = torch.tensor([pc.cycle_alg_bytes()], dtype=torch.float64, device="cpu" if staged else "cuda")
         dist.all_reduce(cab)
@@ -337,14 +342,14 @@ def main():
                    "device_ms_of_timed_solves": ms_dev, "hip_graph": bool(args.graph)},
         "roofline": roofline, "cpu_baseline": cpu,
     }
-    if world > 1:
+    if dist_mode:
         out["config"]["distribute_s"] = info["t_distribute"]
         out["config"]["halo_exchanges_rank0"] = info["comm"]["exchanges"]
         out["config"]["allreduces_rank0"] = info["comm"]["allreduces"]
         if out["roofline"] is not None:
             out["roofline"]["note"] = "kernel timings of rank 0"
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_mode:
         dist.barrier()
         dist.destroy_process_group()
 
