@@ -767,6 +767,27 @@ def mat_mult_powers_share_sparsity(A, coeffs, sparsity_order):
     return InvOp("assembled", mat=cmat)
 
 
+def mat_newton_share_sparsity(A, re, im, sparsity_order):
+    """Assembled Newton-basis polynomial with fixed sparsity
+    (mat_mult_powers_share_sparsity_newton / build_gmres_polynomial_newton_inverse,
+    src/Gmres_Poly_Newton.F90:1203-1990): the matrix form of `newton_apply` started from
+    the identity, every product T*A truncated to pattern(A^sparsity_order) + I."""
+    A = A.tocsr(); A.sort_indices()
+    n = A.shape[0]
+    pat = A
+    for _ in range(2, sparsity_order + 1):
+        pat = (A @ pat).tocsr()
+    pat = copy_plus_diag(pat)
+    pat.sort_indices()
+
+    def on_pat(M):
+        return sp.csr_matrix((values_on_pattern(M.tocsr(), pat), pat.indices, pat.indptr), shape=pat.shape)
+
+    mv = lambda T: on_pat(T @ A)
+    Y = newton_apply(mv, re, im, on_pat(sp.identity(n, format="csr")))
+    return InvOp("assembled", mat=on_pat(Y))
+
+
 def build_gmres_polynomial_inverse(A, poly_order, coeffs, sparsity_order, matrix_free,
                                    diag_scale):
     """src/Gmres_Poly.F90:1522-1813."""
@@ -849,12 +870,29 @@ def build_inverse(A, inverse_type, poly_order, sparsity_order, matrix_free, diag
             asm = build_gmres_polynomial_inverse(A, poly_order, c, sparsity_order, False, diag_scale)
         return op, asm
     if inverse_type in (INV_NEWTON, INV_NEWTON_NO_EXTRA):
-        if not matrix_free:
-            raise NotImplementedError("Newton-basis inverse is matrix-free only here")
         re, im = roots_newton(mv, n, poly_order, inverse_type == INV_NEWTON, seed)
+
+        def assembled():
+            # src/Gmres_Poly_Newton.F90:2010-2098: polynomial of D^-1 A, then scaled by D^-1 on the right
+            dinv = 1.0 / d if diag_scale else None
+            if isinstance(A, DiagMat) or sparsity_order == 0:
+                dd = np.ones(n) if diag_scale else d
+                a = InvOp("diag", d=newton_apply(lambda v: dd * v, re, im, np.ones(n)))
+                if diag_scale:
+                    a.d = a.d * dinv
+                return a
+            if not diag_scale:
+                return mat_newton_share_sparsity(Acsr, re, im, sparsity_order)
+            As = (sp.diags(dinv) @ Acsr).tocsr(); As.sort_indices()
+            a = mat_newton_share_sparsity(As, re, im, sparsity_order)
+            a.mat = (a.mat @ sp.diags(dinv)).tocsr(); a.mat.sort_indices()
+            return a
+
+        if not matrix_free:
+            return assembled(), None
         op = InvOp("newton", A=A, re=re, im=im, diag=d.copy() if diag_scale else None)
         op.spmvs = newton_spmv_count(re, im)
-        return op, None
+        return op, (assembled() if need_assembled else None)
     if inverse_type == INV_NEUMANN:
         c = np.ones(poly_order + 1)
         if matrix_free:
@@ -927,7 +965,7 @@ def horner(mv, coeffs, x):
 def newton_apply(mv, re, im, x):
     """src/Gmres_Poly_Newton.F90:763-875 (Loe et al. Alg. 3)."""
     t = x.copy()
-    y = np.zeros_like(x)
+    y = np.zeros_like(x) if isinstance(x, np.ndarray) else 0.0 * x
     n = re.size
     i = 0
     while i <= n - 2:

@@ -398,6 +398,112 @@ static Csr mat_mult_powers_share_sparsity(const Csr& A, const std::vector<double
   return cmat;
 }
 
+// Assembled Newton-basis GMRES polynomial with fixed sparsity (counterpart of
+// mat_mult_powers_share_sparsity_newton, src/Gmres_Poly_Newton.F90:1203-1872): the matrix recurrence of
+// petsc_newton (Loe et al. Alg. 3; real roots and conjugate pairs in real arithmetic, zero roots skipped)
+// carried out row by row, every product "row * A" constrained to the pattern S = pattern(A^sparsity_order) + I
+// - the same "share sparsity" rule as the monomial version above (terms up to the sparsity order are exact
+// because their pattern lies inside S).
+static Csr mat_newton_share_sparsity(const Csr& A, const std::vector<double>& re, const std::vector<double>& im, int sparsity_order) {
+  std::vector<Csr> powers;
+  const Csr* pat = &A;
+  for (int o = 2; o <= sparsity_order; o++) {
+    powers.push_back(spgemm(A, o == 2 ? A : powers.back()));
+    pat = &powers.back();
+  }
+  Csr cmat = copy_plus_diag(*pat);
+  const int64_t m = A.m;
+  const int nr = (int)re.size();
+#pragma omp parallel
+  {
+    std::vector<int32_t> match_idx; std::vector<double> match_val; std::vector<int64_t> match_ptr;
+    std::vector<double> t, t2, t3, y;
+#pragma omp for schedule(dynamic, 1024)
+    for (int64_t i = 0; i < m; i++) {
+      const int64_t p0 = cmat.rp[i], ncols = cmat.rp[i + 1] - p0;
+      const int32_t* cols = cmat.ci.data() + p0;
+      match_idx.clear(); match_val.clear(); match_ptr.assign(ncols + 1, 0);
+      int64_t dpos = -1;
+      for (int64_t j = 0; j < ncols; j++) {
+        if (cols[j] == i) dpos = j;
+        const int32_t row = cols[j];
+        int64_t a = A.rp[row], ae = A.rp[row + 1], b = 0;
+        while (a < ae && b < ncols) {
+          if (A.ci[a] == cols[b]) { match_idx.push_back((int32_t)b); match_val.push_back(A.v[a]); a++; b++; }
+          else if (A.ci[a] < cols[b]) a++; else b++;
+        }
+        match_ptr[j + 1] = (int64_t)match_idx.size();
+      }
+      // out = in * A restricted to the row's pattern
+      auto mult = [&](const std::vector<double>& in, std::vector<double>& out) {
+        std::fill(out.begin(), out.end(), 0.0);
+        for (int64_t j = 0; j < ncols; j++) {
+          const double pj = in[j];
+          if (pj == 0.0) continue;
+          for (int64_t q = match_ptr[j]; q < match_ptr[j + 1]; q++) out[match_idx[q]] += pj * match_val[q];
+        }
+      };
+      t.assign(ncols, 0.0); t2.assign(ncols, 0.0); t3.assign(ncols, 0.0); y.assign(ncols, 0.0);
+      t[dpos] = 1.0;                                   // row i of the identity
+      int k = 0;
+      while (k <= nr - 2) {
+        if (im[k] == 0.0) {
+          if (std::fabs(re[k]) < TOL_ZERO) { k++; continue; }
+          const double a = 1.0 / re[k];
+          for (int64_t q = 0; q < ncols; q++) y[q] += a * t[q];
+          mult(t, t2);
+          for (int64_t q = 0; q < ncols; q++) t[q] += -a * t2[q];
+          k++;
+        } else {
+          const double sq = re[k] * re[k] + im[k] * im[k];
+          if (sq < TOL_ZERO) { k += 2; continue; }
+          const double tr = 2 * re[k], isq = 1.0 / sq;
+          mult(t, t2);
+          for (int64_t q = 0; q < ncols; q++) { t2[q] = tr * t[q] - t2[q]; y[q] += isq * t2[q]; }
+          if (k <= nr - 3) {
+            mult(t2, t3);
+            for (int64_t q = 0; q < ncols; q++) t[q] += -isq * t3[q];
+          }
+          k += 2;
+        }
+      }
+      if (im[nr - 1] == 0.0 && std::fabs(re[nr - 1]) > TOL_ZERO) {
+        const double a = 1.0 / re[nr - 1];
+        for (int64_t q = 0; q < ncols; q++) y[q] += a * t[q];
+      }
+      for (int64_t q = 0; q < ncols; q++) cmat.v[p0 + q] = y[q];
+    }
+  }
+  return cmat;
+}
+
+// scalar version for a MATDIAGONAL operator: p(d_i)
+static void newton_diag(const double* d, int64_t n, const std::vector<double>& re, const std::vector<double>& im, InvOp& op) {
+  op.kind = InvOp::DIAG; op.d.alloc(n);
+  const int nr = (int)re.size();
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; i++) {
+    double t = 1.0, y = 0.0; const double a_ = d[i];
+    int k = 0;
+    while (k <= nr - 2) {
+      if (im[k] == 0.0) {
+        if (std::fabs(re[k]) < TOL_ZERO) { k++; continue; }
+        const double a = 1.0 / re[k];
+        y += a * t; t += -a * (t * a_); k++;
+      } else {
+        const double sq = re[k] * re[k] + im[k] * im[k];
+        if (sq < TOL_ZERO) { k += 2; continue; }
+        const double t2 = 2 * re[k] * t - t * a_;
+        y += t2 / sq;
+        if (k <= nr - 3) t += -(t2 * a_) / sq;
+        k += 2;
+      }
+    }
+    if (im[nr - 1] == 0.0 && std::fabs(re[nr - 1]) > TOL_ZERO) y += t / re[nr - 1];
+    op.d[i] = y;
+  }
+}
+
 // src/Gmres_Poly.F90:1522-1813
 static void build_gmres_polynomial_inverse(const OpView& A, int poly_order, const std::vector<double>& c,
                                            int sparsity_order, bool matrix_free, bool diag_scale, InvOp& op) {
@@ -484,10 +590,41 @@ void build_inverse(const OpView& A, int inverse_type, int poly_order, int sparsi
     return;
   }
   if (inverse_type == INV_NEWTON || inverse_type == INV_NEWTON_NO_EXTRA) {
-    if (!matrix_free) throw std::runtime_error("Newton-basis inverses can only be applied matrix-free");
-    op.kind = InvOp::NEWTON; op.diag_scale = diag_scale;
-    roots_newton(mv, n, poly_order, inverse_type == INV_NEWTON, seed, op.re, op.im);
+    std::vector<double> re, im;
+    roots_newton(mv, n, poly_order, inverse_type == INV_NEWTON, seed, re, im);
+    // assembled form (build_gmres_polynomial_newton_inverse, src/Gmres_Poly_Newton.F90:1876-1990)
+    auto assemble = [&](InvOp& out) {
+      out = InvOp();
+      Arr<double> dinv, dd(n);
+      if (diag_scale) {
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < n; i++) dd[i] = 1.0;            // diagonal of D^-1 A
+        dinv.alloc(n);
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < n; i++) dinv[i] = 1.0 / d[i];
+      } else {
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < n; i++) dd[i] = d[i];
+      }
+      if (A.diag || sparsity_order == 0) {
+        newton_diag(dd.data(), n, re, im, out);
+      } else {
+        out.kind = InvOp::ASSEMBLED;
+        if (diag_scale) {
+          Csr scaled = A.A->clone();
+          scale_rows(scaled, dinv.data());
+          out.mat = mat_newton_share_sparsity(scaled, re, im, sparsity_order);
+        } else out.mat = mat_newton_share_sparsity(*A.A, re, im, sparsity_order);
+      }
+      if (diag_scale) {
+        if (out.kind == InvOp::DIAG) { for (int64_t i = 0; i < n; i++) out.d[i] *= dinv[i]; }
+        else scale_cols(out.mat, dinv.data());
+      }
+    };
+    if (!matrix_free) { assemble(op); return; }
+    op.kind = InvOp::NEWTON; op.diag_scale = diag_scale; op.re = re; op.im = im;
     op.spmvs = newton_spmv_count(op.re, op.im);
+    if (asm_too) assemble(*asm_too);
     return;
   }
   if (inverse_type == INV_NEUMANN) {

@@ -174,6 +174,42 @@ def test_newton_roots_match_lapack_oracle():
     assert np.allclose(d["re"], re_o, rtol=1e-7, atol=1e-9) and np.allclose(d["im"], im_o, rtol=1e-7, atol=1e-9)
 
 
+@pytest.mark.parametrize("diag_scale", [False, True])
+@pytest.mark.parametrize("po,so", [(6, 1), (3, 1), (2, 1), (6, 2), (2, 2), (5, 3), (4, 0), (1, 1), (0, 0)])
+def test_assembled_newton_inverse_matches_oracle(po, so, diag_scale):
+    """build_gmres_polynomial_newton_inverse (src/Gmres_Poly_Newton.F90:1876-2100), assembled with fixed sparsity:
+    host build vs the oracle, and both equal to the matrix-free application when the sparsity does not constrain"""
+    A = R.gen_adv_diff_fd(2, 14, 14).tocsr()
+    n = A.shape[0]
+    x = np.random.default_rng(3).standard_normal(n)
+    op, _ = R.build_inverse(A, R.INV_NEWTON, po, so, False, diag_scale)
+    pc = P.PCPFLAREINV(type="newton", poly_order=po, sparsity_order=so, matrix_free=False, diag_scale=diag_scale).setup_host_only(A)
+    d = pc.get_inverse(n)
+    y = R.apply_inv(op, x)
+    yh = bridge.to_scipy(d["mat"]) @ x if "mat" in d else d["d"] * x
+    assert np.linalg.norm(yh - y) <= 1e-12 * np.linalg.norm(y)
+    if so >= po:
+        mf, _ = R.build_inverse(A, R.INV_NEWTON, po, so, True, diag_scale)
+        ymf = R.apply_inv(mf, x)
+        assert np.linalg.norm(y - ymf) <= 1e-10 * np.linalg.norm(ymf)
+
+
+def test_pcair_newton_smoothers_host_vs_oracle():
+    """-pc_air_inverse_type newton (tests/Makefile:159-164): assembled Newton A_ff inverse for the smoother and Z"""
+    A = R.gen_adv_diff_fd(2, 20, 20).tocsr(); n = A.shape[0]
+    for mf in (False, True):
+        pc = P.PCAIR(inverse_type="newton", poly_order=3, matrix_free_polys=mf).setup_host_only(A)
+        Ho = R.setup_air(A, R.AirOptions(inverse_type=R.INV_NEWTON, poly_order=3, matrix_free_polys=mf))
+        Hp = bridge.hierarchy_from_product(pc, A)
+        assert np.array_equal(Hp.levels[0].F, Ho.levels[0].F)
+        x = np.random.default_rng(5).standard_normal(n)
+        yo = R.vcycle(Ho, x)
+        if pc.num_levels == Ho.no_levels:
+            assert np.linalg.norm(R.vcycle(Hp, x) - yo) <= 1e-8 * np.linalg.norm(yo)
+        r = R.ksp_gmres(A, lambda v: R.vcycle(Hp, v), np.zeros(n), np.ones(n), rtol=1e-8, max_it=20, pc_side="right")
+        assert r[2] > 0
+
+
 def test_auto_truncation_and_options():
     A = R.gen_adv_diff_fd(2, 40, 40)
     full = P.PCAIR(coarsest_inverse_type="newton", coarsest_poly_order=10, coarsest_matrix_free_polys=True).setup_host_only(A)

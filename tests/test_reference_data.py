@@ -29,13 +29,16 @@ AIR_CASES = [
      dict(EXACT, max_levels=10, coarsest_poly_order=60, coarsest_matrix_free_polys=True, coarsest_inverse_type="newton",
           max_luby_steps=3), dict(ksp="richardson", norm="unpreconditioned"), 1),
     ("157 indefinite power", "e05r0100_petsc", POWER, dict(b_in_f=False), 26),
+    # assembled Newton-basis inverses with fixed sparsity (build_gmres_polynomial_newton_inverse)
+    ("159 indefinite newton", "e05r0100_petsc", dict(a_drop=1e-3, inverse_type="newton"), dict(b_in_f=False), 26),
+    ("162 newton order 2", "mat_stream_2364", dict(inverse_type="newton", poly_order=2), {}, 5),
+    ("164 newton order 3", "mat_stream_2364", dict(inverse_type="newton", poly_order=3), {}, 5),
 ]
-# Not run: tests/Makefile:159,162,164 and :120 need the ASSEMBLED Newton-basis inverse (build_gmres_polynomial_newton_inverse
-# with fixed sparsity), which is outside this build's scope (matrix-free Newton only);
-# :147 needs -mg_coarse_pc_type lu; :201,205 are the assembled variants of the 1138_bus cases.
+# Not run: tests/Makefile:147 needs -mg_coarse_pc_type lu.
 INV_CASES = [
     ("116 pflareinv default", {}, 21),
     ("118 pflareinv power", dict(type="power"), 21),
+    ("120 pflareinv newton assembled", dict(type="newton"), 21),
     ("124 pflareinv newton matrix-free", dict(type="newton", matrix_free=True), 13),
 ]
 
@@ -44,6 +47,8 @@ INV_CASES = [
 BUS_CASES = [
     ("199 1138_bus newton-60 matrix-free", dict(type="newton", poly_order=60, matrix_free=True), 6),
     ("203 1138_bus newton-120 matrix-free", dict(type="newton", poly_order=120, matrix_free=True), 5),
+    ("201 1138_bus newton-60 fixed sparsity", dict(type="newton", poly_order=60, matrix_free=False), 6),
+    ("205 1138_bus newton-120 fixed sparsity", dict(type="newton", poly_order=120, matrix_free=False), 5),
 ]
 
 _INV = dict(power=R.INV_POWER, arnoldi=R.INV_ARNOLDI, newton=R.INV_NEWTON, jacobi=R.INV_JACOBI)
@@ -93,7 +98,7 @@ def test_oracle_pflareinv_meets_reference_bounds(label, opts, bound):
 @pytest.mark.parametrize("label,opts,bound", BUS_CASES, ids=[c[0] for c in BUS_CASES])
 def test_oracle_high_order_newton_on_1138_bus(label, opts, bound):
     A, b, x0 = _problem("1138_bus", b_in_f=False)
-    op = R.pcpflareinv_setup(A, inverse_type=R.INV_NEWTON, poly_order=opts["poly_order"], matrix_free=True)
+    op = R.pcpflareinv_setup(A, inverse_type=R.INV_NEWTON, poly_order=opts["poly_order"], matrix_free=opts["matrix_free"])
     x, its, reason, rn = R.ksp_gmres(A, lambda r: R.apply_inv(op, r), b, x0, rtol=1e-5, max_it=bound, pc_side="right")
     assert reason > 0 and its <= bound, (label, its, reason)
 
