@@ -97,7 +97,9 @@ def main():
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    want = args.threads if args.threads > 0 else min(32, max(1, cores // max(1, args.gpus)))
+    # (in the distributed run rank 0 builds the hierarchy while the other ranks sleep in a receive, so it
+    # may use the whole host up to the measured optimum of 32 threads)
+    want = args.threads if args.threads > 0 else min(32, cores if rank == 0 else max(1, cores // max(1, args.gpus)))
     threads = int(os.environ.get("AIRHIP_NUM_THREADS", max(1, min(want, cores))))
     P.lib().airhip_set_num_threads(threads, None)
     log = (lambda *a: print(*a, file=sys.stderr, flush=True)) if (args.verbose and rank == 0) else (lambda *a: None)
@@ -172,7 +174,26 @@ def main():
         px, py, pz = D.box_dims(world, (M, M, M))
         parallelism = (f"row-block: {px}x{py}x{pz} boxes of the {M}^3 grid, one rank per GPU, hierarchy built on rank 0 "
                        f"and cut; RCCL halo exchange per sparse product, all-reduce for Krylov dots")
-        comm = D.StagedComm() if staged else D.RcclComm()
+        if staged:
+            comm = D.StagedComm()
+        else:
+            # trust the RCCL transport only after a collective self-test (all-pairs pattern exchange + all-reduce
+            # on device buffers); if any rank fails it, every rank falls back to the host-staged transport over
+            # the gloo group - slower halo exchanges, same kernels, same results
+            ok, why = 1, ""
+            try:
+                comm = D.RcclComm()
+                ok = 1 if comm.selftest(1 << 16) else 0
+                why = "" if ok else "pattern mismatch"
+            except Exception as e:
+                ok, why = 0, repr(e)
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=meta)
+            if int(flag.item()) == 0:
+                print(f"[bench] rank {rank}: RCCL transport failed its self-test ({why or 'on another rank'}); "
+                      f"using the host-staged transport", file=sys.stderr, flush=True)
+                comm = D.StagedComm(group=meta)
+                parallelism += " [RCCL self-test failed: host-staged halo transport over gloo]"
         t0 = time.time()
         owner = D.box_owner(M, M, M, world) if rank == 0 else None
         pcl, gid = D.distribute(pc, hm, owner, comm, src=0, meta_group=meta, bulk_group=None, bulk_on_gpu=not staged, log=log)

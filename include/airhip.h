@@ -212,6 +212,10 @@ int airhip_comm_create_rccl(int rank, int size, const void* unique_id128, airhip
 int airhip_comm_create_staged(int rank, int size, airhip_exchange_fn ex, airhip_allreduce_fn ar, void* user,
                               airhip_comm* out);
 int airhip_comm_stats(airhip_comm c, int64_t* exchanges, int64_t* allreduces);
+/* collective check of a transport before it is trusted with a solve: every rank sends `count` doubles of a
+ * known pattern to every other rank (device buffers, twice) and sums a value over the ranks; *ok = 1 if
+ * everything arrived intact on this rank */
+int airhip_comm_selftest(airhip_comm c, int64_t count, int* ok);
 int airhip_comm_destroy(airhip_comm* c);
 /* the communicator must outlive the PCAIR object */
 int airhip_pcair_load_distributed(airhip_pcair pc, airhip_archive piece, airhip_comm comm);

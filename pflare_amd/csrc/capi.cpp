@@ -732,6 +732,13 @@ int airhip_comm_stats(airhip_comm c, int64_t* exchanges, int64_t* allreduces) {
   if (allreduces) *allreduces = c->c->n_allreduces;
   API_END
 }
+int airhip_comm_selftest(airhip_comm c, int64_t count, int* ok) {
+  API_BEGIN
+  REQUIRE(c && ok, AIRHIP_ERR_ARG, "null argument");
+  *ok = 0;
+  *ok = comm_selftest(*c->c, count) ? 1 : 0;
+  API_END
+}
 int airhip_comm_destroy(airhip_comm* c) {
   API_BEGIN
   if (c && *c) { delete *c; *c = nullptr; }

@@ -134,4 +134,44 @@ std::unique_ptr<Comm> make_rccl_comm(int rank, int size, const void* unique_id) 
   return c;
 }
 
+// Every rank sends a distinct pattern to every other rank and checks what arrives, then checks an all-reduce.
+bool comm_selftest(Comm& c, int64_t count) {
+  if (count < 1) count = 1;
+  HaloPlan p;
+  for (int r = 0; r < c.size; r++) if (r != c.rank) p.peers.push_back(r);
+  const int64_t np = (int64_t)p.peers.size();
+  p.send_off.resize(np + 1); p.recv_off.resize(np + 1);
+  for (int64_t k = 0; k <= np; k++) p.send_off[k] = p.recv_off[k] = k * count;
+  p.n_send = p.n_ghost = np * count;
+  hipStream_t s;
+  HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  auto pattern = [](int from, int to, int64_t i) { return (double)from * 4096.0 + (double)to + (double)(i % 1000) * 1e-3; };
+  std::vector<double> hs((size_t)std::max<int64_t>(1, p.n_send)), hr((size_t)std::max<int64_t>(1, p.n_ghost), -1.0);
+  for (int64_t k = 0; k < np; k++)
+    for (int64_t i = 0; i < count; i++) hs[k * count + i] = pattern(c.rank, p.peers[k], i);
+  HIP_CHECK(hipMalloc(&p.sendbuf, hs.size() * sizeof(double)));
+  HIP_CHECK(hipMalloc(&p.recvbuf, hr.size() * sizeof(double)));
+  HIP_CHECK(hipMemcpyAsync(p.sendbuf, hs.data(), hs.size() * sizeof(double), hipMemcpyHostToDevice, s));
+  HIP_CHECK(hipMemcpyAsync(p.recvbuf, hr.data(), hr.size() * sizeof(double), hipMemcpyHostToDevice, s));
+  bool ok = true;
+  for (int rep = 0; rep < 2 && np > 0; rep++) {          // twice: buffers are reused back to back in the cycle
+    c.exchange(p, s);
+    HIP_CHECK(hipMemcpyAsync(hr.data(), p.recvbuf, hr.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    for (int64_t k = 0; k < np; k++)
+      for (int64_t i = 0; i < count; i++) ok = ok && hr[k * count + i] == pattern(p.peers[k], c.rank, i);
+  }
+  double* d = nullptr; double h[2] = {0, 0};
+  HIP_CHECK(hipMalloc(&d, 2 * sizeof(double)));
+  const double mine[2] = {(double)(c.rank + 1), 1.0};
+  HIP_CHECK(hipMemcpyAsync(d, mine, sizeof mine, hipMemcpyHostToDevice, s));
+  c.allreduce_sum(d, h, 2, s);
+  ok = ok && h[0] == 0.5 * c.size * (c.size + 1) && h[1] == (double)c.size;
+  (void)hipFree(d);
+  HIP_CHECK(hipStreamSynchronize(s));
+  (void)hipStreamDestroy(s);
+  c.n_exchanges = c.n_allreduces = 0;
+  return ok;
+}
+
 }  // namespace airhip

@@ -43,5 +43,7 @@ std::unique_ptr<Comm> make_staged_comm(int rank, int size, exchange_cb ex, allre
 // unique_id: 128 bytes from rccl_unique_id() on rank 0, broadcast by the caller
 std::unique_ptr<Comm> make_rccl_comm(int rank, int size, const void* unique_id);
 void rccl_unique_id(void* out128);
+// collective: all-pairs exchange of `count` doubles with a known pattern + an all-reduce, verified
+bool comm_selftest(Comm& c, int64_t count);
 
 }  // namespace airhip

@@ -195,6 +195,14 @@ class StagedComm:
         check(lib().airhip_comm_stats(self._h, C.byref(a), C.byref(b)))
         return dict(exchanges=a.value, allreduces=b.value)
 
+    def selftest(self, count=4096):
+        """Collective: all-pairs exchange of a known pattern + an all-reduce; True if intact on this rank."""
+        ok = C.c_int(0)
+        check(lib().airhip_comm_selftest(self._h, count, C.byref(ok)))
+        if getattr(self, "error", None) is not None:
+            raise self.error
+        return bool(ok.value)
+
     def close(self):
         if self._h:
             lib().airhip_comm_destroy(C.byref(self._h))
@@ -219,6 +227,7 @@ class RcclComm:
         check(lib().airhip_comm_create_rccl(self.rank, self.size, uid.ctypes.data, C.byref(self._h)))
 
     stats = StagedComm.stats
+    selftest = StagedComm.selftest
     close = StagedComm.close
 
 

@@ -54,6 +54,7 @@ def _worker(rank, world, port, case, out):
                 pcg.set_ordering_hint(np.random.default_rng(9).permutation(n))
             pcg.setup(A)
         comm = D.StagedComm()
+        assert comm.selftest(1000)
         pc, gid = D.distribute(pcg, A, owner, comm)
         xb = torch.from_numpy(b[gid]).cuda()
         z = torch.empty_like(xb)
@@ -125,6 +126,7 @@ def _rccl_worker(rank, world, port, out):
         pcg = P.PCAIR(device_upload=False, a_lump=True)
         pcg.setup(A)
         comm = D.RcclComm()              # librccl resolved at run time, unique id through torch.distributed
+        assert comm.selftest(1000)
         pc, gid = D.distribute(pcg, A, D.block_owner(n, 1), comm)
         assert np.array_equal(gid, np.arange(n))
         ksp = P.KSP("gmres", pc_side="right", rtol=1e-10, atol=1e-50)
