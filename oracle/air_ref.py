@@ -63,7 +63,7 @@ INV_POWER, INV_ARNOLDI, INV_NEWTON, INV_NEUMANN, INV_SAI, INV_ISAI, INV_WJACOBI,
     INV_NEWTON_NO_EXTRA = 0, 1, 2, 3, 4, 5, 6, 7, 8
 INV_NAMES = {"power": INV_POWER, "arnoldi": INV_ARNOLDI, "newton": INV_NEWTON,
              "neumann": INV_NEUMANN, "wjacobi": INV_WJACOBI, "jacobi": INV_JACOBI,
-             "newton_no_extra": INV_NEWTON_NO_EXTRA}
+             "newton_no_extra": INV_NEWTON_NO_EXTRA, "sai": INV_SAI, "isai": INV_ISAI}
 
 
 # ----------------------------------------------------------------------------------------
@@ -833,6 +833,67 @@ def build_gmres_polynomial_inverse(A, poly_order, coeffs, sparsity_order, matrix
     return op
 
 
+def _pattern_product(A, B):
+    """symbolic product: the pattern of A*B without numerical cancellation"""
+    A1 = A.tocsr().copy(); A1.data = np.ones(A1.nnz)
+    B1 = B.tocsr().copy(); B1.data = np.ones(B1.nnz)
+    C = (A1 @ B1).tocsr(); C.sort_indices()
+    return C
+
+
+def sai_z(A_ff, A_cf, S, incomplete):
+    """calculate_and_build_sai_z_cpu (src/SAI_Z.F90:24-645): for every row i with pattern J = S[i,:]
+    incomplete (lAIR / ISAI): z A_ff[J,J] = -A_cf[i,J]  (square solve, :520-540);
+    complete (SAI): min ||z A_ff[J,I] + A_cf[i,I]||, I = columns present in the rows J (:330-362, :575-600).
+    A_cf None stands for -I (calculate_and_build_sai, :781-863).  Blocks are always solved directly
+    (the reference switches to GMRES/LSQR with rtol 1e-3 above size 40, its device path never does)."""
+    A_ff = A_ff.tocsr(); A_ff.sort_indices()
+    S = S.tocsr(); S.sort_indices()
+    if A_cf is not None:
+        A_cf = A_cf.tocsr(); A_cf.sort_indices()
+    out = np.zeros(S.nnz)
+    for i in range(S.shape[0]):
+        p0, p1 = S.indptr[i], S.indptr[i + 1]
+        J = S.indices[p0:p1]
+        if J.size == 0:
+            continue
+        if A_cf is not None:
+            jv = np.asarray(A_cf[i, J].todense()).ravel()
+        else:
+            jv = np.where(J == i, -1.0, 0.0)
+        rows = A_ff[J, :]
+        if incomplete:
+            I = J
+        else:
+            I = np.unique(rows.indices)
+        if I.size < J.size:
+            continue
+        B = np.asarray(rows[:, I].todense()).T            # A_ff[J, I]^T
+        e = np.zeros(I.size)
+        pos = np.searchsorted(I, J)
+        ok = (pos < I.size) & (I[np.minimum(pos, I.size - 1)] == J)
+        e[pos[ok]] = -jv[ok]
+        if incomplete:
+            z = np.linalg.solve(B, e)
+        else:
+            z = np.linalg.lstsq(B, e, rcond=None)[0]
+        out[p0:p1] = z
+    return sp.csr_matrix((out, S.indices.copy(), S.indptr.copy()), shape=S.shape)
+
+
+def sai_inverse(A, sparsity_order, incomplete):
+    """calculate_and_build_sai (src/SAI_Z.F90:781-863)."""
+    A = A.tocsr(); A.sort_indices()
+    n = A.shape[0]
+    if sparsity_order == 0:
+        S = sp.identity(n, format="csr")
+    else:
+        S = A
+        for _ in range(2, sparsity_order + 1):
+            S = _pattern_product(A, S)          # mat_mat_symbolic: no numerical cancellation
+    return sai_z(A, None, S, incomplete)
+
+
 def clamp_poly(global_rows, poly_order, sparsity_order):
     """src/Gmres_Poly.F90:64-76."""
     if poly_order + 1 > global_rows:
@@ -913,6 +974,9 @@ def build_inverse(A, inverse_type, poly_order, sparsity_order, matrix_free, diag
         else:
             op.mat = (op.mat @ sp.diags(dinv)).tocsr(); op.mat.sort_indices()
         return op, None
+    if inverse_type in (INV_SAI, INV_ISAI):
+        Ac = A.tocsr()
+        return InvOp("assembled", mat=sai_inverse(Ac, sparsity_order, inverse_type == INV_ISAI)), None
     if inverse_type in (INV_JACOBI, INV_WJACOBI):
         weight = 1.0
         if inverse_type == INV_WJACOBI:
@@ -1052,6 +1116,9 @@ class AirOptions:
     r_drop: float = _f32(0.01)
     a_drop: float = _f32(1e-4)
     a_lump: bool = False
+    strong_r_threshold: float = 0.0       # -pc_air_strong_r_threshold
+    z_type: str = "product"               # -pc_air_z_type product | lair | lair_sai
+    lair_distance: int = 2                # -pc_air_lair_distance
     # -mg_coarse_ksp_type richardson -mg_coarse_ksp_max_it N (0 = preonly, the default)
     coarse_richardson_its: int = 0
     seed: int = 1
@@ -1210,11 +1277,26 @@ def setup_air(A, o: AirOptions) -> Hierarchy:
         A_fc = submatrix(cur, F, C)
         A_cf = submatrix(cur, C, F)
 
+        # strong R threshold (src/AIR_Operators_Setup.F90:46-100, 219-276): Z comes from a copy of A with
+        # the small entries of each row removed (diagonal kept)
+        product_z = o.z_type == "product"
+        r_dropped = o.strong_r_threshold != 0.0
+        if r_dropped:
+            A_drop = remove_small(cur, o.strong_r_threshold, rel=1, drop_diag=0)
+            A_ff_drop = submatrix(A_drop, F, F)
+            A_cf_z = submatrix(A_drop, C, F)
+            A_fc_w = submatrix(A_drop, F, C)
+        else:
+            A_ff_drop, A_cf_z, A_fc_w = A_ff, A_cf, A_fc
+
         inv_ff, inv_ff_asm = build_inverse(A_ff_op, inv_type_aff, o.poly_order, sparsity_aff,
                                            o.matrix_free_polys, o.diag_scale_polys, o.seed,
-                                           need_assembled=True)
+                                           need_assembled=product_z and not r_dropped)
+        if product_z and r_dropped:
+            inv_ff_asm, _ = build_inverse(A_ff_drop, inv_type_aff, o.poly_order, sparsity_aff, False,
+                                          o.diag_scale_polys, o.seed)
         inv_for_Z = inv_ff_asm if inv_ff_asm is not None else inv_ff
-        if inv_for_Z.kind not in ("assembled", "diag"):
+        if product_z and inv_for_Z.kind not in ("assembled", "diag"):
             raise NotImplementedError("grid transfers need an assembled A_ff inverse")
 
         A_cc = inv_cc = None
@@ -1224,18 +1306,31 @@ def setup_air(A, o: AirOptions) -> Hierarchy:
                                       o.c_inverse_sparsity_order, o.matrix_free_polys,
                                       o.diag_scale_polys, o.seed)
 
+        if product_z:
+            Mz = inv_for_Z.mat if inv_for_Z.kind == "assembled" else sp.diags(inv_for_Z.d).tocsr()
         if o.one_point_classical_prolong and not o.symmetric:
             W = one_point_W(A_fc)
         else:
-            Mz = inv_for_Z.mat if inv_for_Z.kind == "assembled" else sp.diags(inv_for_Z.d).tocsr()
-            W = (-(Mz @ A_fc)).tocsr(); W.sort_indices()
+            if not product_z:
+                raise NotImplementedError("lAIR needs the one-point prolongator (AIR_Operators_Setup.F90:478-482)")
+            W = (-(Mz @ A_fc_w)).tocsr(); W.sort_indices()
             W = remove_small(W, o.r_drop, rel=1)
         P = build_P(W, F, C, n)
 
-        Mz = inv_for_Z.mat if inv_for_Z.kind == "assembled" else sp.diags(inv_for_Z.d).tocsr()
-        Z = (A_cf @ Mz).tocsr()
-        Z.data *= -1.0
-        Z.sort_indices()
+        if product_z:
+            Z = (A_cf_z @ Mz).tocsr()
+            Z.data *= -1.0
+            Z.sort_indices()
+        else:
+            # lAIR / SAI (src/AIR_Operators_Setup.F90:698-778)
+            if o.lair_distance == 1:
+                S = A_cf_z
+            else:
+                pw = A_ff_drop
+                for _ in range(3, o.lair_distance + 1):
+                    pw = _pattern_product(A_ff_drop, pw)
+                S = _pattern_product(A_cf_z, pw)
+            Z = sai_z(A_ff, A_cf, S, o.z_type == "lair")
         Z = remove_small(Z, o.r_drop, rel=1)
         R = build_R(Z, F, C, n)
         if o.symmetric:

@@ -146,7 +146,8 @@ static int parse_inv_type(const char* v) {
   if (s == "neumann") return INV_NEUMANN;
   if (s == "wjacobi") return INV_WJACOBI;
   if (s == "jacobi") return INV_JACOBI;
-  if (s == "sai" || s == "isai") return -2;
+  if (s == "sai") return INV_SAI;
+  if (s == "isai") return INV_ISAI;
   char* end = nullptr; long k = std::strtol(v, &end, 10);
   if (end && *end == 0) return (int)k;
   return -1;
@@ -189,7 +190,6 @@ int airhip_pcair_set_option(airhip_pcair pc, const char* name, const char* value
   auto D = [&]() { return std::atof(v); };
   auto inv = [&](int& dst) -> int {
     int t = parse_inv_type(v);
-    if (t == -2) { g_err = "inverse types sai/isai are not supported by this build"; return AIRHIP_ERR_UNSUPPORTED; }
     if (t < 0) { g_err = std::string("unknown inverse type ") + v; return AIRHIP_ERR_ARG; }
     dst = t; return 0;
   };
@@ -228,11 +228,20 @@ int airhip_pcair_set_option(airhip_pcair pc, const char* name, const char* value
   else if (k == "device_upload") pc->device_upload = parse_bool(v);
 
   else if (k == "processor_agglom" || k == "subcomm" || k == "coarsest_subcomm") { /* no-ops on one device */ }
-  else if (k == "symmetric" || k == "z_type" || k == "cf_splitting_type" || k == "full_smoothing_up_and_down" ||
+  else if (k == "strong_r_threshold") o.strong_r_threshold = D();
+  else if (k == "lair_distance") { o.lair_distance = I(); REQUIRE(o.lair_distance >= 1, AIRHIP_ERR_ARG, "lair_distance must be >= 1"); }
+  else if (k == "z_type") {
+    std::string z(v);
+    if (z == "product" || z == "0") o.z_type = 0;
+    else if (z == "lair" || z == "1") o.z_type = 1;
+    else if (z == "lair_sai" || z == "2") o.z_type = 2;
+    else { g_err = "unknown z_type " + z; return AIRHIP_ERR_ARG; }
+  }
+  else if (k == "symmetric" || k == "cf_splitting_type" || k == "full_smoothing_up_and_down" ||
            k == "constrain_z" || k == "constrain_w" || k == "improve_z_its" || k == "improve_w_its" ||
-           k == "strong_r_threshold" || k == "reuse_sparsity" || k == "lair_distance") {
+           k == "reuse_sparsity") {
     bool is_default = (std::string(v) == "0" || std::string(v) == "false" || std::string(v) == "" ) ||
-                      (k == "z_type" && std::string(v) == "product") || (k == "cf_splitting_type" && std::string(v) == "pmisr_ddc");
+                      (k == "cf_splitting_type" && std::string(v) == "pmisr_ddc");
     if (!is_default) { g_err = "option -pc_air_" + k + " is outside this build's scope (SURVEY 8f)"; return AIRHIP_ERR_UNSUPPORTED; }
   } else { g_err = "unknown option -pc_air_" + k; return AIRHIP_ERR_ARG; }
   if (rc) return rc;
@@ -794,7 +803,6 @@ int airhip_pcinv_set_option(airhip_pcinv pc, const char* name, const char* value
   const char* v = value ? value : "";
   if (k == "type") {
     int t = parse_inv_type(v);
-    if (t == -2) { g_err = "inverse types sai/isai are not supported by this build"; return AIRHIP_ERR_UNSUPPORTED; }
     if (t < 0) { g_err = std::string("unknown inverse type ") + v; return AIRHIP_ERR_ARG; }
     pc->type = t;
   } else if (k == "poly_order" || k == "order") pc->poly_order = std::atoi(v);

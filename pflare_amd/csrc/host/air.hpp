@@ -37,6 +37,9 @@ struct AirOptions {
   double r_drop = (double)0.01f;
   double a_drop = (double)1e-4f;
   bool a_lump = false;
+  double strong_r_threshold = 0.0;   // -pc_air_strong_r_threshold: drop tolerance applied to A before Z is built
+  int z_type = 0;                    // -pc_air_z_type: 0 product (AIRG), 1 lair, 2 lair_sai (src/Pflare_Parameters.F90:30-32)
+  int lair_distance = 2;             // -pc_air_lair_distance
   int coarse_richardson_its = 0;  // -mg_coarse_ksp_type richardson -mg_coarse_ksp_max_it N
   bool print_stats_timings = false;
   uint64_t seed = 1;              // comm_rank + 1 in the reference
@@ -93,6 +96,10 @@ void compute_cf_splitting(const Csr& A, const AirOptions& o, Arr<int32_t>& marke
 struct OpView { const Csr* A = nullptr; const double* diag = nullptr; int64_t n = 0; };
 void build_inverse(const OpView& A, int inverse_type, int poly_order, int sparsity_order,
                    bool matrix_free, bool diag_scale, uint64_t seed, InvOp& op, InvOp* assembled_too);
+
+// lAIR / SAI rows by small dense solves (src/SAI_Z.F90): Z on the pattern of S; A_cf == nullptr stands for -I
+Csr sai_z(const Csr& A_ff, const Csr* A_cf, const Csr& S, bool incomplete);
+Csr sai_inverse(const Csr& A, int sparsity_order, bool incomplete);
 
 // Full setup.  A is consumed level by level (the caller's matrix is not modified).
 std::unique_ptr<Hierarchy> setup_air(const Csr& A, const AirOptions& o, SetupAccel* accel = nullptr);

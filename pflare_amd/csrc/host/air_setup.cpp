@@ -167,16 +167,37 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o, SetupAc
       if (inv_type_aff != INV_WJACOBI && o.poly_order > 2)
         for (int i = 0; i < 10; i++) if (L.smooth_order[i] > 0) L.smooth_order[i] = 1;
     }
+    // ---- strong R threshold: Z (and an ideal W) are built from a copy of A with the small entries of every
+    // row removed, diagonal kept (src/AIR_Operators_Setup.F90:46-100, 219-276)
+    Csr Aff_drop, Afc_drop, Acf_drop;
+    const bool r_dropped = o.strong_r_threshold != 0.0;
+    if (r_dropped) {
+      t0 = now_s();
+      Csr Ad = remove_small(*cur, o.strong_r_threshold, 1, false, 0);
+      H->timers[6] += now_s() - t0;
+      t0 = now_s();
+      split_fc(Ad, markers.data(), newidx.data(), L.F, L.C, Aff_drop, Afc_drop, Acf_drop, nullptr);
+      H->timers[1] += now_s() - t0;
+    }
+    const Csr& Acf_z = r_dropped ? Acf_drop : L.A_cf;
+    const Csr& Afc_w = r_dropped ? Afc_drop : L.A_fc;
     // ---- A_ff^-1 for smoothing and for the grid transfers
     t0 = now_s();
     OpView aff; aff.n = n_f;
     if (L.aff_diag) aff.diag = L.aff_d.data(); else aff.A = &L.A_ff;
     InvOp inv_asm;
+    const bool product_z = o.z_type == 0;
     build_inverse(aff, inv_type_aff, o.poly_order, sparsity_aff, o.matrix_free_polys, o.diag_scale_polys,
-                  o.seed, L.inv_ff, &inv_asm);
+                  o.seed, L.inv_ff, (product_z && !r_dropped) ? &inv_asm : nullptr);
+    if (product_z && r_dropped) {
+      // a second, always assembled, inverse of the dropped A_ff (AIR_Operators_Setup.F90:413-438)
+      OpView affd; affd.n = n_f; affd.A = &Aff_drop;
+      InvOp unused;
+      build_inverse(affd, inv_type_aff, o.poly_order, sparsity_aff, false, o.diag_scale_polys, o.seed, inv_asm, nullptr);
+    }
     const InvOp& invZ = (inv_asm.kind != InvOp::NONE) ? inv_asm : L.inv_ff;
-    if (invZ.kind != InvOp::ASSEMBLED && invZ.kind != InvOp::DIAG)
-      throw std::runtime_error("grid transfers need an assembled A_ff inverse (use a non-Newton inverse_type)");
+    if (product_z && invZ.kind != InvOp::ASSEMBLED && invZ.kind != InvOp::DIAG)
+      throw std::runtime_error("grid transfers need an assembled A_ff inverse");
     if (any_c) {
       OpView acc; acc.A = &L.A_cc; acc.n = n_c;
       build_inverse(acc, o.c_inverse_type, o.c_poly_order, o.c_inverse_sparsity_order, o.matrix_free_polys,
@@ -188,22 +209,43 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o, SetupAc
     t0 = now_s();
     Csr Mz_store;
     const Csr* Mz = nullptr;
-    if (invZ.kind == InvOp::ASSEMBLED) Mz = &invZ.mat;
-    else { Mz_store = csr_from_diag(invZ.d.data(), n_f); Mz = &Mz_store; }
+    if (product_z) {
+      if (invZ.kind == InvOp::ASSEMBLED) Mz = &invZ.mat;
+      else { Mz_store = csr_from_diag(invZ.d.data(), n_f); Mz = &Mz_store; }
+    }
     if (o.one_point_classical_prolong && !o.symmetric) {
       L.one_point = true;
       one_point_W(L.A_fc, L.wcol);
     } else {
+      if (!product_z) throw std::runtime_error("lAIR / SAI restrictors need the one-point classical prolongator");
       L.one_point = false;
       SpgemmDrop d; d.enabled = true; d.tol = o.r_drop; d.negate = true;
-      L.W = spgemm(*Mz, L.A_fc, d);
+      L.W = spgemm(*Mz, Afc_w, d);
     }
     H->timers[3] += now_s() - t0;
     // ---- Z / R
     t0 = now_s();
-    {
+    if (product_z) {
       SpgemmDrop d; d.enabled = true; d.tol = o.r_drop; d.negate = true;
-      L.Z = accel ? accel->spgemm(L.A_cf, *Mz, d) : spgemm(L.A_cf, *Mz, d);
+      L.Z = accel ? accel->spgemm(Acf_z, *Mz, d) : spgemm(Acf_z, *Mz, d);
+    } else {
+      // lAIR / SAI (AIR_Operators_Setup.F90:698-778): the F neighbourhood of every C point out to
+      // lair_distance comes from the dropped operators, the values from the full ones
+      Csr Aff_full_store;
+      const Csr* Aff_full = &L.A_ff;
+      if (L.aff_diag) { Aff_full_store = csr_from_diag(L.aff_d.data(), n_f); Aff_full = &Aff_full_store; }
+      const Csr& Aff_pat = r_dropped ? Aff_drop : *Aff_full;
+      Csr S_store;
+      const Csr* S = &Acf_z;
+      if (o.lair_distance >= 2) {
+        Csr Pw;
+        const Csr* pw = &Aff_pat;
+        for (int order = 3; order <= o.lair_distance; order++) { Pw = spgemm(Aff_pat, *pw); pw = &Pw; }
+        S_store = spgemm(Acf_z, *pw);
+        S = &S_store;
+      }
+      Csr Zfull = sai_z(*Aff_full, &L.A_cf, *S, o.z_type == 1);
+      L.Z = remove_small(Zfull, o.r_drop, 1, false, 0);
     }
     Mz_store = Csr();
     inv_asm = InvOp();

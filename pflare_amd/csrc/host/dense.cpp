@@ -41,6 +41,35 @@ std::vector<double> ls_qr(const Dense& A0, const std::vector<double>& b0) {
   return x;
 }
 
+std::vector<double> lu_solve(const Dense& A0, const std::vector<double>& b0) {
+  Dense A = A0;
+  std::vector<double> x = b0;
+  const int n = A.n;
+  for (int k = 0; k < n; k++) {
+    int p = k; double best = std::fabs(A(k, k));
+    for (int i = k + 1; i < n; i++) if (std::fabs(A(i, k)) > best) { best = std::fabs(A(i, k)); p = i; }
+    if (best == 0.0) continue;
+    if (p != k) {
+      for (int c = 0; c < n; c++) std::swap(A(k, c), A(p, c));
+      std::swap(x[k], x[p]);
+    }
+    const double piv = 1.0 / A(k, k);
+    for (int i = k + 1; i < n; i++) {
+      const double l = A(i, k) * piv;
+      if (l == 0.0) continue;
+      A(i, k) = l;
+      for (int c = k + 1; c < n; c++) A(i, c) -= l * A(k, c);
+      x[i] -= l * x[k];
+    }
+  }
+  for (int k = n - 1; k >= 0; k--) {
+    double s = x[k];
+    for (int c = k + 1; c < n; c++) s -= A(k, c) * x[c];
+    x[k] = (A(k, k) == 0.0) ? 0.0 : s / A(k, k);
+  }
+  return x;
+}
+
 // One-sided Jacobi SVD of an m x n matrix with m >= n: on return the columns of A are
 // U*diag(s), V holds the right singular vectors.
 static void jacobi_svd(Dense& A, Dense& V, std::vector<double>& s) {

@@ -20,6 +20,9 @@ struct Dense {
 // min ||A x - b||_2 for full-rank A (m >= n) by Householder QR  (LAPACK gels 'N')
 std::vector<double> ls_qr(const Dense& A, const std::vector<double>& b);
 
+// A x = b for square A by LU with partial pivoting (LAPACK gesv); a zero pivot leaves that unknown at 0
+std::vector<double> lu_solve(const Dense& A, const std::vector<double>& b);
+
 // minimum-norm least squares by SVD, singular values <= rcond*s_max dropped
 // (rcond < 0 -> machine epsilon)  (LAPACK gelsd)
 std::vector<double> ls_minnorm_svd(const Dense& A, const std::vector<double>& b, double rcond);

@@ -658,6 +658,13 @@ void build_inverse(const OpView& A, int inverse_type, int poly_order, int sparsi
     else scale_cols(op.mat, dinv.data());
     return;
   }
+  if (inverse_type == INV_SAI || inverse_type == INV_ISAI) {
+    // always assembled (src/Approx_Inverse_Setup.F90:465-482); a MATDIAGONAL operand is converted first
+    op.kind = InvOp::ASSEMBLED;
+    if (A.diag) { Csr D = csr_from_diag(A.diag, n); op.mat = sai_inverse(D, sparsity_order, inverse_type == INV_ISAI); }
+    else op.mat = sai_inverse(*A.A, sparsity_order, inverse_type == INV_ISAI);
+    return;
+  }
   if (inverse_type == INV_JACOBI || inverse_type == INV_WJACOBI) {
     double weight = 1.0;
     if (inverse_type == INV_WJACOBI) {

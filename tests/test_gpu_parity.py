@@ -51,6 +51,11 @@ CASES = {
                                dict(coarsest_inverse_type="newton", coarsest_poly_order=10,
                                     coarsest_matrix_free_polys=True, inverse_type="power", a_drop=1e-3,
                                     max_levels=4)),
+    # lAIR restrictor with C smoothing (tests/Makefile:638-642), SAI smoother (tests/Makefile:405-406), Newton smoothers
+    "adv2d_30_lair_ffc": (dict(dim=2, M=30, N=30), dict(a_lump=True, smooth_type="ffc", z_type="lair", inverse_type="wjacobi")),
+    "adv3d_10_lair_rthr": (dict(dim=3, M=10, N=10, P=10), dict(z_type="lair", strong_r_threshold=0.01, inverse_type="power")),
+    "diff2d_16_sai": (dict(dim=2, M=16, N=16, u=0, v=0, alpha=1.0), dict(inverse_type="sai", a_drop=1e-3)),
+    "adv2d_24_newton": (dict(dim=2, M=24, N=24), dict(inverse_type="newton", poly_order=3)),
     "adv2d_16_fc": (dict(dim=2, M=16, N=16), dict(smooth_type="fc")),
     "adv2d_16_fcf": (dict(dim=2, M=16, N=16), dict(smooth_type="fcf")),
     "diff2d_12_diagscale": (dict(dim=2, M=12, N=12, u=0, v=0, alpha=1.0), dict(diag_scale_polys=True)),
@@ -106,6 +111,8 @@ KSP_CASES = [
     ("adv2d_30_newton_coarse", "richardson", "left", "preconditioned", 1e-5, 8),
     ("diff2d_12_jacobi_exact", "richardson", "left", "unpreconditioned", 1e-5, 1),  # tests/Makefile:421-424
     ("adv2d_16_fc", "gmres", "left", "preconditioned", 1e-5, 3),       # tests/Makefile:300 (<= 3)
+    ("adv2d_30_lair_ffc", "gmres", "right", "preconditioned", 1e-10, 10),   # tests/Makefile:638-642 shape
+    ("diff2d_16_sai", "gmres", "left", "preconditioned", 1e-5, 6),
 ]
 
 

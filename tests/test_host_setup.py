@@ -56,6 +56,17 @@ OPT_PAIRS = {
     "diagscale": (dict(diag_scale_polys=True), R.AirOptions(diag_scale_polys=True)),
     "sparsity2": (dict(inverse_sparsity_order=2), R.AirOptions(inverse_sparsity_order=2)),
     "ideal_W": (dict(one_point_classical_prolong=False), R.AirOptions(one_point_classical_prolong=False)),
+    # lAIR / SAI restrictors, strong R threshold, SAI / ISAI inverses (src/SAI_Z.F90, src/AIR_Operators_Setup.F90:46-100,698-778)
+    "lair": (dict(z_type="lair"), R.AirOptions(z_type="lair")),
+    "lair_d1": (dict(z_type="lair", lair_distance=1), R.AirOptions(z_type="lair", lair_distance=1)),
+    "lair_d3_rthr": (dict(z_type="lair", lair_distance=3, strong_r_threshold=0.05),
+                     R.AirOptions(z_type="lair", lair_distance=3, strong_r_threshold=0.05)),
+    "lair_sai": (dict(z_type="lair_sai"), R.AirOptions(z_type="lair_sai")),
+    "strong_r": (dict(strong_r_threshold=0.05), R.AirOptions(strong_r_threshold=0.05)),
+    "strong_r_ideal_W": (dict(strong_r_threshold=0.05, one_point_classical_prolong=False),
+                         R.AirOptions(strong_r_threshold=0.05, one_point_classical_prolong=False)),
+    "sai": (dict(inverse_type="sai"), R.AirOptions(inverse_type=R.INV_SAI)),
+    "isai_s2": (dict(inverse_type="isai", inverse_sparsity_order=2), R.AirOptions(inverse_type=R.INV_ISAI, inverse_sparsity_order=2)),
 }
 
 
@@ -217,13 +228,15 @@ def test_auto_truncation_and_options():
                  auto_truncate_start_level=1, auto_truncate_tol=1e-1).setup_host_only(A)
     assert tr.num_levels < full.num_levels
     with pytest.raises(P.AirhipError):
-        P.PCAIR(inverse_type="sai")
+        P.PCAIR(inverse_type="spai")
     with pytest.raises(P.AirhipError):
         P.PCAIR(no_such_option=1)
     with pytest.raises(P.AirhipError):
         P.PCAIR(smooth_type="fxc")
     with pytest.raises(P.AirhipError):
-        P.PCAIR(z_type="lair")
+        P.PCAIR(z_type="lair_product")
+    with pytest.raises(P.AirhipError):
+        P.PCAIR(full_smoothing_up_and_down=True)
 
 
 def test_host_setup_is_bitwise_reproducible_across_thread_counts():

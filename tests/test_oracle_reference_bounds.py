@@ -49,6 +49,13 @@ CASES = [
      R.AirOptions(inverse_type=R.INV_WJACOBI, a_drop=1e-3), dict(max_it=8), 8),
     ("Makefile:417-418 diffusion jacobi", R.gen_adv_diff_fd(**DIFF8),
      R.AirOptions(inverse_type=R.INV_JACOBI, a_drop=1e-3), dict(max_it=5), 5),
+    ("Makefile:405-406 diffusion SAI", R.gen_adv_diff_fd(**DIFF8),
+     R.AirOptions(inverse_type=R.INV_SAI, a_drop=1e-3), dict(max_it=5), 5),
+    ("Makefile:409-410 diffusion ISAI", R.gen_adv_diff_fd(**DIFF8),
+     R.AirOptions(inverse_type=R.INV_ISAI, a_drop=1e-3), dict(max_it=5), 5),
+    ("Makefile:638-642 lAIR 2D advection 50x50 ffc wjacobi", R.gen_adv_diff_fd(2, 50, 50),
+     R.AirOptions(a_lump=True, a_drop=1e-4, smooth_type="ffc", z_type="lair", inverse_type=R.INV_WJACOBI),
+     dict(side="right", rtol=1e-10, max_it=10), 10),
     ("Makefile:556-560 auto truncation + newton coarse", R.gen_adv_diff_fd(2, 10, 10),
      R.AirOptions(auto_truncate_start_level=1, auto_truncate_tol=1e-2, a_drop=1e-3, inverse_type=R.INV_POWER,
                   **NEWTON_COARSE), dict(ksp="richardson", max_it=3), 3),

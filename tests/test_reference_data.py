@@ -22,6 +22,8 @@ AIR_CASES = [
     ("91 a_drop power", "mat_stream_2364", POWER, {}, 5),
     ("93 fcf", "mat_stream_2364", dict(POWER, smooth_type="fcf"), {}, 5),
     ("95 matrix-free", "mat_stream_2364", dict(POWER, matrix_free_polys=True), {}, 5),
+    ("113 lAIR", "mat_stream_2364", dict(POWER, z_type="lair"), {}, 5),
+    ("115 lAIR strong R 0.01", "mat_stream_2364", dict(POWER, z_type="lair", strong_r_threshold=0.01), {}, 5),
     ("131-135 exact, arnoldi-18 coarse", "mat_stream_2364",
      dict(EXACT, mg_coarse_ksp_max_it=5, max_levels=30, coarsest_poly_order=18, coarsest_matrix_free_polys=True,
           coarsest_inverse_type="arnoldi"), dict(ksp="richardson", norm="unpreconditioned"), 1),
