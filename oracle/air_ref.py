@@ -841,6 +841,13 @@ def _pattern_product(A, B):
     return C
 
 
+def _keep_pattern(A, B, prod):
+    """the numeric product `prod` = +-A*B re-expressed on the symbolic pattern of A*B (scipy prunes entries
+    that cancel to exactly zero, PETSc's MatMatMult keeps them)"""
+    pat = _pattern_product(A, B)
+    return sp.csr_matrix((values_on_pattern(prod, pat), pat.indices, pat.indptr), shape=pat.shape)
+
+
 def sai_z(A_ff, A_cf, S, incomplete):
     """calculate_and_build_sai_z_cpu (src/SAI_Z.F90:24-645): for every row i with pattern J = S[i,:]
     incomplete (lAIR / ISAI): z A_ff[J,J] = -A_cf[i,J]  (square solve, :520-540);
@@ -1119,6 +1126,8 @@ class AirOptions:
     strong_r_threshold: float = 0.0       # -pc_air_strong_r_threshold
     z_type: str = "product"               # -pc_air_z_type product | lair | lair_sai
     lair_distance: int = 2                # -pc_air_lair_distance
+    improve_z_its: int = 0                # -pc_air_improve_z_its
+    improve_w_its: int = 0                # -pc_air_improve_w_its
     # -mg_coarse_ksp_type richardson -mg_coarse_ksp_max_it N (0 = preonly, the default)
     coarse_richardson_its: int = 0
     seed: int = 1
@@ -1166,6 +1175,35 @@ class Hierarchy:
     @property
     def no_levels(self):
         return len(self.levels) + 1
+
+
+def _inv_diag(op):
+    """diagonal of an assembled approximate inverse (MatGetDiagonal, src/Grid_Transfer_Improve.F90:235-241)"""
+    if op.kind == "assembled":
+        return np.asarray(op.mat.diagonal())
+    if op.kind == "diag":
+        return op.d
+    raise NotImplementedError("improve_z / improve_w need an assembled A_ff inverse")
+
+
+def improve_z(Z, A_ff, A_cf, dm, its):
+    """src/Grid_Transfer_Improve.F90:200-371: Z <- Z - ((Z A_ff + A_cf) diag(M)) on the pattern of Z."""
+    Aff = A_ff.tocsr() if not isinstance(A_ff, DiagMat) else sp.diags(A_ff.diagonal()).tocsr()
+    Z = Z.tocsr().copy(); Z.sort_indices()
+    for _ in range(its):
+        T = ((Z @ Aff + A_cf) @ sp.diags(dm)).tocsr()
+        Z = sp.csr_matrix((Z.data - values_on_pattern(T, Z), Z.indices, Z.indptr), shape=Z.shape)
+    return Z
+
+
+def improve_w(W, A_ff, A_fc, dm, its):
+    """src/Grid_Transfer_Improve.F90:21-196: W <- W - (diag(M) (A_ff W + A_fc)) on the pattern of W."""
+    Aff = A_ff.tocsr() if not isinstance(A_ff, DiagMat) else sp.diags(A_ff.diagonal()).tocsr()
+    W = W.tocsr().copy(); W.sort_indices()
+    for _ in range(its):
+        T = (sp.diags(dm) @ (Aff @ W + A_fc)).tocsr()
+        W = sp.csr_matrix((W.data - values_on_pattern(T, W), W.indices, W.indptr), shape=W.shape)
+    return W
 
 
 def one_point_W(A_fc):
@@ -1314,6 +1352,8 @@ def setup_air(A, o: AirOptions) -> Hierarchy:
             if not product_z:
                 raise NotImplementedError("lAIR needs the one-point prolongator (AIR_Operators_Setup.F90:478-482)")
             W = (-(Mz @ A_fc_w)).tocsr(); W.sort_indices()
+            if o.improve_w_its:
+                W = improve_w(_keep_pattern(Mz, A_fc_w, W), A_ff_op, A_fc, _inv_diag(inv_ff), o.improve_w_its)
             W = remove_small(W, o.r_drop, rel=1)
         P = build_P(W, F, C, n)
 
@@ -1331,6 +1371,10 @@ def setup_air(A, o: AirOptions) -> Hierarchy:
                     pw = _pattern_product(A_ff_drop, pw)
                 S = _pattern_product(A_cf_z, pw)
             Z = sai_z(A_ff, A_cf, S, o.z_type == "lair")
+        if o.improve_z_its:
+            if product_z:
+                Z = _keep_pattern(A_cf_z, Mz, Z)
+            Z = improve_z(Z, A_ff_op, A_cf, _inv_diag(inv_ff), o.improve_z_its)
         Z = remove_small(Z, o.r_drop, rel=1)
         R = build_R(Z, F, C, n)
         if o.symmetric:

@@ -237,9 +237,10 @@ int airhip_pcair_set_option(airhip_pcair pc, const char* name, const char* value
     else if (z == "lair_sai" || z == "2") o.z_type = 2;
     else { g_err = "unknown z_type " + z; return AIRHIP_ERR_ARG; }
   }
+  else if (k == "improve_z_its") o.improve_z_its = I();
+  else if (k == "improve_w_its") o.improve_w_its = I();
   else if (k == "symmetric" || k == "cf_splitting_type" || k == "full_smoothing_up_and_down" ||
-           k == "constrain_z" || k == "constrain_w" || k == "improve_z_its" || k == "improve_w_its" ||
-           k == "reuse_sparsity") {
+           k == "constrain_z" || k == "constrain_w" || k == "reuse_sparsity") {
     bool is_default = (std::string(v) == "0" || std::string(v) == "false" || std::string(v) == "" ) ||
                       (k == "cf_splitting_type" && std::string(v) == "pmisr_ddc");
     if (!is_default) { g_err = "option -pc_air_" + k + " is outside this build's scope (SURVEY 8f)"; return AIRHIP_ERR_UNSUPPORTED; }

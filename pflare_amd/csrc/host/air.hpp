@@ -40,6 +40,7 @@ struct AirOptions {
   double strong_r_threshold = 0.0;   // -pc_air_strong_r_threshold: drop tolerance applied to A before Z is built
   int z_type = 0;                    // -pc_air_z_type: 0 product (AIRG), 1 lair, 2 lair_sai (src/Pflare_Parameters.F90:30-32)
   int lair_distance = 2;             // -pc_air_lair_distance
+  int improve_z_its = 0, improve_w_its = 0;   // -pc_air_improve_z_its / -pc_air_improve_w_its
   int coarse_richardson_its = 0;  // -mg_coarse_ksp_type richardson -mg_coarse_ksp_max_it N
   bool print_stats_timings = false;
   uint64_t seed = 1;              // comm_rank + 1 in the reference

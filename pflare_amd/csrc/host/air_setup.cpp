@@ -84,6 +84,62 @@ static Csr build_P(const Level& L) {
   return P;
 }
 
+// Richardson improvement of the ideal restrictor on its own pattern (improve_z, src/Grid_Transfer_Improve.F90:200-371):
+//   Z <- Z - ((Z A_ff + A_cf) diag(M)) restricted to pattern(Z),  dm = diagonal of the A_ff inverse.
+// A_ff == nullptr: MATDIAGONAL operator with diagonal aff_d.
+static void improve_z(Csr& Z, const Csr* A_ff, const double* aff_d, const Csr& A_cf, const double* dm, int its) {
+  for (int it = 0; it < its; it++) {
+#pragma omp parallel
+    {
+      std::vector<double> t;
+#pragma omp for schedule(dynamic, 256)
+      for (int64_t i = 0; i < Z.m; i++) {
+        const int64_t p0 = Z.rp[i], nz = Z.rp[i + 1] - p0;
+        if (nz == 0) continue;
+        const int32_t* J = Z.ci.data() + p0;
+        t.assign(nz, 0.0);
+        auto at = [&](int32_t c) -> int64_t { const int32_t* q = std::lower_bound(J, J + nz, c); return (q != J + nz && *q == c) ? q - J : -1; };
+        for (int64_t a = 0; a < nz; a++) {
+          const double z = Z.v[p0 + a];
+          if (A_ff) {
+            for (int64_t k = A_ff->rp[J[a]]; k < A_ff->rp[J[a] + 1]; k++) { const int64_t q = at(A_ff->ci[k]); if (q >= 0) t[q] += z * A_ff->v[k]; }
+          } else t[a] += z * aff_d[J[a]];
+        }
+        for (int64_t k = A_cf.rp[i]; k < A_cf.rp[i + 1]; k++) { const int64_t q = at(A_cf.ci[k]); if (q >= 0) t[q] += A_cf.v[k]; }
+        for (int64_t a = 0; a < nz; a++) Z.v[p0 + a] -= t[a] * dm[J[a]];
+      }
+    }
+  }
+}
+
+// improve_w (src/Grid_Transfer_Improve.F90:21-196): W <- W - (diag(M) (A_ff W + A_fc)) restricted to pattern(W)
+static void improve_w(Csr& W, const Csr* A_ff, const double* aff_d, const Csr& A_fc, const double* dm, int its) {
+  for (int it = 0; it < its; it++) {
+    Arr<double> nv(W.nnz());
+#pragma omp parallel
+    {
+      std::vector<double> t;
+#pragma omp for schedule(dynamic, 256)
+      for (int64_t i = 0; i < W.m; i++) {
+        const int64_t p0 = W.rp[i], nz = W.rp[i + 1] - p0;
+        if (nz == 0) continue;
+        const int32_t* J = W.ci.data() + p0;
+        t.assign(nz, 0.0);
+        auto at = [&](int32_t c) -> int64_t { const int32_t* q = std::lower_bound(J, J + nz, c); return (q != J + nz && *q == c) ? q - J : -1; };
+        auto add_row = [&](int64_t r, double a) {
+          for (int64_t k = W.rp[r]; k < W.rp[r + 1]; k++) { const int64_t q = at(W.ci[k]); if (q >= 0) t[q] += a * W.v[k]; }
+        };
+        if (A_ff) for (int64_t k = A_ff->rp[i]; k < A_ff->rp[i + 1]; k++) add_row(A_ff->ci[k], A_ff->v[k]);
+        else add_row(i, aff_d[i]);
+        for (int64_t k = A_fc.rp[i]; k < A_fc.rp[i + 1]; k++) { const int64_t q = at(A_fc.ci[k]); if (q >= 0) t[q] += A_fc.v[k]; }
+        for (int64_t a = 0; a < nz; a++) nv[p0 + a] = W.v[p0 + a] - dm[i] * t[a];
+      }
+    }
+#pragma omp parallel for schedule(static)
+    for (int64_t k = 0; k < W.nnz(); k++) W.v[k] = nv[k];
+  }
+}
+
 static void coarse_solver(const Csr& A, const AirOptions& o, InvOp& op) {
   OpView v; v.A = &A; v.n = A.m;
   build_inverse(v, o.coarsest_inverse_type, o.coarsest_poly_order, o.coarsest_inverse_sparsity_order,
@@ -205,6 +261,17 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o, SetupAc
     }
     H->timers[2] += now_s() - t0;
 
+    // diagonal of the smoother's A_ff inverse (improve_z / improve_w use only that, Grid_Transfer_Improve.F90:235-241)
+    Arr<double> inv_diag_store;
+    auto inv_diag = [&]() -> Arr<double>& {
+      if (inv_diag_store.size() == 0 && n_f > 0) {
+        inv_diag_store.alloc(n_f);
+        if (L.inv_ff.kind == InvOp::ASSEMBLED) get_diagonal(L.inv_ff.mat, inv_diag_store.data());
+        else if (L.inv_ff.kind == InvOp::DIAG) { for (int64_t i = 0; i < n_f; i++) inv_diag_store[i] = L.inv_ff.d[i]; }
+        else throw std::runtime_error("improve_z / improve_w need an assembled A_ff inverse (not matrix-free)");
+      }
+      return inv_diag_store;
+    };
     // ---- W / P
     t0 = now_s();
     Csr Mz_store;
@@ -220,14 +287,22 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o, SetupAc
       if (!product_z) throw std::runtime_error("lAIR / SAI restrictors need the one-point classical prolongator");
       L.one_point = false;
       SpgemmDrop d; d.enabled = true; d.tol = o.r_drop; d.negate = true;
-      L.W = spgemm(*Mz, Afc_w, d);
+      if (o.improve_w_its == 0) L.W = spgemm(*Mz, Afc_w, d);
+      else {
+        d.enabled = false;
+        Csr Wf = spgemm(*Mz, Afc_w, d);
+        improve_w(Wf, L.aff_diag ? nullptr : &L.A_ff, L.aff_d.data(), L.A_fc, inv_diag().data(), o.improve_w_its);
+        L.W = remove_small(Wf, o.r_drop, 1, false, 0);
+      }
     }
     H->timers[3] += now_s() - t0;
     // ---- Z / R
     t0 = now_s();
+    Csr Zfull;
     if (product_z) {
       SpgemmDrop d; d.enabled = true; d.tol = o.r_drop; d.negate = true;
-      L.Z = accel ? accel->spgemm(Acf_z, *Mz, d) : spgemm(Acf_z, *Mz, d);
+      if (o.improve_z_its == 0) L.Z = accel ? accel->spgemm(Acf_z, *Mz, d) : spgemm(Acf_z, *Mz, d);
+      else { d.enabled = false; Zfull = spgemm(Acf_z, *Mz, d); }
     } else {
       // lAIR / SAI (AIR_Operators_Setup.F90:698-778): the F neighbourhood of every C point out to
       // lair_distance comes from the dropped operators, the values from the full ones
@@ -244,8 +319,15 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o, SetupAc
         S_store = spgemm(Acf_z, *pw);
         S = &S_store;
       }
-      Csr Zfull = sai_z(*Aff_full, &L.A_cf, *S, o.z_type == 1);
+      Zfull = sai_z(*Aff_full, &L.A_cf, *S, o.z_type == 1);
+    }
+    if (!product_z || o.improve_z_its != 0) {
+      // improve_z runs on the undropped Z with the full A_ff / A_cf and the smoother's inverse
+      // (AIR_Operators_Setup.F90:819-830), then the relative row drop
+      if (o.improve_z_its != 0)
+        improve_z(Zfull, L.aff_diag ? nullptr : &L.A_ff, L.aff_d.data(), L.A_cf, inv_diag().data(), o.improve_z_its);
       L.Z = remove_small(Zfull, o.r_drop, 1, false, 0);
+      Zfull = Csr();
     }
     Mz_store = Csr();
     inv_asm = InvOp();

@@ -65,6 +65,11 @@ OPT_PAIRS = {
     "strong_r": (dict(strong_r_threshold=0.05), R.AirOptions(strong_r_threshold=0.05)),
     "strong_r_ideal_W": (dict(strong_r_threshold=0.05, one_point_classical_prolong=False),
                          R.AirOptions(strong_r_threshold=0.05, one_point_classical_prolong=False)),
+    # Richardson improvement of Z / W on their patterns (src/Grid_Transfer_Improve.F90)
+    "improve_z3": (dict(improve_z_its=3), R.AirOptions(improve_z_its=3)),
+    "improve_z1_lair": (dict(improve_z_its=1, z_type="lair"), R.AirOptions(improve_z_its=1, z_type="lair")),
+    "improve_w2": (dict(improve_w_its=2, one_point_classical_prolong=False),
+                   R.AirOptions(improve_w_its=2, one_point_classical_prolong=False)),
     "sai": (dict(inverse_type="sai"), R.AirOptions(inverse_type=R.INV_SAI)),
     "isai_s2": (dict(inverse_type="isai", inverse_sparsity_order=2), R.AirOptions(inverse_type=R.INV_ISAI, inverse_sparsity_order=2)),
 }

@@ -56,6 +56,14 @@ CASES = [
     ("Makefile:638-642 lAIR 2D advection 50x50 ffc wjacobi", R.gen_adv_diff_fd(2, 50, 50),
      R.AirOptions(a_lump=True, a_drop=1e-4, smooth_type="ffc", z_type="lair", inverse_type=R.INV_WJACOBI),
      dict(side="right", rtol=1e-10, max_it=10), 10),
+    ("Makefile:698-699 improve Z 3 its", R.gen_adv_diff_fd(2, 50, 50),
+     R.AirOptions(improve_z_its=3, a_drop=1e-3, inverse_type=R.INV_POWER), dict(max_it=3), 3),
+    ("Makefile:700-701 improve Z 1 it", R.gen_adv_diff_fd(2, 50, 50),
+     R.AirOptions(improve_z_its=1, a_drop=1e-3, inverse_type=R.INV_POWER), dict(max_it=3), 3),
+    ("Makefile:704-706 improve W 3 its", R.gen_adv_diff_fd(2, 50, 50),
+     R.AirOptions(improve_w_its=3, a_drop=1e-3, inverse_type=R.INV_POWER, one_point_classical_prolong=False), dict(max_it=4), 4),
+    ("Makefile:707-709 improve W 1 it", R.gen_adv_diff_fd(2, 50, 50),
+     R.AirOptions(improve_w_its=1, a_drop=1e-3, inverse_type=R.INV_POWER, one_point_classical_prolong=False), dict(max_it=4), 4),
     ("Makefile:556-560 auto truncation + newton coarse", R.gen_adv_diff_fd(2, 10, 10),
      R.AirOptions(auto_truncate_start_level=1, auto_truncate_tol=1e-2, a_drop=1e-3, inverse_type=R.INV_POWER,
                   **NEWTON_COARSE), dict(ksp="richardson", max_it=3), 3),
