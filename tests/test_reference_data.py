@@ -89,6 +89,24 @@ def test_oracle_meets_reference_load_test_bounds(label, fname, opts, kw, bound):
     assert reason > 0 and its <= bound, (label, its, reason)
 
 
+@pytest.mark.parametrize("label,fname,opts,kw,bound", AIR_CASES, ids=[c[0] for c in AIR_CASES])
+def test_product_host_setup_meets_reference_load_test_bounds(label, fname, opts, kw, bound):
+    """the product's own (C++) setup on the reference's data, its hierarchy cycled by the oracle: no GPU needed"""
+    import pflare_amd as P
+    from oracle import bridge
+    kw = dict(kw)
+    A, b, x0 = _problem(fname, kw.pop("b_in_f", True))
+    pc = P.PCAIR(**opts).setup_host_only(A)
+    H = bridge.hierarchy_from_product(pc, A)
+    H.coarse_richardson_its = int(opts.get("mg_coarse_ksp_max_it", 0))
+    pcf = lambda r: R.vcycle(H, r)
+    if kw.get("ksp") == "richardson":
+        x, its, reason, rn = R.ksp_richardson(A, pcf, b, x0, rtol=1e-5, max_it=bound, norm_type=kw["norm"])
+    else:
+        x, its, reason, rn = R.ksp_gmres(A, pcf, b, x0, rtol=1e-5, max_it=bound, pc_side="left")
+    assert reason > 0 and its <= bound, (label, its, reason)
+
+
 @pytest.mark.parametrize("label,opts,bound", INV_CASES, ids=[c[0] for c in INV_CASES])
 def test_oracle_pflareinv_meets_reference_bounds(label, opts, bound):
     A, b, x0 = _problem("mat_stream_2364")
