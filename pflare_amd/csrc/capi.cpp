@@ -55,6 +55,40 @@ int airhip_set_num_threads(int n, int* prev) {
 // ------------------------------------------------------------------------ host matrices
 struct airhip_hostmat_s { Csr A; };
 
+// Operators cross the boundary as caller memory: refuse anything the kernels would index out of range with
+// (an out-of-bounds access on the device can take the whole node down).  Rows must hold strictly ascending
+// column indices (the MatSeqAIJ convention the reference relies on).
+static const char* check_csr(const airhip_csr* a, bool square) {
+  if (!a) return "null matrix";
+  if (a->m < 0 || a->n < 0) return "negative matrix dimension";
+  if (square && a->m != a->n) return "operator must be square";
+  if (a->m > INT32_MAX || a->n > INT32_MAX) return "dimension exceeds 32-bit indices";
+  if (a->m == 0) return nullptr;
+  if (!a->rowptr) return "null rowptr";
+  if (a->rowptr[0] != 0) return "rowptr[0] must be 0";
+  const int64_t m = a->m, n = a->n;
+  int bad = 0;
+#pragma omp parallel for schedule(static) reduction(max : bad)
+  for (int64_t i = 0; i < m; i++) if (a->rowptr[i + 1] < a->rowptr[i]) bad = 1;
+  if (bad) return "rowptr is not non-decreasing";
+  if (a->rowptr[m] > 0 && (!a->col || !a->val)) return "null col / val";
+#pragma omp parallel for schedule(static) reduction(max : bad)
+  for (int64_t i = 0; i < m; i++) {
+    int32_t prev = -1;
+    for (int64_t k = a->rowptr[i]; k < a->rowptr[i + 1]; k++) {
+      const int32_t c = a->col[k];
+      if (c < 0 || c >= n) bad = std::max(bad, 2);
+      else if (c <= prev) bad = std::max(bad, 1);
+      prev = c;
+    }
+  }
+  if (bad == 2) return "column index out of range";
+  if (bad == 1) return "column indices of a row must be strictly ascending";
+  return nullptr;
+}
+#define REQUIRE_CSR(a, square)                                                         \
+  do { if (const char* _w = check_csr((a), (square))) { g_err = _w; return AIRHIP_ERR_ARG; } } while (0)
+
 static void view_csr(const airhip_csr* a, Csr& out) {
   out.m = a->m; out.n = a->n;
   out.rp.view(a->rowptr, a->m + 1);
@@ -91,6 +125,7 @@ int airhip_gen_adv_diff_fd(int dim, int64_t M, int64_t N, int64_t P, double u, d
 int airhip_hostmat_from_csr(const airhip_csr* A, airhip_hostmat* out) {
   API_BEGIN
   REQUIRE(A && out, AIRHIP_ERR_ARG, "null argument");
+  REQUIRE_CSR(A, false);
   auto* h = new airhip_hostmat_s; h->A = copy_csr(A); *out = h;
   API_END
 }
@@ -268,6 +303,7 @@ static void finish_device(airhip_pcair pc) {
 int airhip_pcair_setup(airhip_pcair pc, const airhip_csr* A) {
   API_BEGIN
   REQUIRE(pc && A && A->rowptr && A->m == A->n && A->m > 0, AIRHIP_ERR_ARG, "PCAIR needs a square CSR operator");
+  REQUIRE_CSR(A, true);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
     g_err = "no HIP device: the PCAIR solve phase has no CPU fallback"; return AIRHIP_ERR_HIP;
@@ -310,6 +346,7 @@ int airhip_pcair_setup(airhip_pcair pc, const airhip_csr* A) {
 extern "C" int airhip_pcair_setup_host_only(airhip_pcair pc, const airhip_csr* A) {
   API_BEGIN
   REQUIRE(pc && A && A->rowptr && A->m == A->n && A->m > 0, AIRHIP_ERR_ARG, "PCAIR needs a square CSR operator");
+  REQUIRE_CSR(A, true);
   pc->dev.reset(); pc->H.reset();
   Csr view; view_csr(A, view);
   double t0 = now_s();
@@ -348,6 +385,7 @@ static void fill_inv(const airhip_invop* in, InvOp& out, int64_t n) {
 int airhip_pcair_begin_levels(airhip_pcair pc, int no_levels, const airhip_csr* A_top) {
   API_BEGIN
   REQUIRE(pc && no_levels >= 1 && A_top, AIRHIP_ERR_ARG, "bad argument");
+  REQUIRE_CSR(A_top, true);
   pc->dev.reset();
   pc->H = std::make_unique<Hierarchy>();
   pc->H->opt = pc->opt;
@@ -365,7 +403,26 @@ int airhip_pcair_set_level(airhip_pcair pc, int level, int64_t n, int64_t n_f, i
   API_BEGIN
   REQUIRE(pc && pc->byo && pc->H, AIRHIP_ERR_STATE, "call airhip_pcair_begin_levels first");
   REQUIRE(level >= 0 && level < pc->byo_levels - 1, AIRHIP_ERR_ARG, "level out of range");
-  REQUIRE(F && C && A_fc && inv_ff && Z && (A_ff || aff_diag) && (wcol || W) && n == n_f + n_c, AIRHIP_ERR_ARG, "missing level data");
+  REQUIRE(F && C && A_fc && inv_ff && Z && (A_ff || aff_diag) && (wcol || W) && n == n_f + n_c && n_f >= 0 && n_c >= 0,
+          AIRHIP_ERR_ARG, "missing level data");
+  {
+    // shapes and index ranges of everything the device will index with
+    auto shaped = [&](const airhip_csr* a, int64_t m_, int64_t n_, const char* what) -> bool {
+      if (!a) return true;
+      const char* w = check_csr(a, false);
+      if (!w && (a->m != m_ || a->n != n_)) w = "wrong shape";
+      if (w) { g_err = std::string(what) + ": " + w; return false; }
+      return true;
+    };
+    if (!shaped(A_ff, n_f, n_f, "A_ff") || !shaped(A_fc, n_f, n_c, "A_fc") || !shaped(Z, n_c, n_f, "Z") ||
+        !shaped(W, n_f, n_c, "W") || !shaped(A_cf, n_c, n_f, "A_cf") || !shaped(A_cc, n_c, n_c, "A_cc"))
+      return AIRHIP_ERR_ARG;
+    if (inv_ff->kind == AIRHIP_OP_ASSEMBLED && !shaped(&inv_ff->mat, n_f, n_f, "inv_ff")) return AIRHIP_ERR_ARG;
+    if (inv_cc && inv_cc->kind == AIRHIP_OP_ASSEMBLED && !shaped(&inv_cc->mat, n_c, n_c, "inv_cc")) return AIRHIP_ERR_ARG;
+    for (int64_t i = 0; i < n_f; i++) REQUIRE(F[i] >= 0 && F[i] < n, AIRHIP_ERR_ARG, "F index out of range");
+    for (int64_t i = 0; i < n_c; i++) REQUIRE(C[i] >= 0 && C[i] < n, AIRHIP_ERR_ARG, "C index out of range");
+    if (wcol) for (int64_t i = 0; i < n_f; i++) REQUIRE(wcol[i] >= -1 && wcol[i] < n_c, AIRHIP_ERR_ARG, "wcol out of range");
+  }
   auto Lp = std::make_unique<Level>();
   Level& L = *Lp;
   L.n = n; L.n_f = n_f; L.n_c = n_c;
@@ -395,6 +452,11 @@ int airhip_pcair_set_level(airhip_pcair pc, int level, int64_t n, int64_t n_f, i
 int airhip_pcair_set_coarse(airhip_pcair pc, const airhip_csr* A_coarse, const airhip_invop* inv, int coarse_richardson_its) {
   API_BEGIN
   REQUIRE(pc && pc->byo && pc->H && A_coarse && inv, AIRHIP_ERR_STATE, "bad state / argument");
+  REQUIRE_CSR(A_coarse, true);
+  if (inv->kind == AIRHIP_OP_ASSEMBLED) {
+    REQUIRE_CSR(&inv->mat, true);
+    REQUIRE(inv->mat.m == A_coarse->m, AIRHIP_ERR_ARG, "coarse inverse has the wrong size");
+  }
   pc->H->coarse_A = copy_csr(A_coarse);
   fill_inv(inv, pc->H->coarse_inv, A_coarse->m);
   pc->H->opt.coarse_richardson_its = coarse_richardson_its;
@@ -658,6 +720,7 @@ struct airhip_comm_s { std::unique_ptr<Comm> c; };
 int airhip_partition_create(airhip_pcair pc, const airhip_csr* A_top, int nranks, const int32_t* owner, airhip_partition* out) {
   API_BEGIN
   REQUIRE(pc && pc->H && A_top && owner && out && nranks >= 1, AIRHIP_ERR_ARG, "partitioning needs a PCAIR with its host hierarchy");
+  REQUIRE_CSR(A_top, true);
   auto* h = new airhip_partition_s;
   view_csr(A_top, h->A_view);
   REQUIRE(pc->hint.empty() || (int64_t)pc->hint.size() == A_top->m, AIRHIP_ERR_ARG, "ordering hint: one key per row of the operator is required");
@@ -826,6 +889,7 @@ static void pcinv_build_host(airhip_pcinv pc, const Csr& A) {
 int airhip_pcinv_setup(airhip_pcinv pc, const airhip_csr* A) {
   API_BEGIN
   REQUIRE(pc && A && A->m == A->n && A->m > 0, AIRHIP_ERR_ARG, "PCPFLAREINV needs a square CSR operator");
+  REQUIRE_CSR(A, true);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
     g_err = "no HIP device: the PCPFLAREINV apply has no CPU fallback"; return AIRHIP_ERR_HIP;
@@ -840,6 +904,7 @@ int airhip_pcinv_setup(airhip_pcinv pc, const airhip_csr* A) {
 extern "C" int airhip_pcinv_setup_host_only(airhip_pcinv pc, const airhip_csr* A) {
   API_BEGIN
   REQUIRE(pc && A && A->m == A->n && A->m > 0, AIRHIP_ERR_ARG, "PCPFLAREINV needs a square CSR operator");
+  REQUIRE_CSR(A, true);
   Csr view; view_csr(A, view);
   pcinv_build_host(pc, view);
   API_END
@@ -870,6 +935,7 @@ struct airhip_mat_s { DevMat A; hipStream_t stream = nullptr; int64_t n = 0; std
 int airhip_mat_create(const airhip_csr* A, airhip_mat* out) {
   API_BEGIN
   REQUIRE(A && out, AIRHIP_ERR_ARG, "null argument");
+  REQUIRE_CSR(A, false);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_err = "no HIP device"; return AIRHIP_ERR_HIP; }
   auto* m = new airhip_mat_s;

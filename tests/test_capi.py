@@ -92,3 +92,31 @@ def test_print_stats_timings_output_has_the_reference_labels():
         assert len(re.findall(r"\b" + re.escape(label) + r"\s*:\s*(\S+)", out)) == len(levels), label
     assert re.search(r"~~~~~~~~~~~~ Coarse grid\s+(\d+)", out)
     assert re.search(r"Total cumulative setup time\s*:\s*(\S+)", out)
+
+
+def test_operators_are_validated_at_the_boundary():
+    """anything the kernels would index out of range with is refused with AIRHIP_ERR_ARG, not passed on"""
+    n = 6
+    rp = np.arange(0, 2 * n + 1, 2, dtype=np.int64)
+    good = np.array([[i, (i + 1) % n] if i < n - 1 else [0, i] for i in range(n)], dtype=np.int32)
+    good.sort(axis=1)
+    val = np.ones(2 * n)
+    ok = P.PCAIR().setup_host_only((rp, good.ravel().copy(), val, (n, n)))
+    assert ok.num_levels >= 1
+    cases = {
+        "column index out of range": good.ravel().copy(),
+        "negative": good.ravel().copy(),
+        "strictly ascending": good[:, ::-1].ravel().copy(),
+    }
+    cases["column index out of range"][3] = n
+    cases["negative"][0] = -1
+    for what, col in cases.items():
+        with pytest.raises(P.AirhipError):
+            P.PCAIR().setup_host_only((rp, col, val, (n, n)))
+        with pytest.raises(P.AirhipError):
+            P.PCPFLAREINV().setup_host_only((rp, col, val, (n, n)))
+    bad_rp = rp.copy(); bad_rp[2] = bad_rp[3] + 1
+    with pytest.raises(P.AirhipError):
+        P.PCAIR().setup_host_only((bad_rp, good.ravel().copy(), val, (n, n)))
+    with pytest.raises(P.AirhipError):
+        P.PCAIR().setup_host_only((rp, good.ravel().copy(), val, (n, n + 1)))
