@@ -54,6 +54,11 @@ def as_csr(A) -> CsrArrays:
         v._owner = A
         return v
     if hasattr(A, "indptr"):
+        # the library requires strictly ascending column indices per row (it validates and refuses otherwise);
+        # scipy products routinely come unsorted, so canonicalise a copy here
+        if hasattr(A, "has_canonical_format") and not A.has_canonical_format:
+            A = A.copy()
+            A.sum_duplicates()
         return CsrArrays(A.indptr, A.indices, A.data, A.shape)
     rowptr, col, val, shape = A
     return CsrArrays(rowptr, col, val, shape)

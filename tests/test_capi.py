@@ -120,3 +120,26 @@ def test_operators_are_validated_at_the_boundary():
         P.PCAIR().setup_host_only((bad_rp, good.ravel().copy(), val, (n, n)))
     with pytest.raises(P.AirhipError):
         P.PCAIR().setup_host_only((rp, good.ravel().copy(), val, (n, n + 1)))
+
+
+def test_bring_your_own_hierarchy_is_validated_then_needs_a_device():
+    """an oracle hierarchy passes the boundary checks; without a GPU the upload fails loudly (no CPU fallback);
+    a corrupted operand is refused before that"""
+    import torch
+    from oracle import air_ref as R, bridge
+    A = R.gen_adv_diff_fd(2, 12, 12)
+    H = R.setup_air(A, R.AirOptions(smooth_type="fcf"))
+    levels, cA, cinv = bridge.levels_for_product(H)
+    if not torch.cuda.is_available():
+        with pytest.raises(P.AirhipError, match="no HIP device"):
+            P.PCAIR().set_hierarchy(A, levels, cA, cinv)
+    bad = [dict(lv) for lv in levels]
+    z = bad[0]["Z"].tocsr().copy(); z.sum_duplicates()
+    z.indices = z.indices.copy(); z.indices[0] = z.shape[1] + 5
+    bad[0]["Z"] = P.CsrArrays(z.indptr, z.indices, z.data, z.shape)
+    with pytest.raises(P.AirhipError, match="Z: column index out of range"):
+        P.PCAIR().set_hierarchy(A, bad, cA, cinv)
+    bad = [dict(lv) for lv in levels]
+    bad[0]["F"] = np.asarray(bad[0]["F"]).copy(); bad[0]["F"][0] = A.shape[0]
+    with pytest.raises(P.AirhipError, match="F index out of range"):
+        P.PCAIR().set_hierarchy(A, bad, cA, cinv)
