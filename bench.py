@@ -174,6 +174,9 @@ def main():
         px, py, pz = D.box_dims(world, (M, M, M))
         parallelism = (f"row-block: {px}x{py}x{pz} boxes of the {M}^3 grid, one rank per GPU, hierarchy built on rank 0 "
                        f"and cut; RCCL halo exchange per sparse product, all-reduce for Krylov dots")
+        # ranks > 0 get here minutes before rank 0 (which has been building the hierarchy): wait on the host
+        # (gloo) rather than inside an RCCL collective that would spin on their GPUs for the whole setup
+        dist.barrier(group=meta)
         if staged:
             comm = D.StagedComm()
         else:

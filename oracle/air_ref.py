@@ -1130,6 +1130,7 @@ class AirOptions:
     improve_w_its: int = 0                # -pc_air_improve_w_its
     # -mg_coarse_ksp_type richardson -mg_coarse_ksp_max_it N (0 = preonly, the default)
     coarse_richardson_its: int = 0
+    coarse_lu: bool = False               # -mg_coarse_pc_type lu
     seed: int = 1
 
     def smooth_order(self):
@@ -1263,7 +1264,10 @@ def _is_diag_only(A):
     return bool(np.all(A.indices == np.arange(n)))
 
 
-def _coarse_solver(A, o: AirOptions):
+def _coarse_solver(A, o: AirOptions, final=True):
+    if o.coarse_lu and final:
+        # -mg_coarse_pc_type lu (tests/Makefile:144-147): exact solve of the coarsest operator
+        return InvOp("assembled", mat=sp.csr_matrix(np.linalg.inv(A.toarray())))
     op, _ = build_inverse(A, o.coarsest_inverse_type, o.coarsest_poly_order,
                           o.coarsest_inverse_sparsity_order, o.coarsest_matrix_free_polys,
                           o.coarsest_diag_scale_polys, o.seed)
@@ -1282,7 +1286,7 @@ def setup_air(A, o: AirOptions) -> Hierarchy:
     for our_level in range(1, o.max_levels):
         n = cur.shape[0]
         if o.auto_truncate_start_level != -1 and our_level >= o.auto_truncate_start_level:
-            cop = _coarse_solver(cur, o)
+            cop = _coarse_solver(cur, o, final=False)
             rand = uniform(o.seed + 7919, 0, n)  # PetscRandom stream differs from the poly one
             norm_b = float(np.linalg.norm(rand))
             res = cur @ apply_inv(cop, rand) - rand
@@ -1391,9 +1395,9 @@ def setup_air(A, o: AirOptions) -> Hierarchy:
         cur = coarse
     H.coarse_A = cur
     H.nnzs.append(cur.nnz)
-    if not auto_truncated:
+    if not auto_truncated or o.coarse_lu:
         H.coarse_inv = _coarse_solver(cur, o)
-    if no_levels == 1 and not auto_truncated:
+    if no_levels == 1 and not auto_truncated and not o.coarse_lu:
         # "Only a single level, defaulting to Jacobi PC" (src/AIR_MG_Setup.F90:1167-1174)
         H.coarse_inv = InvOp("diag", d=1.0 / cur.diagonal())
     return H

@@ -257,6 +257,11 @@ int airhip_pcair_set_option(airhip_pcair pc, const char* name, const char* value
   else if (k == "a_lump") o.a_lump = parse_bool(v);
   else if (k == "print_stats_timings") o.print_stats_timings = parse_bool(v);
   else if (k == "mg_coarse_ksp_max_it" || k == "-mg_coarse_ksp_max_it") o.coarse_richardson_its = I();
+  else if (k == "mg_coarse_pc_type" || k == "-mg_coarse_pc_type") {
+    if (std::string(v) == "lu") o.coarse_lu = true;
+    else if (std::string(v) == "shell" || std::string(v) == "") o.coarse_lu = false;
+    else { g_err = std::string("unsupported -mg_coarse_pc_type ") + v; return AIRHIP_ERR_UNSUPPORTED; }
+  }
   else if (k == "seed") o.seed = (uint64_t)std::atoll(v);
   else if (k == "setup_on_device") pc->setup_on_device = parse_bool(v);
   else if (k == "setup_device_min_nnz") pc->setup_device_min_nnz = std::atoll(v);

@@ -42,6 +42,7 @@ struct AirOptions {
   int lair_distance = 2;             // -pc_air_lair_distance
   int improve_z_its = 0, improve_w_its = 0;   // -pc_air_improve_z_its / -pc_air_improve_w_its
   int coarse_richardson_its = 0;  // -mg_coarse_ksp_type richardson -mg_coarse_ksp_max_it N
+  bool coarse_lu = false;         // -mg_coarse_pc_type lu: exact coarsest solve (explicit dense inverse, small systems only)
   bool print_stats_timings = false;
   uint64_t seed = 1;              // comm_rank + 1 in the reference
 

@@ -3,6 +3,7 @@
 // src/AIR_Operators_Setup.F90:36-1085, default AIRG path (z_type product, PMISR+DDC,
 // no reuse, no processor agglomeration, no near-nullspace constraints).
 #include "air.hpp"
+#include "dense.hpp"
 #include <cstdio>
 
 namespace airhip {
@@ -140,7 +141,26 @@ static void improve_w(Csr& W, const Csr* A_ff, const double* aff_d, const Csr& A
   }
 }
 
-static void coarse_solver(const Csr& A, const AirOptions& o, InvOp& op) {
+static void coarse_solver(const Csr& A, const AirOptions& o, InvOp& op, bool final_solver = false) {
+  if (o.coarse_lu && final_solver) {
+    // -mg_coarse_pc_type lu (tests/Makefile:144-147): the inverse of the coarsest operator by LU, applied as a
+    // (dense) assembled operator
+    const int64_t n = A.m;
+    if (n > 4096) throw std::runtime_error("-mg_coarse_pc_type lu: coarsest operator too large for a dense inverse (> 4096 rows)");
+    Dense D((int)n, (int)n);
+    for (int64_t i = 0; i < n; i++) for (int64_t k = A.rp[i]; k < A.rp[i + 1]; k++) D((int)i, A.ci[k]) = A.v[k];
+    op = InvOp(); op.kind = InvOp::ASSEMBLED;
+    Csr& M = op.mat; M.m = M.n = n;
+    M.rp.alloc(n + 1); M.ci.alloc(n * n); M.v.alloc(n * n);
+    for (int64_t i = 0; i <= n; i++) M.rp[i] = i * n;
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int64_t j = 0; j < n; j++) {
+      std::vector<double> e((size_t)n, 0.0); e[j] = 1.0;
+      std::vector<double> x = lu_solve(D, e);                 // column j of the inverse
+      for (int64_t i = 0; i < n; i++) { M.ci[i * n + j] = (int32_t)j; M.v[i * n + j] = x[i]; }
+    }
+    return;
+  }
   OpView v; v.A = &A; v.n = A.m;
   build_inverse(v, o.coarsest_inverse_type, o.coarsest_poly_order, o.coarsest_inverse_sparsity_order,
                 o.coarsest_matrix_free_polys, o.coarsest_diag_scale_polys, o.seed, op, nullptr);
@@ -369,16 +389,16 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o, SetupAc
   if (cur == &A0) H->coarse_A = A0.clone(); else H->coarse_A = std::move(owned);
   if (!auto_truncated) {
     double t0 = now_s();
-    if (H->levels.empty()) {
+    if (H->levels.empty() && !o.coarse_lu) {
       // "Only a single level, defaulting to Jacobi PC" (AIR_MG_Setup.F90:1167-1174)
       H->single_level_jacobi = true;
       const int64_t n = H->coarse_A.m;
       H->coarse_inv.kind = InvOp::DIAG; H->coarse_inv.d.alloc(n);
       get_diagonal(H->coarse_A, H->coarse_inv.d.data());
       for (int64_t i = 0; i < n; i++) H->coarse_inv.d[i] = 1.0 / H->coarse_inv.d[i];
-    } else coarse_solver(H->coarse_A, o, H->coarse_inv);
+    } else coarse_solver(H->coarse_A, o, H->coarse_inv, true);
     H->timers[2] += now_s() - t0;
-  }
+  } else if (o.coarse_lu) coarse_solver(H->coarse_A, o, H->coarse_inv, true);   // PETSc's option overrides the shell PC either way
   if (o.print_stats_timings)
     std::printf(" ~~~~~~~~~~~~ Coarse grid %d\n Global rows %lld\n ~~~~~~~~~~~~\n Total cumulative setup time : %.3f\n ~~~~~~~~~~~~\n",
                 H->no_levels(), (long long)H->coarse_A.m, now_s() - t_setup);

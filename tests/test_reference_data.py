@@ -30,13 +30,14 @@ AIR_CASES = [
     ("140-143 exact, newton-60 coarse", "mat_stream_2364",
      dict(EXACT, max_levels=10, coarsest_poly_order=60, coarsest_matrix_free_polys=True, coarsest_inverse_type="newton",
           max_luby_steps=3), dict(ksp="richardson", norm="unpreconditioned"), 1),
+    ("144-147 exact two-level, LU coarse solve", "spring_chain_40",
+     dict(EXACT, max_levels=2, mg_coarse_pc_type="lu"), dict(ksp="richardson", norm="unpreconditioned"), 1),
     ("157 indefinite power", "e05r0100_petsc", POWER, dict(b_in_f=False), 26),
     # assembled Newton-basis inverses with fixed sparsity (build_gmres_polynomial_newton_inverse)
     ("159 indefinite newton", "e05r0100_petsc", dict(a_drop=1e-3, inverse_type="newton"), dict(b_in_f=False), 26),
     ("162 newton order 2", "mat_stream_2364", dict(inverse_type="newton", poly_order=2), {}, 5),
     ("164 newton order 3", "mat_stream_2364", dict(inverse_type="newton", poly_order=3), {}, 5),
 ]
-# Not run: tests/Makefile:147 needs -mg_coarse_pc_type lu.
 INV_CASES = [
     ("116 pflareinv default", {}, 21),
     ("118 pflareinv power", dict(type="power"), 21),
@@ -73,6 +74,8 @@ def _oracle_opts(o):
             o[k] = _INV[o[k]]
     if "mg_coarse_ksp_max_it" in o:
         o["coarse_richardson_its"] = o.pop("mg_coarse_ksp_max_it")
+    if "mg_coarse_pc_type" in o:
+        o["coarse_lu"] = o.pop("mg_coarse_pc_type") == "lu"
     return R.AirOptions(**o)
 
 
