@@ -122,3 +122,84 @@ def test_level_sizes_of_config_table():
     assert A.shape[0] == 100000 and A.nnz == 199999
     A = R.gen_adv_diff_fd(2, 100, 100)
     assert A.nnz == 3 * 99 * 99 + (100 * 100 - 99 * 99)
+
+
+# ---- tests/ex6f.F90 (tests/Makefile:425-510): 5-point Laplacian on an m x n grid, two successive solves with the
+# diagonal raised by 2 before each; the PC is built once from the ORIGINAL matrix (":59-62", no -regen) or rebuilt
+# for each system (-regen; the reference then reuses the first setup's sparsity, here the setup is simply redone).
+# GMRES(30), left PC, rtol 1e-5, exact solution = step number, previous solution as initial guess.
+def laplace_5pt(m, n):
+    ii, jj = np.meshgrid(np.arange(m), np.arange(n), indexing="ij")
+    II = (ii * n + jj).ravel()
+    rows, cols, vals = [II], [II], [np.full(II.size, 4.0)]
+    for mask, off in ((ii > 0, -n), (ii < m - 1, n), (jj > 0, -1), (jj < n - 1, 1)):
+        r = II[mask.ravel()]
+        rows.append(r); cols.append(r + off); vals.append(np.full(r.size, -1.0))
+    A = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(m * n, m * n))
+    A.sort_indices()
+    return A
+
+
+def ex6f(opts, max_it, regen=False, m=10, n=10, nsteps=2, setup=None):
+    setup = setup or (lambda M: (lambda H: (lambda r: R.vcycle(H, r)))(R.setup_air(M, R.AirOptions(**opts))))
+    A = laplace_5pt(m, n)
+    pc = None if regen else setup(A.copy())
+    x = np.zeros(m * n)
+    worst = 0
+    for count in range(1, nsteps + 1):
+        A = (A + 2.0 * sp.identity(m * n, format="csr")).tocsr(); A.sort_indices()
+        if regen:
+            pc = setup(A)
+        b = A @ np.full(m * n, float(count))
+        x, its, reason, rn = R.ksp_gmres(A, pc, b, x, rtol=1e-5, max_it=max_it, pc_side="left")
+        assert reason > 0, (count, its, reason)
+        assert np.allclose(x, count, rtol=1e-3)
+        worst = max(worst, its)
+    return worst
+
+
+P10 = dict(a_drop=1e-3, inverse_type=R.INV_POWER)
+N10 = dict(a_drop=1e-3, inverse_type=R.INV_NEWTON)
+EX6F_CASES = [
+    ("427 power reused", P10, 10, False), ("429 power regen", P10, 3, True),
+    ("431 ideal W regen", dict(P10, one_point_classical_prolong=False), 3, True),
+    ("433 strong R regen", dict(P10, strong_r_threshold=0.01), 3, True),
+    ("435 lAIR regen", dict(P10, z_type="lair"), 3, True),
+    ("437 lAIR SAI regen", dict(P10, z_type="lair_sai"), 3, True),
+    ("443 strong threshold 0 regen", dict(P10, strong_threshold=0.0), 3, True),
+    ("447 power order 0", dict(P10, poly_order=0), 10, False), ("449 power order 0 regen", dict(P10, poly_order=0), 3, True),
+    ("451 power order 1", dict(P10, poly_order=1), 10, False), ("453 power order 1 regen", dict(P10, poly_order=1), 3, True),
+    ("455 power order 2 sparsity 2", dict(P10, poly_order=2, inverse_sparsity_order=2), 10, False),
+    ("457 power order 2 sparsity 2 regen", dict(P10, poly_order=2, inverse_sparsity_order=2), 3, True),
+    ("459 power sparsity 2 regen", dict(P10, inverse_sparsity_order=2), 3, True),
+    ("461 power sparsity 0", dict(P10, inverse_sparsity_order=0), 10, False),
+    ("463 power sparsity 0 regen", dict(P10, inverse_sparsity_order=0), 3, True),
+    ("465 newton order 0", dict(N10, poly_order=0), 10, False), ("467 newton order 0 regen", dict(N10, poly_order=0), 3, True),
+    ("469 newton order 1", dict(N10, poly_order=1), 10, False), ("471 newton order 1 regen", dict(N10, poly_order=1), 3, True),
+    ("473 newton order 2 sparsity 2", dict(N10, poly_order=2, inverse_sparsity_order=2), 10, False),
+    ("475 newton order 2 sparsity 2 regen", dict(N10, poly_order=2, inverse_sparsity_order=2), 3, True),
+    ("477 newton sparsity 2 regen", dict(N10, inverse_sparsity_order=2), 3, True),
+    ("479 newton sparsity 0", dict(N10, inverse_sparsity_order=0), 10, False),
+    ("481 newton sparsity 0 regen", dict(N10, inverse_sparsity_order=0), 3, True),
+]
+
+
+@pytest.mark.parametrize("label,opts,bound,regen", EX6F_CASES, ids=[c[0] for c in EX6F_CASES])
+def test_ex6f_successive_solves_meet_reference_bounds(label, opts, bound, regen):
+    assert ex6f(opts, bound, regen) <= bound
+
+
+_NAMES = {R.INV_POWER: "power", R.INV_NEWTON: "newton"}
+
+
+@pytest.mark.parametrize("label,opts,bound,regen", EX6F_CASES[::3], ids=[c[0] for c in EX6F_CASES[::3]])
+def test_ex6f_with_the_products_host_setup(label, opts, bound, regen):
+    """same driver, hierarchy built by the product's C++ setup and cycled by the oracle"""
+    import pflare_amd as P
+    from oracle import bridge
+    popts = dict(opts, inverse_type=_NAMES[opts["inverse_type"]])
+
+    def setup(M):
+        H = bridge.hierarchy_from_product(P.PCAIR(**popts).setup_host_only(M), M)
+        return lambda r: R.vcycle(H, r)
+    assert ex6f(opts, bound, regen, setup=setup) <= bound
