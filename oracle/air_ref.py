@@ -124,13 +124,14 @@ def gen_adv_1d(n: int) -> sp.csr_matrix:
 
 
 def gen_adv_diff_fd(dim=2, M=11, N=11, P=11, u=None, v=None, w=None, alpha=0.0,
-                    L_x=1.0, L_y=1.0, L_z=1.0, theta=None, adv_nondim=None) -> sp.csr_matrix:
+                    L_x=1.0, L_y=1.0, L_z=1.0, theta=None, adv_nondim=None, curved_velocity=False,
+                    unit_velocity_opt=True) -> sp.csr_matrix:
     """tests/adv_diff_fd.c:188-257 (option handling) and :366-586 (ComputeMat).
     Row numbering is the natural (k*N + j)*M + i of a single-rank DMDA."""
     uu, vv, ww = 1.0, 1.0, 1.0
     if theta is not None:
         uu, vv, ww = math.cos(theta), math.sin(theta), 0.0
-    unit_velocity = True
+    unit_velocity = bool(unit_velocity_opt)      # -unit_velocity (default true), tests/adv_diff_fd.c:224-231
     if u is not None or v is not None or w is not None:
         unit_velocity = False
     if u is not None:
@@ -141,6 +142,8 @@ def gen_adv_diff_fd(dim=2, M=11, N=11, P=11, u=None, v=None, w=None, alpha=0.0,
         ww = float(w)
     if adv_nondim is None:
         adv_nondim = (alpha == 0.0)
+    if curved_velocity:
+        return _gen_adv_diff_fd_curved(dim, M, N, P, alpha, L_x, L_y, L_z, adv_nondim, unit_velocity)
     vel = [uu, vv, ww]
     if unit_velocity:
         mag = math.sqrt(sum(vel[d] * vel[d] for d in range(dim)))
@@ -223,6 +226,82 @@ def gen_adv_diff_fd(dim=2, M=11, N=11, P=11, u=None, v=None, w=None, alpha=0.0,
         add3(adv_mask, 0, -1, 0, -v_loc * adv_xz)
         add3(adv_mask, -1, 0, 0, -u_loc * adv_yz)
         add3(adv_mask, 0, 0, 0, u_loc * adv_yz + v_loc * adv_xz + w_loc * adv_xy)
+    return _assemble(M * N * P, rows, cols, vals)
+
+
+def _gen_adv_diff_fd_curved(dim, M, N, P, alpha, L_x, L_y, L_z, adv_nondim, unit_velocity):
+    """-curved_velocity (tests/adv_diff_fd.c:64-98): node-wise velocity u = y, v = 1 - x (2D) or u = v = z,
+    w = 2 - x - y (3D), normalised per node with -unit_velocity (the default); same stencils as above."""
+    Hx, Hy = L_x / (M - 1), L_y / (N - 1)
+    Hz = L_z / (P - 1) if dim == 3 else 1.0
+    rows, cols, vals = [], [], []
+    if dim == 2:
+        jj, ii = np.meshgrid(np.arange(N), np.arange(M), indexing="ij")
+        ii = ii.ravel(); jj = jj.ravel(); kk = np.zeros_like(ii)
+        vel = [jj * Hy, 1.0 - ii * Hx, np.zeros(ii.size)]
+    else:
+        kk, jj, ii = np.meshgrid(np.arange(P), np.arange(N), np.arange(M), indexing="ij")
+        ii = ii.ravel(); jj = jj.ravel(); kk = kk.ravel()
+        vel = [kk * Hz, kk * Hz, 2.0 - ii * Hx - jj * Hy]
+    vel = [np.asarray(c, dtype=np.float64) for c in vel]
+    if unit_velocity:
+        mag = np.sqrt(sum(vel[d] ** 2 for d in range(dim)))
+        ok = mag > 1e-12
+        for d in range(dim):
+            vel[d] = np.where(ok, vel[d] / np.where(ok, mag, 1.0), vel[d])
+    ul, vl, wl = vel
+    rid = (kk * N + jj) * M + ii
+
+    def add(mask, di, dj, dk, val):
+        r = rid[mask]
+        rows.append(r)
+        cols.append(((kk[mask] + dk) * N + (jj[mask] + dj)) * M + (ii[mask] + di))
+        vals.append(np.full(r.size, val) if np.isscalar(val) else np.asarray(val)[mask])
+
+    if dim == 2:
+        HxdHy, HydHx = Hx / Hy, Hy / Hx
+        ax, ay = (1.0, HydHx) if adv_nondim else (Hx, Hy)
+        inflow = (ii == 0) | (jj == 0)
+        outflow = ((ii == M - 1) | (jj == N - 1)) & ~inflow
+        interior = ~(inflow | outflow)
+        add(inflow, 0, 0, 0, 1.0)
+        if alpha == 0.0:
+            adv_mask = outflow | (interior & ((ul != 0.0) | (vl != 0.0)))
+        else:
+            add(outflow, 0, 0, 0, 1.0)
+            adv_mask = interior & ((ul != 0.0) | (vl != 0.0))
+            add(interior, 0, -1, 0, -alpha * HxdHy)
+            add(interior, -1, 0, 0, -alpha * HydHx)
+            add(interior, 0, 0, 0, alpha * 2.0 * (HxdHy + HydHx))
+            add(interior, 1, 0, 0, -alpha * HydHx)
+            add(interior, 0, 1, 0, -alpha * HxdHy)
+        add(adv_mask, 0, -1, 0, -vl * ax)
+        add(adv_mask, -1, 0, 0, -ul * ay)
+        add(adv_mask, 0, 0, 0, ul * ay + vl * ax)
+        return _assemble(M * N, rows, cols, vals)
+    HyHz_Hx, HxHz_Hy, HxHy_Hz = Hy * Hz / Hx, Hx * Hz / Hy, Hx * Hy / Hz
+    a_yz, a_xz, a_xy = (HyHz_Hx / Hx, Hz / Hx, Hy / Hx) if adv_nondim else (Hy * Hz, Hx * Hz, Hx * Hy)
+    inflow = (ii == 0) | (jj == 0) | (kk == 0)
+    outflow = ((ii == M - 1) | (jj == N - 1) | (kk == P - 1)) & ~inflow
+    interior = ~(inflow | outflow)
+    moving = (ul != 0.0) | (vl != 0.0) | (wl != 0.0)
+    add(inflow, 0, 0, 0, 1.0)
+    if alpha == 0.0:
+        adv_mask = outflow | (interior & moving)
+    else:
+        add(outflow, 0, 0, 0, 1.0)
+        adv_mask = interior & moving
+        add(interior, 0, 0, -1, -alpha * HxHy_Hz)
+        add(interior, 0, -1, 0, -alpha * HxHz_Hy)
+        add(interior, -1, 0, 0, -alpha * HyHz_Hx)
+        add(interior, 0, 0, 0, alpha * 2.0 * (HyHz_Hx + HxHz_Hy + HxHy_Hz))
+        add(interior, 1, 0, 0, -alpha * HyHz_Hx)
+        add(interior, 0, 1, 0, -alpha * HxHz_Hy)
+        add(interior, 0, 0, 1, -alpha * HxHy_Hz)
+    add(adv_mask, 0, 0, -1, -wl * a_xy)
+    add(adv_mask, 0, -1, 0, -vl * a_xz)
+    add(adv_mask, -1, 0, 0, -ul * a_yz)
+    add(adv_mask, 0, 0, 0, ul * a_yz + vl * a_xz + wl * a_xy)
     return _assemble(M * N * P, rows, cols, vals)
 
 

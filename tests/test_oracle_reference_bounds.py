@@ -64,6 +64,8 @@ CASES = [
      R.AirOptions(improve_w_its=3, a_drop=1e-3, inverse_type=R.INV_POWER, one_point_classical_prolong=False), dict(max_it=4), 4),
     ("Makefile:707-709 improve W 1 it", R.gen_adv_diff_fd(2, 50, 50),
      R.AirOptions(improve_w_its=1, a_drop=1e-3, inverse_type=R.INV_POWER, one_point_classical_prolong=False), dict(max_it=4), 4),
+    ("Makefile:632-635 curved velocity 2D 50x50", R.gen_adv_diff_fd(2, 50, 50, curved_velocity=True),
+     R.AirOptions(a_lump=True), dict(side="right", rtol=1e-10, max_it=5), 5),
     ("Makefile:556-560 auto truncation + newton coarse", R.gen_adv_diff_fd(2, 10, 10),
      R.AirOptions(auto_truncate_start_level=1, auto_truncate_tol=1e-2, a_drop=1e-3, inverse_type=R.INV_POWER,
                   **NEWTON_COARSE), dict(ksp="richardson", max_it=3), 3),
