@@ -148,7 +148,7 @@ int airhip_pcair_destroy(airhip_pcair* pc);
 int airhip_pcair_num_levels(airhip_pcair pc, int* no_levels);
 int airhip_pcair_level_sizes(airhip_pcair pc, int level, int64_t* n, int64_t* n_f, int64_t* n_c,
                              int* aff_diag, int* one_point, int64_t* nnz_A);
-/* which: "F","C" (int32 index lists via idx/len), "A_ff","A_fc","A_cf","A_cc","Z","W","M_ff",
+/* which: "F","C" (int32 index lists via idx/len), "A_ff","A_fc","A_cf","A_cc","A_full","Z","W","M_ff",
  * "M_cc" (CSR), "aff_diag","M_ff_diag","M_cc_diag" (vector via vec/len), "wcol" (idx). */
 int airhip_pcair_level_get(airhip_pcair pc, int level, const char* which, airhip_csr* csr,
                            const int32_t** idx, const double** vec, int64_t* len);

@@ -828,7 +828,8 @@ def mat_mult_powers_share_sparsity(A, coeffs, sparsity_order):
     powers = [A]
     for _ in range(2, sparsity_order + 1):
         Pn = (A @ powers[-1]).tocsr(); Pn.sort_indices()
-        powers.append(Pn)
+        # MatMatMult keeps entries that cancel to exactly zero; scipy prunes them
+        powers.append(_keep_pattern(A, powers[-1], Pn))
     pat = powers[sparsity_order - 1]
     cmat = copy_plus_diag(pat)
     cmat.data *= coeffs[sparsity_order]
@@ -855,7 +856,7 @@ def mat_newton_share_sparsity(A, re, im, sparsity_order):
     n = A.shape[0]
     pat = A
     for _ in range(2, sparsity_order + 1):
-        pat = (A @ pat).tocsr()
+        pat = _pattern_product(A, pat)
     pat = copy_plus_diag(pat)
     pat.sort_indices()
 
@@ -1207,6 +1208,7 @@ class AirOptions:
     lair_distance: int = 2                # -pc_air_lair_distance
     improve_z_its: int = 0                # -pc_air_improve_z_its
     improve_w_its: int = 0                # -pc_air_improve_w_its
+    full_smoothing_up_and_down: bool = False   # -pc_air_full_smoothing_up_and_down
     # -mg_coarse_ksp_type richardson -mg_coarse_ksp_max_it N (0 = preonly, the default)
     coarse_richardson_its: int = 0
     coarse_lu: bool = False               # -mg_coarse_pc_type lu
@@ -1241,6 +1243,9 @@ class Level:
     P: sp.csr_matrix
     smooth_order: list
     aff_diag: bool
+    # -pc_air_full_smoothing_up_and_down: the level operator; its approximate inverse is then kept in inv_A_ff
+    # as the reference does (src/AIR_Operators_Setup.F90:113-119,376-395)
+    A_full: object = None
 
 
 @dataclass
@@ -1251,6 +1256,7 @@ class Hierarchy:
     coarse_richardson_its: int = 0
     A: sp.csr_matrix | None = None
     nnzs: list = field(default_factory=list)
+    full_smoothing: bool = False
 
     @property
     def no_levels(self):
@@ -1356,7 +1362,8 @@ def _coarse_solver(A, o: AirOptions, final=True):
 def setup_air(A, o: AirOptions) -> Hierarchy:
     """src/AIR_MG_Setup.F90:44-1231 (default AIRG path: PMISR+DDC, z_type product,
     no reuse, no processor agglomeration, no constraints)."""
-    H = Hierarchy(A=A.tocsr(), coarse_richardson_its=o.coarse_richardson_its)
+    H = Hierarchy(A=A.tocsr(), coarse_richardson_its=o.coarse_richardson_its,
+                  full_smoothing=o.full_smoothing_up_and_down)
     cur = A.tocsr(); cur.sort_indices()
     so = o.smooth_order()
     any_c = any(s < 0 for s in so)
@@ -1410,18 +1417,21 @@ def setup_air(A, o: AirOptions) -> Hierarchy:
         else:
             A_ff_drop, A_cf_z, A_fc_w = A_ff, A_cf, A_fc
 
-        inv_ff, inv_ff_asm = build_inverse(A_ff_op, inv_type_aff, o.poly_order, sparsity_aff,
+        # the smoother: A_ff^-1, or with full smoothing an approximate inverse of the whole level operator
+        full = o.full_smoothing_up_and_down
+        inv_ff, inv_ff_asm = build_inverse(cur if full else A_ff_op, inv_type_aff, o.poly_order, sparsity_aff,
                                            o.matrix_free_polys, o.diag_scale_polys, o.seed,
-                                           need_assembled=product_z and not r_dropped)
-        if product_z and r_dropped:
-            inv_ff_asm, _ = build_inverse(A_ff_drop, inv_type_aff, o.poly_order, sparsity_aff, False,
-                                          o.diag_scale_polys, o.seed)
+                                           need_assembled=product_z and not r_dropped and not full)
+        if product_z and (r_dropped or full):
+            # second, always assembled, inverse for the grid transfers (src/AIR_Operators_Setup.F90:413-438)
+            inv_ff_asm, _ = build_inverse(A_ff_drop if r_dropped else A_ff_op, inv_type_aff, o.poly_order,
+                                          sparsity_aff, False, o.diag_scale_polys, o.seed)
         inv_for_Z = inv_ff_asm if inv_ff_asm is not None else inv_ff
         if product_z and inv_for_Z.kind not in ("assembled", "diag"):
             raise NotImplementedError("grid transfers need an assembled A_ff inverse")
 
         A_cc = inv_cc = None
-        if any_c:
+        if any_c and not full:
             A_cc = submatrix(cur, C, C)
             inv_cc, _ = build_inverse(A_cc, o.c_inverse_type, o.c_poly_order,
                                       o.c_inverse_sparsity_order, o.matrix_free_polys,
@@ -1469,7 +1479,7 @@ def setup_air(A, o: AirOptions) -> Hierarchy:
 
         H.levels.append(Level(n=n, F=F, C=C, A_ff=A_ff_op, A_fc=A_fc, A_cf=A_cf, A_cc=A_cc,
                               inv_A_ff=inv_ff, inv_A_cc=inv_cc, Z=Z, W=W, R=R, P=P,
-                              smooth_order=smooth, aff_diag=aff_diag))
+                              smooth_order=smooth, aff_diag=aff_diag, A_full=cur if full else None))
         H.nnzs.append(cur.nnz)
         cur = coarse
     H.coarse_A = cur
@@ -1542,9 +1552,28 @@ def coarse_solve(H: Hierarchy, b):
     return x
 
 
+def vcycle_full(H: Hierarchy, b):
+    """-pc_air_full_smoothing_up_and_down (src/AIR_MG_Setup.F90:1014-1079): PCMG multiplicative V-cycle, one
+    Richardson(1) + PCMAT(inv_A) sweep on all points down (zero initial guess) and one up."""
+    bs = [np.asarray(b, dtype=np.float64)]
+    xs = []
+    for L in H.levels:
+        x = apply_inv(L.inv_A_ff, bs[-1])
+        xs.append(x)
+        bs.append(L.R @ (bs[-1] - L.A_full @ x))
+    x = coarse_solve(H, bs[-1])
+    for li in range(len(H.levels) - 1, -1, -1):
+        L = H.levels[li]
+        x = xs[li] + L.P @ x
+        x = x + apply_inv(L.inv_A_ff, bs[li] - L.A_full @ x)
+    return x
+
+
 def vcycle(H: Hierarchy, b):
     """PC_MG_KASKADE cycle: restrict b down, coarse solve, interpolate +
     FC relax on the way up."""
+    if H.full_smoothing:
+        return vcycle_full(H, b)
     bs = [np.asarray(b, dtype=np.float64)]
     for L in H.levels:
         bs.append(L.R @ bs[-1])

@@ -54,7 +54,10 @@ def hierarchy_from_product(pc, A_top) -> R.Hierarchy:
             W = sp.csr_matrix((np.ones(rows.size), (rows, wc[rows])), shape=(F.size, C.size))
         else:
             W = to_scipy(e["W"])
-        inv_ff = _inv_from_dict(e["inv_ff"], A_ff)
+        A_full = to_scipy(e["A_full"]) if e.get("A_full") is not None else None
+        inv_ff = _inv_from_dict(e["inv_ff"], A_full if A_full is not None else A_ff)
+        if A_full is not None:
+            H.full_smoothing = True
         A_cc = inv_cc = None
         if "A_cc" in e:
             A_cc = to_scipy(e["A_cc"])
@@ -62,7 +65,8 @@ def hierarchy_from_product(pc, A_top) -> R.Hierarchy:
         so = [s for s in e["smooth_order"] if s != 0]
         H.levels.append(R.Level(n=n, F=F, C=C, A_ff=A_ff, A_fc=A_fc, A_cf=A_cf, A_cc=A_cc, inv_A_ff=inv_ff,
                                 inv_A_cc=inv_cc, Z=Z, W=W, R=R.build_R(Z, F, C, n), P=R.build_P(W, F, C, n),
-                                smooth_order=so, aff_diag=e["aff_diag"] is not None and e.get("A_ff") is None))
+                                smooth_order=so, aff_diag=e["aff_diag"] is not None and e.get("A_ff") is None,
+                                A_full=A_full))
         H.nnzs.append(e["nnz_A"])
     cA, cinv = pc.export_coarse()
     H.coarse_A = to_scipy(cA)

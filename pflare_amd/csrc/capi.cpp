@@ -279,7 +279,8 @@ int airhip_pcair_set_option(airhip_pcair pc, const char* name, const char* value
   }
   else if (k == "improve_z_its") o.improve_z_its = I();
   else if (k == "improve_w_its") o.improve_w_its = I();
-  else if (k == "symmetric" || k == "cf_splitting_type" || k == "full_smoothing_up_and_down" ||
+  else if (k == "full_smoothing_up_and_down") o.full_smoothing = parse_bool(v);
+  else if (k == "symmetric" || k == "cf_splitting_type" ||
            k == "constrain_z" || k == "constrain_w" || k == "reuse_sparsity") {
     bool is_default = (std::string(v) == "0" || std::string(v) == "false" || std::string(v) == "" ) ||
                       (k == "cf_splitting_type" && std::string(v) == "pmisr_ddc");
@@ -561,6 +562,7 @@ int airhip_pcair_level_get(airhip_pcair pc, int level, const char* which, airhip
   else if (w == "A_fc") rc = give_csr(lv.A_fc);
   else if (w == "A_cf") rc = give_csr(lv.A_cf);
   else if (w == "A_cc") rc = give_csr(lv.A_cc);
+  else if (w == "A_full") rc = give_csr(lv.A_full);     /* only with full up / down smoothing */
   else if (w == "Z") rc = give_csr(lv.Z);
   else if (w == "W") rc = give_csr(lv.W);
   else if (w == "M_ff") rc = give_csr(lv.inv_ff.mat);
@@ -612,6 +614,17 @@ int airhip_pcair_complexities(airhip_pcair pc, double* grid, double* op, double*
     double nnzW = 0;
     if (l.one_point) { for (int64_t i = 0; i < l.n_f; i++) nnzW += l.wcol[i] >= 0 ? 1 : 0; } else nnzW = (double)l.W.nnz();
     double Rn = (double)l.Z.nnz() + l.n_c, Pn = nnzW + l.n_c;
+    if (l.full) {
+      // full smoothing (AIR_MG_Stats.F90:315-330): level operator + its inverse stored; one sweep down (M b, then the
+      // residual) and one up (residual, M r)
+      const double an = (double)l.A_full.nnz();
+      const bool mfl = l.inv_ff.kind == InvOp::HORNER || l.inv_ff.kind == InvOp::NEWTON;
+      const double iw = mfl ? (l.inv_ff.kind == InvOp::HORNER ? (double)l.inv_ff.coeffs.size() : (double)l.inv_ff.spmvs + 1) * an
+                            : inv_nnz(l.inv_ff, (double)l.n);
+      stor += an + inv_nnz(l.inv_ff, (double)l.n) + Rn + Pn;
+      cyc += 2.0 * (iw + an) + Rn + Pn;
+      continue;
+    }
     stor += aff + l.A_fc.nnz() + inv_nnz(l.inv_ff, l.n_f) + Rn + Pn;
     int g = 0, sf = 0, gc = 0, sc = 0;
     for (int s : l.smooth_order) { if (s > 0) { g++; sf += s; } else if (s < 0) { gc++; sc += -s; } }

@@ -202,6 +202,9 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
   auto ng = [&](const HaloHost* h) -> int64_t { return (dist && h) ? h->n_ghost : 0; };
   n_ = A_top.m;
   any_c_ = H.opt.any_c_smooths();
+  full_ = H.opt.full_smoothing && !H.levels.empty() && H.levels[0]->full;
+  if (full_ && dist) throw std::runtime_error("full up / down smoothing is not available for a distributed hierarchy");
+  if (full_) any_c_ = false;
   coarse_richardson_its_ = H.opt.coarse_richardson_its;
   levels_.clear();
   off_.assign(L, 0);
@@ -305,6 +308,40 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
     };
 
     const LevelHalos* hl = dist ? &dist->halos[l] : nullptr;
+    if (full_) {
+      // level operator and its approximate inverse in the level's ordering [F block | level l+1 ...]
+      DBuf<int32_t> pl, ipl;
+      std::vector<int32_t> ipv = inverse(perm[l]);
+      pl.upload(perm[l].data(), h.n); ipl.upload(ipv.data(), h.n);
+      upload_mat(h.A_full, ipl.p, pl.p, d.A_full, stream_);
+      std::vector<double> dg;
+      if ((h.inv_ff.kind == InvOp::HORNER || h.inv_ff.kind == InvOp::NEWTON) && h.inv_ff.diag_scale) {
+        std::vector<double> nat(h.n); get_diagonal(h.A_full, nat.data());
+        dg.resize(h.n);
+        for (int64_t i = 0; i < h.n; i++) dg[perm[l][i]] = nat[i];
+      }
+      upload_inv(h.inv_ff, d.inv_ff, &d.A_full, dg.empty() ? nullptr : dg.data(), nullptr, ipl.p, pl.p, perm[l].data());
+      d.inv_ff.n = h.n;
+      upload_mat(h.Z, ipc.p, Fcol, d.Z, stream_);
+      // the prolongator always as a matrix here (x_f += W e)
+      d.one_point = false;
+      if (h.one_point) {
+        Csr Wc; Wc.m = h.n_f; Wc.n = h.n_c; Wc.rp.alloc(h.n_f + 1);
+        Wc.rp[0] = 0;
+        for (int64_t i = 0; i < h.n_f; i++) Wc.rp[i + 1] = Wc.rp[i] + (h.wcol[i] >= 0 ? 1 : 0);
+        Wc.ci.alloc(Wc.rp[h.n_f]); Wc.v.alloc(Wc.rp[h.n_f]);
+        for (int64_t i = 0; i < h.n_f; i++) if (h.wcol[i] >= 0) { Wc.ci[Wc.rp[i]] = h.wcol[i]; Wc.v[Wc.rp[i]] = 1.0; }
+        upload_mat(Wc, Frow, pc.p, d.W, stream_);
+      } else upload_mat(h.W, Frow, pc.p, d.W, stream_);
+      d.rfull.alloc(h.n);
+      auto S = [](double nnz, double m, double n) { return 12.0 * nnz + 4.0 * (m + 1) + 8.0 * m + 8.0 * n; };
+      double nnzW = h.one_point ? 0.0 : (double)h.W.nnz();
+      if (h.one_point) for (int64_t i = 0; i < h.n_f; i++) nnzW += h.wcol[i] >= 0 ? 1 : 0;
+      cycle_bytes_ += S((double)h.Z.nnz() + h.n_c, h.n_c, h.n) + S(nnzW + h.n_c, h.n, h.n_c)
+                    + 2.0 * (d.A_full.s_bytes() + d.inv_ff.alg_bytes());
+      levels_.push_back(std::move(dl));
+      continue;
+    }
     upload_mat(h.A_fc, Frow, pc.p, d.A_fc, stream_, ng(hl ? &hl->A_fc : nullptr));   // rows F block, cols permuted coarse
     attach_halo(d.A_fc, hl ? &hl->A_fc : nullptr, perm[l + 1].data());
     upload_mat(h.Z, ipc.p, Fcol, d.Z, stream_, ng(hl ? &hl->Z : nullptr));           // rows permuted coarse, cols F block
@@ -403,6 +440,11 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
     if (coarse_richardson_its_ > 0) coarse_r_.alloc(H.coarse_A.m);
     cycle_bytes_ += coarse_inv_.alg_bytes();
   }
+  xfull_.clear();
+  if (full_) {
+    xfull_.resize(L);
+    for (int l = 1; l < L; l++) xfull_[l].alloc(l < L - 1 ? H.levels[l]->n : H.coarse_A.m);
+  }
   cb_.alloc(n_); cx_.alloc(n_);
   b_ptr_.assign(L, nullptr);
   b_sep_.clear(); b_sep_.resize(L);
@@ -418,7 +460,7 @@ double DevPCAIR::storage_bytes() const {
   double b = 0;
   auto sb = [&](const DevMat& m) { if (m.valid()) b += 12.0 * m.nnz + 4.0 * m.m + 12.0 * (m.nblocks + 1); };
   sb(A_perm_); sb(coarse_A_); sb(coarse_inv_.mat);
-  for (auto& l : levels_) { sb(l->A_ff); sb(l->A_fc); sb(l->A_cf); sb(l->A_cc); sb(l->Z); sb(l->W); sb(l->inv_ff.mat); sb(l->inv_cc.mat); }
+  for (auto& l : levels_) { sb(l->A_ff); sb(l->A_fc); sb(l->A_cf); sb(l->A_cc); sb(l->Z); sb(l->W); sb(l->inv_ff.mat); sb(l->inv_cc.mat); sb(l->A_full); }
   return b;
 }
 
@@ -567,7 +609,52 @@ void DevPCAIR::c_smooths(DevLevel& L, int li, bool first, int its) {
   }
 }
 
+// x_L = M_L b_L (KSPPREONLY) or N Richardson steps (-mg_coarse_ksp_type richardson)
+void DevPCAIR::coarse_solve(const double* bL, double* xL) {
+  const int L = no_levels();
+  if (coarse_richardson_its_ <= 0) { apply_inv(coarse_inv_, bL, xL, false, L - 1, "coarse x=M*b"); return; }
+  launch_fill(coarse_inv_.n, 0.0, xL, stream_);
+  for (int it = 0; it < coarse_richardson_its_; it++) {
+    const double* r = bL;
+    if (it > 0) {
+      SpmvEpi e; e.out = coarse_r_.p; e.alpha = -1.0; e.z = bL; e.beta = 1.0;
+      spmv(coarse_A_, xL, e, "coarse r=b-A*x", L - 1);
+      r = coarse_r_.p;
+    }
+    apply_inv(coarse_inv_, r, xL, true, L - 1, "coarse x+=M*r");
+  }
+}
+
+// -pc_air_full_smoothing_up_and_down: PCMG multiplicative V(1,1) cycle, Richardson(1) + PCMAT(inv_A) on all points
+// (src/AIR_MG_Setup.F90:1014-1079).  Level-l vectors are laid out [F block | level l+1 ...], so R = [Z I] turns the
+// C part of the level's residual into the next right-hand side in place, and P = [W; I] adds the coarse solution
+// to the C part and W e to the F part.
+void DevPCAIR::vcycle_full() {
+  const int L = no_levels();
+  auto X = [&](int l) { return l == 0 ? xbase_ : xfull_[l].p; };
+  auto B = [&](int l) -> const double* { return l == 0 ? b0_ : levels_[l - 1]->rfull.p + levels_[l - 1]->n_f; };
+  for (int l = 0; l + 1 < L; l++) {
+    DevLevel& Lv = *levels_[l];
+    apply_inv(Lv.inv_ff, B(l), X(l), false, l, "down x=M*b");                       // zero initial guess
+    SpmvEpi e; e.out = Lv.rfull.p; e.alpha = -1.0; e.z = B(l); e.beta = 1.0;
+    spmv(Lv.A_full, X(l), e, "down r=b-A*x", l);
+    SpmvEpi e2; e2.out = Lv.rfull.p + Lv.n_f; e2.alpha = 1.0; e2.z = Lv.rfull.p + Lv.n_f; e2.beta = 1.0;
+    spmv(Lv.Z, Lv.rfull.p, e2, "restrict(r_c+=Z*r_f)", l);
+  }
+  coarse_solve(B(L - 1), X(L - 1));
+  for (int l = L - 2; l >= 0; l--) {
+    DevLevel& Lv = *levels_[l];
+    launch_axpby(Lv.n_c, 1.0, X(l + 1), 1.0, X(l) + Lv.n_f, X(l) + Lv.n_f, stream_);   // x_c += e
+    SpmvEpi e; e.out = X(l); e.alpha = 1.0; e.z = X(l); e.beta = 1.0;
+    spmv(Lv.W, X(l + 1), e, "prolong(x_f+=W*e)", l);
+    SpmvEpi e2; e2.out = Lv.rfull.p; e2.alpha = -1.0; e2.z = B(l); e2.beta = 1.0;
+    spmv(Lv.A_full, X(l), e2, "up r=b-A*x", l);
+    apply_inv(Lv.inv_ff, Lv.rfull.p, X(l), true, l, "up x+=M*r");
+  }
+}
+
 void DevPCAIR::vcycle() {
+  if (full_) { vcycle_full(); return; }
   const int L = no_levels();
   // DOWN: b_{l+1} = b_c + Z b_f (identity block of R=[Z I] is the in-place b_c)
   for (int l = 0; l + 1 < L; l++) {
@@ -575,23 +662,7 @@ void DevPCAIR::vcycle() {
     SpmvEpi e; e.out = bvec(l + 1); e.alpha = 1.0; e.z = bvec(l) + Lv.n_f; e.beta = 1.0;
     spmv(Lv.Z, bvec(l), e, "restrict(b_c+=Z*b_f)", l);
   }
-  // COARSE: x_L = M_L b_L (KSPPREONLY) or N Richardson steps
-  {
-    double* xL = xvec(L - 1); const double* bL = bvec(L - 1);
-    if (coarse_richardson_its_ <= 0) apply_inv(coarse_inv_, bL, xL, false, L - 1, "coarse x=M*b");
-    else {
-      launch_fill(coarse_inv_.n, 0.0, xL, stream_);
-      for (int it = 0; it < coarse_richardson_its_; it++) {
-        const double* r = bL;
-        if (it > 0) {
-          SpmvEpi e; e.out = coarse_r_.p; e.alpha = -1.0; e.z = bL; e.beta = 1.0;
-          spmv(coarse_A_, xL, e, "coarse r=b-A*x", L - 1);
-          r = coarse_r_.p;
-        }
-        apply_inv(coarse_inv_, r, xL, true, L - 1, "coarse x+=M*r");
-      }
-    }
-  }
+  coarse_solve(bvec(L - 1), xvec(L - 1));
   // UP: x_l = P x_{l+1} (x_c is in place), then FC relaxation
   for (int l = L - 2; l >= 0; l--) {
     DevLevel& Lv = *levels_[l];

@@ -54,7 +54,11 @@ struct DevLevel {
   int smooth_order[10] = {0};
   DBuf<double> t4, r, t4c, rc;
   int64_t nnz_A = 0;
-  ~DevLevel() { devmat_free(A_ff); devmat_free(A_fc); devmat_free(A_cf); devmat_free(A_cc); devmat_free(Z); devmat_free(W); }
+  // full up / down smoothing: the level operator in the level's hierarchical ordering (inv_ff is then n x n) and the
+  // residual of the level, whose C part is the next level's right-hand side
+  DevMat A_full;
+  DBuf<double> rfull;
+  ~DevLevel() { devmat_free(A_ff); devmat_free(A_fc); devmat_free(A_cf); devmat_free(A_cc); devmat_free(Z); devmat_free(W); devmat_free(A_full); }
 };
 
 // one record per call site; `kernel` names the HIP kernel function the site launches (what a
@@ -107,6 +111,10 @@ class DevPCAIR {
 
  private:
   void vcycle();                                        // cb_ -> cx_
+  void vcycle_full();                                   // -pc_air_full_smoothing_up_and_down
+  void coarse_solve(const double* bL, double* xL);
+  bool full_ = false;
+  std::vector<DBuf<double>> xfull_;                     // full smoothing: solutions of levels >= 1
   void run_cycle();                                     // vcycle, through a HIP graph when enabled
   void f_smooths(DevLevel& L, int li, bool first, int its);
   void c_smooths(DevLevel& L, int li, bool first, int its);

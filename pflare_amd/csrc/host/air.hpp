@@ -41,6 +41,10 @@ struct AirOptions {
   int z_type = 0;                    // -pc_air_z_type: 0 product (AIRG), 1 lair, 2 lair_sai (src/Pflare_Parameters.F90:30-32)
   int lair_distance = 2;             // -pc_air_lair_distance
   int improve_z_its = 0, improve_w_its = 0;   // -pc_air_improve_z_its / -pc_air_improve_w_its
+  // -pc_air_full_smoothing_up_and_down: multiplicative V-cycle with one sweep of x += M (b - A x) on ALL points down
+  // and up instead of the F/C relaxation on the way up (src/AIR_MG_Setup.F90:1014-1079); M = approximate inverse
+  // of the whole level operator, kept in inv_ff as the reference keeps it in inv_A_ff
+  bool full_smoothing = false;
   int coarse_richardson_its = 0;  // -mg_coarse_ksp_type richardson -mg_coarse_ksp_max_it N
   bool coarse_lu = false;         // -mg_coarse_pc_type lu: exact coarsest solve (explicit dense inverse, small systems only)
   bool print_stats_timings = false;
@@ -77,6 +81,8 @@ struct Level {
   Csr W;                         // general W (n_f x n_c) when !one_point
   int smooth_order[10] = {0};
   int64_t nnz_A = 0;             // nnz of the level operator (for complexities)
+  bool full = false;             // full up / down smoothing: inv_ff is n x n and A_full holds the level operator
+  Csr A_full;
 };
 
 struct Hierarchy {

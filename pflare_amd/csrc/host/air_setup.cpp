@@ -263,18 +263,24 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o, SetupAc
     if (L.aff_diag) aff.diag = L.aff_d.data(); else aff.A = &L.A_ff;
     InvOp inv_asm;
     const bool product_z = o.z_type == 0;
-    build_inverse(aff, inv_type_aff, o.poly_order, sparsity_aff, o.matrix_free_polys, o.diag_scale_polys,
-                  o.seed, L.inv_ff, (product_z && !r_dropped) ? &inv_asm : nullptr);
-    if (product_z && r_dropped) {
-      // a second, always assembled, inverse of the dropped A_ff (AIR_Operators_Setup.F90:413-438)
-      OpView affd; affd.n = n_f; affd.A = &Aff_drop;
-      InvOp unused;
+    const bool full = o.full_smoothing;
+    if (full && (o.improve_z_its || o.improve_w_its))
+      throw std::runtime_error("improve_z / improve_w are not available with full up / down smoothing");
+    // the smoother: A_ff^-1, or with full smoothing an inverse of the whole level operator (AIR_Operators_Setup.F90:113-119)
+    OpView sm = aff;
+    if (full) { sm = OpView(); sm.A = cur; sm.n = n; }
+    build_inverse(sm, inv_type_aff, o.poly_order, sparsity_aff, o.matrix_free_polys, o.diag_scale_polys,
+                  o.seed, L.inv_ff, (product_z && !r_dropped && !full) ? &inv_asm : nullptr);
+    if (product_z && (r_dropped || full)) {
+      // a second, always assembled, inverse of the (dropped) A_ff for the grid transfers (AIR_Operators_Setup.F90:413-438)
+      OpView affd = aff;
+      if (r_dropped) { affd = OpView(); affd.n = n_f; affd.A = &Aff_drop; }
       build_inverse(affd, inv_type_aff, o.poly_order, sparsity_aff, false, o.diag_scale_polys, o.seed, inv_asm, nullptr);
     }
     const InvOp& invZ = (inv_asm.kind != InvOp::NONE) ? inv_asm : L.inv_ff;
     if (product_z && invZ.kind != InvOp::ASSEMBLED && invZ.kind != InvOp::DIAG)
       throw std::runtime_error("grid transfers need an assembled A_ff inverse");
-    if (any_c) {
+    if (any_c && !full) {
       OpView acc; acc.A = &L.A_cc; acc.n = n_c;
       build_inverse(acc, o.c_inverse_type, o.c_poly_order, o.c_inverse_sparsity_order, o.matrix_free_polys,
                     o.diag_scale_polys, o.seed, L.inv_cc, nullptr);
@@ -380,6 +386,10 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o, SetupAc
                   H->timers[0], H->timers[1], 0.0, H->timers[2], H->timers[4], H->timers[3], 0.0, H->timers[5], 0.0, H->timers[6],
                   H->timers[7]);
     if (o.print_stats_timings) std::fflush(stdout);
+    if (full) {      // the cycle needs the level operator itself
+      L.full = true;
+      if (cur == &owned) L.A_full = std::move(owned); else L.A_full = A0.clone();
+    }
     H->levels.push_back(std::move(Lp));
     owned = std::move(coarse);
     cur = &owned;

@@ -207,6 +207,7 @@ struct Partitioner::Impl {
 Partitioner::~Partitioner() = default;
 
 Partitioner::Partitioner(const Hierarchy& G, const Csr& A_top, int nranks, const int32_t* owner, const int64_t* hint) : impl_(new Impl) {
+  if (G.opt.full_smoothing) throw std::runtime_error("full up / down smoothing is not available for a distributed hierarchy");
   Impl& I = *impl_;
   I.G = &G; I.A_top = &A_top; I.N = nranks; I.hint = hint;
   const int L = G.no_levels();

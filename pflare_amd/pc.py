@@ -315,13 +315,18 @@ class PCAIR:
             out["wcol"] = self._get(level, "wcol")
         else:
             out["W"] = self._get(level, "W")
+        try:        # only a hierarchy built with full_smoothing_up_and_down holds the level operator
+            out["A_full"] = self._get(level, "A_full")
+        except AirhipError:
+            pass
+        full = "A_full" in out
         inv = airhip_invop()
         check(lib().airhip_pcair_level_inv(self._h, level, 0, C.byref(inv)))
-        out["inv_ff"] = _invop_to_dict(inv, s["n_f"], copy)
+        out["inv_ff"] = _invop_to_dict(inv, s["n"] if full else s["n_f"], copy)   # n x n with full smoothing
         so = (C.c_int * 10)()
         check(lib().airhip_pcair_level_smooth_order(self._h, level, so))
         out["smooth_order"] = [int(v) for v in so]
-        if any(v < 0 for v in out["smooth_order"]):
+        if any(v < 0 for v in out["smooth_order"]) and not full:
             out["A_cc"] = self._get(level, "A_cc")
             check(lib().airhip_pcair_level_inv(self._h, level, 1, C.byref(inv)))
             out["inv_cc"] = _invop_to_dict(inv, s["n_c"], copy)

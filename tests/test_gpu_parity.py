@@ -56,6 +56,11 @@ CASES = {
     "adv3d_10_lair_rthr": (dict(dim=3, M=10, N=10, P=10), dict(z_type="lair", strong_r_threshold=0.01, inverse_type="power")),
     "diff2d_16_sai": (dict(dim=2, M=16, N=16, u=0, v=0, alpha=1.0), dict(inverse_type="sai", a_drop=1e-3)),
     "adv2d_24_newton": (dict(dim=2, M=24, N=24), dict(inverse_type="newton", poly_order=3)),
+    # -pc_air_full_smoothing_up_and_down: multiplicative V(1,1) cycle on all points (src/AIR_MG_Setup.F90:1014-1079)
+    "adv2d_24_full": (dict(dim=2, M=24, N=24), dict(full_smoothing_up_and_down=True)),
+    "adv3d_10_full_mf": (dict(dim=3, M=10, N=10, P=10), dict(full_smoothing_up_and_down=True, matrix_free_polys=True, a_lump=True)),
+    "diff2d_16_full_ideal_W": (dict(dim=2, M=16, N=16, u=0, v=0, alpha=1.0),
+                               dict(full_smoothing_up_and_down=True, one_point_classical_prolong=False, inverse_type="neumann")),
     "adv2d_16_fc": (dict(dim=2, M=16, N=16), dict(smooth_type="fc")),
     "adv2d_16_fcf": (dict(dim=2, M=16, N=16), dict(smooth_type="fcf")),
     "diff2d_12_diagscale": (dict(dim=2, M=12, N=12, u=0, v=0, alpha=1.0), dict(diag_scale_polys=True)),
@@ -113,6 +118,8 @@ KSP_CASES = [
     ("adv2d_16_fc", "gmres", "left", "preconditioned", 1e-5, 3),       # tests/Makefile:300 (<= 3)
     ("adv2d_30_lair_ffc", "gmres", "right", "preconditioned", 1e-10, 10),   # tests/Makefile:638-642 shape
     ("diff2d_16_sai", "gmres", "left", "preconditioned", 1e-5, 6),
+    ("adv3d_10_full_mf", "gmres", "right", "preconditioned", 1e-10, 12),
+    ("diff2d_16_full_ideal_W", "gmres", "left", "preconditioned", 1e-5, 8),
 ]
 
 

@@ -70,6 +70,10 @@ OPT_PAIRS = {
     "improve_z1_lair": (dict(improve_z_its=1, z_type="lair"), R.AirOptions(improve_z_its=1, z_type="lair")),
     "improve_w2": (dict(improve_w_its=2, one_point_classical_prolong=False),
                    R.AirOptions(improve_w_its=2, one_point_classical_prolong=False)),
+    # full up / down smoothing: inv_A_ff is the inverse of the whole level operator (src/AIR_Operators_Setup.F90:113-119)
+    "full_smoothing": (dict(full_smoothing_up_and_down=True), R.AirOptions(full_smoothing_up_and_down=True)),
+    "full_smoothing_rthr": (dict(full_smoothing_up_and_down=True, strong_r_threshold=0.05, inverse_sparsity_order=2),
+                            R.AirOptions(full_smoothing_up_and_down=True, strong_r_threshold=0.05, inverse_sparsity_order=2)),
     "sai": (dict(inverse_type="sai"), R.AirOptions(inverse_type=R.INV_SAI)),
     "isai_s2": (dict(inverse_type="isai", inverse_sparsity_order=2), R.AirOptions(inverse_type=R.INV_ISAI, inverse_sparsity_order=2)),
 }
@@ -241,7 +245,7 @@ def test_auto_truncation_and_options():
     with pytest.raises(P.AirhipError):
         P.PCAIR(z_type="lair_product")
     with pytest.raises(P.AirhipError):
-        P.PCAIR(full_smoothing_up_and_down=True)
+        P.PCAIR(symmetric=True)
 
 
 def test_host_setup_is_bitwise_reproducible_across_thread_counts():
