@@ -456,12 +456,54 @@ def ddc(A, markers, fraction_swap):
     return markers
 
 
+def ddc_diag_dom(A, markers, target, seed):
+    """The max_dd_ratio path of ddc / ddc_cpu (src/DDC_Module.F90:56-82, 301-392): while some F row is less
+    diagonally dominant in A_ff than `target`, swap to C an independent set (in A_ff + A_ff^T) of the worst of those
+    rows - PMISR on the measure max(10, 2 max_ratio) - (ratio - rand * 1e-10), rows already below the target
+    excluded.  Returns (markers, max ratio found before the swap)."""
+    F, ratio_f = diag_dom_ratio(A, markers)
+    max_ratio = float(ratio_f.max()) if F.size else 0.0
+    if max_ratio < target:
+        return markers, max_ratio
+    n = A.shape[0]
+    ratio = np.zeros(n); ratio[F] = ratio_f
+    rnd = uniform(seed + 104729, 0, n)
+    measure = np.full(n, np.inf)
+    measure[F] = max(10.0, 2.0 * max_ratio) - (ratio[F] - rnd[F] / 1e10)
+    assigned = np.ones(n, dtype=bool)
+    cand = F[ratio_f >= target]
+    assigned[cand] = False
+    rows = _rows_of(A); cols = A.indices
+    sel = (markers[rows] == F_POINT) & (markers[cols] == F_POINT) & (rows != cols)
+    ei = np.concatenate([rows[sel], cols[sel]]); ej = np.concatenate([cols[sel], rows[sel]])
+    swap = np.zeros(n, dtype=bool)
+    while not assigned.all():
+        live = ~assigned[ei] & ~assigned[ej]
+        li, lj = ei[live], ej[live]
+        worse = (measure[li] > measure[lj]) | ((measure[li] == measure[lj]) & (li > lj))
+        bad = np.zeros(n, dtype=bool)
+        bad[li[worse]] = True
+        in_set = ~assigned & ~bad
+        swap |= in_set
+        assigned[in_set] = True
+        assigned[ej[in_set[ei]]] = True
+    markers = markers.copy()
+    markers[swap] *= -1
+    return markers, max_ratio
+
+
 def compute_cf_splitting(A, strong_threshold=0.5, ddc_its=1, ddc_fraction=_f32(0.1),
-                         symmetric=False, seed=1, max_luby_steps=-1):
-    """src/CF_Splitting.F90:235-392 for CF_PMISR_DDC."""
+                         symmetric=False, seed=1, max_luby_steps=-1, cf_splitting_type="pmisr_ddc"):
+    """src/CF_Splitting.F90:235-392 for CF_PMISR_DDC and CF_DIAG_DOM (the latter repeats the cleanup until every
+    F row reaches the diagonal dominance ratio given by strong_threshold, :361-392)."""
     S = generate_sabs(A, strong_threshold, not symmetric)
     markers = pmisr(S, seed, max_luby_steps)
-    if strong_threshold != 0.0:
+    if strong_threshold != 0.0 and cf_splitting_type == "diag_dom":
+        while True:
+            markers, achieved = ddc_diag_dom(A, markers, strong_threshold, seed)
+            if achieved < strong_threshold:
+                break
+    elif strong_threshold != 0.0:
         for _ in range(ddc_its):
             markers = ddc(A, markers, ddc_fraction)
     F = np.flatnonzero(markers == F_POINT).astype(np.int64)
@@ -1209,6 +1251,7 @@ class AirOptions:
     improve_z_its: int = 0                # -pc_air_improve_z_its
     improve_w_its: int = 0                # -pc_air_improve_w_its
     full_smoothing_up_and_down: bool = False   # -pc_air_full_smoothing_up_and_down
+    cf_splitting_type: str = "pmisr_ddc"       # -pc_air_cf_splitting_type pmisr_ddc | diag_dom
     # -mg_coarse_ksp_type richardson -mg_coarse_ksp_max_it N (0 = preonly, the default)
     coarse_richardson_its: int = 0
     coarse_lu: bool = False               # -mg_coarse_pc_type lu
@@ -1381,7 +1424,7 @@ def setup_air(A, o: AirOptions) -> Hierarchy:
                 H.coarse_inv = cop
         if not auto_truncated:
             F, C = compute_cf_splitting(cur, o.strong_threshold, o.ddc_its, o.ddc_fraction,
-                                        o.symmetric, o.seed, o.max_luby_steps)
+                                        o.symmetric, o.seed, o.max_luby_steps, o.cf_splitting_type)
             n_f, n_c = F.size, C.size
         else:
             n_f = n_c = 0

@@ -280,10 +280,14 @@ int airhip_pcair_set_option(airhip_pcair pc, const char* name, const char* value
   else if (k == "improve_z_its") o.improve_z_its = I();
   else if (k == "improve_w_its") o.improve_w_its = I();
   else if (k == "full_smoothing_up_and_down") o.full_smoothing = parse_bool(v);
-  else if (k == "symmetric" || k == "cf_splitting_type" ||
-           k == "constrain_z" || k == "constrain_w" || k == "reuse_sparsity") {
-    bool is_default = (std::string(v) == "0" || std::string(v) == "false" || std::string(v) == "" ) ||
-                      (k == "cf_splitting_type" && std::string(v) == "pmisr_ddc");
+  else if (k == "cf_splitting_type") {
+    std::string c(v);
+    if (c == "pmisr_ddc" || c == "0") o.cf_splitting_type = 0;
+    else if (c == "diag_dom" || c == "1") o.cf_splitting_type = 1;
+    else { g_err = "-pc_air_cf_splitting_type " + c + " is outside this build's scope (pmisr_ddc, diag_dom)"; return AIRHIP_ERR_UNSUPPORTED; }
+  }
+  else if (k == "symmetric" || k == "constrain_z" || k == "constrain_w" || k == "reuse_sparsity") {
+    bool is_default = (std::string(v) == "0" || std::string(v) == "false" || std::string(v) == "" );
     if (!is_default) { g_err = "option -pc_air_" + k + " is outside this build's scope (SURVEY 8f)"; return AIRHIP_ERR_UNSUPPORTED; }
   } else { g_err = "unknown option -pc_air_" + k; return AIRHIP_ERR_ARG; }
   if (rc) return rc;

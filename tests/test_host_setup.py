@@ -74,6 +74,9 @@ OPT_PAIRS = {
     "full_smoothing": (dict(full_smoothing_up_and_down=True), R.AirOptions(full_smoothing_up_and_down=True)),
     "full_smoothing_rthr": (dict(full_smoothing_up_and_down=True, strong_r_threshold=0.05, inverse_sparsity_order=2),
                             R.AirOptions(full_smoothing_up_and_down=True, strong_r_threshold=0.05, inverse_sparsity_order=2)),
+    # CF_DIAG_DOM: DDC repeated until every F row reaches the diagonal-dominance ratio (src/CF_Splitting.F90:361-392)
+    "diag_dom_0.9": (dict(cf_splitting_type="diag_dom", strong_threshold=0.9), R.AirOptions(cf_splitting_type="diag_dom", strong_threshold=0.9)),
+    "diag_dom_0.3": (dict(cf_splitting_type="diag_dom", strong_threshold=0.3), R.AirOptions(cf_splitting_type="diag_dom", strong_threshold=0.3)),
     "sai": (dict(inverse_type="sai"), R.AirOptions(inverse_type=R.INV_SAI)),
     "isai_s2": (dict(inverse_type="isai", inverse_sparsity_order=2), R.AirOptions(inverse_type=R.INV_ISAI, inverse_sparsity_order=2)),
 }
@@ -246,6 +249,8 @@ def test_auto_truncation_and_options():
         P.PCAIR(z_type="lair_product")
     with pytest.raises(P.AirhipError):
         P.PCAIR(symmetric=True)
+    with pytest.raises(P.AirhipError):
+        P.PCAIR(cf_splitting_type="agg")
 
 
 def test_host_setup_is_bitwise_reproducible_across_thread_counts():

@@ -66,6 +66,11 @@ CASES = [
      R.AirOptions(improve_w_its=1, a_drop=1e-3, inverse_type=R.INV_POWER, one_point_classical_prolong=False), dict(max_it=4), 4),
     ("Makefile:632-635 curved velocity 2D 50x50", R.gen_adv_diff_fd(2, 50, 50, curved_velocity=True),
      R.AirOptions(a_lump=True), dict(side="right", rtol=1e-10, max_it=5), 5),
+    ("Makefile:306 diag_dom CF splitting 10x10", R.gen_adv_diff_fd(2, 10, 10),
+     R.AirOptions(cf_splitting_type="diag_dom", strong_threshold=0.9), dict(max_it=4), 4),
+    ("Makefile:659-663 diag_dom max DD ratio 100x100", R.gen_adv_diff_fd(2, 100, 100),
+     R.AirOptions(cf_splitting_type="diag_dom", strong_threshold=0.50001, a_lump=True, a_drop=1e-4, inverse_type=R.INV_POWER),
+     dict(side="right", rtol=1e-10, max_it=7), 7),
     ("Makefile:556-560 auto truncation + newton coarse", R.gen_adv_diff_fd(2, 10, 10),
      R.AirOptions(auto_truncate_start_level=1, auto_truncate_tol=1e-2, a_drop=1e-3, inverse_type=R.INV_POWER,
                   **NEWTON_COARSE), dict(ksp="richardson", max_it=3), 3),
