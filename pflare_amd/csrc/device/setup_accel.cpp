@@ -5,6 +5,10 @@
 #include "setup_accel.hpp"
 #include "dev.hpp"
 #include "spgemm.hpp"
+#include "../host/air.hpp"
+#include <cmath>
+#include <cstdlib>
+#include <vector>
 
 namespace airhip {
 
@@ -44,6 +48,119 @@ struct DevSetupAccel final : SetupAccel {
     Csr C = down(dC);
     dcsr_free(dC);
     return C;
+  }
+
+  // Auto-truncation test on the device: Arnoldi (classical Gram-Schmidt with the multi-dot / multi-axpy kernels of
+  // the Krylov solvers) -> harmonic-Ritz / Leja roots on the host (tiny) -> Newton-basis apply -> residual.
+  bool truncation_ratio(const Csr& A, int inverse_type, int poly_order, uint64_t seed, double& ratio) override {
+    if (A.nnz() < min_nnz) return false;                     // small levels: the host is as fast
+    static const bool enabled = [] { const char* e = std::getenv("AIRHIP_DEVICE_TRUNC"); return !(e && e[0] == '0'); }();
+    if (!enabled) return false;
+    if (inverse_type != INV_NEWTON && inverse_type != INV_NEWTON_NO_EXTRA) return false;
+    const int64_t n = A.m;
+    const int p = poly_order;
+    if (p < 1 || (int64_t)p + 1 > n) return false;
+    struct Bufs {
+      std::vector<void*> ptrs; DevMat M;
+      ~Bufs() { for (void* q : ptrs) if (q) (void)hipFree(q); devmat_free(M); }
+      double* alloc(size_t count) { void* q = nullptr; HIP_CHECK(hipMalloc(&q, sizeof(double) * std::max<size_t>(count, 1))); ptrs.push_back(q); return (double*)q; }
+    } B;
+    // the level operator: still resident from the previous level's R*A*P, or uploaded once
+    {
+      const bool have = resident_key && resident_key == (const void*)A.rp.data() && resident.m == A.m && resident.nnz == A.nnz();
+      DCsr dA = have ? resident : up(A);
+      devmat_from_csr_device(dA.m, dA.n, dA.rp, dA.ci, dA.v, nullptr, nullptr, B.M, stream);
+      HIP_CHECK(hipStreamSynchronize(stream));
+      if (!have) dcsr_free(dA);
+    }
+    const double t0 = now_s();
+    double* V = B.alloc((size_t)(p + 2) * (size_t)n);
+    double* w = B.alloc((size_t)n);
+    double* scratch = B.alloc((size_t)mdot_scratch_doubles(p + 2));
+    double* d_small = B.alloc((size_t)(p + 4));
+    std::vector<double> hv((size_t)n), h((size_t)p + 2), H((size_t)(p + 2) * (size_t)(p + 1), 0.0);
+    auto norm_of = [&](const double* x) {
+      launch_mdot(n, x, x, n, 1, scratch, d_small, stream);
+      double v = 0.0;
+      HIP_CHECK(hipMemcpyAsync(&v, d_small, sizeof(double), hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+      return std::sqrt(v);
+    };
+    krylov_start_vector(seed, n, hv.data());
+    HIP_CHECK(hipMemcpyAsync(V, hv.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, stream));
+    const double beta = norm_of(V);
+    if (!(beta > 0.0)) return false;
+    launch_axpby(n, 1.0 / beta, V, 0.0, nullptr, V, stream);
+    int m_used = p + 1;
+    for (int m = 1; m <= p + 1; m++) {
+      SpmvEpi e; e.out = w;
+      launch_spmv(B.M, V + (size_t)(m - 1) * (size_t)n, e, stream);
+      launch_mdot(n, w, V, n, m, scratch, d_small, stream);
+      HIP_CHECK(hipMemcpyAsync(h.data(), d_small, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+      for (int i = 0; i < m; i++) { H[(size_t)(m - 1) * (p + 2) + i] = h[i]; h[i] = -h[i]; }
+      HIP_CHECK(hipMemcpyAsync(d_small, h.data(), sizeof(double) * (size_t)m, hipMemcpyHostToDevice, stream));
+      launch_maxpy(n, w, V, n, m, d_small, stream);
+      const double hn = norm_of(w);
+      H[(size_t)(m - 1) * (p + 2) + m] = hn;
+      if (hn < TOL_LUCKY) { m_used = m; break; }
+      launch_axpby(n, 1.0 / hn, w, 0.0, nullptr, V + (size_t)m * (size_t)n, stream);
+    }
+    std::vector<double> re, im;
+    newton_roots_from_hessenberg(H.data(), beta, m_used, p, inverse_type == INV_NEWTON, re, im);
+    const int nr = (int)re.size();
+    if (nr == 0) return false;
+    // y = q(A) x with the roots (petsc_newton, src/Gmres_Poly_Newton.F90:763-875); the Krylov basis is no longer needed
+    double* x = V;                 // test vector
+    double* y = V + (size_t)n;
+    double* ta = V + 2 * (size_t)n;
+    double* tb = V + 3 * (size_t)n;    // p >= 1 gives p + 2 >= 3 vectors; w is the fourth
+    if (p + 2 < 4) tb = B.alloc((size_t)n);
+    double* t2 = w;
+    {
+      const uint64_t key = rng_key(seed + 7919);
+#pragma omp parallel for schedule(static)
+      for (int64_t i = 0; i < n; i++) hv[i] = uniform01(key, (uint64_t)i);
+      HIP_CHECK(hipMemcpyAsync(x, hv.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    launch_fill(n, 0.0, y, stream);
+    const double* t = x;
+    auto other = [&](const double* cur) { return cur == ta ? tb : ta; };
+    int k = 0;
+    while (k <= nr - 2) {
+      if (im[k] == 0.0) {
+        if (std::fabs(re[k]) < TOL_ZERO) { k++; continue; }
+        const double a = 1.0 / re[k];
+        launch_axpby(n, a, t, 1.0, y, y, stream);
+        double* tn = other(t);
+        SpmvEpi e; e.out = tn; e.alpha = -a; e.z = t; e.beta = 1.0;
+        launch_spmv(B.M, t, e, stream);
+        t = tn; k++;
+      } else {
+        const double sq = re[k] * re[k] + im[k] * im[k];
+        if (sq < TOL_ZERO) { k += 2; continue; }
+        SpmvEpi e; e.out = t2; e.alpha = -1.0; e.z = t; e.beta = 2.0 * re[k];
+        launch_spmv(B.M, t, e, stream);
+        launch_axpby(n, 1.0 / sq, t2, 1.0, y, y, stream);
+        if (k <= nr - 3) {
+          double* tn = other(t);
+          SpmvEpi e2; e2.out = tn; e2.alpha = -1.0 / sq; e2.z = t; e2.beta = 1.0;
+          launch_spmv(B.M, t2, e2, stream);
+          t = tn;
+        }
+        k += 2;
+      }
+    }
+    if (im[nr - 1] == 0.0 && std::fabs(re[nr - 1]) > TOL_ZERO) launch_axpby(n, 1.0 / re[nr - 1], t, 1.0, y, y, stream);
+    // r = A y - x
+    SpmvEpi e; e.out = t2; e.alpha = 1.0; e.z = x; e.beta = -1.0;
+    launch_spmv(B.M, y, e, stream);
+    const double rn = norm_of(t2), xn = norm_of(x);
+    t_compute += now_s() - t0;
+    if (!(xn > 0.0) || !(rn == rn)) return false;
+    ratio = rn / xn;
+    return true;
   }
 
   Csr rap(const Csr& R, const Csr& A, const Csr& P, const SpgemmDrop& drop) override {

@@ -110,6 +110,13 @@ void build_inverse(const OpView& A, int inverse_type, int poly_order, int sparsi
 Csr sai_z(const Csr& A_ff, const Csr* A_cf, const Csr& S, bool incomplete);
 Csr sai_inverse(const Csr& A, int sparsity_order, bool incomplete);
 
+// Pieces of the Newton-basis construction for an Arnoldi process that runs elsewhere (device auto-truncation test):
+// the start vector of the Krylov space and the harmonic-Ritz / Leja roots from its Hessenberg matrix
+// (column-major, (poly_order + 2) x (poly_order + 1)).
+void krylov_start_vector(uint64_t seed, int64_t n, double* out);
+void newton_roots_from_hessenberg(const double* H, double beta, int m, int poly_order, bool add_roots,
+                                  std::vector<double>& re, std::vector<double>& im);
+
 // Full setup.  A is consumed level by level (the caller's matrix is not modified).
 std::unique_ptr<Hierarchy> setup_air(const Csr& A, const AirOptions& o, SetupAccel* accel = nullptr);
 

@@ -183,7 +183,21 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o, SetupAc
     if (o.auto_truncate_start_level != -1 && our_level >= o.auto_truncate_start_level) {
       double t0 = now_s();
       InvOp cop;
-      coarse_solver(*cur, o, cop);
+      // the accelerator may evaluate the test (device Arnoldi + Newton apply); its ratio differs from the host's in
+      // the last digits, so it only decides when it is a factor 2 away from the tolerance - anything closer, and
+      // every solver that is kept, goes through the host code below
+      double dev_ratio = 0.0;
+      const bool dev_ok = accel && o.coarsest_matrix_free_polys && !o.coarsest_diag_scale_polys &&
+                          (int64_t)o.coarsest_poly_order + 1 <= n &&
+                          accel->truncation_ratio(*cur, o.coarsest_inverse_type, o.coarsest_poly_order, o.seed, dev_ratio);
+      bool decided = dev_ok && dev_ratio > 2.0 * o.auto_truncate_tol;        // clearly not yet: carry on coarsening
+      if (!decided) {
+        coarse_solver(*cur, o, cop);
+        if (dev_ok && dev_ratio < 0.5 * o.auto_truncate_tol) {                // clearly good enough: truncate here
+          auto_truncated = true; H->coarse_inv = std::move(cop); decided = true;
+        }
+      }
+      if (!decided) {
       Arr<double> rnd(n), sol(n), tmp(n);
       const uint64_t key = rng_key(o.seed + 7919);   // distinct stream from the polynomial RHS
 #pragma omp parallel for schedule(static)
@@ -194,6 +208,7 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o, SetupAc
       const double nb = det_sum(0, n, [&](int64_t i) { return rnd[i] * rnd[i]; });
       const double nr = det_sum(0, n, [&](int64_t i) { const double d = tmp[i] - rnd[i]; return d * d; });
       if (std::sqrt(nr) / std::sqrt(nb) < o.auto_truncate_tol) { auto_truncated = true; H->coarse_inv = std::move(cop); }
+      }
       H->timers[7] += now_s() - t0;
     }
     // ---- CF splitting

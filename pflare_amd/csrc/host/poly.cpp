@@ -246,9 +246,28 @@ static void compute_extra_roots(const std::vector<double>& re, const std::vector
     }
 }
 
+static void roots_from_arnoldi(const ArnoldiOut& a, int poly_order, bool add_roots,
+                               std::vector<double>& re_out, std::vector<double>& im_out);
+
 static void roots_newton(const MatVec& mv, int64_t n, int poly_order, bool add_roots, uint64_t seed,
                          std::vector<double>& re_out, std::vector<double>& im_out) {
   ArnoldiOut a = arnoldi(mv, n, poly_order, seed, -1.0, false);
+  roots_from_arnoldi(a, poly_order, add_roots, re_out, im_out);
+}
+
+// entry points for an Arnoldi process run elsewhere (the device-side auto-truncation test, device/setup_accel.cpp)
+void krylov_start_vector(uint64_t seed, int64_t n, double* out) { box_muller(seed, n, out); }
+void newton_roots_from_hessenberg(const double* H, double beta, int m, int poly_order, bool add_roots,
+                                  std::vector<double>& re, std::vector<double>& im) {
+  ArnoldiOut a;
+  a.beta = beta; a.m = m;
+  a.H = Dense(poly_order + 2, poly_order + 1);
+  for (int j = 0; j < poly_order + 1; j++) for (int i = 0; i < poly_order + 2; i++) a.H(i, j) = H[(size_t)j * (poly_order + 2) + i];
+  roots_from_arnoldi(a, poly_order, add_roots, re, im);
+}
+
+static void roots_from_arnoldi(const ArnoldiOut& a, int poly_order, bool add_roots,
+                               std::vector<double>& re_out, std::vector<double>& im_out) {
   const int p1 = poly_order + 1;
   // harmonic Ritz: H(:,d) += h_{d+1,d}^2 * (H^-T e_d), min-norm solve with rcond
   Dense HT(p1, p1);

@@ -50,6 +50,13 @@ struct SetupAccel {
   // filter(R * (A * P)); the implementation may keep the result resident and recognise it when
   // it comes back as the A of the next level
   virtual Csr rap(const Csr& R, const Csr& A, const Csr& P, const SpgemmDrop& drop) = 0;
+  // Auto-truncation test (src/AIR_MG_Setup.F90:158-256) evaluated by the accelerator: ||A M r - r|| / ||r|| for the
+  // matrix-free Newton coarse solver M built from `seed`.  Returns false when it cannot do it (the host then does).
+  // The value is only used to DECIDE (with a safety margin, see air_setup.cpp); the solver that ends up in the
+  // hierarchy is always built by the host code, so the hierarchy stays bit-identical.
+  virtual bool truncation_ratio(const Csr& A, int inverse_type, int poly_order, uint64_t seed, double& ratio) {
+    (void)A; (void)inverse_type; (void)poly_order; (void)seed; (void)ratio; return false;
+  }
   double t_transfer = 0.0, t_compute = 0.0;
 };
 

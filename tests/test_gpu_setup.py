@@ -92,6 +92,13 @@ SETUP_CASES = {
     "diff2d_40": (dict(dim=2, M=40, N=40, u=0, v=0, alpha=1.0), {}),
     "advdiff2d_50_order4": (dict(dim=2, M=50, N=50, alpha=0.1), dict(poly_order=4, inverse_sparsity_order=2)),
     "adv2d_40_fcf": (dict(dim=2, M=40, N=40), dict(smooth_type="fcf", a_lump=True, a_drop=1e-5)),
+    # auto truncation: the test runs on the device (Arnoldi + Newton apply), decisions and the kept solver must equal the host's
+    "adv3d_24_trunc": (dict(dim=3, M=24, N=24, P=24), dict(a_lump=True, auto_truncate_start_level=1, auto_truncate_tol=1e-1,
+                                                         coarsest_inverse_type="newton", coarsest_matrix_free_polys=True,
+                                                         coarsest_poly_order=10)),
+    "adv2d_80_trunc_1e-2": (dict(dim=2, M=80, N=80), dict(auto_truncate_start_level=2, auto_truncate_tol=1e-2,
+                                                          coarsest_inverse_type="newton_no_extra", coarsest_matrix_free_polys=True,
+                                                          coarsest_poly_order=8)),
 }
 
 
@@ -112,5 +119,9 @@ def test_device_setup_equals_host_setup(gpu, case):
         for k in ("Z", "A_fc", "A_cf", "A_ff"):
             if k in h:
                 _same(d[k], h[k], f"level {lv} {k}")
-    (Ad, _), (Ah, _) = pd.export_coarse(), ph.export_coarse()
+    (Ad, invd), (Ah, invh) = pd.export_coarse(), ph.export_coarse()
     _same(Ad, Ah, "coarse")
+    assert invd["kind"] == invh["kind"]
+    for k in ("re", "im", "coeffs"):
+        if k in invh:
+            assert np.array_equal(invd[k], invh[k]), k
