@@ -71,6 +71,14 @@ CASES = [
     ("Makefile:659-663 diag_dom max DD ratio 100x100", R.gen_adv_diff_fd(2, 100, 100),
      R.AirOptions(cf_splitting_type="diag_dom", strong_threshold=0.50001, a_lump=True, a_drop=1e-4, inverse_type=R.INV_POWER),
      dict(side="right", rtol=1e-10, max_it=7), 7),
+    ("Makefile:302-303 fc smoothing, diagonal-sparsity C smoother", R.gen_adv_diff_fd(2, 8, 8),
+     R.AirOptions(smooth_type="fc", c_inverse_sparsity_order=0), dict(max_it=3), 3),
+    ("Makefile:645-649 ffc, 0th-order C smoother, strong 0.99, no DDC", R.gen_adv_diff_fd(2, 50, 50),
+     R.AirOptions(a_lump=True, a_drop=1e-4, smooth_type="ffc", c_inverse_sparsity_order=0, strong_threshold=0.99, ddc_its=0,
+                  inverse_type=R.INV_POWER), dict(side="right", rtol=1e-10, max_it=7), 7),
+    ("Makefile:652-656 ffc, 0th-order C smoother, strong 0.99, 2 DDC its of 2%", R.gen_adv_diff_fd(2, 50, 50),
+     R.AirOptions(a_lump=True, a_drop=1e-4, smooth_type="ffc", c_inverse_sparsity_order=0, strong_threshold=0.99, ddc_its=2,
+                  ddc_fraction=0.02, inverse_type=R.INV_POWER), dict(side="right", rtol=1e-10, max_it=7), 7),
     ("Makefile:556-560 auto truncation + newton coarse", R.gen_adv_diff_fd(2, 10, 10),
      R.AirOptions(auto_truncate_start_level=1, auto_truncate_tol=1e-2, a_drop=1e-3, inverse_type=R.INV_POWER,
                   **NEWTON_COARSE), dict(ksp="richardson", max_it=3), 3),
@@ -86,6 +94,15 @@ def test_reference_iteration_bounds(label, A, opts, kw, bound):
     assert its <= bound
     if "exact solver" in label:
         assert np.linalg.norm(x) < 1e-7        # exact solution is 0 (b = 0)
+
+
+def test_pflareinv_power_on_diffusion_meets_reference_bound():
+    """tests/Makefile:394-395: single-level power-basis GMRES polynomial on the 8x8 diffusion stencil, <= 8 iterations"""
+    A = R.gen_adv_diff_fd(**DIFF8)
+    n = A.shape[0]
+    op = R.pcpflareinv_setup(A, inverse_type=R.INV_POWER)
+    x, its, reason, rn = R.ksp_gmres(A, lambda r: R.apply_inv(op, r), np.zeros(n), np.ones(n), rtol=1e-5, max_it=8, pc_side="left")
+    assert reason > 0 and its <= 8
 
 
 @pytest.mark.parametrize("itype,mf", [(R.INV_NEWTON, True), (R.INV_ARNOLDI, False), (R.INV_POWER, False)])
