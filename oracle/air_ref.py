@@ -456,22 +456,12 @@ def ddc(A, markers, fraction_swap):
     return markers
 
 
-def ddc_diag_dom(A, markers, target, seed):
-    """The max_dd_ratio path of ddc / ddc_cpu (src/DDC_Module.F90:56-82, 301-392): while some F row is less
-    diagonally dominant in A_ff than `target`, swap to C an independent set (in A_ff + A_ff^T) of the worst of those
-    rows - PMISR on the measure max(10, 2 max_ratio) - (ratio - rand * 1e-10), rows already below the target
-    excluded.  Returns (markers, max ratio found before the swap)."""
-    F, ratio_f = diag_dom_ratio(A, markers)
-    max_ratio = float(ratio_f.max()) if F.size else 0.0
-    if max_ratio < target:
-        return markers, max_ratio
+def _swap_independent_set(A, markers, cand, measure):
+    """pmisr_existing_measure_implicit_transpose on A_ff + A_ff^T (src/PMISR_Module.F90): among the candidate F rows
+    repeatedly take the local minima of `measure` (ties: the larger index loses) and block their neighbours; the rows
+    taken become C points.  Returns (markers, number swapped)."""
     n = A.shape[0]
-    ratio = np.zeros(n); ratio[F] = ratio_f
-    rnd = uniform(seed + 104729, 0, n)
-    measure = np.full(n, np.inf)
-    measure[F] = max(10.0, 2.0 * max_ratio) - (ratio[F] - rnd[F] / 1e10)
     assigned = np.ones(n, dtype=bool)
-    cand = F[ratio_f >= target]
     assigned[cand] = False
     rows = _rows_of(A); cols = A.indices
     sel = (markers[rows] == F_POINT) & (markers[cols] == F_POINT) & (rows != cols)
@@ -489,13 +479,92 @@ def ddc_diag_dom(A, markers, target, seed):
         assigned[ej[in_set[ei]]] = True
     markers = markers.copy()
     markers[swap] *= -1
+    return markers, int(swap.sum())
+
+
+CR_NU, CR_NU_POLY, CR_MAX_ITS, CR_CANDIDATE = 10, 1, 100, 0.1     # src/Pflare_Parameters.F90:44-62
+
+
+def cr_pass(A, markers, target, inverse_type, poly_order, sparsity_order, diag_scale, seed):
+    """One pass of compatible-relaxation coarsening (src/CR_Splitting.F90:36-336): relax A_ff e = 0 from a random e
+    with the (always assembled) A_ff inverse AIRG would smooth with; if the rate (||e_nu|| / ||e_0||)^(1/nu) is above
+    the target, promote an independent set of the rows where the error stayed largest."""
+    F = np.flatnonzero(markers == F_POINT)
+    if F.size == 0:
+        return markers, 0.0, 0
+    n = A.shape[0]
+    Aff = A if F.size == n else submatrix(A, F, F)
+    forced = np.zeros(F.size, dtype=bool)
+    use_poly = inverse_type not in (INV_WJACOBI, INV_JACOBI) and F.size > poly_order + 1
+    nu = CR_NU_POLY if use_poly else CR_NU
+    if use_poly:
+        M, _ = build_inverse(Aff, inverse_type, poly_order, sparsity_order, False, diag_scale, seed)
+        apply_m = lambda v: apply_inv(M, v)
+    else:
+        d = np.asarray(Aff.diagonal(), dtype=np.float64).copy()
+        forced = d == 0.0
+        d[forced] = 1.0
+        weight = 1.0
+        if inverse_type != INV_JACOBI:
+            sc = 1.0 / np.sqrt(np.abs(d))
+            T = sp.diags(sc) @ Aff @ sp.diags(sc)
+            norm_inf = float(np.max(np.abs(T).sum(axis=1))) if T.nnz else 0.0
+            if norm_inf != 0.0:
+                weight = 3.0 / (4.0 * norm_inf)
+        minv = weight / d
+        minv[forced] = 0.0
+        apply_m = lambda v: minv * v
+    rnd = uniform(seed + 15485863, 0, n)
+    e = rnd[F].copy()
+    norm_e0 = float(np.linalg.norm(e))
+    for _ in range(nu):
+        e = e - apply_m(Aff @ e)
+    norm_enu = float(np.linalg.norm(e))
+    rate = (norm_enu / norm_e0) ** (1.0 / nu) if norm_e0 != 0.0 else 0.0
+    if not rate > target:
+        return markers, rate, 0
+    e_inf = float(np.max(np.abs(e)))
+    cm = np.where(forced, 2.0, (np.abs(e) / e_inf) if e_inf != 0.0 else 0.0)
+    is_cand = cm >= CR_CANDIDATE
+    measure = np.full(n, np.inf)
+    measure[F[is_cand]] = 10.0 - (cm[is_cand] - rnd[F[is_cand]] / 1e10)
+    markers, nsw = _swap_independent_set(A, markers, F[is_cand], measure)
+    return markers, rate, nsw
+
+
+def ddc_diag_dom(A, markers, target, seed):
+    """The max_dd_ratio path of ddc / ddc_cpu (src/DDC_Module.F90:56-82, 301-392): while some F row is less
+    diagonally dominant in A_ff than `target`, swap to C an independent set (in A_ff + A_ff^T) of the worst of those
+    rows - PMISR on the measure max(10, 2 max_ratio) - (ratio - rand * 1e-10), rows already below the target
+    excluded.  Returns (markers, max ratio found before the swap)."""
+    F, ratio_f = diag_dom_ratio(A, markers)
+    max_ratio = float(ratio_f.max()) if F.size else 0.0
+    if max_ratio < target:
+        return markers, max_ratio
+    n = A.shape[0]
+    ratio = np.zeros(n); ratio[F] = ratio_f
+    rnd = uniform(seed + 104729, 0, n)
+    measure = np.full(n, np.inf)
+    measure[F] = max(10.0, 2.0 * max_ratio) - (ratio[F] - rnd[F] / 1e10)
+    markers, _ = _swap_independent_set(A, markers, F[ratio_f >= target], measure)
     return markers, max_ratio
 
 
 def compute_cf_splitting(A, strong_threshold=0.5, ddc_its=1, ddc_fraction=_f32(0.1),
-                         symmetric=False, seed=1, max_luby_steps=-1, cf_splitting_type="pmisr_ddc"):
+                         symmetric=False, seed=1, max_luby_steps=-1, cf_splitting_type="pmisr_ddc", cr=None):
     """src/CF_Splitting.F90:235-392 for CF_PMISR_DDC and CF_DIAG_DOM (the latter repeats the cleanup until every
     F row reaches the diagonal dominance ratio given by strong_threshold, :361-392)."""
+    if cf_splitting_type == "cr":
+        # CF_CR (src/CF_Splitting.F90:303-340): everything starts as F, strong_threshold is the target CR rate
+        markers = np.full(A.shape[0], F_POINT, dtype=np.int32)
+        it, po, so, ds = cr if cr is not None else (INV_ARNOLDI, 6, 1, False)
+        for _ in range(CR_MAX_ITS):
+            markers, rate, nsw = cr_pass(A, markers, strong_threshold, it, po, so, ds, seed)
+            if rate <= strong_threshold or nsw == 0:
+                break
+        F = np.flatnonzero(markers == F_POINT).astype(np.int64)
+        C = np.flatnonzero(markers != F_POINT).astype(np.int64)
+        return F, C
     S = generate_sabs(A, strong_threshold, not symmetric)
     markers = pmisr(S, seed, max_luby_steps)
     if strong_threshold != 0.0 and cf_splitting_type == "diag_dom":
@@ -1251,7 +1320,7 @@ class AirOptions:
     improve_z_its: int = 0                # -pc_air_improve_z_its
     improve_w_its: int = 0                # -pc_air_improve_w_its
     full_smoothing_up_and_down: bool = False   # -pc_air_full_smoothing_up_and_down
-    cf_splitting_type: str = "pmisr_ddc"       # -pc_air_cf_splitting_type pmisr_ddc | diag_dom
+    cf_splitting_type: str = "pmisr_ddc"       # -pc_air_cf_splitting_type pmisr_ddc | diag_dom | cr
     # -mg_coarse_ksp_type richardson -mg_coarse_ksp_max_it N (0 = preonly, the default)
     coarse_richardson_its: int = 0
     coarse_lu: bool = False               # -mg_coarse_pc_type lu
@@ -1424,7 +1493,8 @@ def setup_air(A, o: AirOptions) -> Hierarchy:
                 H.coarse_inv = cop
         if not auto_truncated:
             F, C = compute_cf_splitting(cur, o.strong_threshold, o.ddc_its, o.ddc_fraction,
-                                        o.symmetric, o.seed, o.max_luby_steps, o.cf_splitting_type)
+                                        o.symmetric, o.seed, o.max_luby_steps, o.cf_splitting_type,
+                                        cr=(o.inverse_type, o.poly_order, o.inverse_sparsity_order, o.diag_scale_polys))
             n_f, n_c = F.size, C.size
         else:
             n_f = n_c = 0

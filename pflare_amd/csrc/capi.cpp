@@ -284,7 +284,8 @@ int airhip_pcair_set_option(airhip_pcair pc, const char* name, const char* value
     std::string c(v);
     if (c == "pmisr_ddc" || c == "0") o.cf_splitting_type = 0;
     else if (c == "diag_dom" || c == "1") o.cf_splitting_type = 1;
-    else { g_err = "-pc_air_cf_splitting_type " + c + " is outside this build's scope (pmisr_ddc, diag_dom)"; return AIRHIP_ERR_UNSUPPORTED; }
+    else if (c == "cr") o.cf_splitting_type = 2;
+    else { g_err = "-pc_air_cf_splitting_type " + c + " is outside this build's scope (pmisr_ddc, diag_dom, cr)"; return AIRHIP_ERR_UNSUPPORTED; }
   }
   else if (k == "symmetric" || k == "constrain_z" || k == "constrain_w" || k == "reuse_sparsity") {
     bool is_default = (std::string(v) == "0" || std::string(v) == "false" || std::string(v) == "" );

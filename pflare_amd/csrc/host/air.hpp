@@ -45,7 +45,7 @@ struct AirOptions {
   // and up instead of the F/C relaxation on the way up (src/AIR_MG_Setup.F90:1014-1079); M = approximate inverse
   // of the whole level operator, kept in inv_ff as the reference keeps it in inv_A_ff
   bool full_smoothing = false;
-  int cf_splitting_type = 0;       // -pc_air_cf_splitting_type: 0 pmisr_ddc, 1 diag_dom (src/CF_Splitting.F90:19-20)
+  int cf_splitting_type = 0;       // -pc_air_cf_splitting_type: 0 pmisr_ddc, 1 diag_dom, 2 cr (src/CF_Splitting.F90:19-25)
   int coarse_richardson_its = 0;  // -mg_coarse_ksp_type richardson -mg_coarse_ksp_max_it N
   bool coarse_lu = false;         // -mg_coarse_pc_type lu: exact coarsest solve (explicit dense inverse, small systems only)
   bool print_stats_timings = false;

@@ -2,6 +2,7 @@
 // Follows src/PMISR_Module.F90:121-671, src/DDC_Module.F90:221-481,
 // src/MatDiagDom.F90:98-270 and the driver src/CF_Splitting.F90:235-392 (CF_PMISR_DDC).
 #include "air.hpp"
+#include <limits>
 
 namespace airhip {
 
@@ -109,28 +110,11 @@ static void ddc(const Csr& A, double fraction_swap, Arr<int32_t>& markers) {
   for (int64_t i = 0; i < n; i++) if (flip[i]) markers[i] = -markers[i];
 }
 
-// The max_dd_ratio path of ddc / ddc_cpu (src/DDC_Module.F90:56-82, 301-392): while some F row is less diagonally
-// dominant in A_ff than `target`, swap to C an independent set (in A_ff + A_ff^T) of the worst of those rows - Luby
-// rounds on the measure max(10, 2 max_ratio) - (ratio - rand * 1e-10), smallest first, rows already below the target
-// excluded.  Returns the largest ratio found before the swap.
-static double ddc_diag_dom(const Csr& A, double target, uint64_t seed, Arr<int32_t>& markers) {
+// pmisr_existing_measure_implicit_transpose on A_ff + A_ff^T (src/PMISR_Module.F90): among the candidate F rows
+// repeatedly take the local minima of `measure` (ties: the larger index loses) and block their neighbours; the rows
+// taken become C points.  Returns the number of rows swapped.
+static int64_t swap_independent_set(const Csr& A, const Arr<uint8_t>& cand, const Arr<double>& measure, Arr<int32_t>& markers) {
   const int64_t n = A.m;
-  Arr<double> ratio(n);
-  double max_ratio = 0.0;
-#pragma omp parallel for schedule(static) reduction(max : max_ratio)
-  for (int64_t i = 0; i < n; i++) {
-    ratio[i] = 0.0;
-    if (markers[i] != F_POINT) continue;
-    double diag = 0.0, off = 0.0;
-    for (int64_t k = A.rp[i]; k < A.rp[i + 1]; k++) {
-      const int32_t c = A.ci[k];
-      if (markers[c] != F_POINT) continue;
-      if (c == i) diag = std::fabs(A.v[k]); else off += std::fabs(A.v[k]);
-    }
-    if (diag != 0.0) ratio[i] = off / diag;
-    max_ratio = std::max(max_ratio, ratio[i]);
-  }
-  if (max_ratio < target) return max_ratio;
   // adjacency of A_ff + A_ff^T (duplicates are harmless)
   Arr<int64_t> cnt(n + 1), rp(n + 1);
   for (int64_t i = 0; i <= n; i++) cnt[i] = 0;
@@ -148,19 +132,10 @@ static double ddc_diag_dom(const Csr& A, double target, uint64_t seed, Arr<int32
     for (int64_t k = A.rp[i]; k < A.rp[i + 1]; k++)
       if (ff_edge(i, k)) { adj[cnt[i]++] = A.ci[k]; adj[cnt[A.ci[k]]++] = (int32_t)i; }
   }
-  const uint64_t key = rng_key(seed + 104729);
-  const double base = std::max(10.0, 2.0 * max_ratio);
-  Arr<double> measure(n);
   Arr<uint8_t> assigned(n), in_set(n), swap(n);
   int64_t undecided = 0;
 #pragma omp parallel for schedule(static) reduction(+ : undecided)
-  for (int64_t i = 0; i < n; i++) {
-    swap[i] = 0;
-    const bool cand = markers[i] == F_POINT && ratio[i] >= target;
-    assigned[i] = cand ? 0 : 1;
-    measure[i] = base - (ratio[i] - uniform01(key, (uint64_t)i) / 1e10);
-    undecided += cand ? 1 : 0;
-  }
+  for (int64_t i = 0; i < n; i++) { swap[i] = 0; assigned[i] = cand[i] ? 0 : 1; undecided += cand[i] ? 1 : 0; }
   while (undecided != 0) {
 #pragma omp parallel for schedule(dynamic, 8192)
     for (int64_t i = 0; i < n; i++) {
@@ -186,12 +161,147 @@ static double ddc_diag_dom(const Csr& A, double target, uint64_t seed, Arr<int32
 #pragma omp parallel for schedule(static) reduction(+ : undecided)
     for (int64_t i = 0; i < n; i++) undecided += assigned[i] ? 0 : 1;
   }
+  int64_t nsw = 0;
+#pragma omp parallel for schedule(static) reduction(+ : nsw)
+  for (int64_t i = 0; i < n; i++) if (swap[i]) { markers[i] = -markers[i]; nsw++; }
+  return nsw;
+}
+
+// One pass of compatible-relaxation coarsening (src/CR_Splitting.F90:36-336): relax A_ff e = 0 from a random e with the
+// (always assembled) A_ff inverse AIRG would smooth with; if the rate (||e_nu|| / ||e_0||)^(1/nu) is above the target,
+// promote an independent set of the rows where the error stayed largest.  Returns the rate; n_swapped by reference.
+static double cr_pass(const Csr& A, const AirOptions& o, Arr<int32_t>& markers, int64_t& n_swapped) {
+  const int CR_NU = 10, CR_NU_POLY = 1;                 // src/Pflare_Parameters.F90:44-50
+  const double CR_CANDIDATE = 0.1;                      // :62
+  const int64_t n = A.m;
+  n_swapped = 0;
+  Arr<int32_t> pos(n);
+  std::vector<int32_t> F;
+  for (int64_t i = 0; i < n; i++) { pos[i] = -1; if (markers[i] == F_POINT) { pos[i] = (int32_t)F.size(); F.push_back((int32_t)i); } }
+  const int64_t nf = (int64_t)F.size();
+  if (nf == 0) return 0.0;
+  Csr Aff_store;
+  const Csr* Aff = &A;
+  if (nf != n) {
+    Aff_store.m = Aff_store.n = nf; Aff_store.rp.alloc(nf + 1);
+    Aff_store.rp[0] = 0;
+    for (int64_t r = 0; r < nf; r++) {
+      int64_t c = 0;
+      for (int64_t k = A.rp[F[r]]; k < A.rp[F[r] + 1]; k++) c += pos[A.ci[k]] >= 0 ? 1 : 0;
+      Aff_store.rp[r + 1] = Aff_store.rp[r] + c;
+    }
+    Aff_store.ci.alloc(Aff_store.rp[nf]); Aff_store.v.alloc(Aff_store.rp[nf]);
 #pragma omp parallel for schedule(static)
-  for (int64_t i = 0; i < n; i++) if (swap[i]) markers[i] = -markers[i];
+    for (int64_t r = 0; r < nf; r++) {
+      int64_t q = Aff_store.rp[r];
+      for (int64_t k = A.rp[F[r]]; k < A.rp[F[r] + 1]; k++)
+        if (pos[A.ci[k]] >= 0) { Aff_store.ci[q] = pos[A.ci[k]]; Aff_store.v[q] = A.v[k]; q++; }
+    }
+    Aff = &Aff_store;
+  }
+  const bool use_poly = o.inverse_type != INV_WJACOBI && o.inverse_type != INV_JACOBI && nf > (int64_t)o.poly_order + 1;
+  const int nu = use_poly ? CR_NU_POLY : CR_NU;
+  InvOp M;
+  std::vector<uint8_t> forced((size_t)nf, 0);
+  if (use_poly) {
+    OpView v; v.A = Aff; v.n = nf;
+    build_inverse(v, o.inverse_type, o.poly_order, o.inverse_sparsity_order, false, o.diag_scale_polys, o.seed, M, nullptr);
+  } else {
+    // weighted Jacobi with exactly zero diagonals sanitised (those rows are promoted first)
+    M.kind = InvOp::DIAG; M.d.alloc(nf);
+    Arr<double> d(nf);
+    get_diagonal(*Aff, d.data());
+    for (int64_t i = 0; i < nf; i++) if (d[i] == 0.0) { d[i] = 1.0; forced[i] = 1; }
+    double weight = 1.0;
+    if (o.inverse_type != INV_JACOBI) {
+      double norm_inf = 0.0;
+#pragma omp parallel for schedule(static) reduction(max : norm_inf)
+      for (int64_t i = 0; i < nf; i++) {
+        double sacc = 0.0; const double si = 1.0 / std::sqrt(std::fabs(d[i]));
+        for (int64_t k = Aff->rp[i]; k < Aff->rp[i + 1]; k++)
+          sacc += std::fabs(si * Aff->v[k] * (1.0 / std::sqrt(std::fabs(d[Aff->ci[k]]))));
+        norm_inf = std::max(norm_inf, sacc);
+      }
+      if (norm_inf != 0.0) weight = 3.0 / (4.0 * norm_inf);
+    }
+    for (int64_t i = 0; i < nf; i++) M.d[i] = forced[i] ? 0.0 : weight / d[i];
+  }
+  const uint64_t key = rng_key(o.seed + 15485863);
+  Arr<double> e(nf), w1(nf), w2(nf);
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < nf; r++) e[r] = uniform01(key, (uint64_t)F[r]);
+  const double norm_e0 = std::sqrt(det_sum(0, nf, [&](int64_t r) { return e[r] * e[r]; }));
+  OpView av; av.A = Aff; av.n = nf;
+  for (int sweep = 0; sweep < nu; sweep++) {
+    spmv(*Aff, e.data(), w1.data());
+    host_apply_inv(M, av, w1.data(), w2.data());
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < nf; r++) e[r] -= w2[r];
+  }
+  const double norm_enu = std::sqrt(det_sum(0, nf, [&](int64_t r) { return e[r] * e[r]; }));
+  const double rate = norm_e0 != 0.0 ? std::pow(norm_enu / norm_e0, 1.0 / (double)nu) : 0.0;
+  if (!(rate > o.strong_threshold)) return rate;
+  double e_inf = 0.0;
+  for (int64_t r = 0; r < nf; r++) e_inf = std::max(e_inf, std::fabs(e[r]));
+  Arr<uint8_t> cand(n); Arr<double> measure(n);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; i++) { cand[i] = 0; measure[i] = std::numeric_limits<double>::max(); }
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < nf; r++) {
+    const double cm = forced[r] ? 2.0 : (e_inf != 0.0 ? std::fabs(e[r]) / e_inf : 0.0);
+    if (cm >= CR_CANDIDATE) { cand[F[r]] = 1; measure[F[r]] = 10.0 - (cm - uniform01(key, (uint64_t)F[r]) / 1e10); }
+  }
+  n_swapped = swap_independent_set(A, cand, measure, markers);
+  return rate;
+}
+
+// The max_dd_ratio path of ddc / ddc_cpu (src/DDC_Module.F90:56-82, 301-392): while some F row is less diagonally
+// dominant in A_ff than `target`, swap to C an independent set (in A_ff + A_ff^T) of the worst of those rows - Luby
+// rounds on the measure max(10, 2 max_ratio) - (ratio - rand * 1e-10), smallest first, rows already below the target
+// excluded.  Returns the largest ratio found before the swap.
+static double ddc_diag_dom(const Csr& A, double target, uint64_t seed, Arr<int32_t>& markers) {
+  const int64_t n = A.m;
+  Arr<double> ratio(n);
+  double max_ratio = 0.0;
+#pragma omp parallel for schedule(static) reduction(max : max_ratio)
+  for (int64_t i = 0; i < n; i++) {
+    ratio[i] = 0.0;
+    if (markers[i] != F_POINT) continue;
+    double diag = 0.0, off = 0.0;
+    for (int64_t k = A.rp[i]; k < A.rp[i + 1]; k++) {
+      const int32_t c = A.ci[k];
+      if (markers[c] != F_POINT) continue;
+      if (c == i) diag = std::fabs(A.v[k]); else off += std::fabs(A.v[k]);
+    }
+    if (diag != 0.0) ratio[i] = off / diag;
+    max_ratio = std::max(max_ratio, ratio[i]);
+  }
+  if (max_ratio < target) return max_ratio;
+  const uint64_t key = rng_key(seed + 104729);
+  const double base = std::max(10.0, 2.0 * max_ratio);
+  Arr<double> measure(n);
+  Arr<uint8_t> cand(n);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; i++) {
+    cand[i] = (markers[i] == F_POINT && ratio[i] >= target) ? 1 : 0;
+    measure[i] = base - (ratio[i] - uniform01(key, (uint64_t)i) / 1e10);
+  }
+  swap_independent_set(A, cand, measure, markers);
   return max_ratio;
 }
 
 void compute_cf_splitting(const Csr& A, const AirOptions& o, Arr<int32_t>& markers) {
+  if (o.cf_splitting_type == 2) {
+    // CF_CR (src/CF_Splitting.F90:303-340): everything starts as F, strong_threshold carries the target CR rate
+    markers.alloc(A.m);
+    for (int64_t i = 0; i < A.m; i++) markers[i] = F_POINT;
+    for (int its = 0; its < 100; its++) {             // PFLARE_CR_MAX_ITS
+      int64_t nsw = 0;
+      const double rate = cr_pass(A, o, markers, nsw);
+      if (rate <= o.strong_threshold || nsw == 0) break;
+    }
+    return;
+  }
   Arr<int64_t> rp; Arr<int32_t> ci;
   strength_graph(A, o.strong_threshold, !o.symmetric, rp, ci);
   pmisr(rp, ci, A.m, o.seed, o.max_luby_steps, markers);

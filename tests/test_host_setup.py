@@ -77,6 +77,10 @@ OPT_PAIRS = {
     # CF_DIAG_DOM: DDC repeated until every F row reaches the diagonal-dominance ratio (src/CF_Splitting.F90:361-392)
     "diag_dom_0.9": (dict(cf_splitting_type="diag_dom", strong_threshold=0.9), R.AirOptions(cf_splitting_type="diag_dom", strong_threshold=0.9)),
     "diag_dom_0.3": (dict(cf_splitting_type="diag_dom", strong_threshold=0.3), R.AirOptions(cf_splitting_type="diag_dom", strong_threshold=0.3)),
+    # CF_CR: compatible relaxation coarsening, strong_threshold = target CR rate (src/CR_Splitting.F90)
+    "cr_0.1": (dict(cf_splitting_type="cr", strong_threshold=0.1), R.AirOptions(cf_splitting_type="cr", strong_threshold=0.1)),
+    "cr_wjacobi_0.7": (dict(cf_splitting_type="cr", strong_threshold=0.7, inverse_type="wjacobi"),
+                       R.AirOptions(cf_splitting_type="cr", strong_threshold=0.7, inverse_type=R.INV_WJACOBI)),
     "sai": (dict(inverse_type="sai"), R.AirOptions(inverse_type=R.INV_SAI)),
     "isai_s2": (dict(inverse_type="isai", inverse_sparsity_order=2), R.AirOptions(inverse_type=R.INV_ISAI, inverse_sparsity_order=2)),
 }

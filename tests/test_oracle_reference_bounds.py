@@ -79,6 +79,11 @@ CASES = [
     ("Makefile:652-656 ffc, 0th-order C smoother, strong 0.99, 2 DDC its of 2%", R.gen_adv_diff_fd(2, 50, 50),
      R.AirOptions(a_lump=True, a_drop=1e-4, smooth_type="ffc", c_inverse_sparsity_order=0, strong_threshold=0.99, ddc_its=2,
                   ddc_fraction=0.02, inverse_type=R.INV_POWER), dict(side="right", rtol=1e-10, max_it=7), 7),
+    ("Makefile:310 compatible-relaxation CF splitting 10x10", R.gen_adv_diff_fd(2, 10, 10),
+     R.AirOptions(cf_splitting_type="cr", strong_threshold=0.1), dict(max_it=4), 4),
+    ("Makefile:678-682 compatible-relaxation CF splitting 100x100", R.gen_adv_diff_fd(2, 100, 100),
+     R.AirOptions(cf_splitting_type="cr", strong_threshold=0.1, a_lump=True, a_drop=1e-4, inverse_type=R.INV_POWER),
+     dict(side="right", rtol=1e-10, max_it=12), 12),
     ("Makefile:556-560 auto truncation + newton coarse", R.gen_adv_diff_fd(2, 10, 10),
      R.AirOptions(auto_truncate_start_level=1, auto_truncate_tol=1e-2, a_drop=1e-3, inverse_type=R.INV_POWER,
                   **NEWTON_COARSE), dict(ksp="richardson", max_it=3), 3),
