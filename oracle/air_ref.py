@@ -1552,7 +1552,9 @@ def setup_air(A, o: AirOptions) -> Hierarchy:
 
         if product_z:
             Mz = inv_for_Z.mat if inv_for_Z.kind == "assembled" else sp.diags(inv_for_Z.d).tocsr()
-        if o.one_point_classical_prolong and not o.symmetric:
+        if o.symmetric:
+            W = one_point_W(A_fc)      # placeholder: replaced by Z^T once Z exists
+        elif o.one_point_classical_prolong:
             W = one_point_W(A_fc)
         else:
             if not product_z:
@@ -1584,7 +1586,9 @@ def setup_air(A, o: AirOptions) -> Hierarchy:
         Z = remove_small(Z, o.r_drop, rel=1)
         R = build_R(Z, F, C, n)
         if o.symmetric:
+            # -pc_air_symmetric (src/AIR_Operators_Setup.F90:898-902): P = R^T, i.e. W = Z^T
             P = R.T.tocsr(); P.sort_indices()
+            W = Z.T.tocsr(); W.sort_indices()
 
         AP = (cur @ P).tocsr()
         RAP = (R @ AP).tocsr(); RAP.sort_indices()

@@ -287,7 +287,8 @@ int airhip_pcair_set_option(airhip_pcair pc, const char* name, const char* value
     else if (c == "cr") o.cf_splitting_type = 2;
     else { g_err = "-pc_air_cf_splitting_type " + c + " is outside this build's scope (pmisr_ddc, diag_dom, cr)"; return AIRHIP_ERR_UNSUPPORTED; }
   }
-  else if (k == "symmetric" || k == "constrain_z" || k == "constrain_w" || k == "reuse_sparsity") {
+  else if (k == "symmetric") o.symmetric = parse_bool(v);
+  else if (k == "constrain_z" || k == "constrain_w" || k == "reuse_sparsity") {
     bool is_default = (std::string(v) == "0" || std::string(v) == "false" || std::string(v) == "" );
     if (!is_default) { g_err = "option -pc_air_" + k + " is outside this build's scope (SURVEY 8f)"; return AIRHIP_ERR_UNSUPPORTED; }
   } else { g_err = "unknown option -pc_air_" + k; return AIRHIP_ERR_ARG; }

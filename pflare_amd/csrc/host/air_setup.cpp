@@ -85,6 +85,20 @@ static Csr build_P(const Level& L) {
   return P;
 }
 
+static Csr transpose_csr(const Csr& A) {
+  Csr T; T.m = A.n; T.n = A.m;
+  T.rp.alloc(T.m + 1);
+  for (int64_t i = 0; i <= T.m; i++) T.rp[i] = 0;
+  for (int64_t k = 0; k < A.nnz(); k++) T.rp[A.ci[k] + 1]++;
+  for (int64_t i = 0; i < T.m; i++) T.rp[i + 1] += T.rp[i];
+  T.ci.alloc(A.nnz()); T.v.alloc(A.nnz());
+  Arr<int64_t> next(T.m + 1);
+  for (int64_t i = 0; i <= T.m; i++) next[i] = T.rp[i];
+  for (int64_t r = 0; r < A.m; r++)           // rows ascending -> columns of every transposed row ascending
+    for (int64_t k = A.rp[r]; k < A.rp[r + 1]; k++) { const int64_t q = next[A.ci[k]]++; T.ci[q] = (int32_t)r; T.v[q] = A.v[k]; }
+  return T;
+}
+
 // Richardson improvement of the ideal restrictor on its own pattern (improve_z, src/Grid_Transfer_Improve.F90:200-371):
 //   Z <- Z - ((Z A_ff + A_cf) diag(M)) restricted to pattern(Z),  dm = diagonal of the A_ff inverse.
 // A_ff == nullptr: MATDIAGONAL operator with diagonal aff_d.
@@ -321,7 +335,10 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o, SetupAc
       if (invZ.kind == InvOp::ASSEMBLED) Mz = &invZ.mat;
       else { Mz_store = csr_from_diag(invZ.d.data(), n_f); Mz = &Mz_store; }
     }
-    if (o.one_point_classical_prolong && !o.symmetric) {
+    if (o.symmetric) {
+      // -pc_air_symmetric: P = R^T, i.e. W = Z^T, set once Z exists (AIR_Operators_Setup.F90:898-902)
+      L.one_point = false;
+    } else if (o.one_point_classical_prolong) {
       L.one_point = true;
       one_point_W(L.A_fc, L.wcol);
     } else {
@@ -373,7 +390,7 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o, SetupAc
     Mz_store = Csr();
     inv_asm = InvOp();
     H->timers[4] += now_s() - t0;
-    if (o.symmetric) throw std::runtime_error("-pc_air_symmetric is not supported by this build");
+    if (o.symmetric) L.W = transpose_csr(L.Z);
 
     // ---- coarse operator R (A P) with drop / lump (AIR_Operators_Setup.F90:960-1085)
     t0 = now_s();

@@ -81,6 +81,9 @@ OPT_PAIRS = {
     "cr_0.1": (dict(cf_splitting_type="cr", strong_threshold=0.1), R.AirOptions(cf_splitting_type="cr", strong_threshold=0.1)),
     "cr_wjacobi_0.7": (dict(cf_splitting_type="cr", strong_threshold=0.7, inverse_type="wjacobi"),
                        R.AirOptions(cf_splitting_type="cr", strong_threshold=0.7, inverse_type=R.INV_WJACOBI)),
+    # -pc_air_symmetric: P = R^T, strength graph not symmetrised again
+    "symmetric": (dict(symmetric=True), R.AirOptions(symmetric=True)),
+    "symmetric_lair": (dict(symmetric=True, z_type="lair"), R.AirOptions(symmetric=True, z_type="lair")),
     "sai": (dict(inverse_type="sai"), R.AirOptions(inverse_type=R.INV_SAI)),
     "isai_s2": (dict(inverse_type="isai", inverse_sparsity_order=2), R.AirOptions(inverse_type=R.INV_ISAI, inverse_sparsity_order=2)),
 }
@@ -252,7 +255,7 @@ def test_auto_truncation_and_options():
     with pytest.raises(P.AirhipError):
         P.PCAIR(z_type="lair_product")
     with pytest.raises(P.AirhipError):
-        P.PCAIR(symmetric=True)
+        P.PCAIR(constrain_z=True)
     with pytest.raises(P.AirhipError):
         P.PCAIR(cf_splitting_type="agg")
 
