@@ -153,7 +153,7 @@ def test_level_sizes_of_config_table():
     assert A.nnz == 3 * 99 * 99 + (100 * 100 - 99 * 99)
 
 
-# ---- tests/ex6f.F90 (tests/Makefile:425-510): 5-point Laplacian on an m x n grid, two successive solves with the
+# ---- tests/ex6f.F90 (tests/Makefile:426-496): 5-point Laplacian on an m x n grid, two successive solves with the
 # diagonal raised by 2 before each; the PC is built once from the ORIGINAL matrix (":59-62", no -regen) or rebuilt
 # for each system (-regen; the reference then reuses the first setup's sparsity, here the setup is simply redone).
 # GMRES(30), left PC, rtol 1e-5, exact solution = step number, previous solution as initial guess.
@@ -190,32 +190,39 @@ def ex6f(opts, max_it, regen=False, m=10, n=10, nsteps=2, setup=None):
 P10 = dict(a_drop=1e-3, inverse_type=R.INV_POWER)
 N10 = dict(a_drop=1e-3, inverse_type=R.INV_NEWTON)
 EX6F_CASES = [
-    ("427 power reused", P10, 10, False), ("429 power regen", P10, 3, True),
-    ("431 ideal W regen", dict(P10, one_point_classical_prolong=False), 3, True),
-    ("433 strong R regen", dict(P10, strong_r_threshold=0.01), 3, True),
-    ("435 lAIR regen", dict(P10, z_type="lair"), 3, True),
-    ("437 lAIR SAI regen", dict(P10, z_type="lair_sai"), 3, True),
-    ("443 strong threshold 0 regen", dict(P10, strong_threshold=0.0), 3, True),
-    ("447 power order 0", dict(P10, poly_order=0), 10, False), ("449 power order 0 regen", dict(P10, poly_order=0), 3, True),
-    ("451 power order 1", dict(P10, poly_order=1), 10, False), ("453 power order 1 regen", dict(P10, poly_order=1), 3, True),
-    ("455 power order 2 sparsity 2", dict(P10, poly_order=2, inverse_sparsity_order=2), 10, False),
-    ("457 power order 2 sparsity 2 regen", dict(P10, poly_order=2, inverse_sparsity_order=2), 3, True),
-    ("459 power sparsity 2 regen", dict(P10, inverse_sparsity_order=2), 3, True),
-    ("461 power sparsity 0", dict(P10, inverse_sparsity_order=0), 10, False),
-    ("463 power sparsity 0 regen", dict(P10, inverse_sparsity_order=0), 3, True),
-    ("465 newton order 0", dict(N10, poly_order=0), 10, False), ("467 newton order 0 regen", dict(N10, poly_order=0), 3, True),
-    ("469 newton order 1", dict(N10, poly_order=1), 10, False), ("471 newton order 1 regen", dict(N10, poly_order=1), 3, True),
-    ("473 newton order 2 sparsity 2", dict(N10, poly_order=2, inverse_sparsity_order=2), 10, False),
-    ("475 newton order 2 sparsity 2 regen", dict(N10, poly_order=2, inverse_sparsity_order=2), 3, True),
-    ("477 newton sparsity 2 regen", dict(N10, inverse_sparsity_order=2), 3, True),
-    ("479 newton sparsity 0", dict(N10, inverse_sparsity_order=0), 10, False),
-    ("481 newton sparsity 0 regen", dict(N10, inverse_sparsity_order=0), 3, True),
+    ("428 power reused", P10, 10, False), ("430 power regen", P10, 3, True),
+    ("432 ideal W regen", dict(P10, one_point_classical_prolong=False), 3, True),
+    ("434 strong R regen", dict(P10, strong_r_threshold=0.01), 3, True),
+    ("436 lAIR regen", dict(P10, z_type="lair"), 3, True),
+    ("438 lAIR SAI regen", dict(P10, z_type="lair_sai"), 3, True),
+    ("444 strong threshold 0 regen", dict(P10, strong_threshold=0.0), 3, True),
+    ("448 power order 0", dict(P10, poly_order=0), 10, False), ("450 power order 0 regen", dict(P10, poly_order=0), 3, True),
+    ("454 power order 1", dict(P10, poly_order=1), 10, False), ("456 power order 1 regen", dict(P10, poly_order=1), 3, True),
+    ("460 power order 2 sparsity 2", dict(P10, poly_order=2, inverse_sparsity_order=2), 10, False),
+    ("462 power order 2 sparsity 2 regen", dict(P10, poly_order=2, inverse_sparsity_order=2), 3, True),
+    ("464 power sparsity 2 regen", dict(P10, inverse_sparsity_order=2), 3, True),
+    ("468 power sparsity 0", dict(P10, inverse_sparsity_order=0), 10, False),
+    ("470 power sparsity 0 regen", dict(P10, inverse_sparsity_order=0), 3, True),
+    ("474 newton order 0", dict(N10, poly_order=0), 10, False), ("476 newton order 0 regen", dict(N10, poly_order=0), 3, True),
+    ("480 newton order 1", dict(N10, poly_order=1), 10, False), ("482 newton order 1 regen", dict(N10, poly_order=1), 3, True),
+    ("486 newton order 2 sparsity 2", dict(N10, poly_order=2, inverse_sparsity_order=2), 10, False),
+    ("488 newton order 2 sparsity 2 regen", dict(N10, poly_order=2, inverse_sparsity_order=2), 3, True),
+    ("490 newton sparsity 2 regen", dict(N10, inverse_sparsity_order=2), 3, True),
+    ("494 newton sparsity 0", dict(N10, inverse_sparsity_order=0), 10, False),
+    ("496 newton sparsity 0 regen", dict(N10, inverse_sparsity_order=0), 3, True),
 ]
 
 
 @pytest.mark.parametrize("label,opts,bound,regen", EX6F_CASES, ids=[c[0] for c in EX6F_CASES])
 def test_ex6f_successive_solves_meet_reference_bounds(label, opts, bound, regen):
     assert ex6f(opts, bound, regen) <= bound
+
+
+@pytest.mark.parametrize("label,regen", [("532 pflareinv power reused", False), ("534 pflareinv power regen", True)])
+def test_ex6f_pflareinv_power(label, regen):
+    """tests/Makefile:532,534: the same driver with the single-level power-basis polynomial preconditioner, <= 8"""
+    setup = lambda M: (lambda op: (lambda r: R.apply_inv(op, r)))(R.pcpflareinv_setup(M, inverse_type=R.INV_POWER))
+    assert ex6f({}, 8, regen, setup=setup) <= 8
 
 
 _NAMES = {R.INV_POWER: "power", R.INV_NEWTON: "newton"}

@@ -22,27 +22,29 @@ AIR_CASES = [
     ("91 a_drop power", "mat_stream_2364", POWER, {}, 5),
     ("93 fcf", "mat_stream_2364", dict(POWER, smooth_type="fcf"), {}, 5),
     ("95 matrix-free", "mat_stream_2364", dict(POWER, matrix_free_polys=True), {}, 5),
+    ("99 same through the C driver ex6", "mat_stream_2364", POWER, {}, 5),
+    ("208 newton matrix-free smoothers", "mat_stream_2364", dict(a_drop=1e-3, inverse_type="newton", matrix_free_polys=True), {}, 5),
     ("113 lAIR", "mat_stream_2364", dict(POWER, z_type="lair"), {}, 5),
     ("115 lAIR strong R 0.01", "mat_stream_2364", dict(POWER, z_type="lair", strong_r_threshold=0.01), {}, 5),
-    ("131-135 exact, arnoldi-18 coarse", "mat_stream_2364",
+    ("132-135 exact, arnoldi-18 coarse", "mat_stream_2364",
      dict(EXACT, mg_coarse_ksp_max_it=5, max_levels=30, coarsest_poly_order=18, coarsest_matrix_free_polys=True,
           coarsest_inverse_type="arnoldi"), dict(ksp="richardson", norm="unpreconditioned"), 1),
     ("140-143 exact, newton-60 coarse", "mat_stream_2364",
      dict(EXACT, max_levels=10, coarsest_poly_order=60, coarsest_matrix_free_polys=True, coarsest_inverse_type="newton",
           max_luby_steps=3), dict(ksp="richardson", norm="unpreconditioned"), 1),
-    ("144-147 exact two-level, LU coarse solve", "spring_chain_40",
+    ("147-149 exact two-level, LU coarse solve", "spring_chain_40",
      dict(EXACT, max_levels=2, mg_coarse_pc_type="lu"), dict(ksp="richardson", norm="unpreconditioned"), 1),
     ("157 indefinite power", "e05r0100_petsc", POWER, dict(b_in_f=False), 26),
     # assembled Newton-basis inverses with fixed sparsity (build_gmres_polynomial_newton_inverse)
     ("159 indefinite newton", "e05r0100_petsc", dict(a_drop=1e-3, inverse_type="newton"), dict(b_in_f=False), 26),
-    ("162 newton order 2", "mat_stream_2364", dict(inverse_type="newton", poly_order=2), {}, 5),
-    ("164 newton order 3", "mat_stream_2364", dict(inverse_type="newton", poly_order=3), {}, 5),
+    ("163 newton order 2", "mat_stream_2364", dict(inverse_type="newton", poly_order=2), {}, 5),
+    ("165 newton order 3", "mat_stream_2364", dict(inverse_type="newton", poly_order=3), {}, 5),
 ]
 INV_CASES = [
-    ("116 pflareinv default", {}, 21),
-    ("118 pflareinv power", dict(type="power"), 21),
-    ("120 pflareinv newton assembled", dict(type="newton"), 21),
-    ("124 pflareinv newton matrix-free", dict(type="newton", matrix_free=True), 13),
+    ("119 pflareinv default", {}, 21),
+    ("121 pflareinv power", dict(type="power"), 21),
+    ("123 pflareinv newton assembled", dict(type="newton"), 21),
+    ("127 pflareinv newton matrix-free", dict(type="newton", matrix_free=True), 13),
 ]
 
 # tests/Makefile:199,203: the file stores the upper triangle of 1138_bus; MatLoad into AIJ keeps exactly that
