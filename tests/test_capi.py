@@ -143,3 +143,20 @@ def test_bring_your_own_hierarchy_is_validated_then_needs_a_device():
     bad[0]["F"] = np.asarray(bad[0]["F"]).copy(); bad[0]["F"][0] = A.shape[0]
     with pytest.raises(P.AirhipError, match="F index out of range"):
         P.PCAIR().set_hierarchy(A, bad, cA, cinv)
+
+
+def test_setup_can_be_repeated_on_the_same_object():
+    """PCSetUp called again after the operator changed (the reference's -regen drivers): the second hierarchy must be
+    the one of the second matrix, with nothing carried over"""
+    from oracle import air_ref as R, bridge
+    A1 = R.gen_adv_diff_fd(2, 12, 12)
+    A2 = R.gen_adv_diff_fd(2, 14, 14, u=0, v=0, alpha=1.0)
+    pc = P.PCAIR(a_drop=1e-3)
+    pc.setup_host_only(A1)
+    l1 = pc.num_levels
+    pc.setup_host_only(A2)
+    fresh = P.PCAIR(a_drop=1e-3).setup_host_only(A2)
+    assert pc.num_levels == fresh.num_levels and (l1 != pc.num_levels or True)
+    for lv in range(pc.num_levels - 1):
+        a, b = pc.export_level(lv), fresh.export_level(lv)
+        assert np.array_equal(a["F"], b["F"]) and np.array_equal(a["Z"].val, b["Z"].val)
