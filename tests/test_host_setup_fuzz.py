@@ -1,0 +1,81 @@
+"""Randomised option combinations: the product's C++ setup (two-level, host only) against the oracle on the same
+matrix - identical F/C split, Z and W to 1e-8, the same V-cycle output to 1e-7, and the same refusals.  Seeds are
+fixed; each seed draws 40 combinations of inverse type / orders / sparsity / matrix-free / diagonal scaling / Z type /
+strong-R threshold / prolongator / smoothing string / improvement iterations / CF splitting / symmetric / full
+smoothing / lumping on four small advection and diffusion problems."""
+import numpy as np
+import pytest
+
+import pflare_amd as P
+from oracle import air_ref as R, bridge
+
+INV = dict(power=R.INV_POWER, arnoldi=R.INV_ARNOLDI, newton=R.INV_NEWTON, neumann=R.INV_NEUMANN, jacobi=R.INV_JACOBI,
+           wjacobi=R.INV_WJACOBI, sai=R.INV_SAI, isai=R.INV_ISAI, newton_no_extra=R.INV_NEWTON_NO_EXTRA)
+GENS = [dict(dim=2, M=14, N=14), dict(dim=2, M=12, N=12, u=0, v=0, alpha=1.0), dict(dim=3, M=7, N=7, P=7),
+        dict(dim=2, M=13, N=11, alpha=0.1)]
+
+
+def draw(rng):
+    it = str(rng.choice(list(INV)))
+    o = dict(inverse_type=it, poly_order=int(rng.integers(1, 7)), inverse_sparsity_order=int(rng.integers(0, 3)))
+    if it in ("newton", "newton_no_extra", "power", "arnoldi", "neumann") and rng.random() < 0.3:
+        o["matrix_free_polys"] = True
+    if it in ("power", "arnoldi", "newton") and rng.random() < 0.3:
+        o["diag_scale_polys"] = True
+    if rng.random() < 0.3:
+        o["z_type"] = str(rng.choice(["lair", "lair_sai"])); o["lair_distance"] = int(rng.integers(1, 4))
+    if rng.random() < 0.3:
+        o["strong_r_threshold"] = float(rng.choice([0.01, 0.1]))
+    if rng.random() < 0.3 and "z_type" not in o:
+        o["one_point_classical_prolong"] = False
+    if rng.random() < 0.2:
+        o["smooth_type"] = str(rng.choice(["fc", "fcf", "ffc", "f"]))
+    if rng.random() < 0.2 and not o.get("matrix_free_polys"):
+        o["improve_z_its"] = int(rng.integers(1, 3))
+    if rng.random() < 0.2:
+        o["cf_splitting_type"] = str(rng.choice(["diag_dom", "cr"])); o["strong_threshold"] = float(rng.choice([0.2, 0.5, 0.9]))
+    if rng.random() < 0.15:
+        o["symmetric"] = True
+        o.pop("one_point_classical_prolong", None)
+    if rng.random() < 0.15 and "smooth_type" not in o and "improve_z_its" not in o:
+        o["full_smoothing_up_and_down"] = True
+    if rng.random() < 0.2:
+        o["a_lump"] = True
+    return o
+
+
+def rel(a, b):
+    a = a.tocsr(); b = b.tocsr()
+    assert a.shape == b.shape
+    d = abs(a - b).max() if (a.nnz or b.nnz) else 0.0
+    return d / max(abs(b).max() if b.nnz else 0.0, 1e-300)
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_random_option_combinations_match_the_oracle(seed):
+    rng = np.random.default_rng(seed)
+    compared = 0
+    for _ in range(40):
+        gen = GENS[rng.integers(len(GENS))]
+        o = draw(rng)
+        oo = dict(o, inverse_type=INV[o["inverse_type"]])
+        A = R.gen_adv_diff_fd(**gen); n = A.shape[0]
+        try:
+            Ho = R.setup_air(A, R.AirOptions(max_levels=2, **oo))
+        except NotImplementedError:
+            with pytest.raises(P.AirhipError):
+                P.PCAIR(max_levels=2, **o).setup_host_only(A)
+            continue
+        pc = P.PCAIR(max_levels=2, **o).setup_host_only(A)
+        assert pc.num_levels == Ho.no_levels, (o, gen)
+        if pc.num_levels < 2:
+            continue
+        Hp = bridge.hierarchy_from_product(pc, A)
+        Lp, Lo = Hp.levels[0], Ho.levels[0]
+        assert np.array_equal(Lp.F, Lo.F), (o, gen)
+        assert rel(Lp.Z, Lo.Z) <= 1e-8 and rel(Lp.W, Lo.W) <= 1e-8, (o, gen)
+        x = rng.standard_normal(n)
+        zo, zp = R.vcycle(Ho, x), R.vcycle(Hp, x)
+        assert np.linalg.norm(zo - zp) <= 1e-7 * np.linalg.norm(zo), (o, gen)
+        compared += 1
+    assert compared >= 30
