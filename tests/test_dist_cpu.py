@@ -20,6 +20,12 @@ CASES = {
     "adv2d_30_mf_trunc": (dict(dim=2, M=30, N=30), dict(matrix_free_polys=True, max_levels=3,
                                                          coarsest_inverse_type="power", coarsest_poly_order=4,
                                                          coarsest_matrix_free_polys=True), "block"),
+    # scattered ownership (every row's neighbours mostly live elsewhere), lAIR restrictor
+    "adv2d_24_lair_random": (dict(dim=2, M=24, N=24), dict(z_type="lair", lair_distance=3), "random"),
+    # Z from the strong-R-dropped operator, SAI smoother, compatible-relaxation splitting
+    "diff2d_20_rthr_sai_cr_random": (dict(dim=2, M=20, N=20, u=0, v=0, alpha=1.0),
+                                     dict(strong_r_threshold=0.05, inverse_type="sai", cf_splitting_type="cr",
+                                          strong_threshold=0.5), "random"),
 }
 
 
@@ -30,6 +36,8 @@ def _owner(kind, gen, nranks):
     if kind == "box2d":
         return D.box_owner(gen["M"], gen["N"], 1, nranks)
     n = gen["M"] * gen["N"] * gen.get("P", 1)
+    if kind == "random":
+        return np.random.default_rng(17).integers(0, nranks, size=n).astype(np.int32)
     return D.block_owner(n, nranks)
 
 
