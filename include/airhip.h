@@ -93,6 +93,18 @@ int airhip_set_device(int device);
  * (may be null).  n <= 0 leaves the setting unchanged. */
 int airhip_set_num_threads(int n, int* prev);
 
+/* ---------------------------------------------------------------- stand-alone CF splitting */
+/* compute_cf_splitting(Mat, int symmetric, PetscReal strong_threshold, int max_luby_steps, int cf_splitting_type,
+ * int ddc_its, PetscReal fraction_swap, IS* is_fine, IS* is_coarse)  (include/pflare.h:108-113, src/CF_Splitting.F90:235-392).
+ * cf_splitting_type: AIRHIP_CF_PMISR_DDC | AIRHIP_CF_DIAG_DOM | AIRHIP_CF_CR (the reference's enum values); for
+ * DIAG_DOM / CR strong_threshold carries the target ratio / rate.  CR relaxes with the default A_ff inverse
+ * (Arnoldi basis, order 6, sparsity 1).  markers[i] = -1 (F point) or +1 (C point), i < A->m; host arrays. */
+#define AIRHIP_CF_PMISR_DDC 0
+#define AIRHIP_CF_DIAG_DOM 1
+#define AIRHIP_CF_CR 6
+int airhip_compute_cf_splitting(const airhip_csr* A, int symmetric, double strong_threshold, int max_luby_steps,
+                                int cf_splitting_type, int ddc_its, double fraction_swap, int32_t* markers);
+
 /* ---------------------------------------------------------------- synthetic operators */
 /* tests/adv_1d.c:80-105 and tests/adv_diff_fd.c:366-586.  The CSR arrays are owned by the
  * returned handle; release with airhip_hostmat_destroy. */

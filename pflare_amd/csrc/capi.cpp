@@ -104,6 +104,25 @@ static void expose_csr(const Csr& A, airhip_csr* v) {
   v->m = A.m; v->n = A.n; v->rowptr = A.rp.data(); v->col = A.ci.data(); v->val = A.v.data();
 }
 
+int airhip_compute_cf_splitting(const airhip_csr* A, int symmetric, double strong_threshold, int max_luby_steps,
+                                int cf_splitting_type, int ddc_its, double fraction_swap, int32_t* markers) {
+  API_BEGIN
+  REQUIRE(A && markers, AIRHIP_ERR_ARG, "null argument");
+  REQUIRE_CSR(A, true);
+  AirOptions o;
+  o.symmetric = symmetric != 0; o.strong_threshold = strong_threshold; o.max_luby_steps = max_luby_steps;
+  o.ddc_its = ddc_its; o.ddc_fraction = fraction_swap;
+  if (cf_splitting_type == 0) o.cf_splitting_type = 0;
+  else if (cf_splitting_type == 1) o.cf_splitting_type = 1;
+  else if (cf_splitting_type == 6) o.cf_splitting_type = 2;
+  else { g_err = "CF splitting type outside this build's scope (pmisr_ddc, diag_dom, cr)"; return AIRHIP_ERR_UNSUPPORTED; }
+  Csr view; view_csr(A, view);
+  Arr<int32_t> m;
+  compute_cf_splitting(view, o, m);
+  for (int64_t i = 0; i < A->m; i++) markers[i] = m[i];
+  API_END
+}
+
 int airhip_gen_adv_1d(int64_t n, airhip_hostmat* out) {
   API_BEGIN
   REQUIRE(out && n > 0, AIRHIP_ERR_ARG, "bad argument");

@@ -288,3 +288,16 @@ def test_host_setup_is_bitwise_reproducible_across_thread_counts():
             if "mat" in a["inv_ff"]:
                 assert np.array_equal(a["inv_ff"]["mat"].val, b["inv_ff"]["mat"].val)
         assert np.array_equal(c0.val, c1.val)
+
+
+@pytest.mark.parametrize("cf,thr", [(P.CF_PMISR_DDC, 0.5), (P.CF_DIAG_DOM, 0.9), (P.CF_CR, 0.3)])
+def test_standalone_cf_splitting_matches_oracle(cf, thr):
+    """compute_cf_splitting with the reference's argument order (include/pflare.h:113, python/ex2_cf_splitting.py)"""
+    A = R.gen_adv_diff_fd(2, 20, 20)
+    name = {P.CF_PMISR_DDC: "pmisr_ddc", P.CF_DIAG_DOM: "diag_dom", P.CF_CR: "cr"}[cf]
+    isf, isc = P.compute_cf_splitting(A, False, thr, -1, cf, 1, 0.1)
+    F, C = R.compute_cf_splitting(A.tocsr(), thr, 1, 0.1, False, 1, -1, name, cr=(R.INV_ARNOLDI, 6, 1, False))
+    assert np.array_equal(isf, F) and np.array_equal(isc, C)
+    assert isf.size + isc.size == A.shape[0] and isf.size > 0 and isc.size > 0
+    with pytest.raises(P.AirhipError):
+        P.compute_cf_splitting(A, False, 0.5, -1, 4, 1, 0.1)        # aggregation: not built
