@@ -167,12 +167,10 @@ static void coarse_solver(const Csr& A, const AirOptions& o, InvOp& op, bool fin
     Csr& M = op.mat; M.m = M.n = n;
     M.rp.alloc(n + 1); M.ci.alloc(n * n); M.v.alloc(n * n);
     for (int64_t i = 0; i <= n; i++) M.rp[i] = i * n;
-#pragma omp parallel for schedule(dynamic, 8)
-    for (int64_t j = 0; j < n; j++) {
-      std::vector<double> e((size_t)n, 0.0); e[j] = 1.0;
-      std::vector<double> x = lu_solve(D, e);                 // column j of the inverse
-      for (int64_t i = 0; i < n; i++) { M.ci[i * n + j] = (int32_t)j; M.v[i * n + j] = x[i]; }
-    }
+    const Dense X = lu_inverse(D);                            // one factorisation, n right-hand sides
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++)
+      for (int64_t j = 0; j < n; j++) { M.ci[i * n + j] = (int32_t)j; M.v[i * n + j] = X((int)i, (int)j); }
     return;
   }
   OpView v; v.A = &A; v.n = A.m;

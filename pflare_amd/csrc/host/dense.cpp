@@ -70,6 +70,42 @@ std::vector<double> lu_solve(const Dense& A0, const std::vector<double>& b0) {
   return x;
 }
 
+Dense lu_inverse(const Dense& A0) {
+  Dense A = A0;
+  const int n = A.n;
+  std::vector<int> piv((size_t)n);
+  for (int k = 0; k < n; k++) {
+    int p = k; double best = std::fabs(A(k, k));
+    for (int i = k + 1; i < n; i++) if (std::fabs(A(i, k)) > best) { best = std::fabs(A(i, k)); p = i; }
+    piv[k] = p;
+    if (best == 0.0) continue;
+    if (p != k) for (int c = 0; c < n; c++) std::swap(A(k, c), A(p, c));
+    const double d = 1.0 / A(k, k);
+    for (int i = k + 1; i < n; i++) A(i, k) *= d;
+#pragma omp parallel for schedule(static) if (n - k > 256)
+    for (int c = k + 1; c < n; c++) {
+      const double u = A(k, c);
+      if (u == 0.0) continue;
+      for (int i = k + 1; i < n; i++) A(i, c) -= A(i, k) * u;
+    }
+  }
+  Dense X(n, n);
+#pragma omp parallel for schedule(static)
+  for (int j = 0; j < n; j++) {
+    double* x = &X.a[(size_t)j * n];
+    for (int i = 0; i < n; i++) x[i] = 0.0;
+    x[j] = 1.0;
+    for (int k = 0; k < n; k++) if (piv[k] != k) std::swap(x[k], x[piv[k]]);           // P e_j
+    for (int k = 0; k < n; k++) { const double xk = x[k]; if (xk != 0.0) for (int i = k + 1; i < n; i++) x[i] -= A(i, k) * xk; }
+    for (int k = n - 1; k >= 0; k--) {
+      x[k] = (A(k, k) == 0.0) ? 0.0 : x[k] / A(k, k);
+      const double xk = x[k];
+      if (xk != 0.0) for (int i = 0; i < k; i++) x[i] -= A(i, k) * xk;
+    }
+  }
+  return X;
+}
+
 // One-sided Jacobi SVD of an m x n matrix with m >= n: on return the columns of A are
 // U*diag(s), V holds the right singular vectors.
 static void jacobi_svd(Dense& A, Dense& V, std::vector<double>& s) {

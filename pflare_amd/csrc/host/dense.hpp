@@ -23,6 +23,9 @@ std::vector<double> ls_qr(const Dense& A, const std::vector<double>& b);
 // A x = b for square A by LU with partial pivoting (LAPACK gesv); a zero pivot leaves that unknown at 0
 std::vector<double> lu_solve(const Dense& A, const std::vector<double>& b);
 
+// inverse of a square matrix by one LU factorisation with partial pivoting (gesv with n right-hand sides)
+Dense lu_inverse(const Dense& A);
+
 // minimum-norm least squares by SVD, singular values <= rcond*s_max dropped
 // (rcond < 0 -> machine epsilon)  (LAPACK gelsd)
 std::vector<double> ls_minnorm_svd(const Dense& A, const std::vector<double>& b, double rcond);
