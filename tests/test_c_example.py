@@ -34,3 +34,15 @@ def test_c_driver_converges_within_the_reference_bound(gpu):
     assert "iterations=" in r.stdout
     its = int(r.stdout.split("iterations=")[1].split()[0])
     assert its <= 2
+
+
+@pytest.mark.gpu
+def test_python_ex2_runs(gpu=None):
+    """examples/ex2.py: the reference's python/ex2.py (2-D Laplacian, PCAIR configured through the pflare option API)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "ex2.py"), "-m", "16", "-n", "12"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Norm of error" in r.stdout
