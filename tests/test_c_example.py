@@ -42,7 +42,7 @@ def test_python_ex2_runs(gpu=None):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "examples", "ex2.py"), "-m", "16", "-n", "12"],
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "ex2.py"), "-m", "24", "-n", "20"],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Norm of error" in r.stdout
