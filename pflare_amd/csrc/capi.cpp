@@ -7,6 +7,7 @@
 #include "device/comm.hpp"
 #include "host/dist.hpp"
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -45,10 +46,52 @@ namespace airhip { extern int g_spmv_variant; }
 // kernel tuning knob used by the benchmarks (see device/spmv.hip); not part of the stable ABI
 extern "C" int airhip_debug_set_variant(int v) { airhip::g_spmv_variant = v; return 0; }
 
+// ---- host threads.  OpenMP's default is one thread per CPU the process may be scheduled on; in a container
+// with a CPU *quota* (cgroup cpu.max) that is the whole machine, and a team of 128+ threads on a 16-CPU share
+// turns every parallel region of a small setup into a scheduler storm (measured: 16x slower with 64 threads on
+// 8 CPUs).  So unless OMP_NUM_THREADS or airhip_set_num_threads says otherwise, the team is the CPU share,
+// at most 32 (the measured optimum of the memory-bound setup phases), and small operators get fewer threads.
+static int read_int_file(const char* path, long long* a, long long* b) {
+  FILE* f = std::fopen(path, "r");
+  if (!f) return 0;
+  char t0[64] = {0}, t1[64] = {0};
+  int n = std::fscanf(f, "%63s %63s", t0, t1);
+  std::fclose(f);
+  if (n < 1) return 0;
+  if (std::strcmp(t0, "max") == 0) *a = -1; else *a = std::atoll(t0);
+  if (n > 1 && b) *b = std::atoll(t1);
+  return n;
+}
+static int cpu_share() {
+  int n = omp_get_num_procs();                       // honours the affinity mask
+  long long q = -1, per = 100000;
+  if (read_int_file("/sys/fs/cgroup/cpu.max", &q, &per) >= 1 && q > 0 && per > 0)          // cgroup v2
+    n = std::min<long long>(n, std::max<long long>(1, (q + per - 1) / per));
+  else if (read_int_file("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", &q, nullptr) >= 1 && q > 0 &&
+           read_int_file("/sys/fs/cgroup/cpu/cpu.cfs_period_us", &per, nullptr) >= 1 && per > 0)   // cgroup v1
+    n = std::min<long long>(n, std::max<long long>(1, (q + per - 1) / per));
+  return std::max(1, n);
+}
+static int g_team = 0;        // the team size for large operators
+__attribute__((constructor)) static void init_host_threads() {
+  const char* e = std::getenv("OMP_NUM_THREADS");
+  g_team = (e && *e) ? omp_get_max_threads() : std::min(cpu_share(), 32);
+  omp_set_num_threads(g_team);
+}
+// fewer threads for small operators: one thread per ~32k non-zeros
+struct ThreadScope {
+  int prev;
+  explicit ThreadScope(int64_t nnz) : prev(omp_get_max_threads()) {
+    int want = (int)std::min<int64_t>(prev, std::max<int64_t>(1, nnz / 32768));
+    omp_set_num_threads(want);
+  }
+  ~ThreadScope() { omp_set_num_threads(prev); }
+};
+
 int airhip_set_num_threads(int n, int* prev) {
   API_BEGIN
   if (prev) *prev = omp_get_max_threads();
-  if (n > 0) omp_set_num_threads(n);
+  if (n > 0) { omp_set_num_threads(n); g_team = n; }
   API_END
 }
 
@@ -117,6 +160,7 @@ int airhip_compute_cf_splitting(const airhip_csr* A, int symmetric, double stron
   else if (cf_splitting_type == 6) o.cf_splitting_type = 2;
   else { g_err = "CF splitting type outside this build's scope (pmisr_ddc, diag_dom, cr)"; return AIRHIP_ERR_UNSUPPORTED; }
   Csr view; view_csr(A, view);
+  ThreadScope threads(A->rowptr[A->m]);
   Arr<int32_t> m;
   compute_cf_splitting(view, o, m);
   for (int64_t i = 0; i < A->m; i++) markers[i] = m[i];
@@ -341,6 +385,7 @@ int airhip_pcair_setup(airhip_pcair pc, const airhip_csr* A) {
   }
   pc->dev.reset(); pc->H.reset();
   view_csr(A, pc->A_top);
+  ThreadScope threads(A->rowptr[A->m]);
   double t0 = now_s();
   {
     std::unique_ptr<SetupAccel> accel;
@@ -380,6 +425,7 @@ extern "C" int airhip_pcair_setup_host_only(airhip_pcair pc, const airhip_csr* A
   REQUIRE_CSR(A, true);
   pc->dev.reset(); pc->H.reset();
   Csr view; view_csr(A, view);
+  ThreadScope threads(A->rowptr[A->m]);
   double t0 = now_s();
   pc->H = setup_air(view, pc->opt);
   pc->host_setup_s = now_s() - t0;
@@ -938,6 +984,7 @@ int airhip_pcinv_setup(airhip_pcinv pc, const airhip_csr* A) {
     g_err = "no HIP device: the PCPFLAREINV apply has no CPU fallback"; return AIRHIP_ERR_HIP;
   }
   Csr view; view_csr(A, view);
+  ThreadScope threads(A->rowptr[A->m]);
   pcinv_build_host(pc, view);
   view_csr(A, pc->inner.A_top);
   finish_device(&pc->inner);
@@ -949,6 +996,7 @@ extern "C" int airhip_pcinv_setup_host_only(airhip_pcinv pc, const airhip_csr* A
   REQUIRE(pc && A && A->m == A->n && A->m > 0, AIRHIP_ERR_ARG, "PCPFLAREINV needs a square CSR operator");
   REQUIRE_CSR(A, true);
   Csr view; view_csr(A, view);
+  ThreadScope threads(A->rowptr[A->m]);
   pcinv_build_host(pc, view);
   API_END
 }

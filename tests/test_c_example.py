@@ -11,8 +11,8 @@ EX = os.path.join(ROOT, "examples")
 
 
 def _build():
-    subprocess.run(["make", "-s", "-C", EX, "clean"], check=True)
-    subprocess.run(["make", "-s", "-C", EX], check=True)
+    subprocess.run(["make", "-s", "-C", EX, "clean"], check=True, timeout=60)
+    subprocess.run(["make", "-s", "-C", EX], check=True, timeout=120)
     return os.path.join(EX, "adv_1d")
 
 
@@ -21,7 +21,7 @@ def test_c_driver_builds_and_refuses_to_run_without_a_device():
     exe = _build()
     if torch.cuda.is_available():
         pytest.skip("a GPU is present: covered by the gpu test")
-    r = subprocess.run([exe, "-n", "200"], capture_output=True, text=True)
+    r = subprocess.run([exe, "-n", "200"], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0
     assert "no HIP device" in r.stderr and "no CPU fallback" in r.stderr
 
@@ -29,7 +29,7 @@ def test_c_driver_builds_and_refuses_to_run_without_a_device():
 @pytest.mark.gpu
 def test_c_driver_converges_within_the_reference_bound(gpu):
     exe = _build()
-    r = subprocess.run([exe, "-n", "1000", "-ksp_max_it", "2"], capture_output=True, text=True)
+    r = subprocess.run([exe, "-n", "1000", "-ksp_max_it", "2"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "iterations=" in r.stdout
     its = int(r.stdout.split("iterations=")[1].split()[0])

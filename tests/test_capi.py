@@ -83,7 +83,7 @@ def test_print_stats_timings_output_has_the_reference_labels():
             "import pflare_amd as P\n"
             "A = P.HostMat.adv_diff_fd(dim=2, M=30, N=30)\n"
             "P.PCAIR(print_stats_timings=True).setup_host_only(A)\n") % ROOT
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True, timeout=120).stdout
     levels = re.findall(r"~~~~~~~~~~~~ Level\s+(\d+)", out)
     assert levels and levels[0] == "1"
     assert re.search(r"Global rows\s+900\s+Global F-points\s+(\d+)\s+Global C-points\s+(\d+)", out)

@@ -103,13 +103,14 @@ def _free_port():
 
 
 def _worker(rank, world, port, case, out):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import proc_util
+    proc_util.init_rank_env(rank, world, port)
     import torch
     import torch.distributed as dist
     from pflare_amd import dist as D
     from dist_util import Cluster, Piece
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=proc_util.pg_timeout())
     try:
         gen, _, kind = CASES[case]
         n = gen["M"] * gen["N"] * gen.get("P", 1)
@@ -150,9 +151,9 @@ def _worker(rank, world, port, case, out):
 
 @pytest.mark.parametrize("case", ["adv2d_40", "adv3d_14_lump"])
 def test_world_size_2_gloo_vcycle(case, tmp_path):
-    import torch.multiprocessing as mp
+    import proc_util
     out = str(tmp_path / "result.txt")
-    mp.spawn(_worker, args=(2, _free_port(), case, out), nprocs=2, join=True)
+    proc_util.spawn(_worker, (2, _free_port(), case, out), 2)
     err, nexch = open(out).read().split()
     assert float(err) <= 1e-12
     assert int(nexch) > 0

@@ -9,6 +9,8 @@ import sys
 import numpy as np
 import pytest
 
+import proc_util
+
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,7 +30,9 @@ def _free_port():
 
 
 def _worker(rank, world, port, case, out):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import proc_util
+    proc_util.init_rank_env(rank, world, port)
     if case == "adv3d_24_lump":      # exercise the opt-in interior / boundary split (exchange overlap) as well
         os.environ["AIRHIP_OVERLAP"] = "1"
         os.environ["AIRHIP_OVERLAP_MIN_BLOCKS"] = "4"
@@ -37,7 +41,7 @@ def _worker(rank, world, port, case, out):
     import torch.distributed as dist
     import pflare_amd as P
     from pflare_amd import dist as D
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=proc_util.pg_timeout())
     try:
         torch.cuda.set_device(0)
         gen, opts, kind = CASES[case]
@@ -99,9 +103,8 @@ def _worker(rank, world, port, case, out):
 
 @pytest.mark.parametrize("case,world", [(c, 2) for c in sorted(CASES)] + [("adv3d_24_lump", 4)])
 def test_ranks_match_single_gpu(gpu, case, world, tmp_path):
-    import torch.multiprocessing as mp
     out = str(tmp_path / "r.txt")
-    mp.spawn(_worker, args=(world, _free_port(), case, out), nprocs=world, join=True)
+    proc_util.spawn(_worker, (world, _free_port(), case, out), world)
     r = eval(open(out).read())
     assert r["verr"] <= 1e-10, r
     assert r["its"] == [r["its_single"]] * world, r
@@ -111,14 +114,17 @@ def test_ranks_match_single_gpu(gpu, case, world, tmp_path):
 
 
 def _rccl_worker(rank, world, port, out):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import proc_util
+    proc_util.init_rank_env(rank, world, port)
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
     import pflare_amd as P
     from pflare_amd import dist as D
     torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0),
+                            timeout=proc_util.pg_timeout())
     try:
         gen = dict(dim=3, M=20, N=20, P=20)
         A = P.HostMat.adv_diff_fd(**gen)
@@ -147,23 +153,24 @@ def test_rccl_transport_loads_and_reduces(gpu, tmp_path):
     """world_size 1: exercises the run-time binding of librccl, communicator creation from a
     broadcast unique id and the device all-reduce of the Krylov dots (a second rank cannot share
     the GPU under RCCL)."""
-    import torch.multiprocessing as mp
     out = str(tmp_path / "r.txt")
-    mp.spawn(_rccl_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    proc_util.spawn(_rccl_worker, (1, _free_port(), out), 1)
     r = eval(open(out).read())
     assert r["its"] == r["its_single"] and r["diff"] <= 1e-12, r
     assert r["stats"]["allreduces"] > 0
 
 
 def _refdata_worker(rank, world, port, out):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import proc_util
+    proc_util.init_rank_env(rank, world, port)
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
     import pflare_amd as P
     from pflare_amd import dist as D
     from pflare_amd.petscio import load_mat_vec
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=proc_util.pg_timeout())
     try:
         torch.cuda.set_device(0)
         A, b = load_mat_vec(os.path.join(ROOT, "tests", "golden", "reference_data", "mat_stream_2364"))
@@ -201,9 +208,8 @@ def test_reference_parallel_load_test_two_ranks(gpu, tmp_path):
     """tests/Makefile:217-218 (`$(MPIEXEC) -n 2 ./ex6 -f data/mat_stream_2364 -pc_air_a_drop 1e-3
     -pc_air_inverse_type power -pc_air_matrix_free_polys -ksp_max_it 5`): the distributed product must converge
     within the reference's bound (row-block ownership instead of the reference's graph partition)."""
-    import torch.multiprocessing as mp
     out = str(tmp_path / "r.txt")
-    mp.spawn(_refdata_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    proc_util.spawn(_refdata_worker, (2, _free_port(), out), 2)
     r = eval(open(out).read())
     assert all(x > 0 for x in r["reasons"]) and max(r["its"]) <= 5 and len(set(r["its"])) == 1, r
     assert r["rel"] <= 1e-3, r
