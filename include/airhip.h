@@ -93,6 +93,16 @@ int airhip_set_device(int device);
  * (may be null).  n <= 0 leaves the setting unchanged. */
 int airhip_set_num_threads(int n, int* prev);
 
+/* ------------------------------------------------------------- tuning and inspection hooks
+ * Declared so that nothing the library exports is hidden; NOT part of the stable ABI.
+ * airhip_set_tuning: performance knobs of the kernels, process-wide.  Keys: "spmv_wg_per_cu" (workgroups per CU of
+ *   the row-block SpMV grid, 0 = occupancy query), "spmv_pipeline" (0 = no cross-block prefetch; diagnostic).
+ * airhip_pcair_setup_host_only / airhip_pcinv_setup_host_only: build the hierarchy without touching a device (CPU-side
+ *   tests of the setup, hierarchy export); apply / solve then fail with AIRHIP_ERR_STATE.
+ * airhip_spgemm_filtered: C = filter(A*B) with the host (on_device = 0) or the device SpGEMM of the setup, drop / lump /
+ *   negate as in the setup's Z and RAP products; stats[3] = rows per accumulator kind (LDS 1k, LDS 4k, global). */
+int airhip_set_tuning(const char* key, int value);
+
 /* ---------------------------------------------------------------- stand-alone CF splitting */
 /* compute_cf_splitting(Mat, int symmetric, PetscReal strong_threshold, int max_luby_steps, int cf_splitting_type,
  * int ddc_its, PetscReal fraction_swap, IS* is_fine, IS* is_coarse)  (include/pflare.h:108-113, src/CF_Splitting.F90:235-392).
@@ -131,6 +141,7 @@ int airhip_pcair_set_option(airhip_pcair pc, const char* name, const char* value
 int airhip_pcair_set_ordering_hint(airhip_pcair pc, const int64_t* key, int64_t n);
 /* Full setup from the operator: host hierarchy construction + device upload. */
 int airhip_pcair_setup(airhip_pcair pc, const airhip_csr* A);
+int airhip_pcair_setup_host_only(airhip_pcair pc, const airhip_csr* A);   /* see "tuning and inspection hooks" */
 
 /* Bring-your-own hierarchy (e.g. built by PFLARE's own setup under PETSc).  Levels are
  * numbered 0 (finest) .. no_levels-2, all index lists and matrices in the reference's
@@ -238,6 +249,9 @@ int airhip_pcinv_create(airhip_pcinv* pc);
  * "matrix_free", "diag_scale" */
 int airhip_pcinv_set_option(airhip_pcinv pc, const char* name, const char* value);
 int airhip_pcinv_setup(airhip_pcinv pc, const airhip_csr* A);
+int airhip_pcinv_setup_host_only(airhip_pcinv pc, const airhip_csr* A);
+int airhip_spgemm_filtered(const airhip_csr* A, const airhip_csr* B, int drop, double tol, int lump, int negate,
+                           int on_device, airhip_hostmat* out, int64_t* stats);
 int airhip_pcinv_apply(airhip_pcinv pc, const double* d_x, double* d_y);
 int airhip_pcinv_sync(airhip_pcinv pc);
 int airhip_pcinv_get_inv(airhip_pcinv pc, airhip_invop* inv);

@@ -33,6 +33,7 @@ class airhip_ksp_result(C.Structure):
 # every symbol include/airhip.h declares (tests check that the library exports all of them)
 DECLARED_SYMBOLS = [
     "airhip_last_error", "airhip_version", "airhip_device_count", "airhip_set_device", "airhip_set_num_threads",
+    "airhip_set_tuning", "airhip_pcair_setup_host_only", "airhip_pcinv_setup_host_only", "airhip_spgemm_filtered",
     "airhip_gen_adv_1d", "airhip_gen_adv_diff_fd", "airhip_hostmat_from_csr", "airhip_hostmat_get",
     "airhip_hostmat_destroy",
     "airhip_pcair_create", "airhip_pcair_set_option", "airhip_pcair_set_ordering_hint", "airhip_pcair_setup", "airhip_pcair_begin_levels",
@@ -81,6 +82,7 @@ def lib():
         "airhip_device_count": [pint],
         "airhip_set_device": [C.c_int],
         "airhip_set_num_threads": [C.c_int, pint],
+        "airhip_set_tuning": [C.c_char_p, C.c_int],
         "airhip_gen_adv_1d": [C.c_int64, pvp],
         "airhip_gen_adv_diff_fd": [C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double,
                                    C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, pvp],

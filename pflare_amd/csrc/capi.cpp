@@ -42,9 +42,13 @@ int airhip_set_device(int device) {
   API_END
 }
 
-namespace airhip { extern int g_spmv_variant; }
-// kernel tuning knob used by the benchmarks (see device/spmv.hip); not part of the stable ABI
-extern "C" int airhip_debug_set_variant(int v) { airhip::g_spmv_variant = v; return 0; }
+// performance knobs of the kernels (see device/spmv.hip); declared in the header, not part of the stable ABI
+int airhip_set_tuning(const char* key, int value) {
+  API_BEGIN
+  REQUIRE(key, AIRHIP_ERR_ARG, "null argument");
+  if (airhip::spmv_set_tuning(key, value) != 0) { g_err = std::string("unknown tuning key ") + key; return AIRHIP_ERR_ARG; }
+  API_END
+}
 
 // ---- host threads.  OpenMP's default is one thread per CPU the process may be scheduled on; in a container
 // with a CPU *quota* (cgroup cpu.max) that is the whole machine, and a team of 128+ threads on a 16-CPU share
@@ -198,10 +202,10 @@ int airhip_hostmat_get(airhip_hostmat A, airhip_csr* view) {
   expose_csr(A->A, view);
   API_END
 }
-// Test hook (not part of the stable ABI): C = filter(A*B) with the host or the device SpGEMM of
+// Inspection hook (declared in the header, not part of the stable ABI): C = filter(A*B) with the host or the device SpGEMM of
 // the setup; stats = {rows in the 1k-entry LDS bin, rows in the 4k-entry LDS bin, rows redone
 // with a global-memory table}.
-extern "C" int airhip_debug_spgemm(const airhip_csr* A, const airhip_csr* B, int drop, double tol, int lump, int negate,
+int airhip_spgemm_filtered(const airhip_csr* A, const airhip_csr* B, int drop, double tol, int lump, int negate,
                                    int on_device, airhip_hostmat* out, int64_t* stats) {
   API_BEGIN
   REQUIRE(A && B && out && A->n == B->m, AIRHIP_ERR_ARG, "bad arguments");
@@ -419,7 +423,7 @@ int airhip_pcair_setup(airhip_pcair pc, const airhip_csr* A) {
 
 // Host-only setup: builds the hierarchy without touching a device (used by CPU-side tests of
 // the setup and by hierarchy export); apply / solve calls then fail with AIRHIP_ERR_STATE.
-extern "C" int airhip_pcair_setup_host_only(airhip_pcair pc, const airhip_csr* A) {
+int airhip_pcair_setup_host_only(airhip_pcair pc, const airhip_csr* A) {
   API_BEGIN
   REQUIRE(pc && A && A->rowptr && A->m == A->n && A->m > 0, AIRHIP_ERR_ARG, "PCAIR needs a square CSR operator");
   REQUIRE_CSR(A, true);
@@ -991,7 +995,7 @@ int airhip_pcinv_setup(airhip_pcinv pc, const airhip_csr* A) {
   pc->inner.A_top = Csr();
   API_END
 }
-extern "C" int airhip_pcinv_setup_host_only(airhip_pcinv pc, const airhip_csr* A) {
+int airhip_pcinv_setup_host_only(airhip_pcinv pc, const airhip_csr* A) {
   API_BEGIN
   REQUIRE(pc && A && A->m == A->n && A->m > 0, AIRHIP_ERR_ARG, "PCPFLAREINV needs a square CSR operator");
   REQUIRE_CSR(A, true);

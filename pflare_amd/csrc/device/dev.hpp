@@ -1,10 +1,9 @@
 // Device-side data structures and kernel launchers of the PCAIR solve phase (gfx950).
 //
 // Layout decisions:
-//  * matrices live in HBM as SELL-64: rows grouped in slices of 64 (one wavefront), each
-//    slice padded to its longest row and stored column-major inside the slice so that lane
-//    l of a wave streams row l with fully coalesced 512-B (values) / 256-B (indices) wave
-//    loads; no cross-lane reduction is needed.
+//  * matrices live in HBM as row-block CSR: CSR values / column words without padding, rows in vector
+//    order, plus a partition of the rows into blocks of <= 512 non-zeros and <= 128 rows (a longer row is
+//    a block of its own).  One wavefront owns one block at a time and software-pipelines over its blocks.
 //  * level vectors use a hierarchical F/C ordering: the level-l vector is [x_F | x_C] and
 //    x_C *is* the level-(l+1) vector, so the level-l vector is a suffix of the level-1
 //    vector.  Gathers/scatters (VecISCopy) and the identity blocks of R=[Z I], P=[W;I]
@@ -14,44 +13,39 @@
 #include <cstdint>
 #include <vector>
 #include <string>
+#include <stdexcept>
 
 namespace airhip {
 
-// Row-block CSR: plain CSR (no padding, rows in vector order) plus a partition of the rows
-// into blocks of <= ~512 non-zeros.  One wavefront owns one block: it streams the block's
-// non-zeros with fully coalesced loads, stages the products a_ij * x_j in LDS and then every
-// lane sums the LDS segment of "its" rows in column order (CSR-stream); blocks dominated by
-// a long row fall back to a wave-wide reduction per row (CSR-vector).
+// One row block: 16 bytes, read with one scalar load.  cbase >= 0: the block's entries are stored SORTED BY
+// COLUMN, every index word holds (row-major position << 23) | (column - cbase).  cbase < 0 ("raw" block: a
+// column span of 2^23 or more, or a single row longer than 512): entries in row-major order, index word =
+// absolute column.
+struct BlkDesc { int64_t p0; int32_t row; int32_t cbase; };
+
+// Row-block CSR.  One wavefront streams a block's (index word, value) pairs with coalesced loads, gathers x,
+// stages the products a_ij * x_j in LDS at their row-major positions and then sums every row's LDS segment
+// (one lane per row, or T lanes per row when the block holds few long rows).  12 bytes per non-zero for every
+// operator width; 2 bytes per row of block-relative row offsets.
 struct DevMat {
   int64_t m = 0, n = 0;          // rows, cols (n includes the ghost columns of a distributed operand)
   int64_t n_ghost = 0;           // distributed operand: columns [n - n_ghost, n) are ghost values
   struct HaloPlan* halo = nullptr;   // how to obtain them (not owned)
   int64_t nnz = 0;
   int64_t nblocks = 0;
-  int32_t* blk_row = nullptr;    // [nblocks+1] first row of each block
-  int64_t* blk_p0 = nullptr;     // [nblocks+1] first non-zero of each block
-  uint32_t* roff = nullptr;      // [m] start of row r relative to its block's first non-zero
-  int32_t* col = nullptr;        // [nnz]
-  double* val = nullptr;         // [nnz]
-  // Blocks that take the LDS path store their entries sorted by COLUMN (neighbouring lanes then
-  // gather neighbouring x entries: a 64-lane gather touches ~7 instead of ~25 cache lines) and
-  // slot[k] gives the entry's row-major position inside the block, where its product is staged.
-  uint16_t* slot = nullptr;      // [nnz] or null (unsorted, or packed)
-  bool packed = false;           // operators with <= 2^22 columns: slot lives in bits 22..31 of col (12 B/nnz again)
-  // tiles: consecutive row blocks (~2k non-zeros) whose distinct columns are staged in LDS by the
-  // workgroup that owns the tile; entries address the staged copy through a 16-bit local index
-  int64_t ntiles = 0, n_ucol = 0;
-  int32_t* tile_blk = nullptr;   // [ntiles+1] first block of each tile
-  int64_t* tile_u0 = nullptr;    // [ntiles+1] offset of the tile's sorted distinct columns in ucol (empty: direct tile)
-  int32_t* ucol = nullptr;       // [n_ucol]
-  uint16_t* lidx = nullptr;      // [nnz] position of the entry's column in its tile's list
+  BlkDesc* blk = nullptr;        // [nblocks+1]; the last entry holds {nnz, m, 0}
+  uint16_t* roff = nullptr;      // [m] start of row r relative to its block's first non-zero
+  uint32_t* idx = nullptr;       // [nnz+1] index words (one readable padding entry)
+  double* val = nullptr;         // [nnz+1]
   // distributed operand: the row blocks that touch no ghost column (interior) / at least one (boundary);
   // the interior blocks run while the neighbour exchange is in flight
   int32_t* list_int = nullptr; int32_t* list_bnd = nullptr;
   int64_t n_int = 0, n_bnd = 0;
-  bool valid() const { return blk_row != nullptr; }
+  bool valid() const { return blk != nullptr; }
   // algorithmic bytes of one SpMV with this operator: S(X) of SURVEY 8(d)
   double s_bytes() const { return 12.0 * nnz + 4.0 * (m + 1) + 8.0 * m + 8.0 * n; }
+  // bytes the format actually holds
+  double stored_bytes() const { return 12.0 * (nnz + 1) + 2.0 * m + 16.0 * (nblocks + 1); }
 };
 
 // out_i = alpha * s_i + beta * z_i + gamma * w_i,  s = (A x)_i [ * dscale_i ]
@@ -100,6 +94,9 @@ void devmat_from_csr_device(int64_t m, int64_t n, const int64_t* d_rp, const int
                           const int32_t* d_rowsrc, const int32_t* d_colmap, DevMat& out, hipStream_t s,
                           int64_t n_ghost = 0);   // the last n_ghost columns are not remapped
 void devmat_free(DevMat& A);
+
+// performance knobs (not part of the stable ABI; airhip_set_tuning): see spmv.hip
+int spmv_set_tuning(const char* key, int value);
 
 #define HIP_CHECK(expr)                                                                       \
   do {                                                                                        \

@@ -458,7 +458,7 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
 
 double DevPCAIR::storage_bytes() const {
   double b = 0;
-  auto sb = [&](const DevMat& m) { if (m.valid()) b += 12.0 * m.nnz + 4.0 * m.m + 12.0 * (m.nblocks + 1); };
+  auto sb = [&](const DevMat& m) { if (m.valid()) b += m.stored_bytes(); };
   sb(A_perm_); sb(coarse_A_); sb(coarse_inv_.mat);
   for (auto& l : levels_) { sb(l->A_ff); sb(l->A_fc); sb(l->A_cf); sb(l->A_cc); sb(l->Z); sb(l->W); sb(l->inv_ff.mat); sb(l->inv_cc.mat); sb(l->A_full); }
   return b;

@@ -4,24 +4,24 @@
 // Format and mapping (gfx950, wave64):
 //   * the matrix stays in CSR row order (no padding; SELL-64 padded the AIR operators by 1.75x, and
 //     length-sorted SELL-C-sigma destroyed the locality of the x gathers);
-//   * rows are partitioned into blocks of <= BLK_NNZ non-zeros (+ the tail of the last row, at most
-//     BLK_ROWS rows); one WAVE owns one block: phase 1 streams the block's values / column indices
-//     with coalesced wave loads, gathers x and stages the products in LDS (8 KB per wave);
-//     phase 2 lets lane l sum the LDS segment of row r0+l (+64, ...) in column order - the same
-//     summation order as a sequential CSR loop - and apply the fused epilogue, so the z / w / out
-//     vectors are read and written coalesced;
-//   * inside a block that takes the LDS path the (column, value) pairs are stored SORTED BY COLUMN
-//     and a 16-bit slot gives the row-major position where the product is staged: neighbouring
-//     lanes gather neighbouring x entries (the gather is bound by distinct cache lines per wave
-//     instruction, profiles/r01_spmv_experiments.md); results are unchanged bit for bit;
-//   * blocks with <= 4 non-zeros per row on average skip the LDS stage (one lane per row); a block
-//     holding a row longer than the LDS stage uses a wave-wide reduction per row;
+//   * rows are partitioned into blocks of <= BLK_NNZ (512) non-zeros and <= BLK_ROWS (128) rows; a row
+//     longer than that is a block of its own.  Inside a block the (column, value) pairs are stored SORTED
+//     BY COLUMN (neighbouring lanes then gather neighbouring x entries: the gather is bound by distinct
+//     cache lines per wave instruction, profiles/r01_spmv_experiments.md) and the 32-bit index word is
+//     (row-major position << 23) | (column - cbase) with a per-block column base: 12 B per non-zero for
+//     every operator width.  Blocks whose columns span 2^23 or more stay row-major with absolute columns;
+//   * one WAVE owns one block at a time and software-pipelines over its blocks: while the x gather of
+//     block b is in flight the (index, value) stream of block b+1 is already being loaded into registers,
+//     and the block descriptors are fetched two blocks ahead.  Round 1 measured one block every ~7 us per
+//     wave = seven dependent memory round trips (descriptor, indices, gather, row offsets, epilogue
+//     vectors ...) with SQ_WAIT_ANY at 82 %; here a block costs one gather round trip;
+//   * phase 1: products to LDS at their row-major positions (4 KB per wave); phase 2: lane l sums the LDS
+//     segment of rows r0+l and r0+l+64 in column order (the summation order of a sequential CSR loop), or
+//     T lanes share a row when the block holds <= 32 rows; the epilogue vectors are loaded before the
+//     gather is waited for;
 //   * XCD-aware assignment: blocks b and b+8 of the grid share an XCD (observed round-robin
 //     dispatch; a speed assumption only), so each residue class of workgroups walks a contiguous
 //     range of row blocks and an XCD's private L2 sees a contiguous window of x.
-// airhip_debug_set_variant selects timing variants (LDS stage size, non-temporal loads, unroll depth, a
-// no-far-gather diagnostic); the flat-stream diagnostics of profiles/r01_spmv_experiments.md were removed
-// after the measurements.
 #include "dev.hpp"
 #include "kcommon.hpp"
 #include "rb.hpp"
@@ -29,6 +29,7 @@
 #include <vector>
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 namespace airhip {
 
@@ -47,261 +48,308 @@ __device__ __forceinline__ BlockRange my_blocks(int64_t nblocks) {
   return r;
 }
 
-extern int g_spmv_variant;
-static int grid_for_blocks(int64_t nblocks) {
+// ---- tuning knobs (airhip_set_tuning; defaults are what bench.py measures)
+static int g_grid_wg_per_cu = 0;     // 0 = from the occupancy query
+static int g_pipeline = 1;           // 0 = no cross-block prefetch (diagnostic)
+int spmv_set_tuning(const char* key, int value) {
+  if (!std::strcmp(key, "spmv_wg_per_cu")) { g_grid_wg_per_cu = value; return 0; }
+  if (!std::strcmp(key, "spmv_pipeline")) { g_pipeline = value; return 0; }
+  return -1;
+}
+
+struct BlkInfo { int64_t p0; int32_t r0, cbase, nb, nr; };
+
+// Block descriptors are read through the constant address space: the address is wave-uniform, so the
+// compiler emits scalar loads (s_load_dwordx4, counted by lgkmcnt) instead of vector loads whose wait
+// (vmcnt is in order) would drain the prefetched stream.  The arrays are never written by these kernels.
+typedef const BlkDesc __attribute__((address_space(4))) * BlkDescConstPtr;
+typedef const int32_t __attribute__((address_space(4))) * I32ConstPtr;
+
+__device__ __forceinline__ BlkInfo load_blk(const RbView& A, int64_t i) {
+  int64_t b = i;
+  if (A.blk_list) b = (int64_t)((I32ConstPtr)(uintptr_t)A.blk_list)[i];
+  BlkDescConstPtr bp = (BlkDescConstPtr)(uintptr_t)A.blk;
+  BlkInfo o;
+  o.p0 = bp[b].p0;
+  o.r0 = bp[b].row;
+  o.cbase = bp[b].cbase;
+  o.nb = (int)(bp[b + 1].p0 - o.p0);
+  o.nr = bp[b + 1].row - o.r0;
+  return o;
+}
+
+// the block's first 512 (index, value) pairs into registers: unconditional loads of clamped positions, so
+// that the stream stays straight-line code (no exec-mask branches between the loads and their use)
+__device__ __forceinline__ void issue_stream(const RbView& A, const BlkInfo& d, int lane, uint32_t (&ix)[EPL], double (&vv)[EPL]) {
+  const uint32_t* __restrict__ ip = A.idx + d.p0;
+  const double* __restrict__ vp = A.val + d.p0;
+  const int last = d.nb > 0 ? d.nb - 1 : 0;     // nb == 0: the padding / next block's first entry, never used
+#pragma unroll
+  for (int u = 0; u < EPL; u++) { const int k = min(lane + u * WAVE, last); ix[u] = ip[k]; }
+#pragma unroll
+  for (int u = 0; u < EPL; u++) { const int k = min(lane + u * WAVE, last); vv[u] = vp[k]; }
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Epi interface:
+//   Early early(row)            issued with the stream of the NEXT block (loads whose result feeds another load)
+//   Pre   load(row, Early)      issued at the top of the block's own iteration, before the gather is waited for
+//   void  store(row, acc, Pre)  after the row sum is known
+template <bool DIST, bool PIPE, class Epi>
+__device__ __forceinline__ void rb_loop(const RbView& A, const XVec<DIST> x, double* __restrict__ lds, const Epi& epi) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const BlockRange br = my_blocks(A.blk_list ? A.nlist : A.nblocks);
+  if (br.first >= br.last) return;
+  int64_t bi = br.first;
+  BlkInfo d = load_blk(A, bi);
+  BlkInfo dn = load_blk(A, bi + br.stride < br.last ? bi + br.stride : bi);
+  uint32_t ix[EPL]; double vv[EPL];
+  typename Epi::Early early[2];
+  issue_stream(A, d, lane, ix, vv);
+#pragma unroll
+  for (int q = 0; q < 2; q++) early[q] = epi.early(d.r0 + min(lane + q * WAVE, d.nr - 1));
+  for (;;) {
+    // descriptors two blocks ahead (scalar loads)
+    const int64_t b2 = bi + 2 * br.stride;
+    const BlkInfo dnn = load_blk(A, b2 < br.last ? b2 : bi);
+    const bool more = bi + br.stride < br.last;
+    const int nb = d.nb, nr = d.nr;
+    const bool sorted = d.cbase >= 0;
+    // row offsets and epilogue inputs of this lane's (at most two) rows
+    int ra[2], re[2];
+    typename Epi::Pre pre[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int r = min(lane + q * WAVE, nr - 1);
+      ra[q] = (int)A.roff[d.r0 + r];
+      const int rnext = (int)A.roff[d.r0 + min(r + 1, nr - 1)];
+      re[q] = (r + 1 < nr) ? rnext : nb;
+      if (lane + q * WAVE >= nr) re[q] = ra[q];     // no row: nothing to sum
+      pre[q] = epi.load(d.r0 + r, early[q]);
+    }
+    // gather x for the whole block
+    double xx[EPL];
+#pragma unroll
+    for (int u = 0; u < EPL; u++) {
+      const int32_t c = sorted ? d.cbase + (int32_t)(ix[u] & COL_MASK) : (int32_t)ix[u];
+      xx[u] = x[c];
+    }
+    __builtin_amdgcn_sched_barrier(0);   // the gathers go out before the next block's stream (vmcnt is in order)
+    // the next block's stream (or, at the end, the same block once more: the loads stay unconditional)
+    uint32_t nix[EPL]; double nvv[EPL];
+    typename Epi::Early nearly[2];
+    if constexpr (PIPE) {
+      issue_stream(A, dn, lane, nix, nvv);
+#pragma unroll
+      for (int q = 0; q < 2; q++) nearly[q] = epi.early(dn.r0 + min(lane + q * WAVE, dn.nr - 1));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (nb <= BLK_NNZ) {
+      // phase 1: products to their row-major positions
+#pragma unroll
+      for (int u = 0; u < EPL; u++) {
+        const int k = lane + u * WAVE;
+        const int pos = sorted ? (int)(ix[u] >> COL_BITS) : k;
+        lds[k < nb ? pos : BLK_NNZ] = vv[u] * xx[u];     // entries past the block's end go to a dummy slot
+      }
+      wave_lds_sync();
+      if (nr > 32) {
+        // phase 2: one lane per row, column order
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          const int r = lane + q * WAVE;
+          double s = 0.0;
+          for (int j = ra[q]; j < re[q]; j++) s += lds[j];
+          if (r < nr) epi.store(d.r0 + r, s, pre[q]);
+        }
+      } else {
+        // phase 2 for few (longer) rows: T = 64 / 2^ceil(log2 nr) lanes share a row
+        int T = WAVE, sh = 6;
+        while ((WAVE >> sh) < nr) { sh--; }       // 2^(6-sh) >= nr groups
+        T = 1 << sh;
+        const int g = lane >> sh, t = lane & (T - 1);
+        const int a = __shfl(ra[0], g, WAVE), e = __shfl(re[0], g, WAVE);
+        double s = 0.0;
+        if (g < nr) for (int j = a + t; j < e; j += T) s += lds[j];
+        for (int off = T >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
+        const double srow = __shfl(s, (lane << sh) & (WAVE - 1), WAVE);   // row `lane` lives in lanes lane*T ..
+        if (lane < nr) epi.store(d.r0 + lane, srow, pre[0]);
+      }
+      __builtin_amdgcn_wave_barrier();   // LDS is reused by the next block of this wave
+    } else {
+      // one long row: the whole wave reduces it, four independent chains per lane
+      const uint32_t* __restrict__ ip = A.idx + d.p0;
+      const double* __restrict__ vp = A.val + d.p0;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      int j = lane;
+      for (; j + 3 * WAVE < nb; j += 4 * WAVE) {
+        const int32_t c0 = (int32_t)ip[j], c1 = (int32_t)ip[j + WAVE], c2 = (int32_t)ip[j + 2 * WAVE], c3 = (int32_t)ip[j + 3 * WAVE];
+        const double v0 = vp[j], v1 = vp[j + WAVE], v2 = vp[j + 2 * WAVE], v3 = vp[j + 3 * WAVE];
+        const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+        s0 = fma(v0, x0, s0); s1 = fma(v1, x1, s1); s2 = fma(v2, x2, s2); s3 = fma(v3, x3, s3);
+      }
+      for (; j < nb; j += WAVE) s0 = fma(vp[j], x[(int32_t)ip[j]], s0);
+      double s = (s0 + s1) + (s2 + s3);
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
+      if (lane == 0) epi.store(d.r0, s, pre[0]);
+    }
+    if (!more) break;
+    bi += br.stride;
+    d = dn; dn = dnn;
+    if constexpr (PIPE) {
+#pragma unroll
+      for (int u = 0; u < EPL; u++) { ix[u] = nix[u]; vv[u] = nvv[u]; }
+      early[0] = nearly[0]; early[1] = nearly[1];
+    } else {
+      issue_stream(A, d, lane, ix, vv);
+#pragma unroll
+      for (int q = 0; q < 2; q++) early[q] = epi.early(d.r0 + min(lane + q * WAVE, d.nr - 1));
+    }
+  }
+}
+
+// out_i = alpha * s_i [* dscale_i] + beta * z_i + gamma * w_i ;  y2_i += delta * (aux_out ? out_i : w2_i)
+struct EpiAxpby {
+  SpmvEpi e;
+  struct Early {};
+  struct Pre { double z, w, d, y2, w2; };
+  __device__ __forceinline__ Early early(int32_t) const { return Early{}; }
+  __device__ __forceinline__ Pre load(int32_t row, Early) const {
+    Pre p; p.z = 0.0; p.w = 0.0; p.d = 1.0; p.y2 = 0.0; p.w2 = 0.0;
+    if (e.z) p.z = e.z[row];
+    if (e.w) p.w = e.w[row];
+    if (e.dscale) p.d = e.dscale[row];
+    if (e.y2) { p.y2 = e.y2[row]; if (!e.aux_out) p.w2 = e.w2[row]; }
+    return p;
+  }
+  __device__ __forceinline__ void store(int32_t row, double acc, const Pre& p) const {
+    if (e.dscale) acc *= p.d;
+    double o = e.alpha * acc;
+    if (e.z) o += e.beta * p.z;
+    if (e.w) o += e.gamma * p.w;
+    e.out[row] = o;
+    if (e.y2) e.y2[row] = p.y2 + e.delta * (e.aux_out ? o : p.w2);
+  }
+};
+
+template <bool DIST, bool PIPE>
+__global__ __launch_bounds__(BLOCK) void k_rb_spmv(RbView A, XVec<DIST> x, EpiAxpby epi) {
+  __shared__ double lds_all[WAVES_PER_BLOCK][BLK_NNZ + 2];
+  rb_loop<DIST, PIPE>(A, x, lds_all[threadIdx.x >> 6], epi);
+}
+
+// Fused first stage of an F-point relaxation with a one-point prolongator (see dev.hpp)
+template <bool DIST>
+struct EpiFcFirst {
+  const int32_t* __restrict__ wcol; const double* __restrict__ b_f; XVec<DIST> x_c;
+  const double* __restrict__ aff_d; const double* __restrict__ minv;
+  double* __restrict__ t4_out; double* __restrict__ x_f;
+  struct Early { int32_t wc; };
+  struct Pre { double b, x0, ad, mi; };
+  __device__ __forceinline__ Early early(int32_t row) const { return Early{wcol[row]}; }
+  __device__ __forceinline__ Pre load(int32_t row, Early ea) const {
+    Pre p; p.b = b_f[row];
+    p.x0 = 0.0;
+    if (ea.wc >= 0) p.x0 = x_c[ea.wc];
+    p.ad = 0.0; p.mi = 0.0;
+    if (aff_d) { p.ad = aff_d[row]; p.mi = minv[row]; }
+    return p;
+  }
+  __device__ __forceinline__ void store(int32_t row, double acc, const Pre& p) const {
+    const double t4 = p.b + (-1.0) * acc;
+    if (aff_d) {
+      // one F smooth with diagonal A_ff and diagonal inverse (src/FC_Smooth.F90:541-559)
+      double t3 = p.ad * p.x0;
+      t3 = t4 + (-1.0) * t3;
+      x_f[row] = p.x0 + p.mi * t3;
+    } else {
+      t4_out[row] = t4;
+      x_f[row] = p.x0;
+    }
+  }
+};
+
+template <bool DIST, bool PIPE>
+__global__ __launch_bounds__(BLOCK) void k_rb_fc_first(RbView A, XVec<DIST> x_c, EpiFcFirst<DIST> epi) {
+  __shared__ double lds_all[WAVES_PER_BLOCK][BLK_NNZ + 2];
+  rb_loop<DIST, PIPE>(A, x_c, lds_all[threadIdx.x >> 6], epi);
+}
+
+// grid: as many workgroups as are resident at once (the waves loop over their blocks), a multiple of 8
+template <class K>
+static int resident_grid(K kernel, int64_t nblocks) {
+  static int per_cu = 0, cus = 0;
+  if (!per_cu) {
+    int dev = 0; hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDevice(&dev));
+    HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    cus = prop.multiProcessorCount;
+    int n = 0;
+    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, BLOCK, 0));
+    per_cu = n > 0 ? n : 4;
+  }
+  const int wg = g_grid_wg_per_cu > 0 ? g_grid_wg_per_cu : per_cu;
   int64_t blocks = (nblocks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-  // diagnostic: bits 16..23 of the variant override the grid cap in units of 64 workgroups
-  const int64_t cap = ((g_spmv_variant >> 16) & 0xff) ? (int64_t)((g_spmv_variant >> 16) & 0xff) * 64 : MAX_BLOCKS;
+  const int64_t cap = (int64_t)cus * wg;
   if (blocks > cap) blocks = cap;
   blocks = (blocks + 7) / 8 * 8;
   if (blocks < 8) blocks = 8;
   return (int)blocks;
 }
 
-// Calls epi(row, sum_j a_row,j x_j) once for every row of the matrix.
-template <class T, bool NT>
-__device__ __forceinline__ T ldg(const T* p) {
-  if constexpr (NT) return __builtin_nontemporal_load(p); else return *p;
+static void check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) throw std::runtime_error(std::string("HIP error ") + hipGetErrorString(e) + " launching " + what);
 }
-
-// diagnostic only (airhip_debug_set_variant(8)): every gather hits the same 8 KB of x - shows how
-// much of the kernel time is the x-vector gather
-struct XVecNoGather {
-  const double* __restrict__ x;
-  __device__ __forceinline__ double operator[](int32_t c) const { return x[c & 1023]; }
-};
-
-// SORTED: 0 = row-major blocks, 1 = column-sorted blocks + 16-bit slot array, 2 = column-sorted blocks with
-// the slot packed into the upper 10 bits of the column word (operators with <= 2^22 columns: 12 B/nnz again)
-template <int CAP, bool NT, int UNR, int SORTED, class X, class Epi>
-__device__ __forceinline__ void rb_rows(const RbView& A, const X x, double* __restrict__ lds, Epi epi) {
-  const int lane = threadIdx.x & (WAVE - 1);
-  const BlockRange br = my_blocks(A.blk_list ? A.nlist : A.nblocks);
-  for (int64_t bi = br.first; bi < br.last; bi += br.stride) {
-    const int64_t b = A.blk_list ? (int64_t)__builtin_amdgcn_readfirstlane(A.blk_list[bi]) : bi;
-    const int32_t r0 = __builtin_amdgcn_readfirstlane(A.blk_row[b]);
-    const int32_t r1 = __builtin_amdgcn_readfirstlane(A.blk_row[b + 1]);
-    const int64_t p0 = uniform64(A.blk_p0[b]);
-    const int64_t p1 = uniform64(A.blk_p0[b + 1]);
-    const int nb = (int)(p1 - p0);
-    const double* __restrict__ v = A.val + p0;
-    const int32_t* __restrict__ c = A.col + p0;
-    const uint16_t* __restrict__ sl = A.slot + p0;
-    const int nr = r1 - r0;
-    constexpr int32_t CMASK = SORTED == 2 ? 0x3fffff : -1;
-    if (nb <= A.scalar_t * nr) {
-      // very short rows (<= 4 non-zeros on average): one lane per row straight from global
-      // memory - the block's ~6 KB are shared by neighbouring lanes through L1, and the
-      // dependency chain is one round trip shorter than the LDS stage
-      for (int32_t r = r0 + lane; r < r1; r += WAVE) {
-        const int a = (int)A.roff[r];
-        const int e = (r + 1 < r1) ? (int)A.roff[r + 1] : nb;
-        double s = 0.0;
-        for (int j = a; j < e; j++) s += ldg<double, NT>(v + j) * x[ldg<int32_t, NT>(c + j) & CMASK];
-        epi(r, s);
-      }
-    } else if (nb <= CAP) {
-      // phase 1: coalesced stream, products to LDS (UNR independent loads in flight per lane)
-      int k = lane;
-      for (; k + (UNR - 1) * WAVE < nb; k += UNR * WAVE) {
-        int32_t cc[UNR]; double vv[UNR], xx[UNR]; int ss[UNR];
-#pragma unroll
-        for (int u = 0; u < UNR; u++) cc[u] = ldg<int32_t, NT>(c + k + u * WAVE);
-#pragma unroll
-        for (int u = 0; u < UNR; u++) vv[u] = ldg<double, NT>(v + k + u * WAVE);
-#pragma unroll
-        for (int u = 0; u < UNR; u++)
-          ss[u] = SORTED == 2 ? (int)((uint32_t)cc[u] >> 22) : SORTED == 1 ? (int)ldg<uint16_t, NT>(sl + k + u * WAVE) : k + u * WAVE;
-#pragma unroll
-        for (int u = 0; u < UNR; u++) xx[u] = x[cc[u] & CMASK];
-#pragma unroll
-        for (int u = 0; u < UNR; u++) lds[ss[u]] = vv[u] * xx[u];
-      }
-      for (; k < nb; k += WAVE) {
-        const int32_t cw = ldg<int32_t, NT>(c + k);
-        lds[SORTED == 2 ? (int)((uint32_t)cw >> 22) : SORTED == 1 ? (int)sl[k] : k] = ldg<double, NT>(v + k) * x[cw & CMASK];
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (nr > 16) {
-        // phase 2: one lane per row, column order
-        for (int32_t r = r0 + lane; r < r1; r += WAVE) {
-          const int a = (int)A.roff[r];
-          const int e = (r + 1 < r1) ? (int)A.roff[r + 1] : nb;
-          double s = 0.0;
-          for (int j = a; j < e; j++) s += lds[j];
-          epi(r, s);
-        }
-      } else {
-        // phase 2 for a few long rows: T = 64 / 2^ceil(log2 nr) lanes share a row
-        int T = WAVE;
-        while (WAVE / T < nr) T >>= 1;   // nr <= 16  ->  T >= 4
-        const int g = lane / T, t = lane - g * T;
-        const int32_t r = r0 + g;
-        double s = 0.0;
-        if (g < nr) {
-          const int a = (int)A.roff[r];
-          const int e = (r + 1 < r1) ? (int)A.roff[r + 1] : nb;
-          for (int j = a + t; j < e; j += T) s += lds[j];
-        }
-        for (int off = T >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
-        if (g < nr && t == 0) epi(r, s);
-      }
-      __builtin_amdgcn_wave_barrier();   // LDS is reused by the next block of this wave
-    } else {
-      // long rows: the whole wave reduces one row at a time
-      for (int32_t r = r0; r < r1; r++) {
-        const int a = (int)A.roff[r];
-        const int e = (r + 1 < r1) ? (int)A.roff[r + 1] : nb;
-        // four independent (column, value, x) chains in flight per lane
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        int j = a + lane;
-        for (; j + 3 * WAVE < e; j += 4 * WAVE) {
-          const int32_t c0 = c[j] & CMASK, c1 = c[j + WAVE] & CMASK, c2 = c[j + 2 * WAVE] & CMASK, c3 = c[j + 3 * WAVE] & CMASK;
-          const double v0 = v[j], v1 = v[j + WAVE], v2 = v[j + 2 * WAVE], v3 = v[j + 3 * WAVE];
-          const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
-          s0 = fma(v0, x0, s0); s1 = fma(v1, x1, s1); s2 = fma(v2, x2, s2); s3 = fma(v3, x3, s3);
-        }
-        for (; j < e; j += WAVE) s0 = fma(v[j], x[c[j] & CMASK], s0);
-        double s = (s0 + s1) + (s2 + s3);
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
-        if (lane == 0) epi(r, s);
-      }
-    }
-  }
-}
-
-template <int CAP, bool NT, int UNR, int SORTED, class X>
-__global__ __launch_bounds__(BLOCK) void k_rb_spmv(RbView A, X x, SpmvEpi e) {
-  __shared__ double lds_all[WAVES_PER_BLOCK][CAP];
-  double* lds = lds_all[threadIdx.x >> 6];
-  rb_rows<CAP, NT, UNR, SORTED>(A, x, lds, [&](int32_t row, double acc) {
-    if (e.dscale) acc *= e.dscale[row];
-    double o = e.alpha * acc;
-    if (e.z) o += e.beta * e.z[row];
-    if (e.w) o += e.gamma * e.w[row];
-    e.out[row] = o;
-    if (e.y2) {
-      const double a = e.aux_out ? o : e.w2[row];
-      e.y2[row] += e.delta * a;
-    }
-  });
-}
-
-// tuning variant (bit 0: 640-entry LDS stage instead of 1024, bit 1: non-temporal matrix loads,
-// bit 2: 8 instead of 4 loads in flight); set through airhip_debug_set_variant
-// AIRHIP_BLK=256: blocks of <= 255 + row length non-zeros with a 512-entry LDS stage (4 KB per wave ->
-// twice the resident waves; rows longer than ~256 take the wave-per-row path).  Default 512 / 1024.
-static int blk_from_env() {
-  const char* e = std::getenv("AIRHIP_BLK");
-  const int v = e ? std::atoi(e) : BLK_NNZ;
-  return (v == 256 || v == 1024) ? v : BLK_NNZ;
-}
-int g_blk_nnz = blk_from_env();
-// AIRHIP_CAP=768: 6-KB LDS stage per wave (6 instead of 5 workgroups per CU) with 512-nnz blocks
-// AIRHIP_NT=1: non-temporal loads for the matrix stream (keeps L2 / Infinity Cache for the x vector)
-static int g_nt = (std::getenv("AIRHIP_NT") && std::atoi(std::getenv("AIRHIP_NT")) != 0) ? 1 : 0;
-static int g_cap768 = (std::getenv("AIRHIP_CAP") && std::atoi(std::getenv("AIRHIP_CAP")) == 768) ? 1 : 0;
-int g_spmv_variant = std::getenv("AIRHIP_SPMV_VARIANT") ? std::atoi(std::getenv("AIRHIP_SPMV_VARIANT")) : 0;
 
 void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t s, const double* x_ghost,
                  const int32_t* blk_list, int64_t nlist) {
   if (A.m == 0 || (blk_list && nlist == 0)) return;
-  if (!blk_list && g_spmv_variant == 0 && launch_spmv_tiled(A, x, e, s, x_ghost)) return;
-  const dim3 grid(grid_for_blocks(blk_list ? nlist : A.nblocks)), block(BLOCK);
   RbView v = view_of(A);
   v.blk_list = blk_list; v.nlist = nlist;
+  const int64_t nb = blk_list ? nlist : A.nblocks;
+  const EpiAxpby epi{e};
   if (A.n_ghost > 0) {
     // distributed operand: ghost columns start at A.n - A.n_ghost
     if (!x_ghost) throw std::runtime_error("launch_spmv: distributed operand without ghost values");
     const int32_t nl = (int32_t)(A.n - A.n_ghost);
     const XVec<true> xv{x, x_ghost - nl, nl};
-    if (A.packed) hipLaunchKernelGGL((k_rb_spmv<1024, false, 4, 2, XVec<true>>), grid, block, 0, s, v, xv, e);
-    else if (A.slot) hipLaunchKernelGGL((k_rb_spmv<1024, false, 4, 1, XVec<true>>), grid, block, 0, s, v, xv, e);
-    else hipLaunchKernelGGL((k_rb_spmv<1024, false, 4, 0, XVec<true>>), grid, block, 0, s, v, xv, e);
-    return;
+    if (g_pipeline) hipLaunchKernelGGL((k_rb_spmv<true, true>), dim3(resident_grid(k_rb_spmv<true, true>, nb)), dim3(BLOCK), 0, s, v, xv, epi);
+    else hipLaunchKernelGGL((k_rb_spmv<true, false>), dim3(resident_grid(k_rb_spmv<true, false>, nb)), dim3(BLOCK), 0, s, v, xv, epi);
+  } else {
+    const XVec<false> xv{x, nullptr, 0};
+    if (g_pipeline) hipLaunchKernelGGL((k_rb_spmv<false, true>), dim3(resident_grid(k_rb_spmv<false, true>, nb)), dim3(BLOCK), 0, s, v, xv, epi);
+    else hipLaunchKernelGGL((k_rb_spmv<false, false>), dim3(resident_grid(k_rb_spmv<false, false>, nb)), dim3(BLOCK), 0, s, v, xv, epi);
   }
-  if (A.packed) {
-    if (g_spmv_variant) throw std::runtime_error("kernel variants are not available for packed operators (set AIRHIP_NO_PACK=1)");
-    hipLaunchKernelGGL((k_rb_spmv<1024, false, 4, 2, XVec<false>>), grid, block, 0, s, v, XVec<false>{x, nullptr, 0}, e);
-    return;
-  }
-  if (g_spmv_variant & 8) {
-    const XVecNoGather xd{x};
-    hipLaunchKernelGGL((k_rb_spmv<1024, false, 4, 0, XVecNoGather>), grid, block, 0, s, v, xd, e);
-    return;
-  }
-  const XVec<false> xv{x, nullptr, 0};
-  if (A.slot) {   // column-sorted blocks: the production kernel
-    if (g_blk_nnz == 256) hipLaunchKernelGGL((k_rb_spmv<512, false, 4, 1, XVec<false>>), grid, block, 0, s, v, xv, e);
-    else if (g_blk_nnz == 1024) hipLaunchKernelGGL((k_rb_spmv<2048, false, 8, 1, XVec<false>>), grid, block, 0, s, v, xv, e);
-    else if (g_cap768) hipLaunchKernelGGL((k_rb_spmv<768, false, 4, 1, XVec<false>>), grid, block, 0, s, v, xv, e);
-    else if (g_nt) hipLaunchKernelGGL((k_rb_spmv<1024, true, 4, 1, XVec<false>>), grid, block, 0, s, v, xv, e);
-    else hipLaunchKernelGGL((k_rb_spmv<1024, false, 4, 1, XVec<false>>), grid, block, 0, s, v, xv, e);
-    return;
-  }
-#define RB_LAUNCH(CAP, NT, UNR) hipLaunchKernelGGL((k_rb_spmv<CAP, NT, UNR, 0, XVec<false>>), grid, block, 0, s, v, xv, e)
-  switch (g_spmv_variant & 7) {
-    case 0: RB_LAUNCH(1024, false, 4); break;
-    case 1: RB_LAUNCH(640, false, 4); break;
-    case 2: RB_LAUNCH(1024, true, 4); break;
-    case 3: RB_LAUNCH(640, true, 4); break;
-    case 4: RB_LAUNCH(1024, false, 8); break;
-    case 5: RB_LAUNCH(640, false, 8); break;
-    case 6: RB_LAUNCH(1024, true, 8); break;
-    default: RB_LAUNCH(640, true, 8); break;
-  }
-#undef RB_LAUNCH
-}
-
-template <bool DIST, int SORTED, int CAP>
-__global__ __launch_bounds__(BLOCK) void k_rb_fc_first(RbView A, const int32_t* __restrict__ wcol,
-                                                      const double* __restrict__ b_f, XVec<DIST> x_c,
-                                                      const double* __restrict__ aff_d, const double* __restrict__ minv,
-                                                      double* __restrict__ t4_out, double* __restrict__ x_f) {
-  __shared__ double lds_all[WAVES_PER_BLOCK][CAP];
-  double* lds = lds_all[threadIdx.x >> 6];
-  rb_rows<CAP, false, 4, SORTED>(A, x_c, lds, [&](int32_t row, double acc) {
-    const double t4 = b_f[row] + (-1.0) * acc;
-    const int32_t wc = wcol[row];
-    const double x0 = wc >= 0 ? x_c[wc] : 0.0;
-    if (aff_d) {
-      // one F smooth with diagonal A_ff and diagonal inverse (src/FC_Smooth.F90:541-559)
-      double t3 = aff_d[row] * x0;
-      t3 = t4 + (-1.0) * t3;
-      x_f[row] = x0 + minv[row] * t3;
-    } else {
-      t4_out[row] = t4;
-      x_f[row] = x0;
-    }
-  });
+  check_launch("k_rb_spmv");
 }
 
 void launch_fc_first(const DevMat& A_fc, const int32_t* wcol, const double* b_f, const double* x_c,
                      const double* aff_d, const double* minv, double* t4_out, double* x_f, hipStream_t s,
                      const double* x_ghost, const int32_t* blk_list, int64_t nlist) {
   if (A_fc.m == 0 || (blk_list && nlist == 0)) return;
-  if (!blk_list && g_spmv_variant == 0 && launch_fc_first_tiled(A_fc, wcol, b_f, x_c, aff_d, minv, t4_out, x_f, s, x_ghost)) return;
-  const dim3 grid(grid_for_blocks(blk_list ? nlist : A_fc.nblocks)), block(BLOCK);
-  RbView vfc = view_of(A_fc);
-  vfc.blk_list = blk_list; vfc.nlist = nlist;
+  RbView v = view_of(A_fc);
+  v.blk_list = blk_list; v.nlist = nlist;
+  const int64_t nb = blk_list ? nlist : A_fc.nblocks;
   if (A_fc.n_ghost > 0) {
     if (!x_ghost) throw std::runtime_error("launch_fc_first: distributed operand without ghost values");
     const int32_t nl = (int32_t)(A_fc.n - A_fc.n_ghost);
     const XVec<true> xv{x_c, x_ghost - nl, nl};
-    if (A_fc.packed) hipLaunchKernelGGL((k_rb_fc_first<true, 2, 1024>), grid, block, 0, s, vfc, wcol, b_f, xv, aff_d, minv, t4_out, x_f);
-    else if (A_fc.slot) hipLaunchKernelGGL((k_rb_fc_first<true, 1, 1024>), grid, block, 0, s, vfc, wcol, b_f, xv, aff_d, minv, t4_out, x_f);
-    else hipLaunchKernelGGL((k_rb_fc_first<true, 0, 1024>), grid, block, 0, s, vfc, wcol, b_f, xv, aff_d, minv, t4_out, x_f);
+    const EpiFcFirst<true> epi{wcol, b_f, xv, aff_d, minv, t4_out, x_f};
+    if (g_pipeline) hipLaunchKernelGGL((k_rb_fc_first<true, true>), dim3(resident_grid(k_rb_fc_first<true, true>, nb)), dim3(BLOCK), 0, s, v, xv, epi);
+    else hipLaunchKernelGGL((k_rb_fc_first<true, false>), dim3(resident_grid(k_rb_fc_first<true, false>, nb)), dim3(BLOCK), 0, s, v, xv, epi);
   } else {
     const XVec<false> xv{x_c, nullptr, 0};
-    if (A_fc.packed) hipLaunchKernelGGL((k_rb_fc_first<false, 2, 1024>), grid, block, 0, s, vfc, wcol, b_f, xv, aff_d, minv, t4_out, x_f);
-    else if (A_fc.slot && g_blk_nnz == 256) hipLaunchKernelGGL((k_rb_fc_first<false, 1, 512>), grid, block, 0, s, vfc, wcol, b_f, xv, aff_d, minv, t4_out, x_f);
-    else if (A_fc.slot && g_cap768) hipLaunchKernelGGL((k_rb_fc_first<false, 1, 768>), grid, block, 0, s, vfc, wcol, b_f, xv, aff_d, minv, t4_out, x_f);
-    else if (A_fc.slot && g_blk_nnz == 1024) hipLaunchKernelGGL((k_rb_fc_first<false, 1, 2048>), grid, block, 0, s, vfc, wcol, b_f, xv, aff_d, minv, t4_out, x_f);
-    else if (A_fc.slot) hipLaunchKernelGGL((k_rb_fc_first<false, 1, 1024>), grid, block, 0, s, vfc, wcol, b_f, xv, aff_d, minv, t4_out, x_f);
-    else hipLaunchKernelGGL((k_rb_fc_first<false, 0, 1024>), grid, block, 0, s, vfc, wcol, b_f, xv, aff_d, minv, t4_out, x_f);
+    const EpiFcFirst<false> epi{wcol, b_f, xv, aff_d, minv, t4_out, x_f};
+    if (g_pipeline) hipLaunchKernelGGL((k_rb_fc_first<false, true>), dim3(resident_grid(k_rb_fc_first<false, true>, nb)), dim3(BLOCK), 0, s, v, xv, epi);
+    else hipLaunchKernelGGL((k_rb_fc_first<false, false>), dim3(resident_grid(k_rb_fc_first<false, false>, nb)), dim3(BLOCK), 0, s, v, xv, epi);
   }
+  check_launch("k_rb_fc_first");
 }
 
 // ---------------------------------------------------------------------------------------
@@ -368,8 +416,8 @@ int64_t device_exclusive_scan(int64_t n, const int64_t* d_in, int64_t* d_out, hi
   return run;
 }
 
-// copy (and remap) the entries of every destination row; one wave per 64 consecutive entries
-// would need a row lookup, so rows are copied by lanes - setup only
+// copy (and remap) the entries of every destination row; a wave copies one row at a time with
+// coalesced accesses - setup only
 __global__ __launch_bounds__(BLOCK) void k_copy_rows(int64_t m, const int64_t* __restrict__ rp, const int32_t* __restrict__ ci,
                                                     const double* __restrict__ v, const int32_t* __restrict__ rowsrc,
                                                     const int32_t* __restrict__ colmap, int32_t n_mapped,
@@ -378,7 +426,6 @@ __global__ __launch_bounds__(BLOCK) void k_copy_rows(int64_t m, const int64_t* _
   const int lane = threadIdx.x & (WAVE - 1);
   const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * BLOCK) >> 6;
-  // a wave copies one row at a time with coalesced accesses
   for (int64_t r = wave; r < m; r += nwaves) {
     const int64_t src = rowsrc ? rowsrc[r] : r;
     const int64_t a = rp[src], len = rp[src + 1] - a, o = nrp[r];
@@ -390,53 +437,59 @@ __global__ __launch_bounds__(BLOCK) void k_copy_rows(int64_t m, const int64_t* _
   }
 }
 
-// flag[r] = 1 if row r starts a new block: its first non-zero lies in another BLK_NNZ bucket
-// than the previous row's, or BLK_ROWS rows have passed (runs of empty rows, e.g. Dirichlet
-// planes, must not pile up in one block)
-__global__ __launch_bounds__(BLOCK) void k_block_flags(int64_t m, int blk_nnz, const int64_t* __restrict__ nrp, int64_t* __restrict__ flag) {
+// Greedy block partition inside chunks of CHUNK_ROWS rows (one thread per chunk; FILL = false counts the blocks
+// of every chunk, FILL = true writes descriptors and row offsets): a block takes rows while it stays within
+// BLK_NNZ non-zeros and BLK_ROWS rows; a row longer than BLK_NNZ is a block of its own.
+template <bool FILL>
+__global__ __launch_bounds__(BLOCK) void k_chunk_blocks(int64_t m, const int64_t* __restrict__ nrp, int64_t* __restrict__ cnt,
+                                                       const int64_t* __restrict__ first_blk, BlkDesc* __restrict__ blk,
+                                                       uint16_t* __restrict__ roff) {
+  const int64_t nchunks = (m + CHUNK_ROWS - 1) / CHUNK_ROWS;
   const int64_t stride = (int64_t)gridDim.x * BLOCK;
-  for (int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x; r < m; r += stride)
-    flag[r] = (r % BLK_ROWS == 0 || (nrp[r] / blk_nnz) != (nrp[r - 1] / blk_nnz)) ? 1 : 0;
-}
-
-__global__ __launch_bounds__(BLOCK) void k_block_build(int64_t m, const int64_t* __restrict__ nrp, const int64_t* __restrict__ flag,
-                                                      const int64_t* __restrict__ blk_of, int32_t* __restrict__ blk_row,
-                                                      int64_t* __restrict__ blk_p0) {
-  const int64_t stride = (int64_t)gridDim.x * BLOCK;
-  for (int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x; r < m; r += stride)
-    if (flag[r]) { blk_row[blk_of[r]] = (int32_t)r; blk_p0[blk_of[r]] = nrp[r]; }
-}
-
-__global__ __launch_bounds__(BLOCK) void k_row_offsets(int64_t m, const int64_t* __restrict__ nrp, const int64_t* __restrict__ flag,
-                                                      const int64_t* __restrict__ blk_of, const int64_t* __restrict__ blk_p0,
-                                                      uint32_t* __restrict__ roff) {
-  const int64_t stride = (int64_t)gridDim.x * BLOCK;
-  for (int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x; r < m; r += stride) {
-    const int64_t b = blk_of[r] + flag[r] - 1;   // exclusive scan of the flags: block of row r
-    roff[r] = (uint32_t)(nrp[r] - blk_p0[b]);
+  for (int64_t c = (int64_t)blockIdx.x * BLOCK + threadIdx.x; c < nchunks; c += stride) {
+    const int64_t r_lo = c * CHUNK_ROWS, r_hi = min(r_lo + (int64_t)CHUNK_ROWS, m);
+    int64_t nblk = 0, b = FILL ? first_blk[c] : 0;
+    int64_t p_start = nrp[r_lo];
+    int rows = 0;
+    int64_t pr = p_start;                 // nrp[r]
+    for (int64_t r = r_lo; r < r_hi; r++) {
+      const int64_t pn = nrp[r + 1];
+      const int64_t len = pn - pr;
+      if (rows > 0 && (pn - p_start > BLK_NNZ || rows == BLK_ROWS)) { nblk++; rows = 0; p_start = pr; }
+      if (rows == 0 && FILL) { blk[b + nblk].p0 = pr; blk[b + nblk].row = (int32_t)r; blk[b + nblk].cbase = -1; }
+      if (FILL) roff[r] = (uint16_t)(len > BLK_NNZ ? 0 : (pr - p_start));
+      rows++;
+      if (len > BLK_NNZ) { nblk++; rows = 0; p_start = pn; }   // a long row closes its own block
+      pr = pn;
+    }
+    if (rows > 0) nblk++;
+    if (!FILL) cnt[c] = nblk;
   }
 }
 
-// Column-sort the entries of every block that takes the LDS path (4*rows < nnz <= LDS_CAP); other
-// blocks are copied through with slot = identity.  One wave per block, bitonic sort of
-// (column << 16 | position) keys in LDS.
-__global__ __launch_bounds__(BLOCK) void k_block_sort(int64_t nblocks, const int32_t* __restrict__ blk_row, const int64_t* __restrict__ blk_p0,
-                                                     const int32_t* __restrict__ col, const double* __restrict__ val,
-                                                     int32_t* __restrict__ ocol, double* __restrict__ oval, uint16_t* __restrict__ slot,
-                                                     int cap, int scalar_t) {
-  __shared__ unsigned long long keys_all[WAVES_PER_BLOCK][2 * LDS_CAP];
+// One wave per block: blocks of <= BLK_NNZ entries whose columns span less than 2^COL_BITS are sorted by
+// column (bitonic sort of (column << 16 | position) keys in LDS) and get packed index words; the others
+// keep row-major order and absolute columns (cbase stays -1).
+__global__ __launch_bounds__(BLOCK) void k_block_pack(int64_t nblocks, BlkDesc* __restrict__ blk, const int32_t* __restrict__ col,
+                                                     const double* __restrict__ val, uint32_t* __restrict__ oidx, double* __restrict__ oval) {
+  __shared__ unsigned long long keys_all[WAVES_PER_BLOCK][BLK_NNZ];
   unsigned long long* keys = keys_all[threadIdx.x >> 6];
   const int lane = threadIdx.x & (WAVE - 1);
   const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * BLOCK) >> 6;
   for (int64_t b = wave; b < nblocks; b += nwaves) {
-    const int64_t p0 = blk_p0[b], p1 = blk_p0[b + 1];
-    const int nb = (int)(p1 - p0);
-    const int nr = blk_row[b + 1] - blk_row[b];
-    if (p1 - p0 > cap || nb <= scalar_t * nr) {
-      for (int64_t k = p0 + lane; k < p1; k += WAVE) { ocol[k] = col[k]; oval[k] = val[k]; slot[k] = (uint16_t)((k - p0) & 0xffff); }
+    const int64_t p0 = blk[b].p0, p1 = blk[b + 1].p0;
+    const int64_t nbl = p1 - p0;
+    int32_t cmin = 0x7fffffff, cmax = -1;
+    if (nbl <= BLK_NNZ)
+      for (int i = lane; i < (int)nbl; i += WAVE) { const int32_t c = col[p0 + i]; cmin = min(cmin, c); cmax = max(cmax, c); }
+    for (int off = 32; off > 0; off >>= 1) { cmin = min(cmin, __shfl_xor(cmin, off, WAVE)); cmax = max(cmax, __shfl_xor(cmax, off, WAVE)); }
+    const bool pack = nbl > 0 && nbl <= BLK_NNZ && (int64_t)cmax - (int64_t)cmin < (int64_t)(1u << COL_BITS);
+    if (!pack) {
+      for (int64_t k = p0 + lane; k < p1; k += WAVE) { oidx[k] = (uint32_t)col[k]; oval[k] = val[k]; }
       continue;
     }
+    const int nb = (int)nbl;
     int P2 = WAVE; while (P2 < nb) P2 <<= 1;
     for (int i = lane; i < P2; i += WAVE)
       keys[i] = i < nb ? (((unsigned long long)(uint32_t)col[p0 + i]) << 16) | (unsigned long long)i : ~0ull;
@@ -457,46 +510,27 @@ __global__ __launch_bounds__(BLOCK) void k_block_sort(int64_t nblocks, const int
     for (int i = lane; i < nb; i += WAVE) {
       const unsigned long long k = keys[i];
       const int pos = (int)(k & 0xffffull);
-      ocol[p0 + i] = (int32_t)(k >> 16);
+      oidx[p0 + i] = ((uint32_t)pos << COL_BITS) | (uint32_t)((int32_t)(k >> 16) - cmin);
       oval[p0 + i] = val[p0 + pos];
-      slot[p0 + i] = (uint16_t)pos;
     }
+    if (lane == 0) blk[b].cbase = cmin;
     __builtin_amdgcn_wave_barrier();
   }
 }
 
-// col |= slot << 22 for the entries of column-sorted blocks (operators with <= 2^22 columns)
-__global__ __launch_bounds__(BLOCK) void k_pack_slot(int64_t nnz, int32_t* __restrict__ col, const uint16_t* __restrict__ slot) {
-  const int64_t stride = (int64_t)gridDim.x * BLOCK;
-  for (int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x; k < nnz; k += stride)
-    col[k] = (int32_t)((uint32_t)col[k] | ((uint32_t)slot[k] << 22));
-}
-
-// blocks that were not sorted (longer than the LDS stage) keep slot = 0: their slot is never read
-__global__ __launch_bounds__(BLOCK) void k_pack_unsorted_zero(int64_t nblocks, const int64_t* __restrict__ blk_p0, uint16_t* __restrict__ slot, int cap) {
-  const int lane = threadIdx.x & (WAVE - 1);
-  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
-  const int64_t nwaves = ((int64_t)gridDim.x * BLOCK) >> 6;
-  for (int64_t b = wave; b < nblocks; b += nwaves) {
-    const int64_t p0 = blk_p0[b], p1 = blk_p0[b + 1];
-    if (p1 - p0 > cap) for (int64_t k = p0 + lane; k < p1; k += WAVE) slot[k] = 0;
-  }
-}
-
-static bool pack_enabled() {
-  static const bool on = !(std::getenv("AIRHIP_NO_PACK") && std::atoi(std::getenv("AIRHIP_NO_PACK")) != 0);
-  return on;
-}
-
 // flag[b] = 1 if block b references a ghost column (column >= n_local); one wave per block
-__global__ __launch_bounds__(BLOCK) void k_boundary_flags(int64_t nblocks, const int64_t* __restrict__ blk_p0, const int32_t* __restrict__ col,
-                                                         int32_t n_local, int32_t cmask, uint8_t* __restrict__ flag) {
+__global__ __launch_bounds__(BLOCK) void k_boundary_flags(int64_t nblocks, const BlkDesc* __restrict__ blk, const uint32_t* __restrict__ idx,
+                                                         int32_t n_local, uint8_t* __restrict__ flag) {
   const int lane = threadIdx.x & (WAVE - 1);
   const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * BLOCK) >> 6;
   for (int64_t b = wave; b < nblocks; b += nwaves) {
+    const int32_t cbase = blk[b].cbase;
     bool any = false;
-    for (int64_t k = blk_p0[b] + lane; k < blk_p0[b + 1]; k += WAVE) any |= (col[k] & cmask) >= n_local;
+    for (int64_t k = blk[b].p0 + lane; k < blk[b + 1].p0; k += WAVE) {
+      const int32_t c = cbase >= 0 ? cbase + (int32_t)(idx[k] & COL_MASK) : (int32_t)idx[k];
+      any |= c >= n_local;
+    }
     if (__any(any) && lane == 0) flag[b] = 1;
   }
 }
@@ -508,17 +542,10 @@ void devmat_boundary_flags(const DevMat& A, std::vector<uint8_t>& flags, hipStre
   HIP_CHECK(hipMalloc(&d, (size_t)A.nblocks));
   HIP_CHECK(hipMemsetAsync(d, 0, (size_t)A.nblocks, s));
   const int g = (int)std::min<int64_t>((A.nblocks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 4096);
-  // packed operators keep the column in the low 22 bits of the word (unsorted blocks: upper bits are zero)
-  hipLaunchKernelGGL(k_boundary_flags, dim3(g < 1 ? 1 : g), dim3(BLOCK), 0, s, A.nblocks, A.blk_p0, A.col, (int32_t)(A.n - A.n_ghost),
-                     A.packed ? 0x3fffff : -1, d);
+  hipLaunchKernelGGL(k_boundary_flags, dim3(g < 1 ? 1 : g), dim3(BLOCK), 0, s, A.nblocks, A.blk, A.idx, (int32_t)(A.n - A.n_ghost), d);
   HIP_CHECK(hipMemcpyAsync(flags.data(), d, (size_t)A.nblocks, hipMemcpyDeviceToHost, s));
   HIP_CHECK(hipStreamSynchronize(s));
   (void)hipFree(d);
-}
-
-static bool sort_blocks_enabled() {
-  static const bool on = !(std::getenv("AIRHIP_NO_BLOCK_SORT") && std::atoi(std::getenv("AIRHIP_NO_BLOCK_SORT")) != 0);
-  return on;
 }
 
 static int grid1d(int64_t n) {
@@ -533,68 +560,50 @@ void devmat_from_csr_device(int64_t m, int64_t n, const int64_t* d_rp, const int
   devmat_free(out);
   out.m = m; out.n = n; out.n_ghost = n_ghost;
   if (m == 0) return;
-  if (m > 0x7fffffffll) throw std::runtime_error("matrix has too many rows for 32-bit row indices");
-  int64_t *d_len = nullptr, *d_nrp = nullptr, *d_flag = nullptr, *d_blk_of = nullptr;
+  if (m > 0x7fffffffll || n > 0x7fffffffll) throw std::runtime_error("matrix dimension exceeds 32-bit indices");
+  int64_t *d_len = nullptr, *d_nrp = nullptr;
   HIP_CHECK(hipMalloc(&d_len, sizeof(int64_t) * (size_t)m));
   HIP_CHECK(hipMalloc(&d_nrp, sizeof(int64_t) * (size_t)(m + 1)));
   hipLaunchKernelGGL(k_row_len, dim3(grid1d(m)), dim3(BLOCK), 0, s, m, d_rp, d_rowsrc, d_len);
   out.nnz = device_exclusive_scan(m, d_len, d_nrp, s);
   HIP_CHECK(hipMemcpyAsync(d_nrp + m, &out.nnz, sizeof(int64_t), hipMemcpyHostToDevice, s));
-  HIP_CHECK(hipMalloc(&out.col, sizeof(int32_t) * (size_t)(out.nnz > 0 ? out.nnz : 1)));
-  HIP_CHECK(hipMalloc(&out.val, sizeof(double) * (size_t)(out.nnz > 0 ? out.nnz : 1)));
+  (void)hipFree(d_len);
+  // entries in the new row order (plain columns), then packed per block
+  int32_t* tcol = nullptr; double* tval = nullptr;
+  HIP_CHECK(hipMalloc(&tcol, sizeof(int32_t) * (size_t)(out.nnz + 1)));
+  HIP_CHECK(hipMalloc(&tval, sizeof(double) * (size_t)(out.nnz + 1)));
   hipLaunchKernelGGL(k_copy_rows, dim3(MAX_BLOCKS), dim3(BLOCK), 0, s, m, d_rp, d_ci, d_v, d_rowsrc, d_colmap,
-                     (int32_t)(n - n_ghost), d_nrp, out.col, out.val);
-  // row blocks
-  d_flag = d_len;   // reuse
-  HIP_CHECK(hipMalloc(&d_blk_of, sizeof(int64_t) * (size_t)m));
-  hipLaunchKernelGGL(k_block_flags, dim3(grid1d(m)), dim3(BLOCK), 0, s, m, tiles_enabled() ? BLK_NNZ_TILED : g_blk_nnz, d_nrp, d_flag);
-  out.nblocks = device_exclusive_scan(m, d_flag, d_blk_of, s);
-  HIP_CHECK(hipMalloc(&out.blk_row, sizeof(int32_t) * (size_t)(out.nblocks + 1)));
-  HIP_CHECK(hipMalloc(&out.blk_p0, sizeof(int64_t) * (size_t)(out.nblocks + 1)));
-  HIP_CHECK(hipMalloc(&out.roff, sizeof(uint32_t) * (size_t)m));
-  hipLaunchKernelGGL(k_block_build, dim3(grid1d(m)), dim3(BLOCK), 0, s, m, d_nrp, d_flag, d_blk_of, out.blk_row, out.blk_p0);
-  const int32_t m32 = (int32_t)m;
-  HIP_CHECK(hipMemcpyAsync(out.blk_row + out.nblocks, &m32, sizeof(int32_t), hipMemcpyHostToDevice, s));
-  HIP_CHECK(hipMemcpyAsync(out.blk_p0 + out.nblocks, &out.nnz, sizeof(int64_t), hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(k_row_offsets, dim3(grid1d(m)), dim3(BLOCK), 0, s, m, d_nrp, d_flag, d_blk_of, out.blk_p0, out.roff);
+                     (int32_t)(n - n_ghost), d_nrp, tcol, tval);
+  // row blocks: count per chunk, scan, fill
+  const int64_t nchunks = (m + CHUNK_ROWS - 1) / CHUNK_ROWS;
+  int64_t *d_cnt = nullptr, *d_first = nullptr;
+  HIP_CHECK(hipMalloc(&d_cnt, sizeof(int64_t) * (size_t)nchunks));
+  HIP_CHECK(hipMalloc(&d_first, sizeof(int64_t) * (size_t)nchunks));
+  hipLaunchKernelGGL((k_chunk_blocks<false>), dim3(grid1d(nchunks)), dim3(BLOCK), 0, s, m, d_nrp, d_cnt, nullptr, nullptr, nullptr);
+  out.nblocks = device_exclusive_scan(nchunks, d_cnt, d_first, s);
+  HIP_CHECK(hipMalloc(&out.blk, sizeof(BlkDesc) * (size_t)(out.nblocks + 1)));
+  HIP_CHECK(hipMalloc(&out.roff, sizeof(uint16_t) * (size_t)m));
+  hipLaunchKernelGGL((k_chunk_blocks<true>), dim3(grid1d(nchunks)), dim3(BLOCK), 0, s, m, d_nrp, d_cnt, d_first, out.blk, out.roff);
+  const BlkDesc end{out.nnz, (int32_t)m, 0};
+  HIP_CHECK(hipMemcpyAsync(out.blk + out.nblocks, &end, sizeof(BlkDesc), hipMemcpyHostToDevice, s));
+  HIP_CHECK(hipMalloc(&out.idx, sizeof(uint32_t) * (size_t)(out.nnz + 1)));
+  HIP_CHECK(hipMalloc(&out.val, sizeof(double) * (size_t)(out.nnz + 1)));
+  HIP_CHECK(hipMemsetAsync(out.idx + out.nnz, 0, sizeof(uint32_t), s));
+  HIP_CHECK(hipMemsetAsync(out.val + out.nnz, 0, sizeof(double), s));
+  const int g = (int)std::min<int64_t>((out.nblocks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 4096);
+  hipLaunchKernelGGL(k_block_pack, dim3(g < 1 ? 1 : g), dim3(BLOCK), 0, s, out.nblocks, out.blk, tcol, tval, out.idx, out.val);
   HIP_CHECK(hipStreamSynchronize(s));
-  (void)hipFree(d_len); (void)hipFree(d_nrp); (void)hipFree(d_blk_of);
-  if (sort_blocks_enabled() && !tiles_enabled() && out.nnz > 0) {
-    int32_t* ncol = nullptr; double* nval = nullptr;
-    HIP_CHECK(hipMalloc(&ncol, sizeof(int32_t) * (size_t)out.nnz));
-    HIP_CHECK(hipMalloc(&nval, sizeof(double) * (size_t)out.nnz));
-    HIP_CHECK(hipMalloc(&out.slot, sizeof(uint16_t) * (size_t)out.nnz));
-    const int g = (int)std::min<int64_t>((out.nblocks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 4096);
-    hipLaunchKernelGGL(k_block_sort, dim3(g < 1 ? 1 : g), dim3(BLOCK), 0, s, out.nblocks, out.blk_row, out.blk_p0, out.col, out.val, ncol, nval,
-                       out.slot, g_blk_nnz == 256 ? 512 : (g_blk_nnz == 1024 ? 2 * LDS_CAP : (g_cap768 ? 768 : LDS_CAP)), scalar_threshold());
-    HIP_CHECK(hipStreamSynchronize(s));
-    (void)hipFree(out.col); (void)hipFree(out.val);
-    out.col = ncol; out.val = nval;
-    // unsorted blocks carry slot = position, which may exceed 10 bits: only default-shaped blocks are packed
-    if (pack_enabled() && out.n <= (1 << 22) && g_blk_nnz == BLK_NNZ && !g_cap768 && scalar_threshold() == 0) {
-      hipLaunchKernelGGL(k_pack_unsorted_zero, dim3(g < 1 ? 1 : g), dim3(BLOCK), 0, s, out.nblocks, out.blk_p0, out.slot, (int)LDS_CAP);
-      hipLaunchKernelGGL(k_pack_slot, dim3(grid1d(out.nnz)), dim3(BLOCK), 0, s, out.nnz, out.col, out.slot);
-      HIP_CHECK(hipStreamSynchronize(s));
-      (void)hipFree(out.slot); out.slot = nullptr;
-      out.packed = true;
-    }
-  }
-  if (tiles_enabled()) devmat_build_tiles(out, s);
+  check_launch("row-block conversion");
+  (void)hipFree(d_nrp); (void)hipFree(d_cnt); (void)hipFree(d_first); (void)hipFree(tcol); (void)hipFree(tval);
 }
 
 void devmat_free(DevMat& A) {
-  if (A.blk_row) (void)hipFree(A.blk_row);
-  if (A.blk_p0) (void)hipFree(A.blk_p0);
+  if (A.blk) (void)hipFree(A.blk);
   if (A.roff) (void)hipFree(A.roff);
-  if (A.col) (void)hipFree(A.col);
+  if (A.idx) (void)hipFree(A.idx);
   if (A.val) (void)hipFree(A.val);
-  if (A.slot) (void)hipFree(A.slot);
   if (A.list_int) (void)hipFree(A.list_int);
   if (A.list_bnd) (void)hipFree(A.list_bnd);
-  if (A.tile_blk) (void)hipFree(A.tile_blk);
-  if (A.tile_u0) (void)hipFree(A.tile_u0);
-  if (A.ucol) (void)hipFree(A.ucol);
-  if (A.lidx) (void)hipFree(A.lidx);
   A = DevMat();
 }
 

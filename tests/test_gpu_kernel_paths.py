@@ -1,0 +1,191 @@
+"""Every path of the row-block SpMV kernel (csrc/device/spmv.hip), hit on purpose and checked against scipy
+(airhip_mat_mult through the C ABI, <= 1e-13 relative: PFLARE_TOL_MATFREE_13, src/Pflare_Parameters.F90:209):
+
+* packed blocks (column-sorted, block-relative 23-bit columns) and raw blocks (column span >= 2^23: row-major,
+  absolute columns) - the round-1 kernel switched formats on the operator width (2^22 columns) and the wide mode,
+  the one the 464^3 benchmark runs, had no test;
+* a row longer than a block (wave-per-row reduction), rows of exactly 512 / 513 entries;
+* blocks of <= 32 rows (T lanes share a row) for every T, blocks of 128 rows (two rows per lane), empty rows;
+* the software pipeline across blocks: matrices of 1, 2, 3 blocks and of many thousands;
+* the fused epilogues through a polynomial apply (Horner / Newton / Neumann use every epilogue field).
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-13
+
+
+def lcg_vector(n):
+    i = np.arange(n, dtype=np.uint64)
+    return (((np.uint64(1103515245) * (i + np.uint64(12345))) % np.uint64(2 ** 31)).astype(np.float64)
+            / float(2 ** 30) - 1.0)
+
+
+def _check(A, torch, P, x=None):
+    A = sp.csr_matrix(A)
+    A.sum_duplicates(); A.sort_indices()
+    m, n = A.shape
+    x = lcg_vector(n) if x is None else x
+    dm = P.DeviceMat(A)
+    xd = torch.from_numpy(x).cuda()
+    y = torch.full((m,), float("nan"), dtype=torch.float64, device="cuda")
+    dm.mult(xd, y)
+    ref = A @ x
+    scale = np.abs(A) @ np.abs(x)                    # row-wise bound on the rounding error
+    err = np.abs(y.cpu().numpy() - ref)
+    assert np.all(np.isfinite(y.cpu().numpy()))
+    bad = err > TOL * np.maximum(scale, 1e-300)
+    assert not bad.any(), (int(bad.sum()), m, float(err.max()))
+    # a second product with the same object gives the same bits
+    y2 = torch.empty_like(y); dm.mult(xd, y2)
+    assert torch.equal(y, y2)
+    return dm
+
+
+def _rows(lengths, n, rng, local=None):
+    """CSR with the given row lengths; columns random in [0, n) or, with local=w, inside a window of width w"""
+    lengths = np.asarray(lengths, dtype=np.int64)
+    m = lengths.size
+    indptr = np.concatenate([[0], np.cumsum(lengths)])
+    cols = np.empty(indptr[-1], dtype=np.int64)
+    for i in range(m):
+        k = int(lengths[i])
+        if k == 0:
+            continue
+        if local is None:
+            c = rng.choice(n, size=k, replace=False) if k <= n else np.arange(n)
+        else:
+            lo = int(rng.integers(0, max(1, n - local)))
+            c = lo + rng.choice(min(local, n), size=k, replace=False)
+        cols[indptr[i]:indptr[i + 1]] = np.sort(c)
+    vals = rng.standard_normal(indptr[-1]) * 10.0 ** rng.integers(-3, 3, size=indptr[-1])
+    return sp.csr_matrix((vals, cols, indptr), shape=(m, n))
+
+
+@pytest.fixture(scope="module")
+def env(gpu):
+    import torch
+    import pflare_amd as P
+    return torch, P
+
+
+def test_packed_and_raw_blocks_on_a_wide_operator(env):
+    """20 M columns: rows with local columns give packed blocks, rows with columns spread over the whole width
+    give raw blocks (span >= 2^23), both kinds interleaved in one matrix"""
+    torch, P = env
+    rng = np.random.default_rng(1)
+    n = 20_000_000
+    m = 60_000
+    lengths = rng.integers(1, 9, size=m)
+    indptr = np.concatenate([[0], np.cumsum(lengths)])
+    cols = np.empty(indptr[-1], dtype=np.int64)
+    wide = (np.arange(m) // 300) % 2 == 1            # alternate stretches of local / scattered rows
+    for i in range(m):
+        k = lengths[i]
+        if wide[i]:
+            c = rng.integers(0, n, size=k)
+        else:
+            lo = (i * 300) % (n - 5000)
+            c = lo + rng.integers(0, 5000, size=k)
+        cols[indptr[i]:indptr[i + 1]] = c
+    vals = rng.standard_normal(indptr[-1])
+    A = sp.csr_matrix((vals, cols, indptr), shape=(m, n))
+    _check(A, torch, P)
+
+
+def test_long_rows_and_block_size_edges(env):
+    torch, P = env
+    rng = np.random.default_rng(2)
+    n = 30_000
+    lengths = [3, 512, 4, 513, 5, 2000, 0, 0, 1, 511, 1, 1024, 7, 7, 7, 4097, 2]
+    _check(_rows(lengths, n, rng), torch, P)
+    # a matrix that is one long row, and one with only long rows
+    _check(_rows([5000], n, rng), torch, P)
+    _check(_rows([600, 700, 800, 513], n, rng), torch, P)
+
+
+@pytest.mark.parametrize("per_row", [1, 2, 3, 4, 7, 15, 16, 17, 31, 33, 63, 65, 100, 128, 200, 256, 300, 511, 512])
+def test_every_lanes_per_row_mode(env, per_row):
+    """uniform row length L: blocks hold min(128, 512 // L) rows, so L sweeps T = 1 (two rows per lane) ... 64"""
+    torch, P = env
+    rng = np.random.default_rng(100 + per_row)
+    m = 3 * 128 + 5
+    _check(_rows([per_row] * m, 6000, rng, local=2500), torch, P)
+
+
+def test_empty_rows_and_tiny_matrices(env):
+    torch, P = env
+    rng = np.random.default_rng(3)
+    _check(_rows([0] * 700, 50, rng), torch, P)                       # only empty rows (blocks without entries)
+    _check(_rows([0, 0, 5, 0, 0, 0, 9, 0], 40, rng), torch, P)
+    _check(_rows([1], 1, rng), torch, P)
+    _check(_rows([2], 7, rng), torch, P)
+    lengths = np.where(rng.random(5000) < 0.7, 0, rng.integers(1, 30, size=5000))
+    _check(_rows(lengths, 5000, rng, local=800), torch, P)
+
+
+@pytest.mark.parametrize("nblocks", [1, 2, 3, 4, 5, 9])
+def test_pipeline_prologue_and_epilogue(env, nblocks):
+    """few blocks: every wave runs the pipeline's first / last iteration (prefetch of a block that does not exist)"""
+    torch, P = env
+    rng = np.random.default_rng(200 + nblocks)
+    _check(_rows([8] * (64 * nblocks), 3000, rng, local=1000), torch, P)
+
+
+def test_many_blocks_random_structure(env):
+    """a few hundred thousand blocks: every wave of the resident grid loops over many blocks"""
+    torch, P = env
+    rng = np.random.default_rng(4)
+    m = 1_500_000
+    A = sp.random(m, m, density=6.0 / m, format="csr", random_state=7, dtype=np.float64)
+    A = A + sp.diags(rng.standard_normal(m)).tocsr()
+    _check(A, torch, P)
+
+
+def test_banded_operator_with_nan_free_result_for_inf_free_input(env):
+    """values of x with large dynamic range; padding entries (past a block's end) must not leak into a row sum"""
+    torch, P = env
+    m = 40_000
+    d = [np.full(m, 4.0), np.full(m - 1, -1.0), np.full(m - 1, -1.0), np.full(m - 200, -0.5)]
+    A = sp.diags(d, [0, -1, 1, -200]).tocsr()
+    x = lcg_vector(m) * 10.0 ** (np.arange(m) % 60 - 30)
+    _check(A, torch, P, x=x)
+
+
+@pytest.mark.parametrize("itype,order,diag_scale", [("arnoldi", 6, False), ("arnoldi", 4, True), ("neumann", 5, True),
+                                                    ("newton", 8, False), ("newton", 5, True)])
+def test_fused_epilogues_through_matrix_free_polynomials(env, itype, order, diag_scale):
+    """Horner / Newton / Neumann applies use alpha, beta*z, gamma*w, dscale and the auxiliary y2 update of the SpMV
+    epilogue; checked against the oracle's apply on the same coefficients (<= 4e-11: PFLARE_TOL_MATFREE_4EM11)"""
+    torch, P = env
+    from oracle import air_ref as R, bridge
+    A = R.gen_adv_diff_fd(2, 40, 40, alpha=0.05)
+    n = A.shape[0]
+    pc = P.PCPFLAREINV(type=itype, poly_order=order, matrix_free=True, diag_scale=diag_scale).setup(A)
+    op = bridge._inv_from_dict(pc.get_inverse(n), A)
+    x = lcg_vector(n)
+    y = torch.empty(n, dtype=torch.float64, device="cuda")
+    pc.apply(torch.from_numpy(x).cuda(), y)
+    ref = R.apply_inv(op, x)
+    assert np.linalg.norm(y.cpu().numpy() - ref) <= 4e-11 * np.linalg.norm(ref)
+
+
+def test_pipeline_off_gives_the_same_bits(env):
+    """airhip_set_tuning("spmv_pipeline", 0): the diagnostic kernel without cross-block prefetch computes the same
+    sums in the same order"""
+    torch, P = env
+    rng = np.random.default_rng(5)
+    A = _rows(rng.integers(0, 40, size=20000), 20000, rng, local=3000)
+    x = torch.from_numpy(lcg_vector(20000)).cuda()
+    dm = P.DeviceMat(A)
+    y1 = torch.empty(20000, dtype=torch.float64, device="cuda"); dm.mult(x, y1)
+    assert P.lib().airhip_set_tuning(b"spmv_pipeline", 0) == 0
+    try:
+        y0 = torch.empty_like(y1); dm.mult(x, y0)
+    finally:
+        P.lib().airhip_set_tuning(b"spmv_pipeline", 1)
+    assert torch.equal(y0, y1)
+    assert P.lib().airhip_set_tuning(b"no_such_key", 1) != 0

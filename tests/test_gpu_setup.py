@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 def _spgemm(P, A, B, drop=False, tol=0.0, lump=False, negate=False, on_device=True):
     lib = P.lib()
-    fn = lib.airhip_debug_spgemm
+    fn = lib.airhip_spgemm_filtered
     fn.restype = C.c_int
     fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     a, b = P.as_csr(A), P.as_csr(B)
