@@ -136,7 +136,8 @@ __device__ __forceinline__ void rb_loop(const RbView& A, const XVec<DIST> x, dou
     double xx[EPL];
 #pragma unroll
     for (int u = 0; u < EPL; u++) {
-      const int32_t c = sorted ? d.cbase + (int32_t)(ix[u] & COL_MASK) : (int32_t)ix[u];
+      int32_t c = sorted ? d.cbase + (int32_t)(ix[u] & COL_MASK) : (int32_t)ix[u];
+      if (nb == 0) c = 0;       // a block of empty rows holds another block's (or the padding) word in ix
       xx[u] = x[c];
     }
     __builtin_amdgcn_sched_barrier(0);   // the gathers go out before the next block's stream (vmcnt is in order)
@@ -314,6 +315,7 @@ void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t
   v.blk_list = blk_list; v.nlist = nlist;
   const int64_t nb = blk_list ? nlist : A.nblocks;
   const EpiAxpby epi{e};
+  if (A.n == 0) x = A.val;     // no columns: blocks of empty rows still read element 0 of "x"
   if (A.n_ghost > 0) {
     // distributed operand: ghost columns start at A.n - A.n_ghost
     if (!x_ghost) throw std::runtime_error("launch_spmv: distributed operand without ghost values");
@@ -333,6 +335,7 @@ void launch_fc_first(const DevMat& A_fc, const int32_t* wcol, const double* b_f,
                      const double* aff_d, const double* minv, double* t4_out, double* x_f, hipStream_t s,
                      const double* x_ghost, const int32_t* blk_list, int64_t nlist) {
   if (A_fc.m == 0 || (blk_list && nlist == 0)) return;
+  if (A_fc.n == 0) x_c = A_fc.val;
   RbView v = view_of(A_fc);
   v.blk_list = blk_list; v.nlist = nlist;
   const int64_t nb = blk_list ? nlist : A_fc.nblocks;
