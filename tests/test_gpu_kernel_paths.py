@@ -140,8 +140,14 @@ def test_many_blocks_random_structure(env):
     torch, P = env
     rng = np.random.default_rng(4)
     m = 1_500_000
-    A = sp.random(m, m, density=6.0 / m, format="csr", random_state=7, dtype=np.float64)
-    A = A + sp.diags(rng.standard_normal(m)).tocsr()
+    lengths = rng.integers(0, 13, size=m)
+    indptr = np.concatenate([[0], np.cumsum(lengths)])
+    rows = np.repeat(np.arange(m), lengths)
+    # columns near the diagonal with a few far ones (duplicates are summed by _check)
+    cols = (rows + rng.integers(-2000, 2000, size=rows.size)) % m
+    far = rng.random(rows.size) < 0.05
+    cols[far] = rng.integers(0, m, size=int(far.sum()))
+    A = sp.csr_matrix((rng.standard_normal(rows.size), (rows, cols)), shape=(m, m))
     _check(A, torch, P)
 
 
