@@ -50,7 +50,9 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=2)
     ap.add_argument("--graph", type=int, default=0)
     ap.add_argument("--profile-kernels", type=int, default=1)
-    ap.add_argument("--variants", default="", help="diagnostic: comma list of SpMV kernel variants to time")
+    ap.add_argument("--variants", default="", help="diagnostic: ';'-separated kernel tunings to time on the same "
+                    "hierarchy, each a ','-separated list of key=value for airhip_set_tuning (e.g. "
+                    "'spmv_pipeline=0;spmv_occupancy=4,spmv_wg_per_cu=3')")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--hint-brick", type=int, default=16,
                     help="locality hint for the device layout: grid points grouped in BxBxB bricks (0: none, -1: Morton "
@@ -272,8 +274,14 @@ def main():
         return ms
 
     if args.variants:
-        for v in [int(t) for t in args.variants.split(",")]:
-            P.lib().airhip_debug_set_variant(v)
+        base = {}
+        for v in args.variants.split(";"):
+            kv = dict((t.split("=")[0].strip(), int(t.split("=")[1])) for t in v.split(",") if t.strip())
+            for k_, v_ in kv.items():
+                base.setdefault(k_, None)
+                check = P.lib().airhip_set_tuning(k_.encode(), v_)
+                if check != 0:
+                    raise SystemExit(f"unknown tuning {k_}={v_}")
             run_iterations(3)
             pc.profile(True); pc.profile_reset()
             torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -281,11 +289,16 @@ def main():
             torch.cuda.synchronize(); w = time.perf_counter() - t0
             stv = [s_ for s_ in pc.profile_stats() if s_["calls"] > 0]
             pc.profile(False)
-            tot = sum(s_["total_ms"] for s_ in stv)
+            tot = sum(s_["total_ms"] for s_ in stv if s_["level"] >= 0)
+            sp_ms = sum(s_["total_ms"] for s_ in stv if s_["kernel"] == "k_rb_spmv")
+            sp_by = sum(s_["alg_bytes"] * s_["calls"] for s_ in stv if s_["kernel"] == "k_rb_spmv")
             cyc = max(1, next((s_["calls"] for s_ in stv if s_["name"].startswith("restrict") and s_["level"] == 0), 1))
-            log(f"[variant {v}] {args.steps / w:8.2f} it/s  vcycle kernels {tot / cyc:8.3f} ms  "
-                f"{cx['cycle_alg_bytes'] / (tot / cyc * 1e-3) / 1e9:7.1f} GB/s")
-        P.lib().airhip_debug_set_variant(0)
+            print(f"[variant {v or 'default'}] {args.steps / w:8.2f} it/s  vcycle kernels {tot / cyc:8.3f} ms  "
+                  f"{cx['cycle_alg_bytes'] / (tot / cyc * 1e-3) / 1e9:7.1f} GB/s  k_rb_spmv {sp_by / (sp_ms * 1e-3) / 1e9:7.1f} GB/s",
+                  file=sys.stderr, flush=True)
+            # back to the defaults before the next variant
+            for k_ in kv:
+                P.lib().airhip_set_tuning(k_.encode(), {"spmv_pipeline": 1, "spmv_occupancy": 3, "spmv_wg_per_cu": 0}.get(k_, 0))
     run_iterations(args.warmup)
     if args.profile_kernels:
         pc.profile(True)

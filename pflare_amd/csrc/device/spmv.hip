@@ -51,9 +51,11 @@ __device__ __forceinline__ BlockRange my_blocks(int64_t nblocks) {
 // ---- tuning knobs (airhip_set_tuning; defaults are what bench.py measures)
 static int g_grid_wg_per_cu = 0;     // 0 = from the occupancy query
 static int g_pipeline = 1;           // 0 = no cross-block prefetch (diagnostic)
+static int g_occ = 3;                // waves per SIMD the kernel is compiled for (3: ~140 VGPRs, 4: <= 128)
 int spmv_set_tuning(const char* key, int value) {
   if (!std::strcmp(key, "spmv_wg_per_cu")) { g_grid_wg_per_cu = value; return 0; }
   if (!std::strcmp(key, "spmv_pipeline")) { g_pipeline = value; return 0; }
+  if (!std::strcmp(key, "spmv_occupancy")) { if (value != 3 && value != 4) return -1; g_occ = value; return 0; }
   return -1;
 }
 
@@ -238,8 +240,8 @@ struct EpiAxpby {
   }
 };
 
-template <bool DIST, bool PIPE>
-__global__ __launch_bounds__(BLOCK) void k_rb_spmv(RbView A, XVec<DIST> x, EpiAxpby epi) {
+template <bool DIST, bool PIPE, int OCC>
+__global__ __launch_bounds__(BLOCK, OCC) void k_rb_spmv(RbView A, XVec<DIST> x, EpiAxpby epi) {
   __shared__ double lds_all[WAVES_PER_BLOCK][BLK_NNZ + 2];
   rb_loop<DIST, PIPE>(A, x, lds_all[threadIdx.x >> 6], epi);
 }
@@ -275,8 +277,8 @@ struct EpiFcFirst {
   }
 };
 
-template <bool DIST, bool PIPE>
-__global__ __launch_bounds__(BLOCK) void k_rb_fc_first(RbView A, XVec<DIST> x_c, EpiFcFirst<DIST> epi) {
+template <bool DIST, bool PIPE, int OCC>
+__global__ __launch_bounds__(BLOCK, OCC) void k_rb_fc_first(RbView A, XVec<DIST> x_c, EpiFcFirst<DIST> epi) {
   __shared__ double lds_all[WAVES_PER_BLOCK][BLK_NNZ + 2];
   rb_loop<DIST, PIPE>(A, x_c, lds_all[threadIdx.x >> 6], epi);
 }
@@ -308,6 +310,13 @@ static void check_launch(const char* what) {
   if (e != hipSuccess) throw std::runtime_error(std::string("HIP error ") + hipGetErrorString(e) + " launching " + what);
 }
 
+#define RB_LAUNCH(KERNEL, D, ...)                                                                                   \
+  do {                                                                                                               \
+    if (g_pipeline && g_occ == 3) hipLaunchKernelGGL((KERNEL<D, true, 3>), dim3(resident_grid(KERNEL<D, true, 3>, nb)), dim3(BLOCK), 0, s, __VA_ARGS__);   \
+    else if (g_pipeline) hipLaunchKernelGGL((KERNEL<D, true, 4>), dim3(resident_grid(KERNEL<D, true, 4>, nb)), dim3(BLOCK), 0, s, __VA_ARGS__);          \
+    else hipLaunchKernelGGL((KERNEL<D, false, 4>), dim3(resident_grid(KERNEL<D, false, 4>, nb)), dim3(BLOCK), 0, s, __VA_ARGS__);                        \
+  } while (0)
+
 void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t s, const double* x_ghost,
                  const int32_t* blk_list, int64_t nlist) {
   if (A.m == 0 || (blk_list && nlist == 0)) return;
@@ -321,12 +330,10 @@ void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t
     if (!x_ghost) throw std::runtime_error("launch_spmv: distributed operand without ghost values");
     const int32_t nl = (int32_t)(A.n - A.n_ghost);
     const XVec<true> xv{x, x_ghost - nl, nl};
-    if (g_pipeline) hipLaunchKernelGGL((k_rb_spmv<true, true>), dim3(resident_grid(k_rb_spmv<true, true>, nb)), dim3(BLOCK), 0, s, v, xv, epi);
-    else hipLaunchKernelGGL((k_rb_spmv<true, false>), dim3(resident_grid(k_rb_spmv<true, false>, nb)), dim3(BLOCK), 0, s, v, xv, epi);
+    RB_LAUNCH(k_rb_spmv, true, v, xv, epi);
   } else {
     const XVec<false> xv{x, nullptr, 0};
-    if (g_pipeline) hipLaunchKernelGGL((k_rb_spmv<false, true>), dim3(resident_grid(k_rb_spmv<false, true>, nb)), dim3(BLOCK), 0, s, v, xv, epi);
-    else hipLaunchKernelGGL((k_rb_spmv<false, false>), dim3(resident_grid(k_rb_spmv<false, false>, nb)), dim3(BLOCK), 0, s, v, xv, epi);
+    RB_LAUNCH(k_rb_spmv, false, v, xv, epi);
   }
   check_launch("k_rb_spmv");
 }
@@ -344,16 +351,15 @@ void launch_fc_first(const DevMat& A_fc, const int32_t* wcol, const double* b_f,
     const int32_t nl = (int32_t)(A_fc.n - A_fc.n_ghost);
     const XVec<true> xv{x_c, x_ghost - nl, nl};
     const EpiFcFirst<true> epi{wcol, b_f, xv, aff_d, minv, t4_out, x_f};
-    if (g_pipeline) hipLaunchKernelGGL((k_rb_fc_first<true, true>), dim3(resident_grid(k_rb_fc_first<true, true>, nb)), dim3(BLOCK), 0, s, v, xv, epi);
-    else hipLaunchKernelGGL((k_rb_fc_first<true, false>), dim3(resident_grid(k_rb_fc_first<true, false>, nb)), dim3(BLOCK), 0, s, v, xv, epi);
+    RB_LAUNCH(k_rb_fc_first, true, v, xv, epi);
   } else {
     const XVec<false> xv{x_c, nullptr, 0};
     const EpiFcFirst<false> epi{wcol, b_f, xv, aff_d, minv, t4_out, x_f};
-    if (g_pipeline) hipLaunchKernelGGL((k_rb_fc_first<false, true>), dim3(resident_grid(k_rb_fc_first<false, true>, nb)), dim3(BLOCK), 0, s, v, xv, epi);
-    else hipLaunchKernelGGL((k_rb_fc_first<false, false>), dim3(resident_grid(k_rb_fc_first<false, false>, nb)), dim3(BLOCK), 0, s, v, xv, epi);
+    RB_LAUNCH(k_rb_fc_first, false, v, xv, epi);
   }
   check_launch("k_rb_fc_first");
 }
+#undef RB_LAUNCH
 
 // ---------------------------------------------------------------------------------------
 // CSR (device, any row order) -> row-block CSR (setup time)
