@@ -52,9 +52,11 @@ __device__ __forceinline__ BlockRange my_blocks(int64_t nblocks) {
 static int g_grid_wg_per_cu = 0;     // 0 = from the occupancy query
 static int g_pipeline = 1;           // 0 = no cross-block prefetch (diagnostic)
 static int g_occ = 3;                // waves per SIMD the kernel is compiled for (3: ~140 VGPRs, 4: <= 128)
+static int g_nt = 0;                 // 1 = non-temporal loads for the matrix stream (diagnostic)
 int spmv_set_tuning(const char* key, int value) {
   if (!std::strcmp(key, "spmv_wg_per_cu")) { g_grid_wg_per_cu = value; return 0; }
   if (!std::strcmp(key, "spmv_pipeline")) { g_pipeline = value; return 0; }
+  if (!std::strcmp(key, "spmv_nt")) { g_nt = value; return 0; }
   if (!std::strcmp(key, "spmv_occupancy")) { if (value != 3 && value != 4) return -1; g_occ = value; return 0; }
   return -1;
 }
@@ -82,14 +84,15 @@ __device__ __forceinline__ BlkInfo load_blk(const RbView& A, int64_t i) {
 
 // the block's first 512 (index, value) pairs into registers: unconditional loads of clamped positions, so
 // that the stream stays straight-line code (no exec-mask branches between the loads and their use)
+template <bool NT>
 __device__ __forceinline__ void issue_stream(const RbView& A, const BlkInfo& d, int lane, uint32_t (&ix)[EPL], double (&vv)[EPL]) {
   const uint32_t* __restrict__ ip = A.idx + d.p0;
   const double* __restrict__ vp = A.val + d.p0;
   const int last = d.nb > 0 ? d.nb - 1 : 0;     // nb == 0: the padding / next block's first entry, never used
 #pragma unroll
-  for (int u = 0; u < EPL; u++) { const int k = min(lane + u * WAVE, last); ix[u] = ip[k]; }
+  for (int u = 0; u < EPL; u++) { const int k = min(lane + u * WAVE, last); ix[u] = NT ? __builtin_nontemporal_load(ip + k) : ip[k]; }
 #pragma unroll
-  for (int u = 0; u < EPL; u++) { const int k = min(lane + u * WAVE, last); vv[u] = vp[k]; }
+  for (int u = 0; u < EPL; u++) { const int k = min(lane + u * WAVE, last); vv[u] = NT ? __builtin_nontemporal_load(vp + k) : vp[k]; }
 }
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -102,7 +105,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 //   Early early(row)            issued with the stream of the NEXT block (loads whose result feeds another load)
 //   Pre   load(row, Early)      issued at the top of the block's own iteration, before the gather is waited for
 //   void  store(row, acc, Pre)  after the row sum is known
-template <bool DIST, bool PIPE, class Epi>
+template <bool DIST, bool PIPE, bool NT, class Epi>
 __device__ __forceinline__ void rb_loop(const RbView& A, const XVec<DIST> x, double* __restrict__ lds, const Epi& epi) {
   const int lane = threadIdx.x & (WAVE - 1);
   const BlockRange br = my_blocks(A.blk_list ? A.nlist : A.nblocks);
@@ -112,7 +115,7 @@ __device__ __forceinline__ void rb_loop(const RbView& A, const XVec<DIST> x, dou
   BlkInfo dn = load_blk(A, bi + br.stride < br.last ? bi + br.stride : bi);
   uint32_t ix[EPL]; double vv[EPL];
   typename Epi::Early early[2];
-  issue_stream(A, d, lane, ix, vv);
+  issue_stream<NT>(A, d, lane, ix, vv);
 #pragma unroll
   for (int q = 0; q < 2; q++) early[q] = epi.early(d.r0 + min(lane + q * WAVE, d.nr - 1));
   for (;;) {
@@ -147,7 +150,7 @@ __device__ __forceinline__ void rb_loop(const RbView& A, const XVec<DIST> x, dou
     uint32_t nix[EPL]; double nvv[EPL];
     typename Epi::Early nearly[2];
     if constexpr (PIPE) {
-      issue_stream(A, dn, lane, nix, nvv);
+      issue_stream<NT>(A, dn, lane, nix, nvv);
 #pragma unroll
       for (int q = 0; q < 2; q++) nearly[q] = epi.early(dn.r0 + min(lane + q * WAVE, dn.nr - 1));
     }
@@ -209,7 +212,7 @@ __device__ __forceinline__ void rb_loop(const RbView& A, const XVec<DIST> x, dou
       for (int u = 0; u < EPL; u++) { ix[u] = nix[u]; vv[u] = nvv[u]; }
       early[0] = nearly[0]; early[1] = nearly[1];
     } else {
-      issue_stream(A, d, lane, ix, vv);
+      issue_stream<NT>(A, d, lane, ix, vv);
 #pragma unroll
       for (int q = 0; q < 2; q++) early[q] = epi.early(d.r0 + min(lane + q * WAVE, d.nr - 1));
     }
@@ -240,10 +243,10 @@ struct EpiAxpby {
   }
 };
 
-template <bool DIST, bool PIPE, int OCC>
+template <bool DIST, bool PIPE, int OCC, bool NT = false>
 __global__ __launch_bounds__(BLOCK, OCC) void k_rb_spmv(RbView A, XVec<DIST> x, EpiAxpby epi) {
   __shared__ double lds_all[WAVES_PER_BLOCK][BLK_NNZ + 2];
-  rb_loop<DIST, PIPE>(A, x, lds_all[threadIdx.x >> 6], epi);
+  rb_loop<DIST, PIPE, NT>(A, x, lds_all[threadIdx.x >> 6], epi);
 }
 
 // Fused first stage of an F-point relaxation with a one-point prolongator (see dev.hpp)
@@ -277,10 +280,10 @@ struct EpiFcFirst {
   }
 };
 
-template <bool DIST, bool PIPE, int OCC>
+template <bool DIST, bool PIPE, int OCC, bool NT = false>
 __global__ __launch_bounds__(BLOCK, OCC) void k_rb_fc_first(RbView A, XVec<DIST> x_c, EpiFcFirst<DIST> epi) {
   __shared__ double lds_all[WAVES_PER_BLOCK][BLK_NNZ + 2];
-  rb_loop<DIST, PIPE>(A, x_c, lds_all[threadIdx.x >> 6], epi);
+  rb_loop<DIST, PIPE, NT>(A, x_c, lds_all[threadIdx.x >> 6], epi);
 }
 
 // grid: as many workgroups as are resident at once (the waves loop over their blocks), a multiple of 8
@@ -312,7 +315,8 @@ static void check_launch(const char* what) {
 
 #define RB_LAUNCH(KERNEL, D, ...)                                                                                   \
   do {                                                                                                               \
-    if (g_pipeline && g_occ == 3) hipLaunchKernelGGL((KERNEL<D, true, 3>), dim3(resident_grid(KERNEL<D, true, 3>, nb)), dim3(BLOCK), 0, s, __VA_ARGS__);   \
+    if (g_nt) hipLaunchKernelGGL((KERNEL<D, true, 3, true>), dim3(resident_grid(KERNEL<D, true, 3, true>, nb)), dim3(BLOCK), 0, s, __VA_ARGS__);   \
+    else if (g_pipeline && g_occ == 3) hipLaunchKernelGGL((KERNEL<D, true, 3>), dim3(resident_grid(KERNEL<D, true, 3>, nb)), dim3(BLOCK), 0, s, __VA_ARGS__);   \
     else if (g_pipeline) hipLaunchKernelGGL((KERNEL<D, true, 4>), dim3(resident_grid(KERNEL<D, true, 4>, nb)), dim3(BLOCK), 0, s, __VA_ARGS__);          \
     else hipLaunchKernelGGL((KERNEL<D, false, 4>), dim3(resident_grid(KERNEL<D, false, 4>, nb)), dim3(BLOCK), 0, s, __VA_ARGS__);                        \
   } while (0)
