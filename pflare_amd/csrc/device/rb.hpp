@@ -10,7 +10,8 @@ constexpr int BLK_NNZ = 512;        // non-zeros per row block (a longer row is 
 constexpr int BLK_ROWS = 128;       // rows per row block: two per lane
 constexpr int EPL = BLK_NNZ / WAVE; // entries per lane
 constexpr int CHUNK_ROWS = 512;     // the block partition is greedy inside chunks of this many rows
-constexpr int COL_BITS = 23;        // block-relative column bits of an index word; the upper 9 hold the position
+constexpr int COL_BITS = 22;        // block-relative column bits of an index word; the upper 10 hold the 1-based position
+constexpr int LDS_SLOTS = BLK_NNZ + 2;   // products staged per wave: slot 0 is the dummy slot of padding lanes
 constexpr uint32_t COL_MASK = (1u << COL_BITS) - 1u;
 
 struct RbView {

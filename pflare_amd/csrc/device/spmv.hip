@@ -52,11 +52,9 @@ __device__ __forceinline__ BlockRange my_blocks(int64_t nblocks) {
 static int g_grid_wg_per_cu = 0;     // 0 = from the occupancy query
 static int g_pipeline = 1;           // 0 = no cross-block prefetch (diagnostic)
 static int g_occ = 3;                // waves per SIMD the kernel is compiled for (3: ~140 VGPRs, 4: <= 128)
-static int g_nt = 0;                 // 1 = non-temporal loads for the matrix stream (diagnostic)
 int spmv_set_tuning(const char* key, int value) {
   if (!std::strcmp(key, "spmv_wg_per_cu")) { g_grid_wg_per_cu = value; return 0; }
   if (!std::strcmp(key, "spmv_pipeline")) { g_pipeline = value; return 0; }
-  if (!std::strcmp(key, "spmv_nt")) { g_nt = value; return 0; }
   if (!std::strcmp(key, "spmv_occupancy")) { if (value != 3 && value != 4) return -1; g_occ = value; return 0; }
   return -1;
 }
@@ -82,17 +80,31 @@ __device__ __forceinline__ BlkInfo load_blk(const RbView& A, int64_t i) {
   return o;
 }
 
-// the block's first 512 (index, value) pairs into registers: unconditional loads of clamped positions, so
-// that the stream stays straight-line code (no exec-mask branches between the loads and their use)
-template <bool NT>
+// ---- buffer addressing.  Every per-block array (index words, values, row offsets, epilogue vectors) is read
+// through a buffer resource whose extent is the block's: lanes past the end get 0 from the hardware range check
+// (and stores past the end are dropped), so the kernel needs no clamps, no exec-mask branches and one 32-bit
+// offset register per array.  An out-of-range index word 0 decodes to position 0 = the dummy LDS slot and to the
+// block's first column, so padding lanes gather a valid address and park a zero product where nobody reads it.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, int64_t bytes) {
+  const int nrec = bytes > 0x7fffffffll ? 0x7fffffff : (int)bytes;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, nrec, 0x00020000);
+}
+__device__ __forceinline__ double buf_f64(rsrc_t r, int voff, int soff = 0) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store_f64(rsrc_t r, int voff, double v) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((__vector_size__(2 * sizeof(unsigned int)))) unsigned int, v), r, voff, 0, 0);
+}
+
+// the block's first 512 (index, value) pairs into registers
 __device__ __forceinline__ void issue_stream(const RbView& A, const BlkInfo& d, int lane, uint32_t (&ix)[EPL], double (&vv)[EPL]) {
-  const uint32_t* __restrict__ ip = A.idx + d.p0;
-  const double* __restrict__ vp = A.val + d.p0;
-  const int last = d.nb > 0 ? d.nb - 1 : 0;     // nb == 0: the padding / next block's first entry, never used
+  const int n = d.nb < BLK_NNZ ? d.nb : BLK_NNZ;
+  const rsrc_t ri = make_rsrc(A.idx + d.p0, (int64_t)n * 4), rv = make_rsrc(A.val + d.p0, (int64_t)n * 8);
 #pragma unroll
-  for (int u = 0; u < EPL; u++) { const int k = min(lane + u * WAVE, last); ix[u] = NT ? __builtin_nontemporal_load(ip + k) : ip[k]; }
+  for (int u = 0; u < EPL; u++) ix[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(ri, lane * 4, u * WAVE * 4, 0);
 #pragma unroll
-  for (int u = 0; u < EPL; u++) { const int k = min(lane + u * WAVE, last); vv[u] = NT ? __builtin_nontemporal_load(vp + k) : vp[k]; }
+  for (int u = 0; u < EPL; u++) vv[u] = buf_f64(rv, lane * 8, u * WAVE * 8);
 }
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -101,11 +113,19 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Epi interface:
-//   Early early(row)            issued with the stream of the NEXT block (loads whose result feeds another load)
-//   Pre   load(row, Early)      issued at the top of the block's own iteration, before the gather is waited for
-//   void  store(row, acc, Pre)  after the row sum is known
-template <bool DIST, bool PIPE, bool NT, class Epi>
+// x[c] with a 32-bit byte offset from the uniform base (n < 2^29 columns, checked at conversion); the
+// distributed variant selects between the owned segment and the received ghost values
+template <bool DIST>
+__device__ __forceinline__ double xload(const XVec<DIST>& x, int32_t c) {
+  if constexpr (DIST) return x[c];
+  else return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(x.x) + ((uint32_t)c << 3));
+}
+
+// Epi interface (r0 = first row of the block, nr = its rows, lr = this lane's local row, may be >= nr):
+//   Early early(r0, nr, lr)            issued with the stream of the NEXT block (loads whose result feeds another load)
+//   Pre   load(r0, nr, lr, Early)      issued at the top of the block's own iteration, before the gather is waited for
+//   void  store(r0, nr, lr, acc, Pre)  after the row sum is known; rows past the block's end are dropped
+template <bool DIST, bool PIPE, class Epi>
 __device__ __forceinline__ void rb_loop(const RbView& A, const XVec<DIST> x, double* __restrict__ lds, const Epi& epi) {
   const int lane = threadIdx.x & (WAVE - 1);
   const BlockRange br = my_blocks(A.blk_list ? A.nlist : A.nblocks);
@@ -115,9 +135,9 @@ __device__ __forceinline__ void rb_loop(const RbView& A, const XVec<DIST> x, dou
   BlkInfo dn = load_blk(A, bi + br.stride < br.last ? bi + br.stride : bi);
   uint32_t ix[EPL]; double vv[EPL];
   typename Epi::Early early[2];
-  issue_stream<NT>(A, d, lane, ix, vv);
+  issue_stream(A, d, lane, ix, vv);
 #pragma unroll
-  for (int q = 0; q < 2; q++) early[q] = epi.early(d.r0 + min(lane + q * WAVE, d.nr - 1));
+  for (int q = 0; q < 2; q++) early[q] = epi.early(d.r0, d.nr, lane + q * WAVE);
   for (;;) {
     // descriptors two blocks ahead (scalar loads)
     const int64_t b2 = bi + 2 * br.stride;
@@ -128,63 +148,61 @@ __device__ __forceinline__ void rb_loop(const RbView& A, const XVec<DIST> x, dou
     // row offsets and epilogue inputs of this lane's (at most two) rows
     int ra[2], re[2];
     typename Epi::Pre pre[2];
+    const rsrc_t rr = make_rsrc(A.roff + d.r0, (int64_t)nr * 2);
 #pragma unroll
     for (int q = 0; q < 2; q++) {
-      const int r = min(lane + q * WAVE, nr - 1);
-      ra[q] = (int)A.roff[d.r0 + r];
-      const int rnext = (int)A.roff[d.r0 + min(r + 1, nr - 1)];
-      re[q] = (r + 1 < nr) ? rnext : nb;
-      if (lane + q * WAVE >= nr) re[q] = ra[q];     // no row: nothing to sum
-      pre[q] = epi.load(d.r0 + r, early[q]);
+      const int r = lane + q * WAVE;
+      ra[q] = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rr, r * 2, 0, 0);
+      const int rnext = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rr, r * 2 + 2, 0, 0);
+      re[q] = (r + 1 < nr) ? rnext : (r < nr ? nb : 0);       // no row: ra = re = 0, nothing to sum
+      pre[q] = epi.load(d.r0, nr, r, early[q]);
     }
     // gather x for the whole block
     double xx[EPL];
 #pragma unroll
     for (int u = 0; u < EPL; u++) {
-      int32_t c = sorted ? d.cbase + (int32_t)(ix[u] & COL_MASK) : (int32_t)ix[u];
-      if (nb == 0) c = 0;       // a block of empty rows holds another block's (or the padding) word in ix
-      xx[u] = x[c];
+      const int32_t c = sorted ? d.cbase + (int32_t)(ix[u] & COL_MASK) : (int32_t)ix[u];
+      xx[u] = xload(x, c);
     }
     __builtin_amdgcn_sched_barrier(0);   // the gathers go out before the next block's stream (vmcnt is in order)
     // the next block's stream (or, at the end, the same block once more: the loads stay unconditional)
     uint32_t nix[EPL]; double nvv[EPL];
     typename Epi::Early nearly[2];
     if constexpr (PIPE) {
-      issue_stream<NT>(A, dn, lane, nix, nvv);
+      issue_stream(A, dn, lane, nix, nvv);
 #pragma unroll
-      for (int q = 0; q < 2; q++) nearly[q] = epi.early(dn.r0 + min(lane + q * WAVE, dn.nr - 1));
+      for (int q = 0; q < 2; q++) nearly[q] = epi.early(dn.r0, dn.nr, lane + q * WAVE);
     }
     __builtin_amdgcn_sched_barrier(0);
     if (nb <= BLK_NNZ) {
-      // phase 1: products to their row-major positions
+      // phase 1: products to their row-major positions (1-based; position 0 is the dummy slot of padding lanes)
 #pragma unroll
       for (int u = 0; u < EPL; u++) {
         const int k = lane + u * WAVE;
-        const int pos = sorted ? (int)(ix[u] >> COL_BITS) : k;
-        lds[k < nb ? pos : BLK_NNZ] = vv[u] * xx[u];     // entries past the block's end go to a dummy slot
+        const int pos = sorted ? (int)(ix[u] >> COL_BITS) : (k < nb ? k + 1 : 0);
+        lds[pos] = vv[u] * xx[u];
       }
       wave_lds_sync();
       if (nr > 32) {
         // phase 2: one lane per row, column order
 #pragma unroll
         for (int q = 0; q < 2; q++) {
-          const int r = lane + q * WAVE;
           double s = 0.0;
-          for (int j = ra[q]; j < re[q]; j++) s += lds[j];
-          if (r < nr) epi.store(d.r0 + r, s, pre[q]);
+          for (int j = ra[q]; j < re[q]; j++) s += lds[j + 1];
+          epi.store(d.r0, nr, lane + q * WAVE, s, pre[q]);
         }
       } else {
         // phase 2 for few (longer) rows: T = 64 / 2^ceil(log2 nr) lanes share a row
-        int T = WAVE, sh = 6;
+        int sh = 6;
         while ((WAVE >> sh) < nr) { sh--; }       // 2^(6-sh) >= nr groups
-        T = 1 << sh;
+        const int T = 1 << sh;
         const int g = lane >> sh, t = lane & (T - 1);
         const int a = __shfl(ra[0], g, WAVE), e = __shfl(re[0], g, WAVE);
         double s = 0.0;
-        if (g < nr) for (int j = a + t; j < e; j += T) s += lds[j];
+        for (int j = a + t; j < e; j += T) s += lds[j + 1];
         for (int off = T >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
         const double srow = __shfl(s, (lane << sh) & (WAVE - 1), WAVE);   // row `lane` lives in lanes lane*T ..
-        if (lane < nr) epi.store(d.r0 + lane, srow, pre[0]);
+        epi.store(d.r0, nr, lane, srow, pre[0]);
       }
       __builtin_amdgcn_wave_barrier();   // LDS is reused by the next block of this wave
     } else {
@@ -196,13 +214,13 @@ __device__ __forceinline__ void rb_loop(const RbView& A, const XVec<DIST> x, dou
       for (; j + 3 * WAVE < nb; j += 4 * WAVE) {
         const int32_t c0 = (int32_t)ip[j], c1 = (int32_t)ip[j + WAVE], c2 = (int32_t)ip[j + 2 * WAVE], c3 = (int32_t)ip[j + 3 * WAVE];
         const double v0 = vp[j], v1 = vp[j + WAVE], v2 = vp[j + 2 * WAVE], v3 = vp[j + 3 * WAVE];
-        const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+        const double x0 = xload(x, c0), x1 = xload(x, c1), x2 = xload(x, c2), x3 = xload(x, c3);
         s0 = fma(v0, x0, s0); s1 = fma(v1, x1, s1); s2 = fma(v2, x2, s2); s3 = fma(v3, x3, s3);
       }
-      for (; j < nb; j += WAVE) s0 = fma(vp[j], x[(int32_t)ip[j]], s0);
+      for (; j < nb; j += WAVE) s0 = fma(vp[j], xload(x, (int32_t)ip[j]), s0);
       double s = (s0 + s1) + (s2 + s3);
       for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
-      if (lane == 0) epi.store(d.r0, s, pre[0]);
+      epi.store(d.r0, nr, lane, s, pre[0]);      // nr = 1: only lane 0 is inside the block
     }
     if (!more) break;
     bi += br.stride;
@@ -212,9 +230,9 @@ __device__ __forceinline__ void rb_loop(const RbView& A, const XVec<DIST> x, dou
       for (int u = 0; u < EPL; u++) { ix[u] = nix[u]; vv[u] = nvv[u]; }
       early[0] = nearly[0]; early[1] = nearly[1];
     } else {
-      issue_stream<NT>(A, d, lane, ix, vv);
+      issue_stream(A, d, lane, ix, vv);
 #pragma unroll
-      for (int q = 0; q < 2; q++) early[q] = epi.early(d.r0 + min(lane + q * WAVE, d.nr - 1));
+      for (int q = 0; q < 2; q++) early[q] = epi.early(d.r0, d.nr, lane + q * WAVE);
     }
   }
 }
@@ -224,29 +242,31 @@ struct EpiAxpby {
   SpmvEpi e;
   struct Early {};
   struct Pre { double z, w, d, y2, w2; };
-  __device__ __forceinline__ Early early(int32_t) const { return Early{}; }
-  __device__ __forceinline__ Pre load(int32_t row, Early) const {
+  __device__ __forceinline__ Early early(int32_t, int, int) const { return Early{}; }
+  __device__ __forceinline__ Pre load(int32_t r0, int nr, int lr, Early) const {
     Pre p; p.z = 0.0; p.w = 0.0; p.d = 1.0; p.y2 = 0.0; p.w2 = 0.0;
-    if (e.z) p.z = e.z[row];
-    if (e.w) p.w = e.w[row];
-    if (e.dscale) p.d = e.dscale[row];
-    if (e.y2) { p.y2 = e.y2[row]; if (!e.aux_out) p.w2 = e.w2[row]; }
+    const int64_t ext = (int64_t)nr * 8;
+    if (e.z) p.z = buf_f64(make_rsrc(e.z + r0, ext), lr * 8);
+    if (e.w) p.w = buf_f64(make_rsrc(e.w + r0, ext), lr * 8);
+    if (e.dscale) p.d = buf_f64(make_rsrc(e.dscale + r0, ext), lr * 8);
+    if (e.y2) { p.y2 = buf_f64(make_rsrc(e.y2 + r0, ext), lr * 8); if (!e.aux_out) p.w2 = buf_f64(make_rsrc(e.w2 + r0, ext), lr * 8); }
     return p;
   }
-  __device__ __forceinline__ void store(int32_t row, double acc, const Pre& p) const {
+  __device__ __forceinline__ void store(int32_t r0, int nr, int lr, double acc, const Pre& p) const {
     if (e.dscale) acc *= p.d;
     double o = e.alpha * acc;
     if (e.z) o += e.beta * p.z;
     if (e.w) o += e.gamma * p.w;
-    e.out[row] = o;
-    if (e.y2) e.y2[row] = p.y2 + e.delta * (e.aux_out ? o : p.w2);
+    const int64_t ext = (int64_t)nr * 8;
+    buf_store_f64(make_rsrc(e.out + r0, ext), lr * 8, o);
+    if (e.y2) buf_store_f64(make_rsrc(e.y2 + r0, ext), lr * 8, p.y2 + e.delta * (e.aux_out ? o : p.w2));
   }
 };
 
-template <bool DIST, bool PIPE, int OCC, bool NT = false>
+template <bool DIST, bool PIPE, int OCC>
 __global__ __launch_bounds__(BLOCK, OCC) void k_rb_spmv(RbView A, XVec<DIST> x, EpiAxpby epi) {
-  __shared__ double lds_all[WAVES_PER_BLOCK][BLK_NNZ + 2];
-  rb_loop<DIST, PIPE, NT>(A, x, lds_all[threadIdx.x >> 6], epi);
+  __shared__ double lds_all[WAVES_PER_BLOCK][LDS_SLOTS];
+  rb_loop<DIST, PIPE>(A, x, lds_all[threadIdx.x >> 6], epi);
 }
 
 // Fused first stage of an F-point relaxation with a one-point prolongator (see dev.hpp)
@@ -257,33 +277,39 @@ struct EpiFcFirst {
   double* __restrict__ t4_out; double* __restrict__ x_f;
   struct Early { int32_t wc; };
   struct Pre { double b, x0, ad, mi; };
-  __device__ __forceinline__ Early early(int32_t row) const { return Early{wcol[row]}; }
-  __device__ __forceinline__ Pre load(int32_t row, Early ea) const {
-    Pre p; p.b = b_f[row];
-    p.x0 = 0.0;
-    if (ea.wc >= 0) p.x0 = x_c[ea.wc];
+  __device__ __forceinline__ Early early(int32_t r0, int nr, int lr) const {
+    // rows past the block's end read 0 = a valid column
+    return Early{(int32_t)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(wcol + r0, (int64_t)nr * 4), lr * 4, 0, 0)};
+  }
+  __device__ __forceinline__ Pre load(int32_t r0, int nr, int lr, Early ea) const {
+    Pre p;
+    const int64_t ext = (int64_t)nr * 8;
+    p.b = buf_f64(make_rsrc(b_f + r0, ext), lr * 8);
+    p.x0 = xload(x_c, ea.wc >= 0 ? ea.wc : 0);
+    if (ea.wc < 0) p.x0 = 0.0;
     p.ad = 0.0; p.mi = 0.0;
-    if (aff_d) { p.ad = aff_d[row]; p.mi = minv[row]; }
+    if (aff_d) { p.ad = buf_f64(make_rsrc(aff_d + r0, ext), lr * 8); p.mi = buf_f64(make_rsrc(minv + r0, ext), lr * 8); }
     return p;
   }
-  __device__ __forceinline__ void store(int32_t row, double acc, const Pre& p) const {
+  __device__ __forceinline__ void store(int32_t r0, int nr, int lr, double acc, const Pre& p) const {
     const double t4 = p.b + (-1.0) * acc;
+    const int64_t ext = (int64_t)nr * 8;
     if (aff_d) {
       // one F smooth with diagonal A_ff and diagonal inverse (src/FC_Smooth.F90:541-559)
       double t3 = p.ad * p.x0;
       t3 = t4 + (-1.0) * t3;
-      x_f[row] = p.x0 + p.mi * t3;
+      buf_store_f64(make_rsrc(x_f + r0, ext), lr * 8, p.x0 + p.mi * t3);
     } else {
-      t4_out[row] = t4;
-      x_f[row] = p.x0;
+      buf_store_f64(make_rsrc(t4_out + r0, ext), lr * 8, t4);
+      buf_store_f64(make_rsrc(x_f + r0, ext), lr * 8, p.x0);
     }
   }
 };
 
-template <bool DIST, bool PIPE, int OCC, bool NT = false>
+template <bool DIST, bool PIPE, int OCC>
 __global__ __launch_bounds__(BLOCK, OCC) void k_rb_fc_first(RbView A, XVec<DIST> x_c, EpiFcFirst<DIST> epi) {
-  __shared__ double lds_all[WAVES_PER_BLOCK][BLK_NNZ + 2];
-  rb_loop<DIST, PIPE, NT>(A, x_c, lds_all[threadIdx.x >> 6], epi);
+  __shared__ double lds_all[WAVES_PER_BLOCK][LDS_SLOTS];
+  rb_loop<DIST, PIPE>(A, x_c, lds_all[threadIdx.x >> 6], epi);
 }
 
 // grid: as many workgroups as are resident at once (the waves loop over their blocks), a multiple of 8
@@ -315,8 +341,7 @@ static void check_launch(const char* what) {
 
 #define RB_LAUNCH(KERNEL, D, ...)                                                                                   \
   do {                                                                                                               \
-    if (g_nt) hipLaunchKernelGGL((KERNEL<D, true, 3, true>), dim3(resident_grid(KERNEL<D, true, 3, true>, nb)), dim3(BLOCK), 0, s, __VA_ARGS__);   \
-    else if (g_pipeline && g_occ == 3) hipLaunchKernelGGL((KERNEL<D, true, 3>), dim3(resident_grid(KERNEL<D, true, 3>, nb)), dim3(BLOCK), 0, s, __VA_ARGS__);   \
+    if (g_pipeline && g_occ == 3) hipLaunchKernelGGL((KERNEL<D, true, 3>), dim3(resident_grid(KERNEL<D, true, 3>, nb)), dim3(BLOCK), 0, s, __VA_ARGS__);   \
     else if (g_pipeline) hipLaunchKernelGGL((KERNEL<D, true, 4>), dim3(resident_grid(KERNEL<D, true, 4>, nb)), dim3(BLOCK), 0, s, __VA_ARGS__);          \
     else hipLaunchKernelGGL((KERNEL<D, false, 4>), dim3(resident_grid(KERNEL<D, false, 4>, nb)), dim3(BLOCK), 0, s, __VA_ARGS__);                        \
   } while (0)
@@ -523,7 +548,7 @@ __global__ __launch_bounds__(BLOCK) void k_block_pack(int64_t nblocks, BlkDesc* 
     for (int i = lane; i < nb; i += WAVE) {
       const unsigned long long k = keys[i];
       const int pos = (int)(k & 0xffffull);
-      oidx[p0 + i] = ((uint32_t)pos << COL_BITS) | (uint32_t)((int32_t)(k >> 16) - cmin);
+      oidx[p0 + i] = ((uint32_t)(pos + 1) << COL_BITS) | (uint32_t)((int32_t)(k >> 16) - cmin);
       oval[p0 + i] = val[p0 + pos];
     }
     if (lane == 0) blk[b].cbase = cmin;
@@ -573,7 +598,7 @@ void devmat_from_csr_device(int64_t m, int64_t n, const int64_t* d_rp, const int
   devmat_free(out);
   out.m = m; out.n = n; out.n_ghost = n_ghost;
   if (m == 0) return;
-  if (m > 0x7fffffffll || n > 0x7fffffffll) throw std::runtime_error("matrix dimension exceeds 32-bit indices");
+  if (m >= (1ll << 29) || n >= (1ll << 29)) throw std::runtime_error("matrix dimension exceeds the 2^29 rows / columns of the 32-bit byte offsets");
   int64_t *d_len = nullptr, *d_nrp = nullptr;
   HIP_CHECK(hipMalloc(&d_len, sizeof(int64_t) * (size_t)m));
   HIP_CHECK(hipMalloc(&d_nrp, sizeof(int64_t) * (size_t)(m + 1)));
