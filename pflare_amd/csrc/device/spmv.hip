@@ -51,9 +51,11 @@ __device__ __forceinline__ BlockRange my_blocks(int64_t nblocks) {
 // ---- tuning knobs (airhip_set_tuning; defaults are what bench.py measures)
 static int g_grid_wg_per_cu = 0;     // 0 = from the occupancy query
 static int g_pipeline = 1;           // 0 = no cross-block prefetch (diagnostic)
+static int g_probe = 0;              // diagnostic kernels with wrong results (see k_rb_spmv_probe)
 static int g_occ = 3;                // waves per SIMD the kernel is compiled for (3: ~140 VGPRs, 4: <= 128)
 int spmv_set_tuning(const char* key, int value) {
   if (!std::strcmp(key, "spmv_wg_per_cu")) { g_grid_wg_per_cu = value; return 0; }
+  if (!std::strcmp(key, "spmv_probe")) { g_probe = value; return 0; }
   if (!std::strcmp(key, "spmv_pipeline")) { g_pipeline = value; return 0; }
   if (!std::strcmp(key, "spmv_occupancy")) { if (value != 3 && value != 4) return -1; g_occ = value; return 0; }
   return -1;
@@ -125,8 +127,8 @@ __device__ __forceinline__ double xload(const XVec<DIST>& x, int32_t c) {
 //   Early early(r0, nr, lr)            issued with the stream of the NEXT block (loads whose result feeds another load)
 //   Pre   load(r0, nr, lr, Early)      issued at the top of the block's own iteration, before the gather is waited for
 //   void  store(r0, nr, lr, acc, Pre)  after the row sum is known; rows past the block's end are dropped
-template <bool DIST, bool PIPE, class Epi>
-__device__ __forceinline__ void rb_loop(const RbView& A, const XVec<DIST> x, double* __restrict__ lds, const Epi& epi) {
+template <bool DIST, bool PIPE, class Epi, int PROBE = 0>
+__device__ __forceinline__ void rb_loop(const RbView& A, const XVec<DIST> x, double* __restrict__ lds, const Epi& epi, double* __restrict__ xt = nullptr) {
   const int lane = threadIdx.x & (WAVE - 1);
   const BlockRange br = my_blocks(A.blk_list ? A.nlist : A.nblocks);
   if (br.first >= br.last) return;
@@ -162,7 +164,21 @@ __device__ __forceinline__ void rb_loop(const RbView& A, const XVec<DIST> x, dou
 #pragma unroll
     for (int u = 0; u < EPL; u++) {
       const int32_t c = sorted ? d.cbase + (int32_t)(ix[u] & COL_MASK) : (int32_t)ix[u];
-      xx[u] = xload(x, c);
+      if constexpr (PROBE == 0) xx[u] = xload(x, c);
+      else if constexpr (PROBE == 1) xx[u] = 1.0 + (double)(c & 1);          // no memory access at all
+    }
+    if constexpr (PROBE == 2) {
+      // speed-of-light probe of an LDS-staged gather: five wide coalesced loads of an x window into LDS (40 lines),
+      // then the gather reads LDS.  WRONG RESULTS (the window is not the block's column set).
+      const char* xb = reinterpret_cast<const char*>(x.x) + ((uint32_t)d.cbase << 3);
+#pragma unroll
+      for (int t = 0; t < 5; t++) {
+        const double2 v = *reinterpret_cast<const double2*>(xb + t * 1024 + lane * 16);
+        *reinterpret_cast<double2*>(reinterpret_cast<char*>(xt) + t * 1024 + lane * 16) = v;
+      }
+      wave_lds_sync();
+#pragma unroll
+      for (int u = 0; u < EPL; u++) xx[u] = xt[ix[u] & 511];
     }
     __builtin_amdgcn_sched_barrier(0);   // the gathers go out before the next block's stream (vmcnt is in order)
     // the next block's stream (or, at the end, the same block once more: the loads stay unconditional)
@@ -269,6 +285,15 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_rb_spmv(RbView A, XVec<DIST> x, 
   rb_loop<DIST, PIPE>(A, x, lds_all[threadIdx.x >> 6], epi);
 }
 
+// diagnostic kernels (airhip_set_tuning "spmv_probe" = 1 | 2): upper bounds for designs that take the per-element
+// global gather out of the kernel; their results are wrong by construction
+template <int PROBE>
+__global__ __launch_bounds__(BLOCK, 3) void k_rb_spmv_probe(RbView A, XVec<false> x, EpiAxpby epi) {
+  __shared__ double lds_all[WAVES_PER_BLOCK][LDS_SLOTS];
+  __shared__ double xt_all[WAVES_PER_BLOCK][5 * 128];
+  rb_loop<false, true, EpiAxpby, PROBE>(A, x, lds_all[threadIdx.x >> 6], epi, xt_all[threadIdx.x >> 6]);
+}
+
 // Fused first stage of an F-point relaxation with a one-point prolongator (see dev.hpp)
 template <bool DIST>
 struct EpiFcFirst {
@@ -362,7 +387,9 @@ void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t
     RB_LAUNCH(k_rb_spmv, true, v, xv, epi);
   } else {
     const XVec<false> xv{x, nullptr, 0};
-    RB_LAUNCH(k_rb_spmv, false, v, xv, epi);
+    if (g_probe == 1) hipLaunchKernelGGL((k_rb_spmv_probe<1>), dim3(resident_grid(k_rb_spmv_probe<1>, nb)), dim3(BLOCK), 0, s, v, xv, epi);
+    else if (g_probe == 2) hipLaunchKernelGGL((k_rb_spmv_probe<2>), dim3(resident_grid(k_rb_spmv_probe<2>, nb)), dim3(BLOCK), 0, s, v, xv, epi);
+    else RB_LAUNCH(k_rb_spmv, false, v, xv, epi);
   }
   check_launch("k_rb_spmv");
 }

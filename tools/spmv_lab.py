@@ -52,6 +52,14 @@ def run(name, A, reps=20):
 
 if __name__ == "__main__":
     nnz_m = float(sys.argv[1]) if len(sys.argv) > 1 else 64.0
+    if len(sys.argv) > 2:      # probe mode: the diagnostic kernels on a few structures
+        for probe in (0, 1, 2):
+            P.lib().airhip_set_tuning(b"spmv_probe", probe)
+            for L in (4, 16, 64, 512):
+                run(f"probe={probe} banded L={L}", csr_banded(int(nnz_m * 1e6 / L), L))
+            run(f"probe={probe} L=16 10% random far", csr_banded(int(nnz_m * 1e6 / 16), 16, jitter=0.1))
+        P.lib().airhip_set_tuning(b"spmv_probe", 0)
+        sys.exit(0)
     for L in (1, 2, 4, 8, 16, 32, 64, 128, 256, 512):
         m = int(nnz_m * 1e6 / L)
         run(f"banded L={L} (perfect locality)", csr_banded(m, L))
