@@ -18,8 +18,8 @@
 namespace airhip {
 
 // One row block: 16 bytes, read with one scalar load.  cbase >= 0: the block's entries are stored SORTED BY
-// COLUMN, every index word holds ((row-major position + 1) << 22) | (column - cbase).  cbase < 0 ("raw" block: a
-// column span of 2^22 or more, or a single row longer than 512): entries in row-major order, index word =
+// COLUMN, every index word holds ((column - cbase) * 8) << 10 | (row-major position + 1).  cbase < 0 ("raw" block: a
+// column span of 2^19 or more, or a single row longer than 512): entries in row-major order, index word =
 // absolute column.
 struct BlkDesc { int64_t p0; int32_t row; int32_t cbase; };
 

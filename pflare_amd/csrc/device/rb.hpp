@@ -10,9 +10,12 @@ constexpr int BLK_NNZ = 512;        // non-zeros per row block (a longer row is 
 constexpr int BLK_ROWS = 128;       // rows per row block: two per lane
 constexpr int EPL = BLK_NNZ / WAVE; // entries per lane
 constexpr int CHUNK_ROWS = 512;     // the block partition is greedy inside chunks of this many rows
-constexpr int COL_BITS = 22;        // block-relative column bits of an index word; the upper 10 hold the 1-based position
+// index word of a packed block: ((column - cbase) * 8) << POS_BITS | (row-major position + 1); the gather's byte offset
+// is one shift away, the staging slot one mask
+constexpr int POS_BITS = 10;
+constexpr uint32_t POS_MASK = (1u << POS_BITS) - 1u;
+constexpr int COL_BITS = 32 - POS_BITS - 3;   // 19: a packed block's columns span less than 2^19
 constexpr int LDS_SLOTS = BLK_NNZ + 2;   // products staged per wave: slot 0 is the dummy slot of padding lanes
-constexpr uint32_t COL_MASK = (1u << COL_BITS) - 1u;
 
 struct RbView {
   int64_t m, nblocks, nnz;
@@ -32,6 +35,14 @@ template <bool DIST> struct XVec {
   const double* __restrict__ x; const double* __restrict__ xg; int32_t nl;
   __device__ __forceinline__ double operator[](int32_t c) const {
     if constexpr (DIST) return c < nl ? x[c] : xg[c]; else return x[c];
+  }
+  // the same vector seen from column c0 (wave-uniform): byte offsets then count from c0
+  __device__ __forceinline__ XVec shifted(int32_t c0) const { return XVec{x + c0, xg + c0, nl - c0}; }
+  // element at a 32-bit byte offset (a multiple of 8) from the uniform base: one saddr + voffset load on a single
+  // device (operators have fewer than 2^29 columns, checked at conversion)
+  __device__ __forceinline__ double at_byte_offset(uint32_t off) const {
+    if constexpr (DIST) { const int32_t c = (int32_t)(off >> 3); return c < nl ? x[c] : xg[c]; }
+    else return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(x) + off);
   }
 };
 

@@ -52,12 +52,10 @@ __device__ __forceinline__ BlockRange my_blocks(int64_t nblocks) {
 static int g_grid_wg_per_cu = 0;     // 0 = from the occupancy query
 static int g_pipeline = 1;           // 0 = no cross-block prefetch (diagnostic)
 static int g_probe = 0;              // diagnostic kernels with wrong results (see k_rb_spmv_probe)
-static int g_occ = 3;                // waves per SIMD the kernel is compiled for (3: ~140 VGPRs, 4: <= 128)
 int spmv_set_tuning(const char* key, int value) {
   if (!std::strcmp(key, "spmv_wg_per_cu")) { g_grid_wg_per_cu = value; return 0; }
   if (!std::strcmp(key, "spmv_probe")) { g_probe = value; return 0; }
   if (!std::strcmp(key, "spmv_pipeline")) { g_pipeline = value; return 0; }
-  if (!std::strcmp(key, "spmv_occupancy")) { if (value != 3 && value != 4) return -1; g_occ = value; return 0; }
   return -1;
 }
 
@@ -115,14 +113,6 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// x[c] with a 32-bit byte offset from the uniform base (n < 2^29 columns, checked at conversion); the
-// distributed variant selects between the owned segment and the received ghost values
-template <bool DIST>
-__device__ __forceinline__ double xload(const XVec<DIST>& x, int32_t c) {
-  if constexpr (DIST) return x[c];
-  else return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(x.x) + ((uint32_t)c << 3));
-}
-
 // Epi interface (r0 = first row of the block, nr = its rows, lr = this lane's local row, may be >= nr):
 //   Early early(r0, nr, lr)            issued with the stream of the NEXT block (loads whose result feeds another load)
 //   Pre   load(r0, nr, lr, Early)      issued at the top of the block's own iteration, before the gather is waited for
@@ -161,16 +151,22 @@ __device__ __forceinline__ void rb_loop(const RbView& A, const XVec<DIST> x, dou
     }
     // gather x for the whole block
     double xx[EPL];
+    if (sorted) {
+      // packed block: the word's upper 22 bits are the byte offset of the column from the block's base column
+      const XVec<DIST> xb = x.shifted(d.cbase);
 #pragma unroll
-    for (int u = 0; u < EPL; u++) {
-      const int32_t c = sorted ? d.cbase + (int32_t)(ix[u] & COL_MASK) : (int32_t)ix[u];
-      if constexpr (PROBE == 0) xx[u] = xload(x, c);
-      else if constexpr (PROBE == 1) xx[u] = 1.0 + (double)(c & 1);          // no memory access at all
+      for (int u = 0; u < EPL; u++) {
+        if constexpr (PROBE == 0) xx[u] = xb.at_byte_offset(ix[u] >> POS_BITS);
+        else if constexpr (PROBE == 1) xx[u] = 1.0 + (double)(ix[u] & 1);          // no memory access at all
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < EPL; u++) xx[u] = x.at_byte_offset(ix[u] << 3);           // raw block: absolute columns
     }
     if constexpr (PROBE == 2) {
       // speed-of-light probe of an LDS-staged gather: five wide coalesced loads of an x window into LDS (40 lines),
       // then the gather reads LDS.  WRONG RESULTS (the window is not the block's column set).
-      const char* xb = reinterpret_cast<const char*>(x.x) + ((uint32_t)d.cbase << 3);
+      const char* xb = reinterpret_cast<const char*>(x.x) + ((uint32_t)(d.cbase < 0 ? 0 : d.cbase) << 3);
 #pragma unroll
       for (int t = 0; t < 5; t++) {
         const double2 v = *reinterpret_cast<const double2*>(xb + t * 1024 + lane * 16);
@@ -178,7 +174,7 @@ __device__ __forceinline__ void rb_loop(const RbView& A, const XVec<DIST> x, dou
       }
       wave_lds_sync();
 #pragma unroll
-      for (int u = 0; u < EPL; u++) xx[u] = xt[ix[u] & 511];
+      for (int u = 0; u < EPL; u++) xx[u] = xt[(ix[u] >> (POS_BITS + 3)) & 511];
     }
     __builtin_amdgcn_sched_barrier(0);   // the gathers go out before the next block's stream (vmcnt is in order)
     // the next block's stream (or, at the end, the same block once more: the loads stay unconditional)
@@ -192,11 +188,12 @@ __device__ __forceinline__ void rb_loop(const RbView& A, const XVec<DIST> x, dou
     __builtin_amdgcn_sched_barrier(0);
     if (nb <= BLK_NNZ) {
       // phase 1: products to their row-major positions (1-based; position 0 is the dummy slot of padding lanes)
+      if (sorted) {
 #pragma unroll
-      for (int u = 0; u < EPL; u++) {
-        const int k = lane + u * WAVE;
-        const int pos = sorted ? (int)(ix[u] >> COL_BITS) : (k < nb ? k + 1 : 0);
-        lds[pos] = vv[u] * xx[u];
+        for (int u = 0; u < EPL; u++) lds[ix[u] & POS_MASK] = vv[u] * xx[u];
+      } else {
+#pragma unroll
+        for (int u = 0; u < EPL; u++) { const int k = lane + u * WAVE; lds[k < nb ? k + 1 : 0] = vv[u] * xx[u]; }
       }
       wave_lds_sync();
       if (nr > 32) {
@@ -222,18 +219,24 @@ __device__ __forceinline__ void rb_loop(const RbView& A, const XVec<DIST> x, dou
       }
       __builtin_amdgcn_wave_barrier();   // LDS is reused by the next block of this wave
     } else {
-      // one long row: the whole wave reduces it, four independent chains per lane
+      // one long row: the whole wave reduces it.  The first 512 entries are already in registers (stream and
+      // gather above); the rest is read with four independent chains per lane
       const uint32_t* __restrict__ ip = A.idx + d.p0;
       const double* __restrict__ vp = A.val + d.p0;
       double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-      int j = lane;
+#pragma unroll
+      for (int u = 0; u < EPL; u += 4) {
+        s0 = fma(vv[u], xx[u], s0); s1 = fma(vv[u + 1], xx[u + 1], s1);
+        s2 = fma(vv[u + 2], xx[u + 2], s2); s3 = fma(vv[u + 3], xx[u + 3], s3);
+      }
+      int j = BLK_NNZ + lane;
       for (; j + 3 * WAVE < nb; j += 4 * WAVE) {
         const int32_t c0 = (int32_t)ip[j], c1 = (int32_t)ip[j + WAVE], c2 = (int32_t)ip[j + 2 * WAVE], c3 = (int32_t)ip[j + 3 * WAVE];
         const double v0 = vp[j], v1 = vp[j + WAVE], v2 = vp[j + 2 * WAVE], v3 = vp[j + 3 * WAVE];
-        const double x0 = xload(x, c0), x1 = xload(x, c1), x2 = xload(x, c2), x3 = xload(x, c3);
+        const double x0 = x.at_byte_offset((uint32_t)c0 << 3), x1 = x.at_byte_offset((uint32_t)c1 << 3), x2 = x.at_byte_offset((uint32_t)c2 << 3), x3 = x.at_byte_offset((uint32_t)c3 << 3);
         s0 = fma(v0, x0, s0); s1 = fma(v1, x1, s1); s2 = fma(v2, x2, s2); s3 = fma(v3, x3, s3);
       }
-      for (; j < nb; j += WAVE) s0 = fma(vp[j], xload(x, (int32_t)ip[j]), s0);
+      for (; j < nb; j += WAVE) s0 = fma(vp[j], x.at_byte_offset(ip[j] << 3), s0);
       double s = (s0 + s1) + (s2 + s3);
       for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
       epi.store(d.r0, nr, lane, s, pre[0]);      // nr = 1: only lane 0 is inside the block
@@ -254,6 +257,10 @@ __device__ __forceinline__ void rb_loop(const RbView& A, const XVec<DIST> x, dou
 }
 
 // out_i = alpha * s_i [* dscale_i] + beta * z_i + gamma * w_i ;  y2_i += delta * (aux_out ? out_i : w2_i)
+// Which of z / w / dscale / y2 are present is a compile-time mask (EPI_Z ...): the common smoothing and residual
+// products carry one or no extra vector and must not pay registers and branches for the polynomial applies' fields.
+constexpr int EPI_Z = 1, EPI_W = 2, EPI_D = 4, EPI_Y = 8;
+template <int F>
 struct EpiAxpby {
   SpmvEpi e;
   struct Early {};
@@ -262,25 +269,25 @@ struct EpiAxpby {
   __device__ __forceinline__ Pre load(int32_t r0, int nr, int lr, Early) const {
     Pre p; p.z = 0.0; p.w = 0.0; p.d = 1.0; p.y2 = 0.0; p.w2 = 0.0;
     const int64_t ext = (int64_t)nr * 8;
-    if (e.z) p.z = buf_f64(make_rsrc(e.z + r0, ext), lr * 8);
-    if (e.w) p.w = buf_f64(make_rsrc(e.w + r0, ext), lr * 8);
-    if (e.dscale) p.d = buf_f64(make_rsrc(e.dscale + r0, ext), lr * 8);
-    if (e.y2) { p.y2 = buf_f64(make_rsrc(e.y2 + r0, ext), lr * 8); if (!e.aux_out) p.w2 = buf_f64(make_rsrc(e.w2 + r0, ext), lr * 8); }
+    if constexpr ((F & EPI_Z) != 0) p.z = buf_f64(make_rsrc(e.z + r0, ext), lr * 8);
+    if constexpr ((F & EPI_W) != 0) p.w = buf_f64(make_rsrc(e.w + r0, ext), lr * 8);
+    if constexpr ((F & EPI_D) != 0) p.d = buf_f64(make_rsrc(e.dscale + r0, ext), lr * 8);
+    if constexpr ((F & EPI_Y) != 0) { p.y2 = buf_f64(make_rsrc(e.y2 + r0, ext), lr * 8); if (!e.aux_out) p.w2 = buf_f64(make_rsrc(e.w2 + r0, ext), lr * 8); }
     return p;
   }
   __device__ __forceinline__ void store(int32_t r0, int nr, int lr, double acc, const Pre& p) const {
-    if (e.dscale) acc *= p.d;
+    if constexpr ((F & EPI_D) != 0) acc *= p.d;
     double o = e.alpha * acc;
-    if (e.z) o += e.beta * p.z;
-    if (e.w) o += e.gamma * p.w;
+    if constexpr ((F & EPI_Z) != 0) o += e.beta * p.z;
+    if constexpr ((F & EPI_W) != 0) o += e.gamma * p.w;
     const int64_t ext = (int64_t)nr * 8;
     buf_store_f64(make_rsrc(e.out + r0, ext), lr * 8, o);
-    if (e.y2) buf_store_f64(make_rsrc(e.y2 + r0, ext), lr * 8, p.y2 + e.delta * (e.aux_out ? o : p.w2));
+    if constexpr ((F & EPI_Y) != 0) buf_store_f64(make_rsrc(e.y2 + r0, ext), lr * 8, p.y2 + e.delta * (e.aux_out ? o : p.w2));
   }
 };
 
-template <bool DIST, bool PIPE, int OCC>
-__global__ __launch_bounds__(BLOCK, OCC) void k_rb_spmv(RbView A, XVec<DIST> x, EpiAxpby epi) {
+template <bool DIST, bool PIPE, int F>
+__global__ __launch_bounds__(BLOCK) void k_rb_spmv(RbView A, XVec<DIST> x, EpiAxpby<F> epi) {
   __shared__ double lds_all[WAVES_PER_BLOCK][LDS_SLOTS];
   rb_loop<DIST, PIPE>(A, x, lds_all[threadIdx.x >> 6], epi);
 }
@@ -288,10 +295,10 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_rb_spmv(RbView A, XVec<DIST> x, 
 // diagnostic kernels (airhip_set_tuning "spmv_probe" = 1 | 2): upper bounds for designs that take the per-element
 // global gather out of the kernel; their results are wrong by construction
 template <int PROBE>
-__global__ __launch_bounds__(BLOCK, 3) void k_rb_spmv_probe(RbView A, XVec<false> x, EpiAxpby epi) {
+__global__ __launch_bounds__(BLOCK) void k_rb_spmv_probe(RbView A, XVec<false> x, EpiAxpby<0> epi) {
   __shared__ double lds_all[WAVES_PER_BLOCK][LDS_SLOTS];
   __shared__ double xt_all[WAVES_PER_BLOCK][5 * 128];
-  rb_loop<false, true, EpiAxpby, PROBE>(A, x, lds_all[threadIdx.x >> 6], epi, xt_all[threadIdx.x >> 6]);
+  rb_loop<false, true, EpiAxpby<0>, PROBE>(A, x, lds_all[threadIdx.x >> 6], epi, xt_all[threadIdx.x >> 6]);
 }
 
 // Fused first stage of an F-point relaxation with a one-point prolongator (see dev.hpp)
@@ -310,7 +317,7 @@ struct EpiFcFirst {
     Pre p;
     const int64_t ext = (int64_t)nr * 8;
     p.b = buf_f64(make_rsrc(b_f + r0, ext), lr * 8);
-    p.x0 = xload(x_c, ea.wc >= 0 ? ea.wc : 0);
+    p.x0 = x_c.at_byte_offset((uint32_t)(ea.wc >= 0 ? ea.wc : 0) << 3);
     if (ea.wc < 0) p.x0 = 0.0;
     p.ad = 0.0; p.mi = 0.0;
     if (aff_d) { p.ad = buf_f64(make_rsrc(aff_d + r0, ext), lr * 8); p.mi = buf_f64(make_rsrc(minv + r0, ext), lr * 8); }
@@ -331,8 +338,8 @@ struct EpiFcFirst {
   }
 };
 
-template <bool DIST, bool PIPE, int OCC>
-__global__ __launch_bounds__(BLOCK, OCC) void k_rb_fc_first(RbView A, XVec<DIST> x_c, EpiFcFirst<DIST> epi) {
+template <bool DIST, bool PIPE>
+__global__ __launch_bounds__(BLOCK) void k_rb_fc_first(RbView A, XVec<DIST> x_c, EpiFcFirst<DIST> epi) {
   __shared__ double lds_all[WAVES_PER_BLOCK][LDS_SLOTS];
   rb_loop<DIST, PIPE>(A, x_c, lds_all[threadIdx.x >> 6], epi);
 }
@@ -364,12 +371,21 @@ static void check_launch(const char* what) {
   if (e != hipSuccess) throw std::runtime_error(std::string("HIP error ") + hipGetErrorString(e) + " launching " + what);
 }
 
-#define RB_LAUNCH(KERNEL, D, ...)                                                                                   \
-  do {                                                                                                               \
-    if (g_pipeline && g_occ == 3) hipLaunchKernelGGL((KERNEL<D, true, 3>), dim3(resident_grid(KERNEL<D, true, 3>, nb)), dim3(BLOCK), 0, s, __VA_ARGS__);   \
-    else if (g_pipeline) hipLaunchKernelGGL((KERNEL<D, true, 4>), dim3(resident_grid(KERNEL<D, true, 4>, nb)), dim3(BLOCK), 0, s, __VA_ARGS__);          \
-    else hipLaunchKernelGGL((KERNEL<D, false, 4>), dim3(resident_grid(KERNEL<D, false, 4>, nb)), dim3(BLOCK), 0, s, __VA_ARGS__);                        \
-  } while (0)
+template <bool DIST, int F>
+static void launch_spmv_f(const RbView& v, const XVec<DIST>& xv, const SpmvEpi& e, int64_t nb, hipStream_t s) {
+  const EpiAxpby<F> epi{e};
+  if (g_pipeline) hipLaunchKernelGGL((k_rb_spmv<DIST, true, F>), dim3(resident_grid(k_rb_spmv<DIST, true, F>, nb)), dim3(BLOCK), 0, s, v, xv, epi);
+  else hipLaunchKernelGGL((k_rb_spmv<DIST, false, F>), dim3(resident_grid(k_rb_spmv<DIST, false, F>, nb)), dim3(BLOCK), 0, s, v, xv, epi);
+}
+template <bool DIST>
+static void launch_spmv_d(const RbView& v, const XVec<DIST>& xv, const SpmvEpi& e, int64_t nb, hipStream_t s) {
+  const int f = (e.z ? EPI_Z : 0) | (e.w ? EPI_W : 0) | (e.dscale ? EPI_D : 0) | (e.y2 ? EPI_Y : 0);
+  switch (f) {
+#define C(F) case F: launch_spmv_f<DIST, F>(v, xv, e, nb, s); break;
+    C(0) C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15)
+#undef C
+  }
+}
 
 void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t s, const double* x_ghost,
                  const int32_t* blk_list, int64_t nlist) {
@@ -377,21 +393,26 @@ void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t
   RbView v = view_of(A);
   v.blk_list = blk_list; v.nlist = nlist;
   const int64_t nb = blk_list ? nlist : A.nblocks;
-  const EpiAxpby epi{e};
   if (A.n == 0) x = A.val;     // no columns: blocks of empty rows still read element 0 of "x"
   if (A.n_ghost > 0) {
     // distributed operand: ghost columns start at A.n - A.n_ghost
     if (!x_ghost) throw std::runtime_error("launch_spmv: distributed operand without ghost values");
     const int32_t nl = (int32_t)(A.n - A.n_ghost);
-    const XVec<true> xv{x, x_ghost - nl, nl};
-    RB_LAUNCH(k_rb_spmv, true, v, xv, epi);
+    launch_spmv_d<true>(v, XVec<true>{x, x_ghost - nl, nl}, e, nb, s);
   } else {
     const XVec<false> xv{x, nullptr, 0};
-    if (g_probe == 1) hipLaunchKernelGGL((k_rb_spmv_probe<1>), dim3(resident_grid(k_rb_spmv_probe<1>, nb)), dim3(BLOCK), 0, s, v, xv, epi);
-    else if (g_probe == 2) hipLaunchKernelGGL((k_rb_spmv_probe<2>), dim3(resident_grid(k_rb_spmv_probe<2>, nb)), dim3(BLOCK), 0, s, v, xv, epi);
-    else RB_LAUNCH(k_rb_spmv, false, v, xv, epi);
+    const EpiAxpby<0> e0{e};
+    if (g_probe == 1) hipLaunchKernelGGL((k_rb_spmv_probe<1>), dim3(resident_grid(k_rb_spmv_probe<1>, nb)), dim3(BLOCK), 0, s, v, xv, e0);
+    else if (g_probe == 2) hipLaunchKernelGGL((k_rb_spmv_probe<2>), dim3(resident_grid(k_rb_spmv_probe<2>, nb)), dim3(BLOCK), 0, s, v, xv, e0);
+    else launch_spmv_d<false>(v, xv, e, nb, s);
   }
   check_launch("k_rb_spmv");
+}
+
+template <bool DIST>
+static void launch_fc_first_d(const RbView& v, const XVec<DIST>& xv, const EpiFcFirst<DIST>& epi, int64_t nb, hipStream_t s) {
+  if (g_pipeline) hipLaunchKernelGGL((k_rb_fc_first<DIST, true>), dim3(resident_grid(k_rb_fc_first<DIST, true>, nb)), dim3(BLOCK), 0, s, v, xv, epi);
+  else hipLaunchKernelGGL((k_rb_fc_first<DIST, false>), dim3(resident_grid(k_rb_fc_first<DIST, false>, nb)), dim3(BLOCK), 0, s, v, xv, epi);
 }
 
 void launch_fc_first(const DevMat& A_fc, const int32_t* wcol, const double* b_f, const double* x_c,
@@ -406,16 +427,14 @@ void launch_fc_first(const DevMat& A_fc, const int32_t* wcol, const double* b_f,
     if (!x_ghost) throw std::runtime_error("launch_fc_first: distributed operand without ghost values");
     const int32_t nl = (int32_t)(A_fc.n - A_fc.n_ghost);
     const XVec<true> xv{x_c, x_ghost - nl, nl};
-    const EpiFcFirst<true> epi{wcol, b_f, xv, aff_d, minv, t4_out, x_f};
-    RB_LAUNCH(k_rb_fc_first, true, v, xv, epi);
+    launch_fc_first_d<true>(v, xv, EpiFcFirst<true>{wcol, b_f, xv, aff_d, minv, t4_out, x_f}, nb, s);
   } else {
     const XVec<false> xv{x_c, nullptr, 0};
-    const EpiFcFirst<false> epi{wcol, b_f, xv, aff_d, minv, t4_out, x_f};
-    RB_LAUNCH(k_rb_fc_first, false, v, xv, epi);
+    launch_fc_first_d<false>(v, xv, EpiFcFirst<false>{wcol, b_f, xv, aff_d, minv, t4_out, x_f}, nb, s);
   }
   check_launch("k_rb_fc_first");
 }
-#undef RB_LAUNCH
+
 
 // ---------------------------------------------------------------------------------------
 // CSR (device, any row order) -> row-block CSR (setup time)
@@ -575,7 +594,7 @@ __global__ __launch_bounds__(BLOCK) void k_block_pack(int64_t nblocks, BlkDesc* 
     for (int i = lane; i < nb; i += WAVE) {
       const unsigned long long k = keys[i];
       const int pos = (int)(k & 0xffffull);
-      oidx[p0 + i] = ((uint32_t)(pos + 1) << COL_BITS) | (uint32_t)((int32_t)(k >> 16) - cmin);
+      oidx[p0 + i] = ((uint32_t)((int32_t)(k >> 16) - cmin) << (POS_BITS + 3)) | (uint32_t)(pos + 1);
       oval[p0 + i] = val[p0 + pos];
     }
     if (lane == 0) blk[b].cbase = cmin;
@@ -593,7 +612,7 @@ __global__ __launch_bounds__(BLOCK) void k_boundary_flags(int64_t nblocks, const
     const int32_t cbase = blk[b].cbase;
     bool any = false;
     for (int64_t k = blk[b].p0 + lane; k < blk[b + 1].p0; k += WAVE) {
-      const int32_t c = cbase >= 0 ? cbase + (int32_t)(idx[k] & COL_MASK) : (int32_t)idx[k];
+      const int32_t c = cbase >= 0 ? cbase + (int32_t)(idx[k] >> (POS_BITS + 3)) : (int32_t)idx[k];
       any |= c >= n_local;
     }
     if (__any(any) && lane == 0) flag[b] = 1;
