@@ -298,7 +298,7 @@ def main():
                   file=sys.stderr, flush=True)
             # back to the defaults before the next variant
             for k_ in kv:
-                P.lib().airhip_set_tuning(k_.encode(), {"spmv_pipeline": 1, "spmv_wg_per_cu": 0}.get(k_, 0))
+                P.lib().airhip_set_tuning(k_.encode(), 0)
     run_iterations(args.warmup)
     if args.profile_kernels:
         pc.profile(True)

@@ -8,13 +8,20 @@
 //     longer than that is a block of its own.  Inside a block the (column, value) pairs are stored SORTED
 //     BY COLUMN (neighbouring lanes then gather neighbouring x entries: the gather is bound by distinct
 //     cache lines per wave instruction, profiles/r01_spmv_experiments.md) and the 32-bit index word is
-//     (row-major position << 23) | (column - cbase) with a per-block column base: 12 B per non-zero for
-//     every operator width.  Blocks whose columns span 2^23 or more stay row-major with absolute columns;
-//   * one WAVE owns one block at a time and software-pipelines over its blocks: while the x gather of
-//     block b is in flight the (index, value) stream of block b+1 is already being loaded into registers,
-//     and the block descriptors are fetched two blocks ahead.  Round 1 measured one block every ~7 us per
-//     wave = seven dependent memory round trips (descriptor, indices, gather, row offsets, epilogue
-//     vectors ...) with SQ_WAIT_ANY at 82 %; here a block costs one gather round trip;
+//     ((column - cbase) * 8) << 10 | (row-major position + 1) with a per-block column base: 12 B per non-zero
+//     for every operator width, the gather's byte offset one shift and the staging slot one mask away.  Blocks
+//     whose columns span 2^19 or more stay row-major with absolute columns;
+//   * one WAVE owns exactly one block: the grid has as many waves as the matrix has blocks, and the hardware
+//     dispatches workgroups in order, so the waves resident on an XCD at any moment cover one contiguous window
+//     of rows - the matrix stream is read front to back and the x lines a window gathers stay in that XCD's L2.
+//     (Measured at 256^3: a resident-size grid whose waves loop over their blocks, with or without a software
+//     prefetch of the next block's stream, 3.9 TB/s; one block per wave 4.25 TB/s - the looping waves drift
+//     apart and the window dissolves.)  Round 1 measured one block every ~7 us per wave = seven dependent memory
+//     round trips with SQ_WAIT_ANY at 82 %; here the descriptor is a scalar load, every vector the block needs
+//     (index words, values, row offsets, epilogue inputs) is requested before the first wait, and the gather is
+//     the only second round trip;
+//   * every per-block array is read through a buffer resource with the block's extent: the hardware range check
+//     returns 0 past the end (and drops stores), which replaces clamps, exec-mask branches and 64-bit addresses;
 //   * phase 1: products to LDS at their row-major positions (4 KB per wave); phase 2: lane l sums the LDS
 //     segment of rows r0+l and r0+l+64 in column order (the summation order of a sequential CSR loop), or
 //     T lanes share a row when the block holds <= 32 rows; the epilogue vectors are loaded before the
@@ -33,31 +40,20 @@
 
 namespace airhip {
 
-struct BlockRange { int64_t first, last, stride; };
-
-// XCD-aware, grid-strided assignment of row blocks to waves (gridDim.x is a multiple of 8).
-__device__ __forceinline__ BlockRange my_blocks(int64_t nblocks) {
+// XCD-aware assignment of row blocks to waves (gridDim.x is a multiple of 8): workgroup w of residue class
+// g = blockIdx & 7 (one XCD under round-robin dispatch; a speed assumption only) takes four consecutive blocks
+// of the g-th eighth of the matrix.  Returns -1 when the wave has no block.
+__device__ __forceinline__ int64_t my_block(int64_t nblocks) {
   const int g = blockIdx.x & 7;
-  const int bi = blockIdx.x >> 3;
+  const int64_t bi = blockIdx.x >> 3;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  BlockRange r;
-  const int64_t lo = nblocks * g / 8;
-  r.last = nblocks * (g + 1) / 8;
-  r.stride = (int64_t)(gridDim.x >> 3) * WAVES_PER_BLOCK;
-  r.first = lo + (int64_t)bi * WAVES_PER_BLOCK + wid;
-  return r;
+  const int64_t lo = nblocks * g / 8, hi = nblocks * (g + 1) / 8;
+  const int64_t b = lo + bi * WAVES_PER_BLOCK + wid;
+  return b < hi ? b : -1;
 }
 
-// ---- tuning knobs (airhip_set_tuning; defaults are what bench.py measures)
-static int g_grid_wg_per_cu = 0;     // 0 = from the occupancy query
-static int g_pipeline = 1;           // 0 = no cross-block prefetch (diagnostic)
-static int g_probe = 0;              // diagnostic kernels with wrong results (see k_rb_spmv_probe)
-int spmv_set_tuning(const char* key, int value) {
-  if (!std::strcmp(key, "spmv_wg_per_cu")) { g_grid_wg_per_cu = value; return 0; }
-  if (!std::strcmp(key, "spmv_probe")) { g_probe = value; return 0; }
-  if (!std::strcmp(key, "spmv_pipeline")) { g_pipeline = value; return 0; }
-  return -1;
-}
+// ---- tuning knobs (airhip_set_tuning): none at present; the hook stays for experiments
+int spmv_set_tuning(const char*, int) { return -1; }
 
 struct BlkInfo { int64_t p0; int32_t r0, cbase, nb, nr; };
 
@@ -114,145 +110,99 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 // Epi interface (r0 = first row of the block, nr = its rows, lr = this lane's local row, may be >= nr):
-//   Early early(r0, nr, lr)            issued with the stream of the NEXT block (loads whose result feeds another load)
-//   Pre   load(r0, nr, lr, Early)      issued at the top of the block's own iteration, before the gather is waited for
+//   Early early(r0, nr, lr)            loads whose result feeds another load (issued with the stream)
+//   Pre   load(r0, nr, lr, Early)      the epilogue's inputs, issued before the gather is waited for
 //   void  store(r0, nr, lr, acc, Pre)  after the row sum is known; rows past the block's end are dropped
-template <bool DIST, bool PIPE, class Epi, int PROBE = 0>
-__device__ __forceinline__ void rb_loop(const RbView& A, const XVec<DIST> x, double* __restrict__ lds, const Epi& epi, double* __restrict__ xt = nullptr) {
+template <bool DIST, class Epi>
+__device__ __forceinline__ void rb_block(const RbView& A, const XVec<DIST> x, double* __restrict__ lds, const Epi& epi) {
   const int lane = threadIdx.x & (WAVE - 1);
-  const BlockRange br = my_blocks(A.blk_list ? A.nlist : A.nblocks);
-  if (br.first >= br.last) return;
-  int64_t bi = br.first;
-  BlkInfo d = load_blk(A, bi);
-  BlkInfo dn = load_blk(A, bi + br.stride < br.last ? bi + br.stride : bi);
+  const int64_t bi = my_block(A.blk_list ? A.nlist : A.nblocks);
+  if (bi < 0) return;
+  const BlkInfo d = load_blk(A, bi);
+  const int nb = d.nb, nr = d.nr;
+  const bool sorted = d.cbase >= 0;
   uint32_t ix[EPL]; double vv[EPL];
-  typename Epi::Early early[2];
   issue_stream(A, d, lane, ix, vv);
+  // row offsets and epilogue inputs of this lane's (at most two) rows
+  typename Epi::Early early[2];
+  int ra[2], re[2];
+  typename Epi::Pre pre[2];
+  const rsrc_t rr = make_rsrc(A.roff + d.r0, (int64_t)nr * 2);
 #pragma unroll
-  for (int q = 0; q < 2; q++) early[q] = epi.early(d.r0, d.nr, lane + q * WAVE);
-  for (;;) {
-    // descriptors two blocks ahead (scalar loads)
-    const int64_t b2 = bi + 2 * br.stride;
-    const BlkInfo dnn = load_blk(A, b2 < br.last ? b2 : bi);
-    const bool more = bi + br.stride < br.last;
-    const int nb = d.nb, nr = d.nr;
-    const bool sorted = d.cbase >= 0;
-    // row offsets and epilogue inputs of this lane's (at most two) rows
-    int ra[2], re[2];
-    typename Epi::Pre pre[2];
-    const rsrc_t rr = make_rsrc(A.roff + d.r0, (int64_t)nr * 2);
+  for (int q = 0; q < 2; q++) early[q] = epi.early(d.r0, nr, lane + q * WAVE);
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
-      const int r = lane + q * WAVE;
-      ra[q] = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rr, r * 2, 0, 0);
-      const int rnext = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rr, r * 2 + 2, 0, 0);
-      re[q] = (r + 1 < nr) ? rnext : (r < nr ? nb : 0);       // no row: ra = re = 0, nothing to sum
-      pre[q] = epi.load(d.r0, nr, r, early[q]);
-    }
-    // gather x for the whole block
-    double xx[EPL];
+  for (int q = 0; q < 2; q++) {
+    const int r = lane + q * WAVE;
+    ra[q] = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rr, r * 2, 0, 0);
+    const int rnext = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rr, r * 2 + 2, 0, 0);
+    re[q] = (r + 1 < nr) ? rnext : (r < nr ? nb : 0);       // no row: ra = re = 0, nothing to sum
+  }
+  // gather x for the whole block
+  double xx[EPL];
+  if (sorted) {
+    // packed block: the word's upper 22 bits are the byte offset of the column from the block's base column
+    const XVec<DIST> xb = x.shifted(d.cbase);
+#pragma unroll
+    for (int u = 0; u < EPL; u++) xx[u] = xb.at_byte_offset(ix[u] >> POS_BITS);
+  } else {
+#pragma unroll
+    for (int u = 0; u < EPL; u++) xx[u] = x.at_byte_offset(ix[u] << 3);           // raw block: absolute columns
+  }
+#pragma unroll
+  for (int q = 0; q < 2; q++) pre[q] = epi.load(d.r0, nr, lane + q * WAVE, early[q]);
+  if (nb <= BLK_NNZ) {
+    // phase 1: products to their row-major positions (1-based; position 0 is the dummy slot of padding lanes)
     if (sorted) {
-      // packed block: the word's upper 22 bits are the byte offset of the column from the block's base column
-      const XVec<DIST> xb = x.shifted(d.cbase);
 #pragma unroll
-      for (int u = 0; u < EPL; u++) {
-        if constexpr (PROBE == 0) xx[u] = xb.at_byte_offset(ix[u] >> POS_BITS);
-        else if constexpr (PROBE == 1) xx[u] = 1.0 + (double)(ix[u] & 1);          // no memory access at all
-      }
+      for (int u = 0; u < EPL; u++) lds[ix[u] & POS_MASK] = vv[u] * xx[u];
     } else {
 #pragma unroll
-      for (int u = 0; u < EPL; u++) xx[u] = x.at_byte_offset(ix[u] << 3);           // raw block: absolute columns
+      for (int u = 0; u < EPL; u++) { const int k = lane + u * WAVE; lds[k < nb ? k + 1 : 0] = vv[u] * xx[u]; }
     }
-    if constexpr (PROBE == 2) {
-      // speed-of-light probe of an LDS-staged gather: five wide coalesced loads of an x window into LDS (40 lines),
-      // then the gather reads LDS.  WRONG RESULTS (the window is not the block's column set).
-      const char* xb = reinterpret_cast<const char*>(x.x) + ((uint32_t)(d.cbase < 0 ? 0 : d.cbase) << 3);
+    wave_lds_sync();
+    if (nr > 32) {
+      // phase 2: one lane per row, column order
 #pragma unroll
-      for (int t = 0; t < 5; t++) {
-        const double2 v = *reinterpret_cast<const double2*>(xb + t * 1024 + lane * 16);
-        *reinterpret_cast<double2*>(reinterpret_cast<char*>(xt) + t * 1024 + lane * 16) = v;
-      }
-      wave_lds_sync();
-#pragma unroll
-      for (int u = 0; u < EPL; u++) xx[u] = xt[(ix[u] >> (POS_BITS + 3)) & 511];
-    }
-    __builtin_amdgcn_sched_barrier(0);   // the gathers go out before the next block's stream (vmcnt is in order)
-    // the next block's stream (or, at the end, the same block once more: the loads stay unconditional)
-    uint32_t nix[EPL]; double nvv[EPL];
-    typename Epi::Early nearly[2];
-    if constexpr (PIPE) {
-      issue_stream(A, dn, lane, nix, nvv);
-#pragma unroll
-      for (int q = 0; q < 2; q++) nearly[q] = epi.early(dn.r0, dn.nr, lane + q * WAVE);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (nb <= BLK_NNZ) {
-      // phase 1: products to their row-major positions (1-based; position 0 is the dummy slot of padding lanes)
-      if (sorted) {
-#pragma unroll
-        for (int u = 0; u < EPL; u++) lds[ix[u] & POS_MASK] = vv[u] * xx[u];
-      } else {
-#pragma unroll
-        for (int u = 0; u < EPL; u++) { const int k = lane + u * WAVE; lds[k < nb ? k + 1 : 0] = vv[u] * xx[u]; }
-      }
-      wave_lds_sync();
-      if (nr > 32) {
-        // phase 2: one lane per row, column order
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-          double s = 0.0;
-          for (int j = ra[q]; j < re[q]; j++) s += lds[j + 1];
-          epi.store(d.r0, nr, lane + q * WAVE, s, pre[q]);
-        }
-      } else {
-        // phase 2 for few (longer) rows: T = 64 / 2^ceil(log2 nr) lanes share a row
-        int sh = 6;
-        while ((WAVE >> sh) < nr) { sh--; }       // 2^(6-sh) >= nr groups
-        const int T = 1 << sh;
-        const int g = lane >> sh, t = lane & (T - 1);
-        const int a = __shfl(ra[0], g, WAVE), e = __shfl(re[0], g, WAVE);
+      for (int q = 0; q < 2; q++) {
         double s = 0.0;
-        for (int j = a + t; j < e; j += T) s += lds[j + 1];
-        for (int off = T >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
-        const double srow = __shfl(s, (lane << sh) & (WAVE - 1), WAVE);   // row `lane` lives in lanes lane*T ..
-        epi.store(d.r0, nr, lane, srow, pre[0]);
+        for (int j = ra[q]; j < re[q]; j++) s += lds[j + 1];
+        epi.store(d.r0, nr, lane + q * WAVE, s, pre[q]);
       }
-      __builtin_amdgcn_wave_barrier();   // LDS is reused by the next block of this wave
     } else {
-      // one long row: the whole wave reduces it.  The first 512 entries are already in registers (stream and
-      // gather above); the rest is read with four independent chains per lane
-      const uint32_t* __restrict__ ip = A.idx + d.p0;
-      const double* __restrict__ vp = A.val + d.p0;
-      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-      for (int u = 0; u < EPL; u += 4) {
-        s0 = fma(vv[u], xx[u], s0); s1 = fma(vv[u + 1], xx[u + 1], s1);
-        s2 = fma(vv[u + 2], xx[u + 2], s2); s3 = fma(vv[u + 3], xx[u + 3], s3);
-      }
-      int j = BLK_NNZ + lane;
-      for (; j + 3 * WAVE < nb; j += 4 * WAVE) {
-        const int32_t c0 = (int32_t)ip[j], c1 = (int32_t)ip[j + WAVE], c2 = (int32_t)ip[j + 2 * WAVE], c3 = (int32_t)ip[j + 3 * WAVE];
-        const double v0 = vp[j], v1 = vp[j + WAVE], v2 = vp[j + 2 * WAVE], v3 = vp[j + 3 * WAVE];
-        const double x0 = x.at_byte_offset((uint32_t)c0 << 3), x1 = x.at_byte_offset((uint32_t)c1 << 3), x2 = x.at_byte_offset((uint32_t)c2 << 3), x3 = x.at_byte_offset((uint32_t)c3 << 3);
-        s0 = fma(v0, x0, s0); s1 = fma(v1, x1, s1); s2 = fma(v2, x2, s2); s3 = fma(v3, x3, s3);
-      }
-      for (; j < nb; j += WAVE) s0 = fma(vp[j], x.at_byte_offset(ip[j] << 3), s0);
-      double s = (s0 + s1) + (s2 + s3);
-      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
-      epi.store(d.r0, nr, lane, s, pre[0]);      // nr = 1: only lane 0 is inside the block
+      // phase 2 for few (longer) rows: T = 64 / 2^ceil(log2 nr) lanes share a row
+      int sh = 6;
+      while ((WAVE >> sh) < nr) { sh--; }       // 2^(6-sh) >= nr groups
+      const int T = 1 << sh;
+      const int g = lane >> sh, t = lane & (T - 1);
+      const int a = __shfl(ra[0], g, WAVE), e = __shfl(re[0], g, WAVE);
+      double s = 0.0;
+      for (int j = a + t; j < e; j += T) s += lds[j + 1];
+      for (int off = T >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
+      const double srow = __shfl(s, (lane << sh) & (WAVE - 1), WAVE);   // row `lane` lives in lanes lane*T ..
+      epi.store(d.r0, nr, lane, srow, pre[0]);
     }
-    if (!more) break;
-    bi += br.stride;
-    d = dn; dn = dnn;
-    if constexpr (PIPE) {
+  } else {
+    // one long row: the whole wave reduces it.  The first 512 entries are already in registers (stream and
+    // gather above); the rest is read with four independent chains per lane
+    const uint32_t* __restrict__ ip = A.idx + d.p0;
+    const double* __restrict__ vp = A.val + d.p0;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
-      for (int u = 0; u < EPL; u++) { ix[u] = nix[u]; vv[u] = nvv[u]; }
-      early[0] = nearly[0]; early[1] = nearly[1];
-    } else {
-      issue_stream(A, d, lane, ix, vv);
-#pragma unroll
-      for (int q = 0; q < 2; q++) early[q] = epi.early(d.r0, d.nr, lane + q * WAVE);
+    for (int u = 0; u < EPL; u += 4) {
+      s0 = fma(vv[u], xx[u], s0); s1 = fma(vv[u + 1], xx[u + 1], s1);
+      s2 = fma(vv[u + 2], xx[u + 2], s2); s3 = fma(vv[u + 3], xx[u + 3], s3);
     }
+    int j = BLK_NNZ + lane;
+    for (; j + 3 * WAVE < nb; j += 4 * WAVE) {
+      const uint32_t c0 = ip[j], c1 = ip[j + WAVE], c2 = ip[j + 2 * WAVE], c3 = ip[j + 3 * WAVE];
+      const double v0 = vp[j], v1 = vp[j + WAVE], v2 = vp[j + 2 * WAVE], v3 = vp[j + 3 * WAVE];
+      const double x0 = x.at_byte_offset(c0 << 3), x1 = x.at_byte_offset(c1 << 3), x2 = x.at_byte_offset(c2 << 3), x3 = x.at_byte_offset(c3 << 3);
+      s0 = fma(v0, x0, s0); s1 = fma(v1, x1, s1); s2 = fma(v2, x2, s2); s3 = fma(v3, x3, s3);
+    }
+    for (; j < nb; j += WAVE) s0 = fma(vp[j], x.at_byte_offset(ip[j] << 3), s0);
+    double s = (s0 + s1) + (s2 + s3);
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
+    epi.store(d.r0, nr, lane, s, pre[0]);      // nr = 1: only lane 0 is inside the block
   }
 }
 
@@ -286,19 +236,10 @@ struct EpiAxpby {
   }
 };
 
-template <bool DIST, bool PIPE, int F>
+template <bool DIST, int F>
 __global__ __launch_bounds__(BLOCK) void k_rb_spmv(RbView A, XVec<DIST> x, EpiAxpby<F> epi) {
   __shared__ double lds_all[WAVES_PER_BLOCK][LDS_SLOTS];
-  rb_loop<DIST, PIPE>(A, x, lds_all[threadIdx.x >> 6], epi);
-}
-
-// diagnostic kernels (airhip_set_tuning "spmv_probe" = 1 | 2): upper bounds for designs that take the per-element
-// global gather out of the kernel; their results are wrong by construction
-template <int PROBE>
-__global__ __launch_bounds__(BLOCK) void k_rb_spmv_probe(RbView A, XVec<false> x, EpiAxpby<0> epi) {
-  __shared__ double lds_all[WAVES_PER_BLOCK][LDS_SLOTS];
-  __shared__ double xt_all[WAVES_PER_BLOCK][5 * 128];
-  rb_loop<false, true, EpiAxpby<0>, PROBE>(A, x, lds_all[threadIdx.x >> 6], epi, xt_all[threadIdx.x >> 6]);
+  rb_block<DIST>(A, x, lds_all[threadIdx.x >> 6], epi);
 }
 
 // Fused first stage of an F-point relaxation with a one-point prolongator (see dev.hpp)
@@ -338,32 +279,20 @@ struct EpiFcFirst {
   }
 };
 
-template <bool DIST, bool PIPE>
+template <bool DIST>
 __global__ __launch_bounds__(BLOCK) void k_rb_fc_first(RbView A, XVec<DIST> x_c, EpiFcFirst<DIST> epi) {
   __shared__ double lds_all[WAVES_PER_BLOCK][LDS_SLOTS];
-  rb_loop<DIST, PIPE>(A, x_c, lds_all[threadIdx.x >> 6], epi);
+  rb_block<DIST>(A, x_c, lds_all[threadIdx.x >> 6], epi);
 }
 
-// grid: as many workgroups as are resident at once (the waves loop over their blocks), a multiple of 8
-template <class K>
-static int resident_grid(K kernel, int64_t nblocks) {
-  static int per_cu = 0, cus = 0;
-  if (!per_cu) {
-    int dev = 0; hipDeviceProp_t prop;
-    HIP_CHECK(hipGetDevice(&dev));
-    HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-    cus = prop.multiProcessorCount;
-    int n = 0;
-    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, BLOCK, 0));
-    per_cu = n > 0 ? n : 4;
-  }
-  const int wg = g_grid_wg_per_cu > 0 ? g_grid_wg_per_cu : per_cu;
-  int64_t blocks = (nblocks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-  const int64_t cap = (int64_t)cus * wg;
-  if (blocks > cap) blocks = cap;
-  blocks = (blocks + 7) / 8 * 8;
-  if (blocks < 8) blocks = 8;
-  return (int)blocks;
+// grid: one wave per block, four waves per workgroup, a multiple of 8 workgroups (every XCD class gets
+// ceil(its blocks / 4) workgroups)
+static unsigned grid_for(int64_t nblocks) {
+  const int64_t per_class = (nblocks + 7) / 8;                       // blocks of the largest eighth
+  int64_t wgs = 8 * ((per_class + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+  if (wgs < 8) wgs = 8;
+  if (wgs > 0x7fffffffll) throw std::runtime_error("matrix has too many row blocks for one launch");
+  return (unsigned)wgs;
 }
 
 static void check_launch(const char* what) {
@@ -374,8 +303,7 @@ static void check_launch(const char* what) {
 template <bool DIST, int F>
 static void launch_spmv_f(const RbView& v, const XVec<DIST>& xv, const SpmvEpi& e, int64_t nb, hipStream_t s) {
   const EpiAxpby<F> epi{e};
-  if (g_pipeline) hipLaunchKernelGGL((k_rb_spmv<DIST, true, F>), dim3(resident_grid(k_rb_spmv<DIST, true, F>, nb)), dim3(BLOCK), 0, s, v, xv, epi);
-  else hipLaunchKernelGGL((k_rb_spmv<DIST, false, F>), dim3(resident_grid(k_rb_spmv<DIST, false, F>, nb)), dim3(BLOCK), 0, s, v, xv, epi);
+  hipLaunchKernelGGL((k_rb_spmv<DIST, F>), dim3(grid_for(nb)), dim3(BLOCK), 0, s, v, xv, epi);
 }
 template <bool DIST>
 static void launch_spmv_d(const RbView& v, const XVec<DIST>& xv, const SpmvEpi& e, int64_t nb, hipStream_t s) {
@@ -400,19 +328,14 @@ void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t
     const int32_t nl = (int32_t)(A.n - A.n_ghost);
     launch_spmv_d<true>(v, XVec<true>{x, x_ghost - nl, nl}, e, nb, s);
   } else {
-    const XVec<false> xv{x, nullptr, 0};
-    const EpiAxpby<0> e0{e};
-    if (g_probe == 1) hipLaunchKernelGGL((k_rb_spmv_probe<1>), dim3(resident_grid(k_rb_spmv_probe<1>, nb)), dim3(BLOCK), 0, s, v, xv, e0);
-    else if (g_probe == 2) hipLaunchKernelGGL((k_rb_spmv_probe<2>), dim3(resident_grid(k_rb_spmv_probe<2>, nb)), dim3(BLOCK), 0, s, v, xv, e0);
-    else launch_spmv_d<false>(v, xv, e, nb, s);
+    launch_spmv_d<false>(v, XVec<false>{x, nullptr, 0}, e, nb, s);
   }
   check_launch("k_rb_spmv");
 }
 
 template <bool DIST>
 static void launch_fc_first_d(const RbView& v, const XVec<DIST>& xv, const EpiFcFirst<DIST>& epi, int64_t nb, hipStream_t s) {
-  if (g_pipeline) hipLaunchKernelGGL((k_rb_fc_first<DIST, true>), dim3(resident_grid(k_rb_fc_first<DIST, true>, nb)), dim3(BLOCK), 0, s, v, xv, epi);
-  else hipLaunchKernelGGL((k_rb_fc_first<DIST, false>), dim3(resident_grid(k_rb_fc_first<DIST, false>, nb)), dim3(BLOCK), 0, s, v, xv, epi);
+  hipLaunchKernelGGL((k_rb_fc_first<DIST>), dim3(grid_for(nb)), dim3(BLOCK), 0, s, v, xv, epi);
 }
 
 void launch_fc_first(const DevMat& A_fc, const int32_t* wcol, const double* b_f, const double* x_c,

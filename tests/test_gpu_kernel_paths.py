@@ -6,7 +6,7 @@
   the one the 464^3 benchmark runs, had no test;
 * a row longer than a block (wave-per-row reduction), rows of exactly 512 / 513 entries;
 * blocks of <= 32 rows (T lanes share a row) for every T, blocks of 128 rows (two rows per lane), empty rows;
-* the software pipeline across blocks: matrices of 1, 2, 3 blocks and of many thousands;
+* matrices of 1, 2, 3 ... blocks (waves without a block, partly filled workgroups) and of many thousands;
 * the fused epilogues through a polynomial apply (Horner / Newton / Neumann use every epilogue field).
 """
 import numpy as np
@@ -128,8 +128,8 @@ def test_empty_rows_and_tiny_matrices(env):
 
 
 @pytest.mark.parametrize("nblocks", [1, 2, 3, 4, 5, 9])
-def test_pipeline_prologue_and_epilogue(env, nblocks):
-    """few blocks: every wave runs the pipeline's first / last iteration (prefetch of a block that does not exist)"""
+def test_few_blocks(env, nblocks):
+    """fewer blocks than the 8 x 4 waves of the smallest grid: most waves have no block"""
     torch, P = env
     rng = np.random.default_rng(200 + nblocks)
     _check(_rows([8] * (64 * nblocks), 3000, rng, local=1000), torch, P)
@@ -179,19 +179,9 @@ def test_fused_epilogues_through_matrix_free_polynomials(env, itype, order, diag
     assert np.linalg.norm(y.cpu().numpy() - ref) <= 4e-11 * np.linalg.norm(ref)
 
 
-def test_pipeline_off_gives_the_same_bits(env):
-    """airhip_set_tuning("spmv_pipeline", 0): the diagnostic kernel without cross-block prefetch computes the same
-    sums in the same order"""
+def test_tuning_hook_refuses_unknown_keys(env):
+    """airhip_set_tuning is declared in the header; the kernels currently expose no knob, so every key is refused
+    with AIRHIP_ERR_ARG and an error text"""
     torch, P = env
-    rng = np.random.default_rng(5)
-    A = _rows(rng.integers(0, 40, size=20000), 20000, rng, local=3000)
-    x = torch.from_numpy(lcg_vector(20000)).cuda()
-    dm = P.DeviceMat(A)
-    y1 = torch.empty(20000, dtype=torch.float64, device="cuda"); dm.mult(x, y1)
-    assert P.lib().airhip_set_tuning(b"spmv_pipeline", 0) == 0
-    try:
-        y0 = torch.empty_like(y1); dm.mult(x, y0)
-    finally:
-        P.lib().airhip_set_tuning(b"spmv_pipeline", 1)
-    assert torch.equal(y0, y1)
     assert P.lib().airhip_set_tuning(b"no_such_key", 1) != 0
+    assert b"no_such_key" in P.lib().airhip_last_error()
