@@ -64,6 +64,16 @@ def main():
                          "largest size it was validated at in round 1 - it changes the setup time only, the "
                          "hierarchy is identical")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks as a CHILD torch.distributed.run (nothing
+        # here has touched the GPU yet - no torch import, no HIP call) and exit with its code
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     if "AIRHIP_DEVICE_TRUNC" not in os.environ:
         on = args.device_trunc if args.device_trunc >= 0 else (1 if args.size <= 256 else 0)
         os.environ["AIRHIP_DEVICE_TRUNC"] = str(on)
@@ -94,12 +104,13 @@ def main():
         import torch.distributed as dist
         for k_, v_ in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29577"), ("RANK", "0"), ("WORLD_SIZE", "1")):
             os.environ.setdefault(k_, v_)
+        # the only long wait is rank 0's setup (about 4 minutes at 464^3): everything else must fail inside a lease
+        t_setup_wait = datetime.timedelta(minutes=float(os.environ.get("AIRHIP_BENCH_SETUP_TIMEOUT_MIN", "15")))
         if staged:
-            dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=90))
+            dist.init_process_group("gloo", timeout=t_setup_wait)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank),
-                                    timeout=datetime.timedelta(minutes=90))
-            meta = dist.new_group(backend="gloo", timeout=datetime.timedelta(minutes=90))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=t_setup_wait)
+            meta = dist.new_group(backend="gloo", timeout=t_setup_wait)
     # host threads for the setup phase and the CPU baseline: this rank's share of the host
     cores = os.cpu_count() or 1
     try:
@@ -178,6 +189,7 @@ def main():
         info = dict(nnzA=nnzA, t_setup=t_setup, st=st, cx=cx, levels=pc.num_levels)
     parallelism = "single GPU"
     comm = None
+    transport = None            # "rccl" | "staged" (rehearsal on one GPU) | "staged-fallback" (RCCL failed its self-test)
     if dist_mode:
         from pflare_amd import dist as D
         px, py, pz = D.box_dims(world, (M, M, M))
@@ -188,7 +200,9 @@ def main():
         dist.barrier(group=meta)
         if staged:
             comm = D.StagedComm()
+            transport = "staged"
         else:
+            transport = "rccl"
             # trust the RCCL transport only after a collective self-test (all-pairs pattern exchange + all-reduce
             # on device buffers); if any rank fails it, every rank falls back to the host-staged transport over
             # the gloo group - slower halo exchanges, same kernels, same results
@@ -205,10 +219,13 @@ def main():
                 print(f"[bench] rank {rank}: RCCL transport failed its self-test ({why or 'on another rank'}); "
                       f"using the host-staged transport", file=sys.stderr, flush=True)
                 comm = D.StagedComm(group=meta)
+                transport = "staged-fallback"
                 parallelism += " [RCCL self-test failed: host-staged halo transport over gloo]"
         t0 = time.time()
         owner = D.box_owner(M, M, M, world) if rank == 0 else None
-        pcl, gid = D.distribute(pc, hm, owner, comm, src=0, meta_group=meta, bulk_group=None, bulk_on_gpu=not staged, log=log)
+        # the bulk arrays travel GPU -> GPU over RCCL only when RCCL has just proved itself; otherwise over gloo
+        pcl, gid = D.distribute(pc, hm, owner, comm, src=0, meta_group=meta, bulk_group=None if transport == "rccl" else meta,
+                                bulk_on_gpu=(transport == "rccl"), log=log)
         box = [info]
         dist.broadcast_object_list(box, src=0, group=meta)
         info = box[0]
@@ -373,7 +390,7 @@ def main():
         "metric": "KSP iterations/sec (right-preconditioned GMRES(30) + PCAIR V-cycle)",
         "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic", "transport": transport,
         "config": {"workload": f"3D upwind advection (tests/adv_diff_fd.c) {M}^3 = {M ** 3} DoF, nnz(A)={nnzA}, b=0, x0=1, "
                                f"GMRES(30) right PC rtol 1e-10, PCAIR recipe '{args.recipe}' {opts}",
                    "parallelism": parallelism,

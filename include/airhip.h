@@ -161,9 +161,23 @@ int airhip_pcair_set_coarse(airhip_pcair pc, const airhip_csr* A_coarse, const a
                             int coarse_richardson_its);
 int airhip_pcair_finalize(airhip_pcair pc);
 
-/* y = M x : one AIR V-cycle, natural ordering, device pointers; runs on the library's
- * stream and is complete on return only after airhip_pcair_sync (or a later solve). */
+/* Stream contract of every call that reads or writes caller vectors (apply, mult, solve).
+ * The library launches on a private non-blocking stream per object.  On entry that stream is made to wait (event, no
+ * host synchronisation) for everything already queued on the CALLER'S stream, so vectors produced by earlier
+ * kernels of the caller are complete before they are read.  The caller's stream is the `stream` argument of the
+ * *_on_stream entry points (a hipStream_t passed as void*; NULL = the legacy default stream) and the legacy default
+ * stream for the entry points without one.
+ *   - *_on_stream variants of apply / mult also make the caller's stream wait for the result on exit: they return
+ *     without synchronising the host and the output may be consumed by work queued on `stream` afterwards.  This is
+ *     what a host Krylov solver (PETSc KSP_PCApply) needs: no host synchronisation per PCApply
+ *     (the reference synchronises after every gather / scatter: src/VecISCopyLocalk.kokkos.cxx:192).
+ *   - airhip_pcair_apply / airhip_pcinv_apply return after queueing; the result is complete after
+ *     airhip_pcair_sync / airhip_pcinv_sync (or a later solve on the same object).
+ *   - airhip_mat_mult and airhip_ksp_solve synchronise the host before they return. */
+
+/* y = M x : one AIR V-cycle, natural ordering, device pointers (PCApply_AIR_c, src/PCAIR.c:150-166). */
 int airhip_pcair_apply(airhip_pcair pc, const double* d_x, double* d_y);
+int airhip_pcair_apply_on_stream(airhip_pcair pc, const double* d_x, double* d_y, void* stream);
 int airhip_pcair_sync(airhip_pcair pc);
 int airhip_pcair_destroy(airhip_pcair* pc);
 
@@ -252,7 +266,8 @@ int airhip_pcinv_setup(airhip_pcinv pc, const airhip_csr* A);
 int airhip_pcinv_setup_host_only(airhip_pcinv pc, const airhip_csr* A);
 int airhip_spgemm_filtered(const airhip_csr* A, const airhip_csr* B, int drop, double tol, int lump, int negate,
                            int on_device, airhip_hostmat* out, int64_t* stats);
-int airhip_pcinv_apply(airhip_pcinv pc, const double* d_x, double* d_y);
+int airhip_pcinv_apply(airhip_pcinv pc, const double* d_x, double* d_y);      /* PCApply_PFLAREINV_c, src/PCPFLAREINV.c:618-626 */
+int airhip_pcinv_apply_on_stream(airhip_pcinv pc, const double* d_x, double* d_y, void* stream);
 int airhip_pcinv_sync(airhip_pcinv pc);
 int airhip_pcinv_get_inv(airhip_pcinv pc, airhip_invop* inv);
 int airhip_pcinv_destroy(airhip_pcinv* pc);
@@ -260,6 +275,7 @@ int airhip_pcinv_destroy(airhip_pcinv* pc);
 /* ------------------------------------------------------------------ device matrices */
 int airhip_mat_create(const airhip_csr* A, airhip_mat* out);
 int airhip_mat_mult(airhip_mat A, const double* d_x, double* d_y); /* y = A x, synchronous */
+int airhip_mat_mult_on_stream(airhip_mat A, const double* d_x, double* d_y, void* stream); /* asynchronous, see above */
 int airhip_mat_destroy(airhip_mat* A);
 
 /* ---------------------------------------------------------------------------- KSP */
@@ -285,6 +301,10 @@ void airhip_ksp_default_options(airhip_ksp_options* o);
 int airhip_ksp_solve(const airhip_ksp_options* o, airhip_mat A, airhip_pcair pcair, airhip_pcinv pcinv,
                      const double* d_b, double* d_x, airhip_ksp_result* res,
                      double* history, int history_cap, int* history_len);
+/* the same with the caller's stream named (b and x0 may have been produced on it) */
+int airhip_ksp_solve_on_stream(const airhip_ksp_options* o, airhip_mat A, airhip_pcair pcair, airhip_pcinv pcinv,
+                               const double* d_b, double* d_x, airhip_ksp_result* res,
+                               double* history, int history_cap, int* history_len, void* stream);
 
 #ifdef __cplusplus
 }

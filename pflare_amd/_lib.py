@@ -37,7 +37,8 @@ DECLARED_SYMBOLS = [
     "airhip_gen_adv_1d", "airhip_gen_adv_diff_fd", "airhip_hostmat_from_csr", "airhip_hostmat_get",
     "airhip_hostmat_destroy",
     "airhip_pcair_create", "airhip_pcair_set_option", "airhip_pcair_set_ordering_hint", "airhip_pcair_setup", "airhip_pcair_begin_levels",
-    "airhip_pcair_set_level", "airhip_pcair_set_coarse", "airhip_pcair_finalize", "airhip_pcair_apply",
+    "airhip_pcair_set_level", "airhip_pcair_set_coarse", "airhip_pcair_finalize", "airhip_pcair_apply", "airhip_pcair_apply_on_stream", "airhip_pcinv_apply_on_stream",
+    "airhip_mat_mult_on_stream", "airhip_ksp_solve_on_stream",
     "airhip_pcair_sync", "airhip_pcair_destroy", "airhip_pcair_num_levels", "airhip_pcair_level_sizes",
     "airhip_pcair_level_get", "airhip_pcair_level_inv", "airhip_pcair_level_smooth_order",
     "airhip_pcair_coarse_get", "airhip_pcair_complexities", "airhip_pcair_cycle_alg_bytes", "airhip_pcair_setup_times",
@@ -100,6 +101,7 @@ def lib():
         "airhip_pcair_set_coarse": [vp, pcsr, pinv, C.c_int],
         "airhip_pcair_finalize": [vp],
         "airhip_pcair_apply": [vp, vp, vp],
+        "airhip_pcair_apply_on_stream": [vp, vp, vp, vp],
         "airhip_pcair_sync": [vp],
         "airhip_pcair_destroy": [pvp],
         "airhip_pcair_num_levels": [vp, pint],
@@ -123,15 +125,19 @@ def lib():
         "airhip_pcinv_setup": [vp, pcsr],
         "airhip_pcinv_setup_host_only": [vp, pcsr],
         "airhip_pcinv_apply": [vp, vp, vp],
+        "airhip_pcinv_apply_on_stream": [vp, vp, vp, vp],
         "airhip_pcinv_sync": [vp],
         "airhip_pcinv_get_inv": [vp, pinv],
         "airhip_pcinv_destroy": [pvp],
         "airhip_mat_create": [pcsr, pvp],
         "airhip_mat_mult": [vp, vp, vp],
+        "airhip_mat_mult_on_stream": [vp, vp, vp, vp],
         "airhip_mat_destroy": [pvp],
         "airhip_ksp_default_options": [C.POINTER(airhip_ksp_options)],
         "airhip_ksp_solve": [C.POINTER(airhip_ksp_options), vp, vp, vp, vp, vp, C.POINTER(airhip_ksp_result), pd,
                              C.c_int, pint],
+        "airhip_ksp_solve_on_stream": [C.POINTER(airhip_ksp_options), vp, vp, vp, vp, vp, C.POINTER(airhip_ksp_result), pd,
+                                       C.c_int, pint, vp],
         "airhip_partition_create": [vp, pcsr, C.c_int, pi32, pvp],
         "airhip_partition_extract": [vp, C.c_int, pvp],
         "airhip_partition_destroy": [pvp],

@@ -255,6 +255,24 @@ static int parse_inv_type(const char* v) {
   return -1;
 }
 
+// Event pair that orders a private library stream after / before a caller's stream without host synchronisation.
+struct StreamLink {
+  hipEvent_t in = nullptr, out = nullptr;
+  ~StreamLink() { if (in) (void)hipEventDestroy(in); if (out) (void)hipEventDestroy(out); }
+  // everything queued on `caller` so far happens before what is queued on `lib` from now on
+  void after_caller(hipStream_t lib, hipStream_t caller) {
+    if (!in) HIP_CHECK(hipEventCreateWithFlags(&in, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(in, caller));
+    HIP_CHECK(hipStreamWaitEvent(lib, in, 0));
+  }
+  // everything queued on `lib` so far happens before what is queued on `caller` from now on
+  void before_caller(hipStream_t lib, hipStream_t caller) {
+    if (!out) HIP_CHECK(hipEventCreateWithFlags(&out, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(out, lib));
+    HIP_CHECK(hipStreamWaitEvent(caller, out, 0));
+  }
+};
+
 struct airhip_pcair_s {
   AirOptions opt;
   std::unique_ptr<Hierarchy> H;
@@ -271,6 +289,7 @@ struct airhip_pcair_s {
   bool device_upload = true;      // false: keep the hierarchy on the host only (it will be partitioned)
   std::vector<int64_t> hint;      // optional locality keys of the fine rows (device layout only)
   double accel_transfer_s = 0, accel_compute_s = 0;
+  StreamLink link;                // orders the library stream against the caller's
 };
 
 int airhip_pcair_create(airhip_pcair* pc) {
@@ -561,7 +580,18 @@ int airhip_pcair_apply(airhip_pcair pc, const double* d_x, double* d_y) {
   API_BEGIN
   REQUIRE(pc && pc->dev, AIRHIP_ERR_STATE, "PCAIR is not set up on a device");
   REQUIRE(d_x && d_y, AIRHIP_ERR_ARG, "null vector");
+  pc->link.after_caller(pc->dev->stream(), nullptr);      // inputs may come from the legacy default stream
   pc->dev->apply_natural(d_x, d_y);
+  API_END
+}
+int airhip_pcair_apply_on_stream(airhip_pcair pc, const double* d_x, double* d_y, void* stream) {
+  API_BEGIN
+  REQUIRE(pc && pc->dev, AIRHIP_ERR_STATE, "PCAIR is not set up on a device");
+  REQUIRE(d_x && d_y, AIRHIP_ERR_ARG, "null vector");
+  hipStream_t caller = (hipStream_t)stream;
+  pc->link.after_caller(pc->dev->stream(), caller);
+  pc->dev->apply_natural(d_x, d_y);
+  pc->link.before_caller(pc->dev->stream(), caller);
   API_END
 }
 int airhip_pcair_sync(airhip_pcair pc) {
@@ -1008,6 +1038,10 @@ int airhip_pcinv_apply(airhip_pcinv pc, const double* d_x, double* d_y) {
   REQUIRE(pc, AIRHIP_ERR_ARG, "null argument");
   return airhip_pcair_apply(&pc->inner, d_x, d_y);
 }
+int airhip_pcinv_apply_on_stream(airhip_pcinv pc, const double* d_x, double* d_y, void* stream) {
+  REQUIRE(pc, AIRHIP_ERR_ARG, "null argument");
+  return airhip_pcair_apply_on_stream(&pc->inner, d_x, d_y, stream);
+}
 int airhip_pcinv_sync(airhip_pcinv pc) {
   REQUIRE(pc, AIRHIP_ERR_ARG, "null argument");
   return airhip_pcair_sync(&pc->inner);
@@ -1025,7 +1059,7 @@ int airhip_pcinv_destroy(airhip_pcinv* pc) {
 }
 
 // ------------------------------------------------------------------- device matrices
-struct airhip_mat_s { DevMat A; hipStream_t stream = nullptr; int64_t n = 0; std::unique_ptr<DevKSP> ksp; };
+struct airhip_mat_s { DevMat A; hipStream_t stream = nullptr; int64_t n = 0; std::unique_ptr<DevKSP> ksp; StreamLink link; };
 
 int airhip_mat_create(const airhip_csr* A, airhip_mat* out) {
   API_BEGIN
@@ -1044,9 +1078,20 @@ int airhip_mat_create(const airhip_csr* A, airhip_mat* out) {
 int airhip_mat_mult(airhip_mat A, const double* d_x, double* d_y) {
   API_BEGIN
   REQUIRE(A && d_x && d_y, AIRHIP_ERR_ARG, "null argument");
+  A->link.after_caller(A->stream, nullptr);
   SpmvEpi e; e.out = d_y;
   launch_spmv(A->A, d_x, e, A->stream);
   HIP_CHECK(hipStreamSynchronize(A->stream));
+  API_END
+}
+int airhip_mat_mult_on_stream(airhip_mat A, const double* d_x, double* d_y, void* stream) {
+  API_BEGIN
+  REQUIRE(A && d_x && d_y, AIRHIP_ERR_ARG, "null argument");
+  hipStream_t caller = (hipStream_t)stream;
+  A->link.after_caller(A->stream, caller);
+  SpmvEpi e; e.out = d_y;
+  launch_spmv(A->A, d_x, e, A->stream);
+  A->link.before_caller(A->stream, caller);
   API_END
 }
 int airhip_mat_destroy(airhip_mat* A) {
@@ -1064,7 +1109,13 @@ void airhip_ksp_default_options(airhip_ksp_options* o) {
 int airhip_ksp_solve(const airhip_ksp_options* o, airhip_mat A, airhip_pcair pcair, airhip_pcinv pcinv,
                      const double* d_b, double* d_x, airhip_ksp_result* res, double* history, int history_cap,
                      int* history_len) {
+  return airhip_ksp_solve_on_stream(o, A, pcair, pcinv, d_b, d_x, res, history, history_cap, history_len, nullptr);
+}
+int airhip_ksp_solve_on_stream(const airhip_ksp_options* o, airhip_mat A, airhip_pcair pcair, airhip_pcinv pcinv,
+                               const double* d_b, double* d_x, airhip_ksp_result* res, double* history, int history_cap,
+                               int* history_len, void* stream) {
   API_BEGIN
+  hipStream_t caller = (hipStream_t)stream;
   REQUIRE(o && d_b && d_x && res, AIRHIP_ERR_ARG, "null argument");
   REQUIRE(!(pcair && pcinv), AIRHIP_ERR_ARG, "give at most one preconditioner");
   KspOptions ko; ko.type = o->type; ko.pc_side = o->pc_side; ko.norm_type = o->norm_type; ko.rtol = o->rtol;
@@ -1077,6 +1128,7 @@ int airhip_ksp_solve(const airhip_ksp_options* o, airhip_mat A, airhip_pcair pca
     DevPCAIR& dev = *pc->dev;
     const int64_t n = dev.n();
     if (!pc->ksp) { pc->ksp = std::make_unique<DevKSP>(n); pc->kb.alloc(n); pc->kx.alloc(n); }
+    pc->link.after_caller(dev.stream(), caller);
     dev.to_permuted(d_b, pc->kb.p);
     dev.to_permuted(d_x, pc->kx.p);
     KspOperator op; op.A = &dev.A_perm(); op.stream = dev.stream(); op.comm = dev.comm();
@@ -1088,6 +1140,7 @@ int airhip_ksp_solve(const airhip_ksp_options* o, airhip_mat A, airhip_pcair pca
   } else {
     REQUIRE(A, AIRHIP_ERR_ARG, "an operator is required without a preconditioner");
     if (!A->ksp) A->ksp = std::make_unique<DevKSP>(A->n);
+    A->link.after_caller(A->stream, caller);
     KspOperator op; op.A = &A->A; op.stream = A->stream;
     r = A->ksp->solve(op, ko, d_b, d_x);
     HIP_CHECK(hipStreamSynchronize(A->stream));

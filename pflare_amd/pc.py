@@ -142,6 +142,15 @@ def _ptr(t):
     return C.c_void_p(int(t))
 
 
+def _caller_stream(t):
+    """the HIP stream the caller's torch work is queued on (torch's current stream of the tensor's device), as the
+    void* the *_on_stream entry points take; None (NULL = legacy default stream) for raw pointers"""
+    if hasattr(t, "data_ptr"):
+        import torch
+        return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return None
+
+
 def _invop_to_dict(inv: airhip_invop, n, copy=True):
     d = {"kind": int(inv.kind), "diag_scale": bool(inv.diag_scale), "neumann": bool(inv.neumann)}
     if inv.kind == OP_ASSEMBLED:
@@ -277,10 +286,13 @@ class PCAIR:
 
     # -- apply
     def apply(self, x, y):
-        """y = M x : one AIR V-cycle (PCApply_AIR_c), torch float64 CUDA tensors."""
-        check(lib().airhip_pcair_apply(self._h, _ptr(x), _ptr(y)))
-        check(lib().airhip_pcair_sync(self._h))
+        """y = M x : one AIR V-cycle (PCApply_AIR_c), torch float64 CUDA tensors.  Ordered on torch's current
+        stream (input and output side); no host synchronisation."""
+        check(lib().airhip_pcair_apply_on_stream(self._h, _ptr(x), _ptr(y), _caller_stream(x)))
         return y
+
+    def sync(self):
+        check(lib().airhip_pcair_sync(self._h))
 
     # -- inspection
     @property
@@ -430,8 +442,7 @@ class PCPFLAREINV:
         return self
 
     def apply(self, x, y):
-        check(lib().airhip_pcinv_apply(self._h, _ptr(x), _ptr(y)))
-        check(lib().airhip_pcinv_sync(self._h))
+        check(lib().airhip_pcinv_apply_on_stream(self._h, _ptr(x), _ptr(y), _caller_stream(x)))
         return y
 
     def get_inverse(self, n):
@@ -448,7 +459,7 @@ class PCPFLAREINV:
 
 
 class DeviceMat:
-    """Device-resident AIJ matrix (SELL-64) with MatMult."""
+    """Device-resident AIJ matrix (row-block CSR) with MatMult."""
 
     def __init__(self, A):
         self._h = C.c_void_p()
@@ -458,6 +469,11 @@ class DeviceMat:
 
     def mult(self, x, y):
         check(lib().airhip_mat_mult(self._h, _ptr(x), _ptr(y)))
+        return y
+
+    def mult_async(self, x, y):
+        """y = A x ordered on torch's current stream, no host synchronisation"""
+        check(lib().airhip_mat_mult_on_stream(self._h, _ptr(x), _ptr(y), _caller_stream(x)))
         return y
 
     def __del__(self):
@@ -494,7 +510,7 @@ class KSP:
         pcair = pc._h if isinstance(pc, PCAIR) else None
         pcinv = pc._h if isinstance(pc, PCPFLAREINV) else None
         amat = A._h if A is not None else None
-        check(lib().airhip_ksp_solve(C.byref(self.o), amat, pcair, pcinv, _ptr(b), _ptr(x), C.byref(res), hist, 4096,
-                                     C.byref(hl)))
+        check(lib().airhip_ksp_solve_on_stream(C.byref(self.o), amat, pcair, pcinv, _ptr(b), _ptr(x), C.byref(res), hist,
+                                               4096, C.byref(hl), _caller_stream(x)))
         return dict(its=res.its, reason=res.reason, reason_name=KSP_REASONS.get(res.reason, str(res.reason)),
                     rnorm=res.rnorm, solve_ms=res.solve_ms, history=[hist[i] for i in range(min(hl.value, 4096))])
