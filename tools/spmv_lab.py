@@ -8,8 +8,6 @@ import time
 import os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
-import pflare_amd as P
 
 
 def csr_banded(m, L, spread=1, jitter=0, seed=0):
@@ -32,6 +30,8 @@ def csr_banded(m, L, spread=1, jitter=0, seed=0):
 
 
 def run(name, A, reps=20):
+    import torch
+    import pflare_amd as P
     m, n = A[3]
     nnz = int(A[0][-1])
     dm = P.DeviceMat(A)
@@ -51,6 +51,7 @@ def run(name, A, reps=20):
 
 
 if __name__ == "__main__":
+    import pflare_amd as P
     nnz_m = float(sys.argv[1]) if len(sys.argv) > 1 else 64.0
     if len(sys.argv) > 2:      # probe mode: the diagnostic kernels on a few structures
         for probe in (0, 1, 2):
