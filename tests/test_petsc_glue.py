@@ -1,0 +1,49 @@
+"""pflare_amd/csrc/petsc_glue.c cannot be compiled here (no PETSc in the image), so what can be checked is checked:
+it exports the reference's plugin symbols with the reference's vtable, calls nothing but what include/airhip.h
+declares, forwards only options the library knows, and the Makefile target refuses to run without PETSC_DIR."""
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = open(os.path.join(ROOT, "pflare_amd", "csrc", "petsc_glue.c")).read()
+HDR = open(os.path.join(ROOT, "include", "airhip.h")).read()
+
+
+def test_exports_the_references_plugin_symbols():
+    # src/PCAIR.c:3601-3663, src/PCPFLAREINV.c:887-957
+    for sig in (r"PETSC_EXTERN PetscErrorCode PCCreate_AIR\(PC pc\)", r"PETSC_EXTERN void PCRegister_AIR\(void\)",
+                r"PETSC_EXTERN PetscErrorCode PCCreate_PFLAREINV\(PC pc\)", r"PETSC_EXTERN void PCRegister_PFLAREINV\(void\)",
+                r"PETSC_EXTERN PetscErrorCode PetscDLLibraryRegister_petscpflare\(void\)"):
+        assert re.search(sig, SRC), sig
+    assert 'PCRegister("air", PCCreate_AIR)' in SRC and 'PCRegister("pflareinv", PCCreate_PFLAREINV)' in SRC
+    for op in ("apply", "setup", "destroy", "view", "reset", "setfromoptions"):      # src/PCAIR.c:3636-3641
+        assert re.search(r"pc->ops->%s\s*=" % op, SRC), op
+
+
+def test_calls_only_declared_abi_functions():
+    called = set(re.findall(r"\b(airhip_[a-z0-9_]+)\s*\(", SRC)) - {"airhip_push_option", "airhip_make_handle"}
+    declared = set(re.findall(r"\b(airhip_[a-z0-9_]+)\s*\(", HDR))
+    assert called and called <= declared, called - declared
+    # the apply path goes through the stream-ordered entry points (no host synchronisation per PCApply)
+    assert "airhip_pcair_apply_on_stream" in called and "airhip_pcinv_apply_on_stream" in called
+
+
+def test_forwarded_options_are_known_to_the_library():
+    import pflare_amd as P
+    air = re.search(r"air_options\[\] = \{(.*?)NULL\}", SRC, re.S).group(1)
+    inv = re.search(r"inv_options\[\] = \{(.*?)NULL\}", SRC, re.S).group(1)
+    sample = {"smooth_type": "ff", "inverse_type": "arnoldi", "c_inverse_type": "arnoldi", "coarsest_inverse_type": "arnoldi",
+              "z_type": "product", "cf_splitting_type": "0", "type": "arnoldi"}
+    pc = P.PCAIR()
+    for name in re.findall(r'"([a-z_0-9]+)"', air):
+        pc.set_option(name, sample.get(name, "1"))          # raises on an unknown name
+    pi = P.PCPFLAREINV()
+    for name in re.findall(r'"([a-z_0-9]+)"', inv):
+        pi.set_option(name, sample.get(name, "1"))
+
+
+def test_make_target_needs_petsc():
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "pflare_amd", "csrc"), "petsc_glue", "PETSC_DIR="],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "PETSC_DIR" in (r.stdout + r.stderr)
