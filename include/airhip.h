@@ -114,6 +114,10 @@ int airhip_set_tuning(const char* key, int value);
 #define AIRHIP_CF_CR 6
 int airhip_compute_cf_splitting(const airhip_csr* A, int symmetric, double strong_threshold, int max_luby_steps,
                                 int cf_splitting_type, int ddc_its, double fraction_swap, int32_t* markers);
+/* the same splitting (PMISR + DDC only) computed by the device kernels; markers are identical to the host's
+ * (reference device twins: src/PMISR_Modulek.kokkos.cxx, src/DDC_Modulek.kokkos.cxx, src/MatDiagDomk.kokkos.cxx) */
+int airhip_compute_cf_splitting_on_device(const airhip_csr* A, int symmetric, double strong_threshold, int max_luby_steps,
+                                          int ddc_its, double fraction_swap, int32_t* markers);
 
 /* ---------------------------------------------------------------- synthetic operators */
 /* tests/adv_1d.c:80-105 and tests/adv_diff_fd.c:366-586.  The CSR arrays are owned by the

@@ -171,6 +171,25 @@ int airhip_compute_cf_splitting(const airhip_csr* A, int symmetric, double stron
   API_END
 }
 
+// the same splitting computed by the device kernels (device/cfsplit.hip); PMISR + DDC only
+int airhip_compute_cf_splitting_on_device(const airhip_csr* A, int symmetric, double strong_threshold, int max_luby_steps,
+                                          int ddc_its, double fraction_swap, int32_t* markers) {
+  API_BEGIN
+  REQUIRE(A && markers, AIRHIP_ERR_ARG, "null argument");
+  REQUIRE_CSR(A, true);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_err = "no HIP device"; return AIRHIP_ERR_HIP; }
+  AirOptions o;
+  o.symmetric = symmetric != 0; o.strong_threshold = strong_threshold; o.max_luby_steps = max_luby_steps;
+  o.ddc_its = ddc_its; o.ddc_fraction = fraction_swap; o.cf_splitting_type = 0;
+  Csr view; view_csr(A, view);
+  auto accel = make_device_setup_accel(nullptr, 0);
+  Arr<int32_t> m;
+  REQUIRE(accel->cf_splitting(view, o, m), AIRHIP_ERR_STATE, "the device CF splitting is disabled (AIRHIP_DEVICE_CFSPLIT=0)");
+  for (int64_t i = 0; i < A->m; i++) markers[i] = m[i];
+  API_END
+}
+
 int airhip_gen_adv_1d(int64_t n, airhip_hostmat* out) {
   API_BEGIN
   REQUIRE(out && n > 0, AIRHIP_ERR_ARG, "bad argument");

@@ -5,6 +5,7 @@
 #include "setup_accel.hpp"
 #include "dev.hpp"
 #include "spgemm.hpp"
+#include "cfsplit_dev.hpp"
 #include "../host/air.hpp"
 #include <cmath>
 #include <cstdlib>
@@ -48,6 +49,21 @@ struct DevSetupAccel final : SetupAccel {
     Csr C = down(dC);
     dcsr_free(dC);
     return C;
+  }
+
+  // CF splitting of the level operator where it already is (the previous level's R*A*P; the top level is uploaded
+  // once and stays resident for its own R*A*P)
+  bool cf_splitting(const Csr& A, const AirOptions& o, Arr<int32_t>& markers) override {
+    static const bool enabled = [] { const char* e = std::getenv("AIRHIP_DEVICE_CFSPLIT"); return !(e && e[0] == '0'); }();
+    if (!enabled || o.cf_splitting_type != 0 || A.nnz() < min_nnz) return false;
+    const bool have = resident_key && resident_key == (const void*)A.rp.data() && resident.m == A.m && resident.nnz == A.nnz();
+    if (!have) { dcsr_free(resident); resident = up(A); resident_key = (const void*)A.rp.data(); }
+    const double t0 = now_s();
+    markers.alloc(A.m);
+    dev_cf_splitting_pmisr_ddc(resident, o.strong_threshold, !o.symmetric, o.max_luby_steps, rng_key(o.seed), o.ddc_its,
+                               o.ddc_fraction, markers.data(), stream);
+    t_cfsplit += now_s() - t0;
+    return true;
   }
 
   // Auto-truncation test on the device: Arnoldi (classical Gram-Schmidt with the multi-dot / multi-axpy kernels of

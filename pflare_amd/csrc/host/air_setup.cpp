@@ -228,7 +228,7 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o, SetupAc
     int64_t n_f = 0, n_c = 0;
     if (!auto_truncated) {
       double t0 = now_s();
-      compute_cf_splitting(*cur, o, markers);
+      if (!(accel && accel->cf_splitting(*cur, o, markers))) compute_cf_splitting(*cur, o, markers);
 #pragma omp parallel for schedule(static) reduction(+ : n_f)
       for (int64_t i = 0; i < n; i++) n_f += (markers[i] == F_POINT) ? 1 : 0;
       n_c = n - n_f;

@@ -57,7 +57,12 @@ struct SetupAccel {
   virtual bool truncation_ratio(const Csr& A, int inverse_type, int poly_order, uint64_t seed, double& ratio) {
     (void)A; (void)inverse_type; (void)poly_order; (void)seed; (void)ratio; return false;
   }
-  double t_transfer = 0.0, t_compute = 0.0;
+  // CF splitting of the level operator by the accelerator (device/cfsplit.hip); markers must come out identical to
+  // compute_cf_splitting.  Returns false when it declines (splitting types other than PMISR + DDC, small operators).
+  virtual bool cf_splitting(const Csr& A, const struct AirOptions& o, Arr<int32_t>& markers) {
+    (void)A; (void)o; (void)markers; return false;
+  }
+  double t_transfer = 0.0, t_compute = 0.0, t_cfsplit = 0.0;
 };
 
 void spmv(const Csr& A, const double* x, double* y);

@@ -170,11 +170,19 @@ CF_PMISR_DDC, CF_DIAG_DOM, CF_CR = 0, 1, 6
 
 
 def compute_cf_splitting(A, symmetric=False, strong_threshold=0.5, max_luby_steps=-1, cf_splitting_type=CF_PMISR_DDC,
-                         ddc_its=1, fraction_swap=0.1):
+                         ddc_its=1, fraction_swap=0.1, on_device=False):
     """Stand-alone CF splitting with the reference's argument order (pflare.compute_cf_splitting,
-    include/pflare.h:113); returns (is_fine, is_coarse) as ascending index arrays.  Host-side."""
+    include/pflare.h:113); returns (is_fine, is_coarse) as ascending index arrays.  on_device: the HIP kernels
+    (PMISR + DDC only; identical result)."""
     a = as_csr(A)
     markers = np.empty(a.shape[0], dtype=np.int32)
+    if on_device:
+        if cf_splitting_type != CF_PMISR_DDC:
+            raise ValueError("the device splitting implements pmisr_ddc only")
+        check(lib().airhip_compute_cf_splitting_on_device(a.ref(), int(bool(symmetric)), float(strong_threshold),
+                                                          int(max_luby_steps), int(ddc_its), float(fraction_swap),
+                                                          markers.ctypes.data_as(C.POINTER(C.c_int32))))
+        return np.flatnonzero(markers == -1), np.flatnonzero(markers != -1)
     check(lib().airhip_compute_cf_splitting(a.ref(), int(bool(symmetric)), float(strong_threshold), int(max_luby_steps),
                                             int(cf_splitting_type), int(ddc_its), float(fraction_swap),
                                             markers.ctypes.data_as(C.POINTER(C.c_int32))))

@@ -125,3 +125,53 @@ def test_device_setup_equals_host_setup(gpu, case):
     for k in ("re", "im", "coeffs"):
         if k in invh:
             assert np.array_equal(invd[k], invh[k]), k
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CF splitting on the device (csrc/device/cfsplit.hip): markers identical to the host code, which tests/test_host_setup.py
+# checks against the oracle's restatement of src/PMISR_Module.F90 / src/DDC_Module.F90
+CF_CASES = [
+    ("adv2d_70", dict(dim=2, M=70, N=70), {}),
+    ("adv3d_24", dict(dim=3, M=24, N=24, P=24), {}),
+    ("diff2d_50", dict(dim=2, M=50, N=50, u=0, v=0, alpha=1.0), {}),
+    ("advdiff2d_60_theta0.25", dict(dim=2, M=60, N=60, alpha=0.05), dict(strong_threshold=0.25)),
+    ("adv2d_50_symmetric", dict(dim=2, M=50, N=50), dict(symmetric=True)),               # directed graph, no S + S^T
+    ("adv2d_50_theta0", dict(dim=2, M=50, N=50), dict(strong_threshold=0.0)),            # exact independent set, no DDC
+    ("diff2d_50_ddc2", dict(dim=2, M=50, N=50, u=0, v=0, alpha=1.0), dict(ddc_its=2, fraction_swap=0.3)),
+    ("diff2d_50_ddc_threshold", dict(dim=2, M=50, N=50, u=0, v=0, alpha=1.0), dict(fraction_swap=-0.6)),
+    ("adv3d_20_luby2", dict(dim=3, M=20, N=20, P=20), dict(max_luby_steps=2)),
+]
+
+
+@pytest.mark.parametrize("name,gen,kw", CF_CASES, ids=[c[0] for c in CF_CASES])
+def test_device_cf_splitting_equals_host(gpu, name, gen, kw):
+    import pflare_amd as P
+    A = P.HostMat.adv_diff_fd(**gen)
+    Fh, Ch = P.compute_cf_splitting(A, **kw)
+    Fd, Cd = P.compute_cf_splitting(A, on_device=True, **kw)
+    assert np.array_equal(Fh, Fd) and np.array_equal(Ch, Cd)
+    assert Fh.size > 0 and Ch.size > 0
+
+
+def test_device_cf_splitting_on_the_coarse_operators_of_a_hierarchy_and_on_reference_data(gpu):
+    """denser rows, general values: every level operator of a 3D hierarchy, and the reference's own test matrix"""
+    import os
+    import pflare_amd as P
+    from pflare_amd.petscio import load_mat_vec
+    from oracle import bridge
+    A = P.HostMat.adv_diff_fd(dim=3, M=18, N=18, P=18)
+    pc = P.PCAIR(a_lump=True, max_levels=6).setup_host_only(A)
+    H = bridge.hierarchy_from_product(pc, bridge.to_scipy(A.csr()))
+    mats = [bridge.to_scipy(A.csr())]
+    cur = mats[0]
+    for L in H.levels:                      # R A P of every level, recomputed with scipy (only the pattern / values matter)
+        cur = (L.R @ (cur @ L.P)).tocsr(); cur.sort_indices()
+        mats.append(cur)
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_data", "mat_stream_2364")
+    mats.append(load_mat_vec(root)[0])
+    for M in mats:
+        if M.shape[0] < 8:
+            continue
+        Fh, Ch = P.compute_cf_splitting(M)
+        Fd, Cd = P.compute_cf_splitting(M, on_device=True)
+        assert np.array_equal(Fh, Fd) and np.array_equal(Ch, Cd), M.shape
