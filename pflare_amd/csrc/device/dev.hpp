@@ -57,6 +57,9 @@ struct SpmvEpi {
   const double* dscale = nullptr;     // multiply s by dscale_i (holds 1/d)
   double* out = nullptr;
   double* y2 = nullptr; const double* w2 = nullptr; double delta = 0.0; int aux_out = 0;
+  // products of the setup phase (the device auto-truncation test) launch the same code under the kernel name
+  // k_rb_spmv_setup, so that a kernel trace of a run separates them from the solve phase's k_rb_spmv
+  int setup_phase = 0;
 };
 
 // x_ghost: the received ghost values of a distributed operand (A.n_ghost entries), else null

@@ -109,7 +109,7 @@ struct DevSetupAccel final : SetupAccel {
     launch_axpby(n, 1.0 / beta, V, 0.0, nullptr, V, stream);
     int m_used = p + 1;
     for (int m = 1; m <= p + 1; m++) {
-      SpmvEpi e; e.out = w;
+      SpmvEpi e; e.setup_phase = 1; e.out = w;
       launch_spmv(B.M, V + (size_t)(m - 1) * (size_t)n, e, stream);
       launch_mdot(n, w, V, n, m, scratch, d_small, stream);
       HIP_CHECK(hipMemcpyAsync(h.data(), d_small, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, stream));
@@ -150,18 +150,18 @@ struct DevSetupAccel final : SetupAccel {
         const double a = 1.0 / re[k];
         launch_axpby(n, a, t, 1.0, y, y, stream);
         double* tn = other(t);
-        SpmvEpi e; e.out = tn; e.alpha = -a; e.z = t; e.beta = 1.0;
+        SpmvEpi e; e.setup_phase = 1; e.out = tn; e.alpha = -a; e.z = t; e.beta = 1.0;
         launch_spmv(B.M, t, e, stream);
         t = tn; k++;
       } else {
         const double sq = re[k] * re[k] + im[k] * im[k];
         if (sq < TOL_ZERO) { k += 2; continue; }
-        SpmvEpi e; e.out = t2; e.alpha = -1.0; e.z = t; e.beta = 2.0 * re[k];
+        SpmvEpi e; e.setup_phase = 1; e.out = t2; e.alpha = -1.0; e.z = t; e.beta = 2.0 * re[k];
         launch_spmv(B.M, t, e, stream);
         launch_axpby(n, 1.0 / sq, t2, 1.0, y, y, stream);
         if (k <= nr - 3) {
           double* tn = other(t);
-          SpmvEpi e2; e2.out = tn; e2.alpha = -1.0 / sq; e2.z = t; e2.beta = 1.0;
+          SpmvEpi e2; e2.setup_phase = 1; e2.out = tn; e2.alpha = -1.0 / sq; e2.z = t; e2.beta = 1.0;
           launch_spmv(B.M, t2, e2, stream);
           t = tn;
         }
@@ -170,7 +170,7 @@ struct DevSetupAccel final : SetupAccel {
     }
     if (im[nr - 1] == 0.0 && std::fabs(re[nr - 1]) > TOL_ZERO) launch_axpby(n, 1.0 / re[nr - 1], t, 1.0, y, y, stream);
     // r = A y - x
-    SpmvEpi e; e.out = t2; e.alpha = 1.0; e.z = x; e.beta = -1.0;
+    SpmvEpi e; e.setup_phase = 1; e.out = t2; e.alpha = 1.0; e.z = x; e.beta = -1.0;
     launch_spmv(B.M, y, e, stream);
     const double rn = norm_of(t2), xn = norm_of(x);
     t_compute += now_s() - t0;

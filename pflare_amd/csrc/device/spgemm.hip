@@ -155,6 +155,29 @@ __device__ __forceinline__ bool spgemm_row(const CsrView& A, const CsrView& B, i
     }
   }
   if (overflow) return false;
+  if (!FILL && !dp.dbg) {
+    // count mode: the number of entries the filter keeps needs neither the compaction nor the sort - the row
+    // maximum, "is the diagonal kept / created" and the number of large off-diagonal entries are order-free
+    if (!dp.enabled) { if (lane == 0) *count_out = unique; return true; }
+    double mx = 0.0;
+    for (int h = lane; h < HT; h += WAVE) if (tab.ldk(h) != EMPTY) mx = fmax(mx, fabs(tab.ldv(h)));
+    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, WAVE));
+    const double tolc = dp.tol * mx;
+    bool have_diag = false, need_diag = false;
+    int cnt = 0;
+    for (int base = 0; base < HT; base += WAVE) {
+      const int32_t k = tab.ldk(base + lane);
+      const bool in = k != EMPTY;
+      const double v = in ? tab.ldv(base + lane) : 0.0;
+      const bool big = in && fabs(v) >= tolc;
+      const bool isd = in && k == (int32_t)i;
+      if (__any(isd && big)) have_diag = true;
+      if (__any(in && !big && (dp.lump || isd))) need_diag = true;
+      cnt += __popcll(__ballot(big && !isd));
+    }
+    if (lane == 0) *count_out = (int64_t)cnt + ((have_diag || need_diag) ? 1 : 0);
+    return true;
+  }
   // ---- compact the used slots to the front of the table (in place, chunk by chunk)
   int nu = 0;
   if (dp.dbg & 2) { if (lane == 0) *count_out = unique; return true; }
@@ -214,19 +237,31 @@ __device__ __forceinline__ bool spgemm_row(const CsrView& A, const CsrView& B, i
     write_diag = have_diag || need_diag;
     kept = cnt + (write_diag ? 1 : 0);
     if (write_diag && FILL) {
-      // kept diagonal value first, then the removed entries in column order: summed by one
-      // lane so that the result is bit-identical to the sequential host code
-      if (lane == 0) {
-        double s = 0.0;
-        for (int h = 0; h < nu; h++) { const double v = tab.ldv(h); if (tab.ldk(h) == (int32_t)i && fabs(v) >= tol) s = v; }
-        for (int h = 0; h < nu; h++) {
-          const double v = tab.ldv(h);
-          if (fabs(v) >= tol) continue;
-          if (dp.lump || tab.ldk(h) == (int32_t)i) s += v;
-        }
-        dsum = s;
+      // kept diagonal value first, then the removed entries in column order, added one after the other so that
+      // the result is bit-identical to the sequential host code.  The table is read 64 slots at a time; only the
+      // additions are sequential (every lane performs them on broadcast values, so the sum stays wave-uniform).
+      double sacc = 0.0;
+      for (int base = 0; base < nu; base += WAVE) {
+        const int h = base + lane;
+        const bool in = h < nu;
+        const double v = in ? tab.ldv(h) : 0.0;
+        const bool hit = in && tab.ldk(h) == (int32_t)i && fabs(v) >= tol;
+        const unsigned long long b = __ballot(hit);
+        if (b) sacc = __shfl(v, __ffsll((long long)b) - 1, WAVE);       // the kept diagonal (unique column)
       }
-      dsum = __shfl(dsum, 0, WAVE);
+      for (int base = 0; base < nu; base += WAVE) {
+        const int h = base + lane;
+        const bool in = h < nu;
+        const double v = in ? tab.ldv(h) : 0.0;
+        const bool add = in && !(fabs(v) >= tol) && (dp.lump || tab.ldk(h) == (int32_t)i);
+        unsigned long long b = __ballot(add);
+        while (b) {
+          const int t = __ffsll((long long)b) - 1;
+          sacc += __shfl(v, t, WAVE);
+          b &= b - 1;
+        }
+      }
+      dsum = sacc;
     }
   }
   if (!FILL) { if (lane == 0) *count_out = kept; return true; }

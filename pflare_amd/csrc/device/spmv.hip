@@ -241,6 +241,12 @@ __global__ __launch_bounds__(BLOCK) void k_rb_spmv(RbView A, XVec<DIST> x, EpiAx
   __shared__ double lds_all[WAVES_PER_BLOCK][LDS_SLOTS];
   rb_block<DIST>(A, x, lds_all[threadIdx.x >> 6], epi);
 }
+// the same kernel under another name for the products of the setup phase (SpmvEpi::setup_phase)
+template <int F>
+__global__ __launch_bounds__(BLOCK) void k_rb_spmv_setup(RbView A, XVec<false> x, EpiAxpby<F> epi) {
+  __shared__ double lds_all[WAVES_PER_BLOCK][LDS_SLOTS];
+  rb_block<false>(A, x, lds_all[threadIdx.x >> 6], epi);
+}
 
 // Fused first stage of an F-point relaxation with a one-point prolongator (see dev.hpp)
 template <bool DIST>
@@ -303,6 +309,9 @@ static void check_launch(const char* what) {
 template <bool DIST, int F>
 static void launch_spmv_f(const RbView& v, const XVec<DIST>& xv, const SpmvEpi& e, int64_t nb, hipStream_t s) {
   const EpiAxpby<F> epi{e};
+  if constexpr (!DIST && (F == 0 || F == 1 || F == 9)) {      // the epilogues the setup's Arnoldi / Newton apply use
+    if (e.setup_phase) { hipLaunchKernelGGL((k_rb_spmv_setup<F>), dim3(grid_for(nb)), dim3(BLOCK), 0, s, v, xv, epi); return; }
+  }
   hipLaunchKernelGGL((k_rb_spmv<DIST, F>), dim3(grid_for(nb)), dim3(BLOCK), 0, s, v, xv, epi);
 }
 template <bool DIST>
