@@ -40,15 +40,22 @@
 
 namespace airhip {
 
+// waves (= row blocks) per workgroup of the SpMV kernels
+#ifndef AIRHIP_SPMV_WAVES
+#define AIRHIP_SPMV_WAVES 4
+#endif
+constexpr int SPMV_WAVES = AIRHIP_SPMV_WAVES;
+constexpr int SPMV_BLOCK = SPMV_WAVES * WAVE;
+
 // XCD-aware assignment of row blocks to waves (gridDim.x is a multiple of 8): workgroup w of residue class
-// g = blockIdx & 7 (one XCD under round-robin dispatch; a speed assumption only) takes four consecutive blocks
-// of the g-th eighth of the matrix.  Returns -1 when the wave has no block.
+// g = blockIdx & 7 (one XCD under round-robin dispatch; a speed assumption only) takes SPMV_WAVES consecutive
+// blocks of the g-th eighth of the matrix.  Returns -1 when the wave has no block.
 __device__ __forceinline__ int64_t my_block(int64_t nblocks) {
   const int g = blockIdx.x & 7;
   const int64_t bi = blockIdx.x >> 3;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int64_t lo = nblocks * g / 8, hi = nblocks * (g + 1) / 8;
-  const int64_t b = lo + bi * WAVES_PER_BLOCK + wid;
+  const int64_t b = lo + bi * SPMV_WAVES + wid;
   return b < hi ? b : -1;
 }
 
@@ -237,14 +244,14 @@ struct EpiAxpby {
 };
 
 template <bool DIST, int F>
-__global__ __launch_bounds__(BLOCK) void k_rb_spmv(RbView A, XVec<DIST> x, EpiAxpby<F> epi) {
-  __shared__ double lds_all[WAVES_PER_BLOCK][LDS_SLOTS];
+__global__ __launch_bounds__(SPMV_BLOCK) void k_rb_spmv(RbView A, XVec<DIST> x, EpiAxpby<F> epi) {
+  __shared__ double lds_all[SPMV_WAVES][LDS_SLOTS];
   rb_block<DIST>(A, x, lds_all[threadIdx.x >> 6], epi);
 }
 // the same kernel under another name for the products of the setup phase (SpmvEpi::setup_phase)
 template <int F>
-__global__ __launch_bounds__(BLOCK) void k_rb_spmv_setup(RbView A, XVec<false> x, EpiAxpby<F> epi) {
-  __shared__ double lds_all[WAVES_PER_BLOCK][LDS_SLOTS];
+__global__ __launch_bounds__(SPMV_BLOCK) void k_rb_spmv_setup(RbView A, XVec<false> x, EpiAxpby<F> epi) {
+  __shared__ double lds_all[SPMV_WAVES][LDS_SLOTS];
   rb_block<false>(A, x, lds_all[threadIdx.x >> 6], epi);
 }
 
@@ -286,8 +293,8 @@ struct EpiFcFirst {
 };
 
 template <bool DIST>
-__global__ __launch_bounds__(BLOCK) void k_rb_fc_first(RbView A, XVec<DIST> x_c, EpiFcFirst<DIST> epi) {
-  __shared__ double lds_all[WAVES_PER_BLOCK][LDS_SLOTS];
+__global__ __launch_bounds__(SPMV_BLOCK) void k_rb_fc_first(RbView A, XVec<DIST> x_c, EpiFcFirst<DIST> epi) {
+  __shared__ double lds_all[SPMV_WAVES][LDS_SLOTS];
   rb_block<DIST>(A, x_c, lds_all[threadIdx.x >> 6], epi);
 }
 
@@ -295,7 +302,7 @@ __global__ __launch_bounds__(BLOCK) void k_rb_fc_first(RbView A, XVec<DIST> x_c,
 // ceil(its blocks / 4) workgroups)
 static unsigned grid_for(int64_t nblocks) {
   const int64_t per_class = (nblocks + 7) / 8;                       // blocks of the largest eighth
-  int64_t wgs = 8 * ((per_class + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+  int64_t wgs = 8 * ((per_class + SPMV_WAVES - 1) / SPMV_WAVES);
   if (wgs < 8) wgs = 8;
   if (wgs > 0x7fffffffll) throw std::runtime_error("matrix has too many row blocks for one launch");
   return (unsigned)wgs;
@@ -310,9 +317,9 @@ template <bool DIST, int F>
 static void launch_spmv_f(const RbView& v, const XVec<DIST>& xv, const SpmvEpi& e, int64_t nb, hipStream_t s) {
   const EpiAxpby<F> epi{e};
   if constexpr (!DIST && (F == 0 || F == 1 || F == 9)) {      // the epilogues the setup's Arnoldi / Newton apply use
-    if (e.setup_phase) { hipLaunchKernelGGL((k_rb_spmv_setup<F>), dim3(grid_for(nb)), dim3(BLOCK), 0, s, v, xv, epi); return; }
+    if (e.setup_phase) { hipLaunchKernelGGL((k_rb_spmv_setup<F>), dim3(grid_for(nb)), dim3(SPMV_BLOCK), 0, s, v, xv, epi); return; }
   }
-  hipLaunchKernelGGL((k_rb_spmv<DIST, F>), dim3(grid_for(nb)), dim3(BLOCK), 0, s, v, xv, epi);
+  hipLaunchKernelGGL((k_rb_spmv<DIST, F>), dim3(grid_for(nb)), dim3(SPMV_BLOCK), 0, s, v, xv, epi);
 }
 template <bool DIST>
 static void launch_spmv_d(const RbView& v, const XVec<DIST>& xv, const SpmvEpi& e, int64_t nb, hipStream_t s) {
@@ -344,7 +351,7 @@ void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t
 
 template <bool DIST>
 static void launch_fc_first_d(const RbView& v, const XVec<DIST>& xv, const EpiFcFirst<DIST>& epi, int64_t nb, hipStream_t s) {
-  hipLaunchKernelGGL((k_rb_fc_first<DIST>), dim3(grid_for(nb)), dim3(BLOCK), 0, s, v, xv, epi);
+  hipLaunchKernelGGL((k_rb_fc_first<DIST>), dim3(grid_for(nb)), dim3(SPMV_BLOCK), 0, s, v, xv, epi);
 }
 
 void launch_fc_first(const DevMat& A_fc, const int32_t* wcol, const double* b_f, const double* x_c,
