@@ -135,14 +135,19 @@ __device__ __forceinline__ void rb_block(const RbView& A, const XVec<DIST> x, do
   int ra[2], re[2];
   typename Epi::Pre pre[2];
   const rsrc_t rr = make_rsrc(A.roff + d.r0, (int64_t)nr * 2);
-#pragma unroll
-  for (int q = 0; q < 2; q++) early[q] = epi.early(d.r0, nr, lane + q * WAVE);
+  const bool two = nr > WAVE;          // blocks of <= 64 rows (most of them) issue nothing for a second row per lane
+  early[0] = epi.early(d.r0, nr, lane);
+  early[1] = early[0];
+  if (two) early[1] = epi.early(d.r0, nr, lane + WAVE);
 #pragma unroll
   for (int q = 0; q < 2; q++) {
-    const int r = lane + q * WAVE;
-    ra[q] = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rr, r * 2, 0, 0);
-    const int rnext = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rr, r * 2 + 2, 0, 0);
-    re[q] = (r + 1 < nr) ? rnext : (r < nr ? nb : 0);       // no row: ra = re = 0, nothing to sum
+    ra[q] = 0; re[q] = 0;
+    if (q == 0 || two) {
+      const int r = lane + q * WAVE;
+      ra[q] = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rr, r * 2, 0, 0);
+      const int rnext = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rr, r * 2 + 2, 0, 0);
+      re[q] = (r + 1 < nr) ? rnext : (r < nr ? nb : 0);       // no row: ra = re = 0, nothing to sum
+    }
   }
   // gather x for the whole block
   double xx[EPL];
@@ -155,8 +160,9 @@ __device__ __forceinline__ void rb_block(const RbView& A, const XVec<DIST> x, do
 #pragma unroll
     for (int u = 0; u < EPL; u++) xx[u] = x.at_byte_offset(ix[u] << 3);           // raw block: absolute columns
   }
-#pragma unroll
-  for (int q = 0; q < 2; q++) pre[q] = epi.load(d.r0, nr, lane + q * WAVE, early[q]);
+  pre[0] = epi.load(d.r0, nr, lane, early[0]);
+  pre[1] = pre[0];
+  if (two) pre[1] = epi.load(d.r0, nr, lane + WAVE, early[1]);
   if (nb <= BLK_NNZ) {
     // phase 1: products to their row-major positions (1-based; position 0 is the dummy slot of padding lanes)
     if (sorted) {
@@ -171,6 +177,7 @@ __device__ __forceinline__ void rb_block(const RbView& A, const XVec<DIST> x, do
       // phase 2: one lane per row, column order
 #pragma unroll
       for (int q = 0; q < 2; q++) {
+        if (q == 1 && !two) break;
         double s = 0.0;
         for (int j = ra[q]; j < re[q]; j++) s += lds[j + 1];
         epi.store(d.r0, nr, lane + q * WAVE, s, pre[q]);
