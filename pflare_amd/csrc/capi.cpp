@@ -1016,11 +1016,17 @@ int airhip_pcinv_set_option(airhip_pcinv pc, const char* name, const char* value
   else if (k == "matrix_free") pc->matrix_free = parse_bool(v);
   else if (k == "diag_scale") pc->diag_scale = parse_bool(v);
   else if (k == "seed") pc->seed = (uint64_t)std::atoll(v);
+  else if (k == "setup_on_device") pc->inner.setup_on_device = parse_bool(v);
+  else if (k == "setup_device_min_nnz") pc->inner.setup_device_min_nnz = std::atoll(v);
   else { g_err = "unknown option -pc_pflareinv_" + k; return AIRHIP_ERR_ARG; }
   API_END
 }
 
-static void pcinv_build_host(airhip_pcinv pc, const Csr& A) {
+static void pcinv_build_host(airhip_pcinv pc, const Csr& A, bool device_assist = false) {
+  // with a device: the fixed-sparsity polynomial assembly may run there (bit-identical; device/polyasm.hip)
+  std::unique_ptr<SetupAccel> accel;
+  if (device_assist && pc->inner.setup_on_device) accel = make_device_setup_accel(nullptr, pc->inner.setup_device_min_nnz);
+  struct Scope { SetupAccel* prev; explicit Scope(SetupAccel* a) : prev(g_setup_accel) { g_setup_accel = a; } ~Scope() { g_setup_accel = prev; } } scope(accel.get());
   auto H = std::make_unique<Hierarchy>();
   OpView v; v.A = &A; v.n = A.m;
   build_inverse(v, pc->type, pc->poly_order, pc->sparsity_order, pc->matrix_free, pc->diag_scale, pc->seed, H->coarse_inv, nullptr);
@@ -1038,7 +1044,7 @@ int airhip_pcinv_setup(airhip_pcinv pc, const airhip_csr* A) {
   }
   Csr view; view_csr(A, view);
   ThreadScope threads(A->rowptr[A->m]);
-  pcinv_build_host(pc, view);
+  pcinv_build_host(pc, view, true);
   view_csr(A, pc->inner.A_top);
   finish_device(&pc->inner);
   pc->inner.A_top = Csr();

@@ -1,0 +1,174 @@
+// Fixed-sparsity assembly of a GMRES polynomial inverse on the device (reference: the CPU routine
+// mat_mult_powers_share_sparsity_cpu src/Gmres_Poly.F90:920-1337 and its device twin src/Gmres_Polyk.kokkos.cxx):
+//
+//     M = c_0 I + c_1 A + sum_{t >= 2} c_t [A^t]_P ,      P = pattern(A)  (sparsity order 1, the default)
+//
+// where every power is truncated to P row by row:  row_i([A^t]_P) = sum_{j in P(i)} [A^(t-1)]_P(i,j) * A(j, P(i)).
+// One WAVE builds one row: P(i) sits in LDS with a small hash map column -> position, the previous power's row is a
+// vector over P(i); for j ascending the wave sweeps row j of A with its 64 lanes (distinct columns, so no two lanes
+// hit the same position in one step) and adds prev_j * A(j,c) to the position of c if c is in P(i).  Every entry is
+// therefore accumulated in exactly the order of the host code (host/poly.cpp: mat_mult_powers_share_sparsity), with
+// separate multiply and add roundings: the result is bit-identical (tests/test_gpu_setup.py).
+#include "dev.hpp"
+#include "kcommon.hpp"
+#include "rb.hpp"
+#include "spgemm.hpp"
+#include "polyasm.hpp"
+#include <vector>
+#include <stdexcept>
+#include <algorithm>
+
+namespace airhip {
+
+namespace {
+
+constexpr int MAXC = 16;                  // coefficients (polynomial order <= 15)
+struct Coefs { double c[MAXC]; int n; };
+constexpr int32_t EMPTYK = -1;
+
+__device__ __forceinline__ uint32_t hcol(int32_t c) { return (uint32_t)c * 2654435761u; }
+
+// rows per bin / diagonal presence: cnt[i] = len_i + (row i holds its diagonal ? 0 : 1)
+__global__ __launch_bounds__(BLOCK) void k_poly_count(int64_t m, const int64_t* __restrict__ rp, const int32_t* __restrict__ ci,
+                                                     int64_t* __restrict__ cnt) {
+  const int64_t stride = (int64_t)gridDim.x * BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < m; i += stride) {
+    int64_t lo = rp[i], hi = rp[i + 1];
+    const int64_t e = hi;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (ci[mid] < (int32_t)i) lo = mid + 1; else hi = mid; }
+    const bool has = lo < e && ci[lo] == (int32_t)i;
+    cnt[i] = (e - rp[i]) + (has ? 0 : 1);
+  }
+}
+
+// CAP: longest row the bin handles; HT = 2 * CAP hash slots.  WPB waves per workgroup.
+template <int CAP, int WPB>
+__global__ __launch_bounds__(WPB * WAVE) void k_poly_rows(int64_t nrows, const int32_t* __restrict__ rows, const int64_t* __restrict__ rp,
+                                                         const int32_t* __restrict__ ci, const double* __restrict__ v, Coefs cf,
+                                                         const int64_t* __restrict__ orp, int32_t* __restrict__ oci, double* __restrict__ ov) {
+#pragma clang fp contract(off)   // a*b + c rounds twice, as the host code does
+  constexpr int HT = 2 * CAP;
+  __shared__ int32_t s_cols[WPB][CAP];
+  __shared__ int32_t s_hkey[WPB][HT];
+  __shared__ uint16_t s_hpos[WPB][HT];
+  __shared__ double s_prev[WPB][CAP], s_cur[WPB][CAP], s_acc[WPB][CAP];
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1);
+  int32_t* cols = s_cols[wid]; int32_t* hkey = s_hkey[wid]; uint16_t* hpos = s_hpos[wid];
+  double* prev = s_prev[wid]; double* cur = s_cur[wid]; double* acc = s_acc[wid];
+  auto sync = [] { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+  const int64_t nw = (int64_t)gridDim.x * WPB;
+  for (int64_t w = (int64_t)blockIdx.x * WPB + wid; w < nrows; w += nw) {
+    const int64_t i = rows[w];
+    const int64_t p0 = rp[i];
+    const int nc = (int)(rp[i + 1] - p0);
+    // P(i), the previous power (= the row of A itself), the accumulator, the hash map
+    for (int h = lane; h < HT; h += WAVE) hkey[h] = EMPTYK;
+    for (int q = lane; q < nc; q += WAVE) { cols[q] = ci[p0 + q]; prev[q] = v[p0 + q]; acc[q] = 0.0; }
+    sync();
+    for (int q = lane; q < nc; q += WAVE) {
+      const int32_t c = cols[q];
+      uint32_t h = hcol(c) & (HT - 1);
+      for (;;) {
+        // the columns of a row are distinct: a plain compare-and-swap claims the slot
+        const int32_t old = atomicCAS(&hkey[h], EMPTYK, c);
+        if (old == EMPTYK) { hpos[h] = (uint16_t)q; break; }
+        h = (h + 1) & (HT - 1);
+      }
+    }
+    sync();
+    for (int term = 2; term < cf.n; term++) {
+      for (int q = lane; q < nc; q += WAVE) cur[q] = 0.0;
+      sync();
+      for (int j = 0; j < nc; j++) {
+        const double pj = prev[j];
+        const int64_t r = cols[j];
+        const int64_t a0 = rp[r], a1 = rp[r + 1];
+        for (int64_t a = a0 + lane; a < a1; a += WAVE) {
+          const int32_t c = ci[a];
+          uint32_t h = hcol(c) & (HT - 1);
+          for (;;) {
+            const int32_t k = hkey[h];
+            if (k == c) { const int b = hpos[h]; cur[b] += pj * v[a]; break; }
+            if (k == EMPTYK) break;
+            h = (h + 1) & (HT - 1);
+          }
+        }
+        sync();    // the next j may hit the same positions
+      }
+      const double ct = cf.c[term];
+      if (ct != 0.0) for (int q = lane; q < nc; q += WAVE) acc[q] += ct * cur[q];
+      for (int q = lane; q < nc; q += WAVE) prev[q] = cur[q];
+      sync();
+    }
+    // row of M: pattern P(i) plus the diagonal; value = A_ik * c_1 (+ c_0 on the diagonal) + acc
+    const int64_t o = orp[i];
+    const bool grows = (int)(orp[i + 1] - o) != nc;          // the diagonal is not in P(i)
+    int d = 0;                                               // its insertion position
+    if (grows) {
+      for (int q = lane; q < nc; q += WAVE) d += cols[q] < (int32_t)i ? 1 : 0;
+      for (int off = 32; off > 0; off >>= 1) d += __shfl_xor(d, off, WAVE);
+    }
+    for (int q = lane; q < nc; q += WAVE) {
+      const int32_t c = cols[q];
+      double t = v[p0 + q] * cf.c[1];
+      if (c == (int32_t)i) t = t + cf.c[0];
+      t = t + acc[q];
+      const int64_t pos = o + q + ((grows && q >= d) ? 1 : 0);
+      oci[pos] = c; ov[pos] = t;
+    }
+    if (grows && lane == 0) { oci[o + d] = (int32_t)i; ov[o + d] = 0.0 * cf.c[1] + cf.c[0]; }
+    sync();
+  }
+}
+
+template <class T> T* dalloc(int64_t n) { T* p = nullptr; HIP_CHECK(hipMalloc(&p, sizeof(T) * (size_t)(n > 0 ? n : 1))); return p; }
+
+}  // namespace
+
+bool dev_poly_assemble(const DCsr& A, const double* c, int nterms, DCsr& M, hipStream_t s) {
+  if (nterms < 3 || nterms > MAXC || A.m != A.n) return false;
+  const int64_t m = A.m;
+  // row lengths decide the bins; a row longer than the large bin's capacity sends the whole matrix back to the host
+  std::vector<int64_t> rp(m + 1);
+  HIP_CHECK(hipMemcpyAsync(rp.data(), A.rp, sizeof(int64_t) * (size_t)(m + 1), hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  std::vector<int32_t> small, big;
+  small.reserve(m);
+  for (int64_t i = 0; i < m; i++) {
+    const int64_t len = rp[i + 1] - rp[i];
+    if (len > 1024) return false;
+    (len <= 128 ? small : big).push_back((int32_t)i);
+  }
+  Coefs cf; cf.n = nterms;
+  for (int k = 0; k < MAXC; k++) cf.c[k] = k < nterms ? c[k] : 0.0;
+  M = DCsr(); M.m = m; M.n = m;
+  int64_t* cnt = dalloc<int64_t>(m);
+  M.rp = dalloc<int64_t>(m + 1);
+  const int g1 = (int)std::max<int64_t>(1, std::min<int64_t>((m + BLOCK - 1) / BLOCK, 65535));
+  hipLaunchKernelGGL(k_poly_count, dim3(g1), dim3(BLOCK), 0, s, m, A.rp, A.ci, cnt);
+  M.nnz = device_exclusive_scan(m, cnt, M.rp, s);
+  HIP_CHECK(hipMemcpyAsync(M.rp + m, &M.nnz, sizeof(int64_t), hipMemcpyHostToDevice, s));
+  (void)hipFree(cnt);
+  M.ci = dalloc<int32_t>(M.nnz); M.v = dalloc<double>(M.nnz);
+  int32_t* d_small = dalloc<int32_t>((int64_t)small.size());
+  int32_t* d_big = dalloc<int32_t>((int64_t)big.size());
+  if (!small.empty()) HIP_CHECK(hipMemcpyAsync(d_small, small.data(), sizeof(int32_t) * small.size(), hipMemcpyHostToDevice, s));
+  if (!big.empty()) HIP_CHECK(hipMemcpyAsync(d_big, big.data(), sizeof(int32_t) * big.size(), hipMemcpyHostToDevice, s));
+  if (!small.empty()) {
+    const int64_t wgs = std::min<int64_t>(((int64_t)small.size() + 3) / 4, 256 * 16);
+    hipLaunchKernelGGL((k_poly_rows<128, 4>), dim3((unsigned)wgs), dim3(4 * WAVE), 0, s, (int64_t)small.size(), d_small, A.rp, A.ci, A.v, cf,
+                       M.rp, M.ci, M.v);
+  }
+  if (!big.empty()) {
+    const int64_t wgs = std::min<int64_t>((int64_t)big.size(), 256 * 4);
+    hipLaunchKernelGGL((k_poly_rows<1024, 1>), dim3((unsigned)wgs), dim3(WAVE), 0, s, (int64_t)big.size(), d_big, A.rp, A.ci, A.v, cf, M.rp,
+                       M.ci, M.v);
+  }
+  HIP_CHECK(hipStreamSynchronize(s));
+  const hipError_t e = hipGetLastError();
+  (void)hipFree(d_small); (void)hipFree(d_big);
+  if (e != hipSuccess) throw std::runtime_error(std::string("HIP error ") + hipGetErrorString(e) + " in the device polynomial assembly");
+  return true;
+}
+
+}  // namespace airhip

@@ -6,6 +6,7 @@
 #include "dev.hpp"
 #include "spgemm.hpp"
 #include "cfsplit_dev.hpp"
+#include "polyasm.hpp"
 #include "../host/air.hpp"
 #include <cmath>
 #include <cstdlib>
@@ -63,6 +64,20 @@ struct DevSetupAccel final : SetupAccel {
     dev_cf_splitting_pmisr_ddc(resident, o.strong_threshold, !o.symmetric, o.max_luby_steps, rng_key(o.seed), o.ddc_its,
                                o.ddc_fraction, markers.data(), stream);
     t_cfsplit += now_s() - t0;
+    return true;
+  }
+
+  bool poly_assemble(const Csr& A, const std::vector<double>& c, Csr& M) override {
+    static const bool enabled = [] { const char* e = std::getenv("AIRHIP_DEVICE_POLY"); return !(e && e[0] == '0'); }();
+    if (!enabled || A.nnz() < min_nnz || c.size() < 3) return false;
+    DCsr dA = up(A), dM;
+    const double t0 = now_s();
+    const bool ok = dev_poly_assemble(dA, c.data(), (int)c.size(), dM, stream);
+    t_poly += now_s() - t0;
+    dcsr_free(dA);
+    if (!ok) return false;
+    M = down(dM);
+    dcsr_free(dM);
     return true;
   }
 

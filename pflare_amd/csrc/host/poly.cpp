@@ -333,6 +333,8 @@ static int newton_spmv_count(const std::vector<double>& re, const std::vector<do
 // ---------------------------------------------------------------------------------------
 // Fixed-sparsity assembled polynomial (src/Gmres_Poly.F90:920-1337)
 // ---------------------------------------------------------------------------------------
+thread_local SetupAccel* g_setup_accel = nullptr;
+
 static void poly_diag_sparsity(const double* d, int64_t n, const std::vector<double>& c, InvOp& op) {
   // build_gmres_polynomial_inverse_0th_order_sparsity (Gmres_Poly.F90:1868-1928)
   op.kind = InvOp::DIAG; op.d.alloc(n);
@@ -572,7 +574,9 @@ static void build_gmres_polynomial_inverse(const OpView& A, int poly_order, cons
       }
   } else if (sparsity_order < poly_order) {
     op.kind = InvOp::ASSEMBLED;
-    op.mat = mat_mult_powers_share_sparsity(*As, c, sparsity_order);
+    // the default case (sparsity order 1) may run on the device, bit-identically (device/polyasm.hip)
+    if (!(sparsity_order == 1 && g_setup_accel && g_setup_accel->poly_assemble(*As, c, op.mat)))
+      op.mat = mat_mult_powers_share_sparsity(*As, c, sparsity_order);
   } else {
     // unconstrained: sum of true matrix powers
     op.kind = InvOp::ASSEMBLED;

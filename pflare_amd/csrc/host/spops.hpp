@@ -1,5 +1,6 @@
 // Sparse building blocks of the host setup (OpenMP, row-parallel, deterministic).
 #pragma once
+#include <vector>
 #include "common.hpp"
 
 namespace airhip {
@@ -62,8 +63,13 @@ struct SetupAccel {
   virtual bool cf_splitting(const Csr& A, const struct AirOptions& o, Arr<int32_t>& markers) {
     (void)A; (void)o; (void)markers; return false;
   }
-  double t_transfer = 0.0, t_compute = 0.0, t_cfsplit = 0.0;
+  // Assembled GMRES polynomial with the sparsity of A (sparsity order 1): M = c0 I + c1 A + sum c_t [A^t]_P
+  // (host/poly.cpp::mat_mult_powers_share_sparsity).  Returns false when it declines.
+  virtual bool poly_assemble(const Csr& A, const std::vector<double>& c, Csr& M) { (void)A; (void)c; (void)M; return false; }
+  double t_transfer = 0.0, t_compute = 0.0, t_cfsplit = 0.0, t_poly = 0.0;
 };
+// the accelerator the polynomial assembly may use (set by setup_air for its duration; null = host only)
+extern thread_local SetupAccel* g_setup_accel;
 
 void spmv(const Csr& A, const double* x, double* y);
 // y = (A x) ./ d

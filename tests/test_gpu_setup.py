@@ -175,3 +175,44 @@ def test_device_cf_splitting_on_the_coarse_operators_of_a_hierarchy_and_on_refer
         Fh, Ch = P.compute_cf_splitting(M)
         Fd, Cd = P.compute_cf_splitting(M, on_device=True)
         assert np.array_equal(Fh, Fd) and np.array_equal(Ch, Cd), M.shape
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# fixed-sparsity polynomial assembly on the device (csrc/device/polyasm.hip): bit-identical to host/poly.cpp, which
+# tests/test_host_setup.py checks against the oracle's restatement of src/Gmres_Poly.F90:920-1337
+POLY_CASES = [
+    ("adv2d_60_arnoldi6", dict(dim=2, M=60, N=60), dict(type="arnoldi", poly_order=6)),
+    ("advdiff2d_50_power4", dict(dim=2, M=50, N=50, alpha=0.1), dict(type="power", poly_order=4)),
+    ("diff3d_14_arnoldi6", dict(dim=3, M=14, N=14, P=14, u=0, v=0, w=0, alpha=1.0), dict(type="arnoldi", poly_order=6)),
+    ("diff2d_40_order2", dict(dim=2, M=40, N=40, u=0, v=0, alpha=1.0), dict(type="arnoldi", poly_order=2)),
+    ("diff2d_40_diag_scale", dict(dim=2, M=40, N=40, u=0, v=0, alpha=1.0), dict(type="arnoldi", poly_order=6, diag_scale=True)),
+]
+
+
+@pytest.mark.parametrize("name,gen,kw", POLY_CASES, ids=[c[0] for c in POLY_CASES])
+def test_device_polynomial_assembly_bitwise(gpu, name, gen, kw):
+    import pflare_amd as P
+    A = P.HostMat.adv_diff_fd(**gen)
+    n = A.shape[0]
+    pd = P.PCPFLAREINV(setup_device_min_nnz=0, **kw).setup(A)
+    ph = P.PCPFLAREINV(**kw).setup_host_only(A)
+    d, h = pd.get_inverse(n), ph.get_inverse(n)
+    assert d["kind"] == h["kind"] == 1          # assembled
+    _same(d["mat"], h["mat"], name)
+
+
+def test_device_polynomial_assembly_on_denser_operators(gpu):
+    """rows of a few hundred entries (the large bin), rows without a stored diagonal, empty rows"""
+    import pflare_amd as P
+    rng = np.random.default_rng(11)
+    n = 3000
+    A = (_rand(n, n, 30, 5) + sp.eye(n, format="csr") * 40.0).tolil()
+    for i in (3, 77, 500):                      # rows without a diagonal entry
+        A[i, i] = 0.0
+    A[1234, :] = 0.0                            # an empty row
+    A = A.tocsr(); A.eliminate_zeros(); A.sort_indices()
+    dense = sp.csr_matrix(rng.standard_normal((1, n)) * (rng.random((1, n)) < 0.12))
+    A = sp.vstack([A[:10], dense, A[11:]]).tocsr(); A.sort_indices()        # one row of ~360 entries
+    pd = P.PCPFLAREINV(type="power", poly_order=3, setup_device_min_nnz=0).setup(A)
+    ph = P.PCPFLAREINV(type="power", poly_order=3).setup_host_only(A)
+    _same(pd.get_inverse(n)["mat"], ph.get_inverse(n)["mat"], "dense rows")
