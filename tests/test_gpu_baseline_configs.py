@@ -38,3 +38,56 @@ def test_config2_adv2d_1000_truncation_keeps_the_iteration_count(gpu):
         out[name] = (res["its"], pc.num_levels)
     assert out["full"][0] == out["truncated"][0], out
     assert out["truncated"][1] < out["full"][1], out
+
+
+def _lcg(n):
+    import numpy as np
+    i = np.arange(n, dtype=np.uint64)
+    return (((np.uint64(1103515245) * (i + np.uint64(12345))) % np.uint64(2 ** 31)).astype(np.float64) / float(2 ** 30) - 1.0)
+
+
+def _parity_against_c_oracle(P, torch, A, pc, ksp_kw, max_it):
+    """V-cycle <= 1e-10 and identical GMRES iteration count / reason against oracle/air_oracle.c on the SAME hierarchy"""
+    import numpy as np
+    from oracle import c_oracle
+    n = A.shape[0]
+    ch = c_oracle.CHierarchy(pc)
+    x = _lcg(n)
+    z = torch.empty(n, dtype=torch.float64, device="cuda")
+    pc.apply(torch.from_numpy(x).cuda(), z)
+    zr = ch.vcycle(x)
+    assert np.linalg.norm(z.cpu().numpy() - zr) <= 1e-10 * np.linalg.norm(zr)
+    b = torch.zeros(n, dtype=torch.float64, device="cuda"); sol = torch.ones_like(b)
+    res = P.KSP(max_it=max_it, **ksp_kw).solve(b, sol, pc=pc)
+    _, its, reason, rn, _ = ch.ksp(A, np.zeros(n), np.ones(n), ksp_kw["ksp_type"], ksp_kw["pc_side"], rtol=ksp_kw["rtol"],
+                                   atol=ksp_kw.get("atol", 1e-50), max_it=max_it)
+    assert res["reason"] > 0 and res["its"] == its and res["reason"] == reason, (res, its, reason)
+    assert abs(res["rnorm"] - rn) <= 0.05 * max(rn, 1e-300)
+    return res
+
+
+def test_config3_3d_advection_mid_size_against_the_c_oracle(gpu):
+    """BASELINE config 3 (3D upwind advection, bench.py's recipe: -pc_air_a_lump + truncation + Newton coarse solver)
+    at 96^3 = 0.88 M DoF - a size at which the C/OpenMP oracle still checks it in a few seconds: V-cycle parity and
+    identical iteration count (the reference asks <= 4 iterations at 10^3 without truncation, tests/Makefile:543-545;
+    the truncated hierarchies need 8-12 from 96^3 to 464^3)"""
+    import torch
+    import pflare_amd as P
+    A = P.HostMat.adv_diff_fd(dim=3, M=96, N=96, P=96)
+    pc = P.PCAIR(a_lump=True, auto_truncate_start_level=1, auto_truncate_tol=1e-1, **NEWTON_COARSE).setup(A)
+    res = _parity_against_c_oracle(P, torch, A, pc, dict(ksp_type="gmres", pc_side="right", rtol=1e-10, atol=1e-50), 30)
+    assert res["its"] <= 12, res
+
+
+def test_config5_anisotropic_diffusion_neumann_smoother_against_the_c_oracle(gpu):
+    """BASELINE config 5 on one GPU: the reference's FD diffusion stencil (tests/adv_diff_fd.c:545-562) made anisotropic
+    with -L_z 0.01, -pc_air_inverse_type neumann assembled and matrix-free (tests/Makefile:398-402 options) at 80^3"""
+    import torch
+    import pflare_amd as P
+    A = P.HostMat.adv_diff_fd(dim=3, M=80, N=80, P=80, u=0, v=0, w=0, alpha=1.0, L_z=0.01)
+    its = {}
+    for mf in (False, True):
+        pc = P.PCAIR(inverse_type="neumann", a_drop=1e-3, matrix_free_polys=mf).setup(A)
+        res = _parity_against_c_oracle(P, torch, A, pc, dict(ksp_type="gmres", pc_side="left", rtol=1e-5), 60)
+        its[mf] = res["its"]
+    assert its[False] == its[True] or abs(its[False] - its[True]) <= 2, its

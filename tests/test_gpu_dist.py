@@ -21,6 +21,9 @@ CASES = {
                                                       coarsest_inverse_type="newton", coarsest_poly_order=10,
                                                       coarsest_matrix_free_polys=True), "box2d"),
     "advdiff2d_50_mf": (dict(dim=2, M=50, N=50, alpha=0.02), dict(matrix_free_polys=True), "block"),
+    # 640 k rows stored in a random order: the column span of almost every row block exceeds 2^19, so the distributed
+    # operands consist of RAW blocks (row-major, absolute columns, [owned | ghost] select per entry)
+    "adv2d_800_raw_blocks": (dict(dim=2, M=800, N=800), dict(a_lump=True, max_levels=6), "box2d"),
 }
 
 
@@ -54,7 +57,7 @@ def _worker(rank, world, port, case, out):
             owner = (D.box_owner(gen["M"], gen["N"], gen.get("P", 1), world) if kind != "block"
                      else D.block_owner(n, world))
             pcg = P.PCAIR(device_upload=False, **opts)
-            if case == "adv3d_24_lump":      # also exercise the locality hint through the partitioner
+            if case in ("adv3d_24_lump", "adv2d_800_raw_blocks"):      # the locality hint through the partitioner
                 pcg.set_ordering_hint(np.random.default_rng(9).permutation(n))
             pcg.setup(A)
         comm = D.StagedComm()
@@ -82,7 +85,10 @@ def _worker(rank, world, port, case, out):
             for g, zz, xx, *_ in got:
                 zf[g] = zz; xf[g] = xx
             # single-GPU reference through the same library
-            pcs = P.PCAIR(**opts); pcs.setup(A)
+            pcs = P.PCAIR(**opts)
+            if case == "adv2d_800_raw_blocks":
+                pcs.set_ordering_hint(np.random.default_rng(9).permutation(n))
+            pcs.setup(A)
             bs = torch.from_numpy(b).cuda(); zs = torch.empty_like(bs)
             pcs.apply(bs, zs)
             rs = torch.zeros_like(bs); xs = torch.ones_like(bs)
