@@ -84,7 +84,7 @@ template <bool GLOBAL> struct Tab {
 // Returns false if the table overflowed (row must be redone with a larger table).
 template <bool FILL, bool GLOBAL>
 __device__ __forceinline__ bool spgemm_row(const CsrView& A, const CsrView& B, int64_t i, const Tab<GLOBAL> tab, int HT,
-                                           const DropParams& dp, int64_t* count_out, const int64_t* out_rp,
+                                           const DropParams& dp, int64_t* count_out, int64_t out_base,
                                            int32_t* __restrict__ out_ci, double* __restrict__ out_v) {
 #pragma clang fp contract(off)   // a*b + c must round twice, as the host code does
   const int lane = threadIdx.x & (WAVE - 1);
@@ -264,9 +264,10 @@ __device__ __forceinline__ bool spgemm_row(const CsrView& A, const CsrView& B, i
       dsum = sacc;
     }
   }
-  if (!FILL) { if (lane == 0) *count_out = kept; return true; }
+  if (lane == 0) *count_out = kept;
+  if (!FILL) return true;
   // ---- write the row in column order
-  int64_t o = out_rp[i];
+  int64_t o = out_base;
   if (!dp.enabled) {
     for (int h = lane; h < nu; h += WAVE) { out_ci[o + h] = tab.ldk(h); out_v[o + h] = tab.ldv(h); }
     return true;
@@ -307,7 +308,7 @@ __device__ __forceinline__ bool spgemm_row(const CsrView& A, const CsrView& B, i
 template <int HT, bool FILL>
 __global__ __launch_bounds__(HT <= 1024 ? BLOCK : WAVE) void k_spgemm_lds(CsrView A, CsrView B, const int32_t* __restrict__ rows,
                                                                             int64_t nrows, DropParams dp, int64_t* __restrict__ cnt,
-                                                                            const int64_t* __restrict__ out_rp, int32_t* out_ci,
+                                                                            const int64_t* __restrict__ out_off, int32_t* out_ci,
                                                                             double* out_v, int32_t* __restrict__ failed) {
   constexpr int WPB = HT <= 1024 ? WAVES_PER_BLOCK : 1;
   __shared__ int32_t keys_all[WPB][HT];
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(HT <= 1024 ? BLOCK : WAVE) void k_spgemm_lds(CsrVie
   for (int64_t w = wave; w < nrows; w += nw) {
     const int64_t i = rows[w];
     const Tab<false> tab{keys_all[wid], vals_all[wid]};
-    const bool ok = spgemm_row<FILL, false>(A, B, i, tab, HT, dp, cnt + i, out_rp, out_ci, out_v);
+    const bool ok = spgemm_row<FILL, false>(A, B, i, tab, HT, dp, cnt + i, FILL ? out_off[w] : 0, out_ci, out_v);
     if (!ok && (threadIdx.x & 63) == 0) failed[w] = 1;
     __builtin_amdgcn_wave_barrier();
   }
@@ -329,14 +330,14 @@ template <bool FILL>
 __global__ __launch_bounds__(BLOCK) void k_spgemm_glb(CsrView A, CsrView B, const int32_t* __restrict__ rows, int64_t nrows,
                                                      const int64_t* __restrict__ tab_off, const int32_t* __restrict__ tab_size,
                                                      int32_t* keys_pool, double* vals_pool, DropParams dp, int64_t* __restrict__ cnt,
-                                                     const int64_t* __restrict__ out_rp, int32_t* out_ci, double* out_v,
+                                                     const int64_t* __restrict__ out_off, int32_t* out_ci, double* out_v,
                                                      int32_t* __restrict__ failed) {
   const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * BLOCK) >> 6;
   for (int64_t w = wave; w < nrows; w += nw) {
     const int64_t i = rows[w];
     const Tab<true> tab{keys_pool + tab_off[w], vals_pool + tab_off[w]};
-    const bool ok = spgemm_row<FILL, true>(A, B, i, tab, tab_size[w], dp, cnt + i, out_rp, out_ci, out_v);
+    const bool ok = spgemm_row<FILL, true>(A, B, i, tab, tab_size[w], dp, cnt + i, FILL ? out_off[w] : 0, out_ci, out_v);
     if (!ok && (threadIdx.x & 63) == 0) failed[w] = 1;
   }
 }
@@ -371,150 +372,196 @@ void dcsr_download(const DCsr& d, int64_t* rp, int32_t* ci, double* v) {
   }
 }
 
-// host-side exclusive scan helper on a downloaded count array (counts are m int64: cheap next
-// to the product itself)
-static int64_t scan_counts(std::vector<int64_t>& c) {
-  int64_t run = 0;
-  for (auto& x : c) { int64_t t = x; x = run; run += t; }
-  c.push_back(run);
-  return run;
+// rows of a chunk from the scratch pool (at src_off[w], cnt entries) to their final place (dst_off[w]); one wave per row
+__global__ __launch_bounds__(BLOCK) void k_compact_rows(int64_t nrows, const int64_t* __restrict__ src_off, const int64_t* __restrict__ dst_off,
+                                                       const int64_t* __restrict__ n_of, const int32_t* __restrict__ tci,
+                                                       const double* __restrict__ tv, int32_t* __restrict__ oci, double* __restrict__ ov) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * BLOCK) >> 6;
+  for (int64_t w = wave; w < nrows; w += nw) {
+    const int64_t a = src_off[w], o = dst_off[w], n = n_of[w];
+    for (int64_t k = lane; k < n; k += WAVE) { oci[o + k] = tci[a + k]; ov[o + k] = tv[a + k]; }
+  }
 }
 
+// One numeric pass (round 2; round 1 ran every product twice, once to count and once to fill): the rows are processed
+// in chunks of consecutive rows; a chunk's finished (sorted, filtered) rows go to a scratch pool at offsets given by
+// their upper bounds, the counts come back, and the chunk is compacted into its final, contiguous piece of C.  The
+// pieces are consecutive row ranges, so C is their concatenation.
 DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, bool lump, bool negate, hipStream_t s,
                 SpgemmStats* stats) {
   if (A.n != B.m) throw std::runtime_error("dev_spgemm: shape mismatch");
   static const bool trace = std::getenv("AIRHIP_SPGEMM_TRACE") != nullptr;
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t_begin = now();
-  double t_ub = 0, t_bin = 0, t_p1 = 0, t_scan = 0, t_p2 = 0;
   const int64_t m = A.m;
   DCsr C; C.m = m; C.n = B.n;
   C.rp = dmalloc<int64_t>(m + 1);
   if (m == 0) { int64_t z = 0; HIP_CHECK(hipMemcpy(C.rp, &z, sizeof(int64_t), hipMemcpyHostToDevice)); return C; }
   const CsrView av = cview(A), bv = cview(B);
-  DropParams dp{drop_enabled ? 1 : 0, tol, lump ? 1 : 0, negate ? 1 : 0, 0};
-  // ---- candidate upper bounds and binning (host side: m ints)
+  const DropParams dp{drop_enabled ? 1 : 0, tol, lump ? 1 : 0, negate ? 1 : 0, 0};
+  // ---- candidate upper bounds (host side: m ints)
   int64_t* d_ub = dmalloc<int64_t>(m);
   hipLaunchKernelGGL(k_row_ub, dim3(MAX_BLOCKS), dim3(BLOCK), 0, s, av, bv, d_ub);
   std::vector<int64_t> ub(m);
   HIP_CHECK(hipMemcpyAsync(ub.data(), d_ub, sizeof(int64_t) * (size_t)m, hipMemcpyDeviceToHost, s));
   HIP_CHECK(hipStreamSynchronize(s));
-  t_ub = now() - t_begin;
-  std::vector<int32_t> small, big;
-  small.reserve(m);
-  for (int64_t i = 0; i < m; i++) (ub[i] <= 768 ? small : big).push_back((int32_t)i);
-  int32_t* d_small = dmalloc<int32_t>((int64_t)small.size());
-  int32_t* d_big = dmalloc<int32_t>((int64_t)big.size());
-  if (!small.empty()) HIP_CHECK(hipMemcpyAsync(d_small, small.data(), sizeof(int32_t) * small.size(), hipMemcpyHostToDevice, s));
-  if (!big.empty()) HIP_CHECK(hipMemcpyAsync(d_big, big.data(), sizeof(int32_t) * big.size(), hipMemcpyHostToDevice, s));
-  int32_t* d_fail_s = dmalloc<int32_t>((int64_t)small.size());
-  int32_t* d_fail_b = dmalloc<int32_t>((int64_t)big.size());
-  HIP_CHECK(hipMemsetAsync(d_fail_s, 0, sizeof(int32_t) * std::max<size_t>(small.size(), 1), s));
-  HIP_CHECK(hipMemsetAsync(d_fail_b, 0, sizeof(int32_t) * std::max<size_t>(big.size(), 1), s));
+  (void)hipFree(d_ub);
+  const double t_ub = now() - t_begin;
+  // scratch capacity of a row: it cannot keep more entries than it has candidates, than its hash table holds, or than
+  // B has columns - plus one for a diagonal created by lumping
+  constexpr int64_t SMALL_UB = 768, SMALL_CAP = 1024 - 1024 / 8, BIG_CAP = 4096 - 4096 / 8;
+  auto cap_lds = [&](int64_t u) { return std::min<int64_t>(u, u <= SMALL_UB ? SMALL_CAP : BIG_CAP) + 1; };
+  const int64_t POOL = std::max<int64_t>(4ll << 20, std::min<int64_t>(512ll << 20, (A.nnz + B.nnz) * 2));   // entries (12 B each)
+  int32_t* pool_ci = dmalloc<int32_t>(POOL); double* pool_v = dmalloc<double>(POOL);
   int64_t* d_cnt = dmalloc<int64_t>(m + 1);
-
+  struct Piece { int64_t r0, r1, nnz; int32_t* ci; double* v; };
+  std::vector<Piece> pieces;
+  std::vector<int64_t> rp_host(m + 1);
+  rp_host[0] = 0;
+  int64_t n_small = 0, n_big = 0, n_huge = 0;
+  double t_kern = 0, t_compact = 0;
   auto grid_small = [&](size_t n) { int64_t b = ((int64_t)n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK; return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(b, 256 * 12))); };
   auto grid_big = [&](size_t n) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)n, 256 * 3))); };
 
-  if (trace && big.size() > 100000) {
-    // phase breakdown of the big-bin kernel (timing only; results are overwritten below)
-    const char* nm[5] = {"init only", "init+insert", "+compact", "+sort", "all"};
-    const int flag[5] = {1 | 2, 2, 4, 8, 0};
-    for (int v = 0; v < 5; v++) {
-      HIP_CHECK(hipStreamSynchronize(s));
-      const double t0 = now();
-      DropParams d2 = dp; d2.dbg = flag[v];
-      hipLaunchKernelGGL((k_spgemm_lds<4096, false>), grid_big(big.size()), dim3(WAVE), 0, s, av, bv, d_big, (int64_t)big.size(), d2, d_cnt,
-                         (const int64_t*)nullptr, (int32_t*)nullptr, (double*)nullptr, d_fail_b);
-      HIP_CHECK(hipStreamSynchronize(s));
-      std::printf("      big-bin %-12s %.3f s\n", nm[v], now() - t0);
+  std::vector<int32_t> small, big, fs, fb;
+  std::vector<int64_t> off_s, off_b, src_all, dst_all, n_all, cnt_h;
+  for (int64_t r0 = 0; r0 < m;) {
+    // ---- a chunk of consecutive rows whose scratch needs fit the pool
+    small.clear(); big.clear(); off_s.clear(); off_b.clear();
+    int64_t used = 0, r1 = r0;
+    while (r1 < m) {
+      const int64_t c = cap_lds(ub[r1]);
+      if (used + c > POOL && r1 > r0) break;
+      if (ub[r1] <= SMALL_UB) { small.push_back((int32_t)r1); off_s.push_back(used); } else { big.push_back((int32_t)r1); off_b.push_back(used); }
+      used += c; r1++;
     }
-    HIP_CHECK(hipMemsetAsync(d_fail_b, 0, sizeof(int32_t) * big.size(), s));
-  }
-  t_bin = now() - t_begin - t_ub;
-  // ---- pass 1: counts
-  if (!small.empty())
-    hipLaunchKernelGGL((k_spgemm_lds<1024, false>), grid_small(small.size()), dim3(BLOCK), 0, s, av, bv, d_small, (int64_t)small.size(),
-                       dp, d_cnt, (const int64_t*)nullptr, (int32_t*)nullptr, (double*)nullptr, d_fail_s);
-  if (!big.empty())
-    hipLaunchKernelGGL((k_spgemm_lds<4096, false>), grid_big(big.size()), dim3(WAVE), 0, s, av, bv, d_big, (int64_t)big.size(), dp, d_cnt,
-                       (const int64_t*)nullptr, (int32_t*)nullptr, (double*)nullptr, d_fail_b);
-  // rows that overflowed their LDS table -> global-memory tables
-  std::vector<int32_t> fs(small.size()), fb(big.size());
-  if (!small.empty()) HIP_CHECK(hipMemcpyAsync(fs.data(), d_fail_s, sizeof(int32_t) * fs.size(), hipMemcpyDeviceToHost, s));
-  if (!big.empty()) HIP_CHECK(hipMemcpyAsync(fb.data(), d_fail_b, sizeof(int32_t) * fb.size(), hipMemcpyDeviceToHost, s));
-  HIP_CHECK(hipStreamSynchronize(s));
-  std::vector<int32_t> huge;
-  for (size_t w = 0; w < fs.size(); w++) if (fs[w]) huge.push_back(small[w]);
-  for (size_t w = 0; w < fb.size(); w++) if (fb[w]) huge.push_back(big[w]);
-  int32_t* d_huge = nullptr; int64_t* d_toff = nullptr; int32_t* d_tsize = nullptr; int32_t* d_kpool = nullptr; double* d_vpool = nullptr;
-  int32_t* d_fail_h = nullptr;
-  if (!huge.empty()) {
-    std::vector<int64_t> toff(huge.size()); std::vector<int32_t> tsize(huge.size());
-    int64_t run = 0;
-    for (size_t w = 0; w < huge.size(); w++) {
-      int64_t want = 2 * std::min<int64_t>(ub[huge[w]], B.n) + 64;
-      int64_t cap = 8192; while (cap < want) cap <<= 1;
-      if (cap > 0x40000000ll) throw std::runtime_error("dev_spgemm: row too long");
-      toff[w] = run; tsize[w] = (int32_t)cap; run += cap;
+    if (used > POOL) throw std::runtime_error("dev_spgemm: scratch pool too small for one row");
+    const int64_t nrows = r1 - r0;
+    const double tk0 = now();
+    int32_t* d_small = dmalloc<int32_t>((int64_t)small.size()); int32_t* d_big = dmalloc<int32_t>((int64_t)big.size());
+    int64_t* d_off_s = dmalloc<int64_t>((int64_t)small.size()); int64_t* d_off_b = dmalloc<int64_t>((int64_t)big.size());
+    int32_t* d_fail_s = dmalloc<int32_t>((int64_t)small.size()); int32_t* d_fail_b = dmalloc<int32_t>((int64_t)big.size());
+    if (!small.empty()) {
+      HIP_CHECK(hipMemcpyAsync(d_small, small.data(), sizeof(int32_t) * small.size(), hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(d_off_s, off_s.data(), sizeof(int64_t) * small.size(), hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipMemsetAsync(d_fail_s, 0, sizeof(int32_t) * small.size(), s));
+      hipLaunchKernelGGL((k_spgemm_lds<1024, true>), grid_small(small.size()), dim3(BLOCK), 0, s, av, bv, d_small, (int64_t)small.size(), dp,
+                         d_cnt, d_off_s, pool_ci, pool_v, d_fail_s);
     }
-    d_huge = dmalloc<int32_t>((int64_t)huge.size()); d_toff = dmalloc<int64_t>((int64_t)huge.size());
-    d_tsize = dmalloc<int32_t>((int64_t)huge.size()); d_kpool = dmalloc<int32_t>(run); d_vpool = dmalloc<double>(run);
-    d_fail_h = dmalloc<int32_t>((int64_t)huge.size());
-    HIP_CHECK(hipMemcpy(d_huge, huge.data(), sizeof(int32_t) * huge.size(), hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemcpy(d_toff, toff.data(), sizeof(int64_t) * huge.size(), hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemcpy(d_tsize, tsize.data(), sizeof(int32_t) * huge.size(), hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemsetAsync(d_fail_h, 0, sizeof(int32_t) * huge.size(), s));
-    const unsigned gb = (unsigned)std::min<int64_t>(((int64_t)huge.size() + 3) / 4, 2048);
-    hipLaunchKernelGGL((k_spgemm_glb<false>), dim3(gb), dim3(BLOCK), 0, s, av, bv, d_huge, (int64_t)huge.size(), d_toff, d_tsize,
-                       d_kpool, d_vpool, dp, d_cnt, (const int64_t*)nullptr, (int32_t*)nullptr, (double*)nullptr, d_fail_h);
-    std::vector<int32_t> fh(huge.size());
-    HIP_CHECK(hipMemcpyAsync(fh.data(), d_fail_h, sizeof(int32_t) * fh.size(), hipMemcpyDeviceToHost, s));
+    if (!big.empty()) {
+      HIP_CHECK(hipMemcpyAsync(d_big, big.data(), sizeof(int32_t) * big.size(), hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(d_off_b, off_b.data(), sizeof(int64_t) * big.size(), hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipMemsetAsync(d_fail_b, 0, sizeof(int32_t) * big.size(), s));
+      hipLaunchKernelGGL((k_spgemm_lds<4096, true>), grid_big(big.size()), dim3(WAVE), 0, s, av, bv, d_big, (int64_t)big.size(), dp, d_cnt,
+                         d_off_b, pool_ci, pool_v, d_fail_b);
+    }
+    fs.assign(small.size(), 0); fb.assign(big.size(), 0);
+    if (!small.empty()) HIP_CHECK(hipMemcpyAsync(fs.data(), d_fail_s, sizeof(int32_t) * fs.size(), hipMemcpyDeviceToHost, s));
+    if (!big.empty()) HIP_CHECK(hipMemcpyAsync(fb.data(), d_fail_b, sizeof(int32_t) * fb.size(), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
-    for (int32_t f : fh) if (f) throw std::runtime_error("dev_spgemm: global hash table overflow");
+    // ---- rows that overflowed their LDS table: global-memory tables, their own scratch
+    std::vector<int32_t> huge;
+    for (size_t w = 0; w < fs.size(); w++) if (fs[w]) huge.push_back(small[w]);
+    for (size_t w = 0; w < fb.size(); w++) if (fb[w]) huge.push_back(big[w]);
+    std::sort(huge.begin(), huge.end());
+    int32_t* hpool_ci = nullptr; double* hpool_v = nullptr;
+    std::vector<int64_t> hoff(huge.size());
+    if (!huge.empty()) {
+      std::vector<int64_t> toff(huge.size()); std::vector<int32_t> tsize(huge.size());
+      int64_t run = 0, hrun = 0;
+      for (size_t w = 0; w < huge.size(); w++) {
+        const int64_t want = 2 * std::min<int64_t>(ub[huge[w]], B.n) + 64;
+        int64_t cap = 8192; while (cap < want) cap <<= 1;
+        if (cap > 0x40000000ll) throw std::runtime_error("dev_spgemm: row too long");
+        toff[w] = run; tsize[w] = (int32_t)cap; run += cap;
+        hoff[w] = hrun; hrun += std::min<int64_t>(ub[huge[w]], B.n) + 1;
+      }
+      int32_t* d_huge = dmalloc<int32_t>((int64_t)huge.size()); int64_t* d_toff = dmalloc<int64_t>((int64_t)huge.size());
+      int32_t* d_tsize = dmalloc<int32_t>((int64_t)huge.size()); int32_t* d_kpool = dmalloc<int32_t>(run); double* d_vpool = dmalloc<double>(run);
+      int32_t* d_fail_h = dmalloc<int32_t>((int64_t)huge.size()); int64_t* d_hoff = dmalloc<int64_t>((int64_t)huge.size());
+      hpool_ci = dmalloc<int32_t>(hrun); hpool_v = dmalloc<double>(hrun);
+      HIP_CHECK(hipMemcpy(d_huge, huge.data(), sizeof(int32_t) * huge.size(), hipMemcpyHostToDevice));
+      HIP_CHECK(hipMemcpy(d_toff, toff.data(), sizeof(int64_t) * huge.size(), hipMemcpyHostToDevice));
+      HIP_CHECK(hipMemcpy(d_tsize, tsize.data(), sizeof(int32_t) * huge.size(), hipMemcpyHostToDevice));
+      HIP_CHECK(hipMemcpy(d_hoff, hoff.data(), sizeof(int64_t) * huge.size(), hipMemcpyHostToDevice));
+      HIP_CHECK(hipMemsetAsync(d_fail_h, 0, sizeof(int32_t) * huge.size(), s));
+      const unsigned gb = (unsigned)std::min<int64_t>(((int64_t)huge.size() + 3) / 4, 2048);
+      hipLaunchKernelGGL((k_spgemm_glb<true>), dim3(gb), dim3(BLOCK), 0, s, av, bv, d_huge, (int64_t)huge.size(), d_toff, d_tsize, d_kpool,
+                         d_vpool, dp, d_cnt, d_hoff, hpool_ci, hpool_v, d_fail_h);
+      std::vector<int32_t> fh(huge.size());
+      HIP_CHECK(hipMemcpyAsync(fh.data(), d_fail_h, sizeof(int32_t) * fh.size(), hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+      (void)hipFree(d_huge); (void)hipFree(d_toff); (void)hipFree(d_tsize); (void)hipFree(d_kpool); (void)hipFree(d_vpool);
+      (void)hipFree(d_fail_h); (void)hipFree(d_hoff);
+      for (int32_t f : fh) if (f) throw std::runtime_error("dev_spgemm: global hash table overflow");
+      n_huge += (int64_t)huge.size();
+    }
+    n_small += (int64_t)small.size(); n_big += (int64_t)big.size();
+    t_kern += now() - tk0;
+    // ---- counts of the chunk, its row pointers, compaction into its piece of C
+    const double tc0 = now();
+    cnt_h.resize(nrows);
+    HIP_CHECK(hipMemcpyAsync(cnt_h.data(), d_cnt + r0, sizeof(int64_t) * (size_t)nrows, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    src_all.assign(nrows, 0); dst_all.assign(nrows, 0); n_all.assign(nrows, 0);
+    int64_t run = 0;
+    for (int64_t r = r0; r < r1; r++) { dst_all[r - r0] = run; n_all[r - r0] = cnt_h[r - r0]; run += cnt_h[r - r0]; rp_host[r + 1] = rp_host[r] + cnt_h[r - r0]; }
+    for (size_t w = 0; w < small.size(); w++) src_all[small[w] - r0] = off_s[w];
+    for (size_t w = 0; w < big.size(); w++) src_all[big[w] - r0] = off_b[w];
+    Piece pc{r0, r1, run, dmalloc<int32_t>(run), dmalloc<double>(run)};
+    int64_t* d_src = dmalloc<int64_t>(nrows); int64_t* d_dst = dmalloc<int64_t>(nrows); int64_t* d_n = dmalloc<int64_t>(nrows);
+    if (!huge.empty()) {
+      // the overflow rows come from their own pool: compact them first (their src offsets refer to hpool), then mask them
+      std::vector<int64_t> hs(huge.size()), hd(huge.size()), hn(huge.size());
+      for (size_t w = 0; w < huge.size(); w++) { hs[w] = hoff[w]; hd[w] = dst_all[huge[w] - r0]; hn[w] = n_all[huge[w] - r0]; n_all[huge[w] - r0] = 0; }
+      int64_t* d_hs = dmalloc<int64_t>((int64_t)huge.size()); int64_t* d_hd = dmalloc<int64_t>((int64_t)huge.size()); int64_t* d_hn = dmalloc<int64_t>((int64_t)huge.size());
+      HIP_CHECK(hipMemcpy(d_hs, hs.data(), sizeof(int64_t) * hs.size(), hipMemcpyHostToDevice));
+      HIP_CHECK(hipMemcpy(d_hd, hd.data(), sizeof(int64_t) * hd.size(), hipMemcpyHostToDevice));
+      HIP_CHECK(hipMemcpy(d_hn, hn.data(), sizeof(int64_t) * hn.size(), hipMemcpyHostToDevice));
+      const unsigned g = (unsigned)std::min<int64_t>(((int64_t)huge.size() + 3) / 4, 2048);
+      hipLaunchKernelGGL(k_compact_rows, dim3(g), dim3(BLOCK), 0, s, (int64_t)huge.size(), d_hs, d_hd, d_hn, hpool_ci, hpool_v, pc.ci, pc.v);
+      HIP_CHECK(hipStreamSynchronize(s));
+      (void)hipFree(d_hs); (void)hipFree(d_hd); (void)hipFree(d_hn); (void)hipFree(hpool_ci); (void)hipFree(hpool_v);
+    }
+    HIP_CHECK(hipMemcpyAsync(d_src, src_all.data(), sizeof(int64_t) * (size_t)nrows, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(d_dst, dst_all.data(), sizeof(int64_t) * (size_t)nrows, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(d_n, n_all.data(), sizeof(int64_t) * (size_t)nrows, hipMemcpyHostToDevice, s));
+    const unsigned g = (unsigned)std::max<int64_t>(1, std::min<int64_t>((nrows + 3) / 4, 4096));
+    hipLaunchKernelGGL(k_compact_rows, dim3(g), dim3(BLOCK), 0, s, nrows, d_src, d_dst, d_n, pool_ci, pool_v, pc.ci, pc.v);
+    HIP_CHECK(hipStreamSynchronize(s));
+    (void)hipFree(d_src); (void)hipFree(d_dst); (void)hipFree(d_n);
+    (void)hipFree(d_small); (void)hipFree(d_big); (void)hipFree(d_off_s); (void)hipFree(d_off_b); (void)hipFree(d_fail_s); (void)hipFree(d_fail_b);
+    pieces.push_back(pc);
+    t_compact += now() - tc0;
+    r0 = r1;
   }
-  t_p1 = now() - t_begin - t_ub - t_bin;
-  // ---- row pointers
-  std::vector<int64_t> cnt(m);
-  HIP_CHECK(hipMemcpyAsync(cnt.data(), d_cnt, sizeof(int64_t) * (size_t)m, hipMemcpyDeviceToHost, s));
+  (void)hipFree(pool_ci); (void)hipFree(pool_v); (void)hipFree(d_cnt);
+  // ---- C = concatenation of the pieces
+  C.nnz = rp_host[m];
+  HIP_CHECK(hipMemcpyAsync(C.rp, rp_host.data(), sizeof(int64_t) * (size_t)(m + 1), hipMemcpyHostToDevice, s));
+  if (pieces.size() == 1) { C.ci = pieces[0].ci; C.v = pieces[0].v; }
+  else {
+    C.ci = dmalloc<int32_t>(C.nnz); C.v = dmalloc<double>(C.nnz);
+    for (const Piece& pc : pieces) {
+      if (pc.nnz) {
+        HIP_CHECK(hipMemcpyAsync(C.ci + rp_host[pc.r0], pc.ci, sizeof(int32_t) * (size_t)pc.nnz, hipMemcpyDeviceToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(C.v + rp_host[pc.r0], pc.v, sizeof(double) * (size_t)pc.nnz, hipMemcpyDeviceToDevice, s));
+      }
+    }
+    HIP_CHECK(hipStreamSynchronize(s));
+    for (const Piece& pc : pieces) { (void)hipFree(pc.ci); (void)hipFree(pc.v); }
+  }
   HIP_CHECK(hipStreamSynchronize(s));
-  C.nnz = scan_counts(cnt);
-  HIP_CHECK(hipMemcpyAsync(C.rp, cnt.data(), sizeof(int64_t) * (size_t)(m + 1), hipMemcpyHostToDevice, s));
-  C.ci = dmalloc<int32_t>(C.nnz); C.v = dmalloc<double>(C.nnz);
-  t_scan = now() - t_begin - t_ub - t_bin - t_p1;
-  // ---- pass 2: fill (rows that overflowed in pass 1 are skipped here and done by the global kernel)
-  if (!huge.empty()) {
-    // remove the overflow rows from the LDS lists
-    std::vector<int32_t> s2, b2;
-    for (size_t w = 0; w < fs.size(); w++) if (!fs[w]) s2.push_back(small[w]);
-    for (size_t w = 0; w < fb.size(); w++) if (!fb[w]) b2.push_back(big[w]);
-    small.swap(s2); big.swap(b2);
-    if (!small.empty()) HIP_CHECK(hipMemcpyAsync(d_small, small.data(), sizeof(int32_t) * small.size(), hipMemcpyHostToDevice, s));
-    if (!big.empty()) HIP_CHECK(hipMemcpyAsync(d_big, big.data(), sizeof(int32_t) * big.size(), hipMemcpyHostToDevice, s));
-  }
-  if (!small.empty())
-    hipLaunchKernelGGL((k_spgemm_lds<1024, true>), grid_small(small.size()), dim3(BLOCK), 0, s, av, bv, d_small, (int64_t)small.size(),
-                       dp, d_cnt, C.rp, C.ci, C.v, d_fail_s);
-  if (!big.empty())
-    hipLaunchKernelGGL((k_spgemm_lds<4096, true>), grid_big(big.size()), dim3(WAVE), 0, s, av, bv, d_big, (int64_t)big.size(), dp, d_cnt,
-                       C.rp, C.ci, C.v, d_fail_b);
-  if (!huge.empty()) {
-    const unsigned gb = (unsigned)std::min<int64_t>(((int64_t)huge.size() + 3) / 4, 2048);
-    hipLaunchKernelGGL((k_spgemm_glb<true>), dim3(gb), dim3(BLOCK), 0, s, av, bv, d_huge, (int64_t)huge.size(), d_toff, d_tsize, d_kpool,
-                       d_vpool, dp, d_cnt, C.rp, C.ci, C.v, d_fail_h);
-  }
-  HIP_CHECK(hipStreamSynchronize(s));
-  t_p2 = now() - t_begin - t_ub - t_bin - t_p1 - t_scan;
   if (trace) {
     int64_t ubt = 0; for (int64_t i = 0; i < m; i++) ubt += ub[i];
-    std::printf("   [spgemm] m=%lld nnzA=%lld nnzB=%lld cand=%lld nnzC=%lld bins=%zu/%zu/%zu  ub %.3f bin %.3f pass1 %.3f scan %.3f pass2 %.3f s\n",
-                (long long)m, (long long)A.nnz, (long long)B.nnz, (long long)ubt, (long long)C.nnz, small.size(), big.size(), huge.size(),
-                t_ub, t_bin, t_p1, t_scan, t_p2);
+    std::printf("   [spgemm] m=%lld nnzA=%lld nnzB=%lld cand=%lld nnzC=%lld bins=%lld/%lld/%lld chunks=%zu  ub %.3f kernels %.3f compact %.3f total %.3f s\n",
+                (long long)m, (long long)A.nnz, (long long)B.nnz, (long long)ubt, (long long)C.nnz, (long long)n_small, (long long)n_big,
+                (long long)n_huge, pieces.size(), t_ub, t_kern, t_compact, now() - t_begin);
     std::fflush(stdout);
   }
-  if (stats) { stats->rows_small = (int64_t)small.size(); stats->rows_big = (int64_t)big.size(); stats->rows_global = (int64_t)huge.size(); }
-  (void)hipFree(d_ub); (void)hipFree(d_small); (void)hipFree(d_big); (void)hipFree(d_fail_s); (void)hipFree(d_fail_b); (void)hipFree(d_cnt);
-  if (d_huge) { (void)hipFree(d_huge); (void)hipFree(d_toff); (void)hipFree(d_tsize); (void)hipFree(d_kpool); (void)hipFree(d_vpool); (void)hipFree(d_fail_h); }
+  if (stats) { stats->rows_small = n_small; stats->rows_big = n_big; stats->rows_global = n_huge; }
   return C;
 }
 
