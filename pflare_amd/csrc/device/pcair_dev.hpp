@@ -2,6 +2,7 @@
 #pragma once
 #include "dev.hpp"
 #include "comm.hpp"
+#include "staged_copy.hpp"
 #include "../host/air.hpp"
 #include "../host/dist.hpp"
 #include <map>
@@ -21,7 +22,7 @@ struct DBuf {
   ~DBuf() { release(); }
   void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
   void alloc(int64_t n_) { release(); n = n_; HIP_CHECK(hipMalloc(&p, sizeof(T) * (size_t)(n_ > 0 ? n_ : 1))); }
-  void upload(const T* h, int64_t n_) { alloc(n_); if (n_ > 0) HIP_CHECK(hipMemcpy(p, h, sizeof(T) * (size_t)n_, hipMemcpyHostToDevice)); }
+  void upload(const T* h, int64_t n_) { alloc(n_); if (n_ > 0) staged_h2d(p, h, sizeof(T) * (size_t)n_); }
 };
 
 // Upload a host CSR and convert it to SELL-64 on the device (rows/cols optionally permuted).

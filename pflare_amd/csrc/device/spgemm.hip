@@ -15,6 +15,7 @@
 #include "dev.hpp"
 #include "kcommon.hpp"
 #include "spgemm.hpp"
+#include "staged_copy.hpp"
 #include <stdexcept>
 #include <algorithm>
 #include <chrono>
@@ -31,7 +32,7 @@ constexpr int32_t EMPTY = 0x7fffffff;   // sorts last
 struct CsrView { int64_t m, n; const int64_t* rp; const int32_t* ci; const double* v; };
 static CsrView cview(const DCsr& A) { return CsrView{A.m, A.n, A.rp, A.ci, A.v}; }
 
-struct DropParams { int enabled; double tol; int lump; int negate; int dbg; };
+struct DropParams { int enabled; double tol; int lump; int negate; };
 
 __device__ __forceinline__ uint32_t hash_col(int32_t c) { return (uint32_t)c * 2654435761u; }
 
@@ -79,14 +80,20 @@ template <bool GLOBAL> struct Tab {
   }
 };
 
+// where the finished rows go: a pool with a bump allocator (the rows end up in completion order; a gather pass puts
+// them in row order once all counts are known)
+struct RowPool { unsigned long long* cursor; int64_t capacity; int32_t* ci; double* v; int64_t* row_pos; };
+constexpr int ROW_OK = 0, ROW_TABLE_OVERFLOW = 1, ROW_POOL_FULL = 2;
+
 // One output row by one wave.  tab: table of HT entries owned by this wave (HT power of two).
-// Count mode stores the number of kept entries; fill mode writes them at out_rp[i].
-// Returns false if the table overflowed (row must be redone with a larger table).
-template <bool FILL, bool GLOBAL>
-__device__ __forceinline__ bool spgemm_row(const CsrView& A, const CsrView& B, int64_t i, const Tab<GLOBAL> tab, int HT,
-                                           const DropParams& dp, int64_t* count_out, int64_t out_base,
-                                           int32_t* __restrict__ out_ci, double* __restrict__ out_v) {
+// Stores the number of kept entries in *count_out, takes that many entries from the pool and writes the row there.
+// ROW_TABLE_OVERFLOW: the row must be redone with a larger table; ROW_POOL_FULL: with a fresh pool.
+template <bool GLOBAL>
+__device__ __forceinline__ int spgemm_row(const CsrView& A, const CsrView& B, int64_t i, const Tab<GLOBAL> tab, int HT,
+                                          const DropParams& dp, int64_t* count_out, const RowPool& pool) {
 #pragma clang fp contract(off)   // a*b + c must round twice, as the host code does
+  constexpr bool FILL = true;
+  int32_t* __restrict__ out_ci = pool.ci; double* __restrict__ out_v = pool.v;
   const int lane = threadIdx.x & (WAVE - 1);
   const uint32_t mask = (uint32_t)HT - 1;
   const unsigned long long lt = (1ull << lane) - 1ull;
@@ -100,7 +107,7 @@ __device__ __forceinline__ bool spgemm_row(const CsrView& A, const CsrView& B, i
   // The loads of PIPE steps are issued back to back before their insertions so that a wave keeps
   // PIPE x 12 B x 64 in flight (the kernel is latency-bound otherwise: LDS limits the occupancy).
   constexpr int PIPE = 8;
-  for (int64_t kb = a0; kb < a1 && !overflow && !(dp.dbg & 1); kb += WAVE) {
+  for (int64_t kb = a0; kb < a1 && !overflow; kb += WAVE) {
     // a chunk of A(i,:): lane t holds entry k = kb + t and the extent of B(j_t,:)
     const int64_t kk = kb + lane;
     const bool valid = kk < a1;
@@ -154,33 +161,9 @@ __device__ __forceinline__ bool spgemm_row(const CsrView& A, const CsrView& B, i
       }
     }
   }
-  if (overflow) return false;
-  if (!FILL && !dp.dbg) {
-    // count mode: the number of entries the filter keeps needs neither the compaction nor the sort - the row
-    // maximum, "is the diagonal kept / created" and the number of large off-diagonal entries are order-free
-    if (!dp.enabled) { if (lane == 0) *count_out = unique; return true; }
-    double mx = 0.0;
-    for (int h = lane; h < HT; h += WAVE) if (tab.ldk(h) != EMPTY) mx = fmax(mx, fabs(tab.ldv(h)));
-    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, WAVE));
-    const double tolc = dp.tol * mx;
-    bool have_diag = false, need_diag = false;
-    int cnt = 0;
-    for (int base = 0; base < HT; base += WAVE) {
-      const int32_t k = tab.ldk(base + lane);
-      const bool in = k != EMPTY;
-      const double v = in ? tab.ldv(base + lane) : 0.0;
-      const bool big = in && fabs(v) >= tolc;
-      const bool isd = in && k == (int32_t)i;
-      if (__any(isd && big)) have_diag = true;
-      if (__any(in && !big && (dp.lump || isd))) need_diag = true;
-      cnt += __popcll(__ballot(big && !isd));
-    }
-    if (lane == 0) *count_out = (int64_t)cnt + ((have_diag || need_diag) ? 1 : 0);
-    return true;
-  }
+  if (overflow) return ROW_TABLE_OVERFLOW;
   // ---- compact the used slots to the front of the table (in place, chunk by chunk)
   int nu = 0;
-  if (dp.dbg & 2) { if (lane == 0) *count_out = unique; return true; }
   for (int base = 0; base < HT; base += WAVE) {
     const int32_t k = tab.ldk(base + lane);
     const double v = tab.ldv(base + lane);
@@ -192,7 +175,6 @@ __device__ __forceinline__ bool spgemm_row(const CsrView& A, const CsrView& B, i
     nu += __popcll(bal);
     tab.sync();
   }
-  if (dp.dbg & 4) { if (lane == 0) *count_out = nu; return true; }
   int P2 = 64; while (P2 < nu) P2 <<= 1;
   for (int h = nu + lane; h < P2; h += WAVE) { tab.stk(h, EMPTY); tab.stv(h, 0.0); }
   tab.sync();
@@ -212,7 +194,6 @@ __device__ __forceinline__ bool spgemm_row(const CsrView& A, const CsrView& B, i
       }
       tab.sync();
     }
-  if (dp.dbg & 8) { if (lane == 0) *count_out = nu; return true; }
   // ---- filter (remove_small_from_sparse, relative to the row max incl. the diagonal)
   int64_t kept = nu;
   double dsum = 0.0; bool write_diag = false; double tol = 0.0;
@@ -264,13 +245,17 @@ __device__ __forceinline__ bool spgemm_row(const CsrView& A, const CsrView& B, i
       dsum = sacc;
     }
   }
-  if (lane == 0) *count_out = kept;
-  if (!FILL) return true;
+  // ---- a place in the pool
+  unsigned long long base = 0;
+  if (lane == 0) base = atomicAdd(pool.cursor, (unsigned long long)kept);
+  base = (unsigned long long)uniform64((int64_t)base);
+  if ((int64_t)base + kept > pool.capacity) return ROW_POOL_FULL;
+  if (lane == 0) { *count_out = kept; pool.row_pos[i] = (int64_t)base; }
   // ---- write the row in column order
-  int64_t o = out_base;
+  int64_t o = (int64_t)base;
   if (!dp.enabled) {
     for (int h = lane; h < nu; h += WAVE) { out_ci[o + h] = tab.ldk(h); out_v[o + h] = tab.ldv(h); }
-    return true;
+    return ROW_OK;
   }
   bool diag_written = !write_diag;
   for (int base = 0; base < nu; base += WAVE) {
@@ -302,14 +287,13 @@ __device__ __forceinline__ bool spgemm_row(const CsrView& A, const CsrView& B, i
     o += __popcll(kbal);
   }
   if (!diag_written && lane == 0) { out_ci[o] = (int32_t)i; out_v[o] = dsum; }
-  return true;
+  return ROW_OK;
 }
 
-template <int HT, bool FILL>
+template <int HT>
 __global__ __launch_bounds__(HT <= 1024 ? BLOCK : WAVE) void k_spgemm_lds(CsrView A, CsrView B, const int32_t* __restrict__ rows,
                                                                             int64_t nrows, DropParams dp, int64_t* __restrict__ cnt,
-                                                                            const int64_t* __restrict__ out_off, int32_t* out_ci,
-                                                                            double* out_v, int32_t* __restrict__ failed) {
+                                                                            RowPool pool, int32_t* __restrict__ status) {
   constexpr int WPB = HT <= 1024 ? WAVES_PER_BLOCK : 1;
   __shared__ int32_t keys_all[WPB][HT];
   __shared__ double vals_all[WPB][HT];
@@ -319,26 +303,24 @@ __global__ __launch_bounds__(HT <= 1024 ? BLOCK : WAVE) void k_spgemm_lds(CsrVie
   for (int64_t w = wave; w < nrows; w += nw) {
     const int64_t i = rows[w];
     const Tab<false> tab{keys_all[wid], vals_all[wid]};
-    const bool ok = spgemm_row<FILL, false>(A, B, i, tab, HT, dp, cnt + i, FILL ? out_off[w] : 0, out_ci, out_v);
-    if (!ok && (threadIdx.x & 63) == 0) failed[w] = 1;
+    const int st = spgemm_row<false>(A, B, i, tab, HT, dp, cnt + i, pool);
+    if (st != ROW_OK && (threadIdx.x & 63) == 0) status[w] = st;
     __builtin_amdgcn_wave_barrier();
   }
 }
 
 // rows that overflowed the LDS table: one wave per row with a private global-memory table
-template <bool FILL>
 __global__ __launch_bounds__(BLOCK) void k_spgemm_glb(CsrView A, CsrView B, const int32_t* __restrict__ rows, int64_t nrows,
                                                      const int64_t* __restrict__ tab_off, const int32_t* __restrict__ tab_size,
                                                      int32_t* keys_pool, double* vals_pool, DropParams dp, int64_t* __restrict__ cnt,
-                                                     const int64_t* __restrict__ out_off, int32_t* out_ci, double* out_v,
-                                                     int32_t* __restrict__ failed) {
+                                                     RowPool pool, int32_t* __restrict__ status) {
   const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * BLOCK) >> 6;
   for (int64_t w = wave; w < nrows; w += nw) {
     const int64_t i = rows[w];
     const Tab<true> tab{keys_pool + tab_off[w], vals_pool + tab_off[w]};
-    const bool ok = spgemm_row<FILL, true>(A, B, i, tab, tab_size[w], dp, cnt + i, FILL ? out_off[w] : 0, out_ci, out_v);
-    if (!ok && (threadIdx.x & 63) == 0) failed[w] = 1;
+    const int st = spgemm_row<true>(A, B, i, tab, tab_size[w], dp, cnt + i, pool);
+    if (st != ROW_OK && (threadIdx.x & 63) == 0) status[w] = st;
   }
 }
 
@@ -356,39 +338,48 @@ void dcsr_free(DCsr& A) {
 DCsr dcsr_upload(int64_t m, int64_t n, const int64_t* rp, const int32_t* ci, const double* v) {
   DCsr d; d.m = m; d.n = n; d.nnz = rp[m];
   d.rp = dmalloc<int64_t>(m + 1); d.ci = dmalloc<int32_t>(d.nnz); d.v = dmalloc<double>(d.nnz);
-  HIP_CHECK(hipMemcpy(d.rp, rp, sizeof(int64_t) * (size_t)(m + 1), hipMemcpyHostToDevice));
+  staged_h2d(d.rp, rp, sizeof(int64_t) * (size_t)(m + 1));
   if (d.nnz) {
-    HIP_CHECK(hipMemcpy(d.ci, ci, sizeof(int32_t) * (size_t)d.nnz, hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemcpy(d.v, v, sizeof(double) * (size_t)d.nnz, hipMemcpyHostToDevice));
+    staged_h2d(d.ci, ci, sizeof(int32_t) * (size_t)d.nnz);
+    staged_h2d(d.v, v, sizeof(double) * (size_t)d.nnz);
   }
   return d;
 }
 
 void dcsr_download(const DCsr& d, int64_t* rp, int32_t* ci, double* v) {
-  HIP_CHECK(hipMemcpy(rp, d.rp, sizeof(int64_t) * (size_t)(d.m + 1), hipMemcpyDeviceToHost));
+  staged_d2h(rp, d.rp, sizeof(int64_t) * (size_t)(d.m + 1));
   if (d.nnz) {
-    HIP_CHECK(hipMemcpy(ci, d.ci, sizeof(int32_t) * (size_t)d.nnz, hipMemcpyDeviceToHost));
-    HIP_CHECK(hipMemcpy(v, d.v, sizeof(double) * (size_t)d.nnz, hipMemcpyDeviceToHost));
+    staged_d2h(ci, d.ci, sizeof(int32_t) * (size_t)d.nnz);
+    staged_d2h(v, d.v, sizeof(double) * (size_t)d.nnz);
   }
 }
 
-// rows of a chunk from the scratch pool (at src_off[w], cnt entries) to their final place (dst_off[w]); one wave per row
-__global__ __launch_bounds__(BLOCK) void k_compact_rows(int64_t nrows, const int64_t* __restrict__ src_off, const int64_t* __restrict__ dst_off,
-                                                       const int64_t* __restrict__ n_of, const int32_t* __restrict__ tci,
-                                                       const double* __restrict__ tv, int32_t* __restrict__ oci, double* __restrict__ ov) {
+// host-side exclusive scan of a downloaded count array (m int64: cheap next to the product itself)
+static int64_t scan_counts(std::vector<int64_t>& c) {
+  int64_t run = 0;
+  for (auto& x : c) { int64_t t = x; x = run; run += t; }
+  c.push_back(run);
+  return run;
+}
+
+// the finished rows from their places in a pool to row order; one wave per row
+__global__ __launch_bounds__(BLOCK) void k_gather_rows(int64_t nrows, const int32_t* __restrict__ rows, const int64_t* __restrict__ row_pos,
+                                                      const int64_t* __restrict__ rp, const int32_t* __restrict__ pci,
+                                                      const double* __restrict__ pv, int32_t* __restrict__ oci, double* __restrict__ ov) {
   const int lane = threadIdx.x & (WAVE - 1);
   const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * BLOCK) >> 6;
   for (int64_t w = wave; w < nrows; w += nw) {
-    const int64_t a = src_off[w], o = dst_off[w], n = n_of[w];
-    for (int64_t k = lane; k < n; k += WAVE) { oci[o + k] = tci[a + k]; ov[o + k] = tv[a + k]; }
+    const int64_t i = rows ? (int64_t)rows[w] : w;
+    const int64_t a = row_pos[i], o = rp[i], n = rp[i + 1] - o;
+    for (int64_t k = lane; k < n; k += WAVE) { oci[o + k] = pci[a + k]; ov[o + k] = pv[a + k]; }
   }
 }
 
-// One numeric pass (round 2; round 1 ran every product twice, once to count and once to fill): the rows are processed
-// in chunks of consecutive rows; a chunk's finished (sorted, filtered) rows go to a scratch pool at offsets given by
-// their upper bounds, the counts come back, and the chunk is compacted into its final, contiguous piece of C.  The
-// pieces are consecutive row ranges, so C is their concatenation.
+// One numeric pass (round 2; round 1 ran every product twice, once to count and once to fill): every wave computes
+// its row, takes as many entries as the row keeps from a pool (atomic bump allocator) and writes the sorted, filtered
+// row there; once all counts are known a gather pass puts the rows in row order.  The pool is sized generously from
+// the free device memory; if it still fills up, the rows that found no place are redone with a fresh pool.
 DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, bool lump, bool negate, hipStream_t s,
                 SpgemmStats* stats) {
   if (A.n != B.m) throw std::runtime_error("dev_spgemm: shape mismatch");
@@ -400,8 +391,8 @@ DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, boo
   C.rp = dmalloc<int64_t>(m + 1);
   if (m == 0) { int64_t z = 0; HIP_CHECK(hipMemcpy(C.rp, &z, sizeof(int64_t), hipMemcpyHostToDevice)); return C; }
   const CsrView av = cview(A), bv = cview(B);
-  const DropParams dp{drop_enabled ? 1 : 0, tol, lump ? 1 : 0, negate ? 1 : 0, 0};
-  // ---- candidate upper bounds (host side: m ints)
+  const DropParams dp{drop_enabled ? 1 : 0, tol, lump ? 1 : 0, negate ? 1 : 0};
+  // ---- candidate upper bounds and binning (host side: m ints)
   int64_t* d_ub = dmalloc<int64_t>(m);
   hipLaunchKernelGGL(k_row_ub, dim3(MAX_BLOCKS), dim3(BLOCK), 0, s, av, bv, d_ub);
   std::vector<int64_t> ub(m);
@@ -409,156 +400,115 @@ DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, boo
   HIP_CHECK(hipStreamSynchronize(s));
   (void)hipFree(d_ub);
   const double t_ub = now() - t_begin;
-  // scratch capacity of a row: it cannot keep more entries than it has candidates, than its hash table holds, or than
-  // B has columns - plus one for a diagonal created by lumping
-  constexpr int64_t SMALL_UB = 768, SMALL_CAP = 1024 - 1024 / 8, BIG_CAP = 4096 - 4096 / 8;
-  auto cap_lds = [&](int64_t u) { return std::min<int64_t>(u, u <= SMALL_UB ? SMALL_CAP : BIG_CAP) + 1; };
-  const int64_t POOL = std::max<int64_t>(4ll << 20, std::min<int64_t>(512ll << 20, (A.nnz + B.nnz) * 2));   // entries (12 B each)
-  int32_t* pool_ci = dmalloc<int32_t>(POOL); double* pool_v = dmalloc<double>(POOL);
+  std::vector<int32_t> small, big, huge;
+  small.reserve(m);
+  int64_t ub_total = 0;
+  for (int64_t i = 0; i < m; i++) { (ub[i] <= 768 ? small : big).push_back((int32_t)i); ub_total += std::min<int64_t>(ub[i], B.n) + 1; }
   int64_t* d_cnt = dmalloc<int64_t>(m + 1);
-  struct Piece { int64_t r0, r1, nnz; int32_t* ci; double* v; };
-  std::vector<Piece> pieces;
-  std::vector<int64_t> rp_host(m + 1);
-  rp_host[0] = 0;
-  int64_t n_small = 0, n_big = 0, n_huge = 0;
-  double t_kern = 0, t_compact = 0;
+  int64_t* d_pos = dmalloc<int64_t>(m);
+  unsigned long long* d_cursor = dmalloc<unsigned long long>(1);
   auto grid_small = [&](size_t n) { int64_t b = ((int64_t)n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK; return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(b, 256 * 12))); };
   auto grid_big = [&](size_t n) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)n, 256 * 3))); };
-
-  std::vector<int32_t> small, big, fs, fb;
-  std::vector<int64_t> off_s, off_b, src_all, dst_all, n_all, cnt_h;
-  for (int64_t r0 = 0; r0 < m;) {
-    // ---- a chunk of consecutive rows whose scratch needs fit the pool
-    small.clear(); big.clear(); off_s.clear(); off_b.clear();
-    int64_t used = 0, r1 = r0;
-    while (r1 < m) {
-      const int64_t c = cap_lds(ub[r1]);
-      if (used + c > POOL && r1 > r0) break;
-      if (ub[r1] <= SMALL_UB) { small.push_back((int32_t)r1); off_s.push_back(used); } else { big.push_back((int32_t)r1); off_b.push_back(used); }
-      used += c; r1++;
-    }
-    if (used > POOL) throw std::runtime_error("dev_spgemm: scratch pool too small for one row");
-    const int64_t nrows = r1 - r0;
-    const double tk0 = now();
-    int32_t* d_small = dmalloc<int32_t>((int64_t)small.size()); int32_t* d_big = dmalloc<int32_t>((int64_t)big.size());
-    int64_t* d_off_s = dmalloc<int64_t>((int64_t)small.size()); int64_t* d_off_b = dmalloc<int64_t>((int64_t)big.size());
-    int32_t* d_fail_s = dmalloc<int32_t>((int64_t)small.size()); int32_t* d_fail_b = dmalloc<int32_t>((int64_t)big.size());
-    if (!small.empty()) {
-      HIP_CHECK(hipMemcpyAsync(d_small, small.data(), sizeof(int32_t) * small.size(), hipMemcpyHostToDevice, s));
-      HIP_CHECK(hipMemcpyAsync(d_off_s, off_s.data(), sizeof(int64_t) * small.size(), hipMemcpyHostToDevice, s));
-      HIP_CHECK(hipMemsetAsync(d_fail_s, 0, sizeof(int32_t) * small.size(), s));
-      hipLaunchKernelGGL((k_spgemm_lds<1024, true>), grid_small(small.size()), dim3(BLOCK), 0, s, av, bv, d_small, (int64_t)small.size(), dp,
-                         d_cnt, d_off_s, pool_ci, pool_v, d_fail_s);
-    }
-    if (!big.empty()) {
-      HIP_CHECK(hipMemcpyAsync(d_big, big.data(), sizeof(int32_t) * big.size(), hipMemcpyHostToDevice, s));
-      HIP_CHECK(hipMemcpyAsync(d_off_b, off_b.data(), sizeof(int64_t) * big.size(), hipMemcpyHostToDevice, s));
-      HIP_CHECK(hipMemsetAsync(d_fail_b, 0, sizeof(int32_t) * big.size(), s));
-      hipLaunchKernelGGL((k_spgemm_lds<4096, true>), grid_big(big.size()), dim3(WAVE), 0, s, av, bv, d_big, (int64_t)big.size(), dp, d_cnt,
-                         d_off_b, pool_ci, pool_v, d_fail_b);
-    }
-    fs.assign(small.size(), 0); fb.assign(big.size(), 0);
-    if (!small.empty()) HIP_CHECK(hipMemcpyAsync(fs.data(), d_fail_s, sizeof(int32_t) * fs.size(), hipMemcpyDeviceToHost, s));
-    if (!big.empty()) HIP_CHECK(hipMemcpyAsync(fb.data(), d_fail_b, sizeof(int32_t) * fb.size(), hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipStreamSynchronize(s));
-    // ---- rows that overflowed their LDS table: global-memory tables, their own scratch
-    std::vector<int32_t> huge;
-    for (size_t w = 0; w < fs.size(); w++) if (fs[w]) huge.push_back(small[w]);
-    for (size_t w = 0; w < fb.size(); w++) if (fb[w]) huge.push_back(big[w]);
-    std::sort(huge.begin(), huge.end());
-    int32_t* hpool_ci = nullptr; double* hpool_v = nullptr;
-    std::vector<int64_t> hoff(huge.size());
-    if (!huge.empty()) {
-      std::vector<int64_t> toff(huge.size()); std::vector<int32_t> tsize(huge.size());
-      int64_t run = 0, hrun = 0;
-      for (size_t w = 0; w < huge.size(); w++) {
-        const int64_t want = 2 * std::min<int64_t>(ub[huge[w]], B.n) + 64;
+  // run one list through a kernel and split it by outcome
+  auto run_list = [&](std::vector<int32_t>& rows, int kind, const RowPool& pool, std::vector<int32_t>& done, std::vector<int32_t>& overflow,
+                      std::vector<int32_t>& retry) {
+    if (rows.empty()) return;
+    int32_t* d_rows = dmalloc<int32_t>((int64_t)rows.size());
+    int32_t* d_st = dmalloc<int32_t>((int64_t)rows.size());
+    HIP_CHECK(hipMemcpyAsync(d_rows, rows.data(), sizeof(int32_t) * rows.size(), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemsetAsync(d_st, 0, sizeof(int32_t) * rows.size(), s));
+    int32_t* d_kpool = nullptr; double* d_vpool = nullptr; int64_t* d_toff = nullptr; int32_t* d_tsize = nullptr;
+    if (kind == 0) hipLaunchKernelGGL((k_spgemm_lds<1024>), grid_small(rows.size()), dim3(BLOCK), 0, s, av, bv, d_rows, (int64_t)rows.size(), dp, d_cnt, pool, d_st);
+    else if (kind == 1) hipLaunchKernelGGL((k_spgemm_lds<4096>), grid_big(rows.size()), dim3(WAVE), 0, s, av, bv, d_rows, (int64_t)rows.size(), dp, d_cnt, pool, d_st);
+    else {
+      std::vector<int64_t> toff(rows.size()); std::vector<int32_t> tsize(rows.size());
+      int64_t run = 0;
+      for (size_t w = 0; w < rows.size(); w++) {
+        const int64_t want = 2 * std::min<int64_t>(ub[rows[w]], B.n) + 64;
         int64_t cap = 8192; while (cap < want) cap <<= 1;
         if (cap > 0x40000000ll) throw std::runtime_error("dev_spgemm: row too long");
         toff[w] = run; tsize[w] = (int32_t)cap; run += cap;
-        hoff[w] = hrun; hrun += std::min<int64_t>(ub[huge[w]], B.n) + 1;
       }
-      int32_t* d_huge = dmalloc<int32_t>((int64_t)huge.size()); int64_t* d_toff = dmalloc<int64_t>((int64_t)huge.size());
-      int32_t* d_tsize = dmalloc<int32_t>((int64_t)huge.size()); int32_t* d_kpool = dmalloc<int32_t>(run); double* d_vpool = dmalloc<double>(run);
-      int32_t* d_fail_h = dmalloc<int32_t>((int64_t)huge.size()); int64_t* d_hoff = dmalloc<int64_t>((int64_t)huge.size());
-      hpool_ci = dmalloc<int32_t>(hrun); hpool_v = dmalloc<double>(hrun);
-      HIP_CHECK(hipMemcpy(d_huge, huge.data(), sizeof(int32_t) * huge.size(), hipMemcpyHostToDevice));
-      HIP_CHECK(hipMemcpy(d_toff, toff.data(), sizeof(int64_t) * huge.size(), hipMemcpyHostToDevice));
-      HIP_CHECK(hipMemcpy(d_tsize, tsize.data(), sizeof(int32_t) * huge.size(), hipMemcpyHostToDevice));
-      HIP_CHECK(hipMemcpy(d_hoff, hoff.data(), sizeof(int64_t) * huge.size(), hipMemcpyHostToDevice));
-      HIP_CHECK(hipMemsetAsync(d_fail_h, 0, sizeof(int32_t) * huge.size(), s));
-      const unsigned gb = (unsigned)std::min<int64_t>(((int64_t)huge.size() + 3) / 4, 2048);
-      hipLaunchKernelGGL((k_spgemm_glb<true>), dim3(gb), dim3(BLOCK), 0, s, av, bv, d_huge, (int64_t)huge.size(), d_toff, d_tsize, d_kpool,
-                         d_vpool, dp, d_cnt, d_hoff, hpool_ci, hpool_v, d_fail_h);
-      std::vector<int32_t> fh(huge.size());
-      HIP_CHECK(hipMemcpyAsync(fh.data(), d_fail_h, sizeof(int32_t) * fh.size(), hipMemcpyDeviceToHost, s));
+      d_toff = dmalloc<int64_t>((int64_t)rows.size()); d_tsize = dmalloc<int32_t>((int64_t)rows.size());
+      d_kpool = dmalloc<int32_t>(run); d_vpool = dmalloc<double>(run);
+      HIP_CHECK(hipMemcpyAsync(d_toff, toff.data(), sizeof(int64_t) * rows.size(), hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(d_tsize, tsize.data(), sizeof(int32_t) * rows.size(), hipMemcpyHostToDevice, s));
       HIP_CHECK(hipStreamSynchronize(s));
-      (void)hipFree(d_huge); (void)hipFree(d_toff); (void)hipFree(d_tsize); (void)hipFree(d_kpool); (void)hipFree(d_vpool);
-      (void)hipFree(d_fail_h); (void)hipFree(d_hoff);
-      for (int32_t f : fh) if (f) throw std::runtime_error("dev_spgemm: global hash table overflow");
-      n_huge += (int64_t)huge.size();
+      const unsigned gb = (unsigned)std::min<int64_t>(((int64_t)rows.size() + 3) / 4, 2048);
+      hipLaunchKernelGGL(k_spgemm_glb, dim3(gb), dim3(BLOCK), 0, s, av, bv, d_rows, (int64_t)rows.size(), d_toff, d_tsize, d_kpool, d_vpool, dp,
+                         d_cnt, pool, d_st);
     }
-    n_small += (int64_t)small.size(); n_big += (int64_t)big.size();
+    std::vector<int32_t> st(rows.size());
+    HIP_CHECK(hipMemcpyAsync(st.data(), d_st, sizeof(int32_t) * st.size(), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    for (size_t w = 0; w < rows.size(); w++) {
+      if (st[w] == ROW_OK) done.push_back(rows[w]);
+      else if (st[w] == ROW_TABLE_OVERFLOW) { if (kind == 2) throw std::runtime_error("dev_spgemm: global hash table overflow"); overflow.push_back(rows[w]); }
+      else retry.push_back(rows[w]);
+    }
+    (void)hipFree(d_rows); (void)hipFree(d_st);
+    if (d_kpool) { (void)hipFree(d_kpool); (void)hipFree(d_vpool); (void)hipFree(d_toff); (void)hipFree(d_tsize); }
+  };
+  struct Round { int32_t* ci; double* v; std::vector<int32_t> done; };
+  std::vector<Round> rounds;
+  int64_t n_small = (int64_t)small.size(), n_big = (int64_t)big.size(), n_huge = 0;
+  double t_kern = 0;
+  int64_t longest = 0;
+  for (int64_t i = 0; i < m; i++) longest = std::max<int64_t>(longest, std::min<int64_t>(ub[i], B.n) + 1);
+  while (!small.empty() || !big.empty() || !huge.empty()) {
+    // pool: a few times the inputs, never more than the sum of the bounds, never more than a third of the free memory
+    size_t mem_free = 0, mem_total = 0;
+    HIP_CHECK(hipMemGetInfo(&mem_free, &mem_total));
+    int64_t capacity = std::max<int64_t>(4 * (A.nnz + B.nnz) + (1 << 20), 2 * longest);
+    capacity = std::min<int64_t>(capacity, ub_total);
+    capacity = std::min<int64_t>(capacity, (int64_t)(mem_free / 3 / 12));
+    if (capacity < longest) throw std::runtime_error("dev_spgemm: not enough device memory for the output pool");
+    Round rd; rd.ci = dmalloc<int32_t>(capacity); rd.v = dmalloc<double>(capacity);
+    HIP_CHECK(hipMemsetAsync(d_cursor, 0, sizeof(unsigned long long), s));
+    const RowPool pool{d_cursor, capacity, rd.ci, rd.v, d_pos};
+    const double tk0 = now();
+    std::vector<int32_t> retry_s, retry_b, retry_h, over;
+    run_list(small, 0, pool, rd.done, over, retry_s);
+    run_list(big, 1, pool, rd.done, over, retry_b);
+    huge.insert(huge.end(), over.begin(), over.end());
+    n_huge += (int64_t)over.size();
+    std::vector<int32_t> over2;
+    run_list(huge, 2, pool, rd.done, over2, retry_h);
     t_kern += now() - tk0;
-    // ---- counts of the chunk, its row pointers, compaction into its piece of C
-    const double tc0 = now();
-    cnt_h.resize(nrows);
-    HIP_CHECK(hipMemcpyAsync(cnt_h.data(), d_cnt + r0, sizeof(int64_t) * (size_t)nrows, hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipStreamSynchronize(s));
-    src_all.assign(nrows, 0); dst_all.assign(nrows, 0); n_all.assign(nrows, 0);
-    int64_t run = 0;
-    for (int64_t r = r0; r < r1; r++) { dst_all[r - r0] = run; n_all[r - r0] = cnt_h[r - r0]; run += cnt_h[r - r0]; rp_host[r + 1] = rp_host[r] + cnt_h[r - r0]; }
-    for (size_t w = 0; w < small.size(); w++) src_all[small[w] - r0] = off_s[w];
-    for (size_t w = 0; w < big.size(); w++) src_all[big[w] - r0] = off_b[w];
-    Piece pc{r0, r1, run, dmalloc<int32_t>(run), dmalloc<double>(run)};
-    int64_t* d_src = dmalloc<int64_t>(nrows); int64_t* d_dst = dmalloc<int64_t>(nrows); int64_t* d_n = dmalloc<int64_t>(nrows);
-    if (!huge.empty()) {
-      // the overflow rows come from their own pool: compact them first (their src offsets refer to hpool), then mask them
-      std::vector<int64_t> hs(huge.size()), hd(huge.size()), hn(huge.size());
-      for (size_t w = 0; w < huge.size(); w++) { hs[w] = hoff[w]; hd[w] = dst_all[huge[w] - r0]; hn[w] = n_all[huge[w] - r0]; n_all[huge[w] - r0] = 0; }
-      int64_t* d_hs = dmalloc<int64_t>((int64_t)huge.size()); int64_t* d_hd = dmalloc<int64_t>((int64_t)huge.size()); int64_t* d_hn = dmalloc<int64_t>((int64_t)huge.size());
-      HIP_CHECK(hipMemcpy(d_hs, hs.data(), sizeof(int64_t) * hs.size(), hipMemcpyHostToDevice));
-      HIP_CHECK(hipMemcpy(d_hd, hd.data(), sizeof(int64_t) * hd.size(), hipMemcpyHostToDevice));
-      HIP_CHECK(hipMemcpy(d_hn, hn.data(), sizeof(int64_t) * hn.size(), hipMemcpyHostToDevice));
-      const unsigned g = (unsigned)std::min<int64_t>(((int64_t)huge.size() + 3) / 4, 2048);
-      hipLaunchKernelGGL(k_compact_rows, dim3(g), dim3(BLOCK), 0, s, (int64_t)huge.size(), d_hs, d_hd, d_hn, hpool_ci, hpool_v, pc.ci, pc.v);
-      HIP_CHECK(hipStreamSynchronize(s));
-      (void)hipFree(d_hs); (void)hipFree(d_hd); (void)hipFree(d_hn); (void)hipFree(hpool_ci); (void)hipFree(hpool_v);
-    }
-    HIP_CHECK(hipMemcpyAsync(d_src, src_all.data(), sizeof(int64_t) * (size_t)nrows, hipMemcpyHostToDevice, s));
-    HIP_CHECK(hipMemcpyAsync(d_dst, dst_all.data(), sizeof(int64_t) * (size_t)nrows, hipMemcpyHostToDevice, s));
-    HIP_CHECK(hipMemcpyAsync(d_n, n_all.data(), sizeof(int64_t) * (size_t)nrows, hipMemcpyHostToDevice, s));
-    const unsigned g = (unsigned)std::max<int64_t>(1, std::min<int64_t>((nrows + 3) / 4, 4096));
-    hipLaunchKernelGGL(k_compact_rows, dim3(g), dim3(BLOCK), 0, s, nrows, d_src, d_dst, d_n, pool_ci, pool_v, pc.ci, pc.v);
-    HIP_CHECK(hipStreamSynchronize(s));
-    (void)hipFree(d_src); (void)hipFree(d_dst); (void)hipFree(d_n);
-    (void)hipFree(d_small); (void)hipFree(d_big); (void)hipFree(d_off_s); (void)hipFree(d_off_b); (void)hipFree(d_fail_s); (void)hipFree(d_fail_b);
-    pieces.push_back(pc);
-    t_compact += now() - tc0;
-    r0 = r1;
+    const size_t left = retry_s.size() + retry_b.size() + retry_h.size();
+    if (left && rd.done.empty()) throw std::runtime_error("dev_spgemm: no progress (output pool too small)");
+    small.swap(retry_s); big.swap(retry_b); huge.swap(retry_h);
+    rounds.push_back(std::move(rd));
   }
-  (void)hipFree(pool_ci); (void)hipFree(pool_v); (void)hipFree(d_cnt);
-  // ---- C = concatenation of the pieces
-  C.nnz = rp_host[m];
-  HIP_CHECK(hipMemcpyAsync(C.rp, rp_host.data(), sizeof(int64_t) * (size_t)(m + 1), hipMemcpyHostToDevice, s));
-  if (pieces.size() == 1) { C.ci = pieces[0].ci; C.v = pieces[0].v; }
-  else {
-    C.ci = dmalloc<int32_t>(C.nnz); C.v = dmalloc<double>(C.nnz);
-    for (const Piece& pc : pieces) {
-      if (pc.nnz) {
-        HIP_CHECK(hipMemcpyAsync(C.ci + rp_host[pc.r0], pc.ci, sizeof(int32_t) * (size_t)pc.nnz, hipMemcpyDeviceToDevice, s));
-        HIP_CHECK(hipMemcpyAsync(C.v + rp_host[pc.r0], pc.v, sizeof(double) * (size_t)pc.nnz, hipMemcpyDeviceToDevice, s));
-      }
-    }
-    HIP_CHECK(hipStreamSynchronize(s));
-    for (const Piece& pc : pieces) { (void)hipFree(pc.ci); (void)hipFree(pc.v); }
-  }
+  // ---- row pointers, then the rows of every round into row order
+  const double tg0 = now();
+  std::vector<int64_t> cnt(m);
+  HIP_CHECK(hipMemcpyAsync(cnt.data(), d_cnt, sizeof(int64_t) * (size_t)m, hipMemcpyDeviceToHost, s));
   HIP_CHECK(hipStreamSynchronize(s));
+  C.nnz = scan_counts(cnt);
+  HIP_CHECK(hipMemcpyAsync(C.rp, cnt.data(), sizeof(int64_t) * (size_t)(m + 1), hipMemcpyHostToDevice, s));
+  C.ci = dmalloc<int32_t>(C.nnz); C.v = dmalloc<double>(C.nnz);
+  for (Round& rd : rounds) {
+    const int64_t nr = (int64_t)rd.done.size();
+    if (nr) {
+      int32_t* d_rows = nullptr;
+      if (rounds.size() > 1) {
+        d_rows = dmalloc<int32_t>(nr);
+        HIP_CHECK(hipMemcpyAsync(d_rows, rd.done.data(), sizeof(int32_t) * (size_t)nr, hipMemcpyHostToDevice, s));
+      }
+      const unsigned g = (unsigned)std::max<int64_t>(1, std::min<int64_t>((nr + 3) / 4, 8192));
+      hipLaunchKernelGGL(k_gather_rows, dim3(g), dim3(BLOCK), 0, s, nr, d_rows, d_pos, C.rp, rd.ci, rd.v, C.ci, C.v);
+      HIP_CHECK(hipStreamSynchronize(s));
+      if (d_rows) (void)hipFree(d_rows);
+    }
+    (void)hipFree(rd.ci); (void)hipFree(rd.v);
+  }
+  const double t_gather = now() - tg0;
+  (void)hipFree(d_cnt); (void)hipFree(d_pos); (void)hipFree(d_cursor);
   if (trace) {
-    int64_t ubt = 0; for (int64_t i = 0; i < m; i++) ubt += ub[i];
-    std::printf("   [spgemm] m=%lld nnzA=%lld nnzB=%lld cand=%lld nnzC=%lld bins=%lld/%lld/%lld chunks=%zu  ub %.3f kernels %.3f compact %.3f total %.3f s\n",
-                (long long)m, (long long)A.nnz, (long long)B.nnz, (long long)ubt, (long long)C.nnz, (long long)n_small, (long long)n_big,
-                (long long)n_huge, pieces.size(), t_ub, t_kern, t_compact, now() - t_begin);
+    std::printf("   [spgemm] m=%lld nnzA=%lld nnzB=%lld bound=%lld nnzC=%lld bins=%lld/%lld/%lld rounds=%zu  ub %.3f kernels %.3f gather %.3f total %.3f s\n",
+                (long long)m, (long long)A.nnz, (long long)B.nnz, (long long)ub_total, (long long)C.nnz, (long long)n_small, (long long)n_big,
+                (long long)n_huge, rounds.size(), t_ub, t_kern, t_gather, now() - t_begin);
     std::fflush(stdout);
   }
   if (stats) { stats->rows_small = n_small; stats->rows_big = n_big; stats->rows_global = n_huge; }
