@@ -95,12 +95,13 @@ int airhip_set_num_threads(int n, int* prev);
 
 /* ------------------------------------------------------------- tuning and inspection hooks
  * Declared so that nothing the library exports is hidden; NOT part of the stable ABI.
- * airhip_set_tuning: performance knobs of the kernels, process-wide.  Keys: "spmv_wg_per_cu" (workgroups per CU of
- *   the row-block SpMV grid, 0 = occupancy query), "spmv_pipeline" (0 = no cross-block prefetch; diagnostic).
+ * airhip_set_tuning: process-wide knobs for experiments and tests.  Keys: "spgemm_pool_entries" (caps the output pool
+ *   of the device SpGEMM at that many entries, 0 = sized from the operands; a small cap forces the multi-round path).
  * airhip_pcair_setup_host_only / airhip_pcinv_setup_host_only: build the hierarchy without touching a device (CPU-side
  *   tests of the setup, hierarchy export); apply / solve then fail with AIRHIP_ERR_STATE.
  * airhip_spgemm_filtered: C = filter(A*B) with the host (on_device = 0) or the device SpGEMM of the setup, drop / lump /
- *   negate as in the setup's Z and RAP products; stats[3] = rows per accumulator kind (LDS 1k, LDS 4k, global). */
+ *   negate as in the setup's Z and RAP products; stats[4] = rows per accumulator kind (registers, LDS 1k, LDS 4k,
+ *   global-memory table). */
 int airhip_set_tuning(const char* key, int value);
 
 /* ---------------------------------------------------------------- stand-alone CF splitting */

@@ -46,7 +46,8 @@ int airhip_set_device(int device) {
 int airhip_set_tuning(const char* key, int value) {
   API_BEGIN
   REQUIRE(key, AIRHIP_ERR_ARG, "null argument");
-  if (airhip::spmv_set_tuning(key, value) != 0) { g_err = std::string("unknown tuning key ") + key; return AIRHIP_ERR_ARG; }
+  if (std::string(key) == "spgemm_pool_entries") airhip::spgemm_set_pool_limit(value);
+  else if (airhip::spmv_set_tuning(key, value) != 0) { g_err = std::string("unknown tuning key ") + key; return AIRHIP_ERR_ARG; }
   API_END
 }
 
@@ -222,8 +223,8 @@ int airhip_hostmat_get(airhip_hostmat A, airhip_csr* view) {
   API_END
 }
 // Inspection hook (declared in the header, not part of the stable ABI): C = filter(A*B) with the host or the device SpGEMM of
-// the setup; stats = {rows in the 1k-entry LDS bin, rows in the 4k-entry LDS bin, rows redone
-// with a global-memory table}.
+// the setup; stats[4] = {rows accumulated in registers, rows in the 1k-entry LDS bin, rows in the 4k-entry LDS bin,
+// rows redone with a global-memory table}.
 int airhip_spgemm_filtered(const airhip_csr* A, const airhip_csr* B, int drop, double tol, int lump, int negate,
                                    int on_device, airhip_hostmat* out, int64_t* stats) {
   API_BEGIN
@@ -241,7 +242,7 @@ int airhip_spgemm_filtered(const airhip_csr* A, const airhip_csr* B, int drop, d
     h->A.rp.alloc(dc.m + 1); h->A.ci.alloc(dc.nnz); h->A.v.alloc(dc.nnz);
     dcsr_download(dc, h->A.rp.data(), h->A.ci.data(), h->A.v.data());
     dcsr_free(da); dcsr_free(db); dcsr_free(dc);
-    if (stats) { stats[0] = st.rows_small; stats[1] = st.rows_big; stats[2] = st.rows_global; }
+    if (stats) { stats[0] = st.rows_tiny; stats[1] = st.rows_small; stats[2] = st.rows_big; stats[3] = st.rows_global; }
   }
   *out = h;
   API_END

@@ -5,7 +5,8 @@
 //
 // One WAVE computes one output row.  The sparse accumulator is an open-addressing hash
 // table keyed by the column (LDS for the common case, a global-memory table for rows that
-// do not fit).  The rows of B are consumed one after the other (k ascending) with the 64
+// do not fit; rows with at most 64 candidates skip the table and are sorted in registers).
+// The rows of B are consumed one after the other (k ascending) with the 64
 // lanes spread over the entries of B(k,:), whose columns are distinct - so no two lanes ever
 // accumulate into the same key in the same step and every output entry is summed in exactly
 // the order of a sequential Gustavson accumulator.  The finished row is sorted by column
@@ -14,6 +15,7 @@
 // Results are therefore bit-identical to the host implementation (host/spops.cpp).
 #include "dev.hpp"
 #include "kcommon.hpp"
+#include "rb.hpp"
 #include "spgemm.hpp"
 #include "staged_copy.hpp"
 #include <stdexcept>
@@ -34,20 +36,41 @@ static CsrView cview(const DCsr& A) { return CsrView{A.m, A.n, A.rp, A.ci, A.v};
 
 struct DropParams { int enabled; double tol; int lump; int negate; };
 
-__device__ __forceinline__ uint32_t hash_col(int32_t c) { return (uint32_t)c * 2654435761u; }
+// Accumulator kinds.  ub_i = sum_k nnz(B(k,:)) bounds the candidates of row i:
+//   TINY   ub <= 64 (and <= 64 entries in A(i,:)): the candidates sit one per lane and are sorted in registers
+//   MID    ub <= 768: LDS hash table of <= 1024 slots, four waves (rows) per workgroup
+//   BIG    LDS hash table of 4096 slots, one wave per workgroup; rows with more than 3584 distinct columns overflow to
+//   GLOBAL a hash table in device memory
+constexpr int BIN_TINY = 0, BIN_MID = 1, BIN_BIG = 2, BIN_GLOBAL = 3;
+constexpr int TINY_MAX = 64, MID_MAX = 768, MID_HT = 1024, BIG_HT = 4096;
+__host__ __device__ inline int bin_of(int64_t ub, int64_t na) { return (ub <= TINY_MAX && na <= TINY_MAX) ? BIN_TINY : ub <= MID_MAX ? BIN_MID : BIN_BIG; }
 
-// per-row upper bound of candidates: ub_i = sum_k nnz(B(k,:))
-__global__ __launch_bounds__(BLOCK) void k_row_ub(CsrView A, CsrView B, int64_t* __restrict__ ub) {
+// what the bounds add up to (decides the pool size and which kernels run; no per-row list leaves the device)
+struct UbStats { unsigned long long total, longest, rows[3]; };
+
+// per-row upper bound of candidates
+__global__ __launch_bounds__(BLOCK) void k_row_ub(CsrView A, CsrView B, int64_t* __restrict__ ub, UbStats* __restrict__ st) {
   const int lane = threadIdx.x & (WAVE - 1);
   const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * BLOCK) >> 6;
+  unsigned long long tot = 0, longest = 0, rows[3] = {0, 0, 0};
   for (int64_t i = wave; i < A.m; i += nw) {
     int64_t s = 0;
-    for (int64_t k = A.rp[i] + lane; k < A.rp[i + 1]; k += WAVE) { const int32_t j = A.ci[k]; s += B.rp[j + 1] - B.rp[j]; }
+    const int64_t a0 = A.rp[i], a1 = A.rp[i + 1];
+    for (int64_t k = a0 + lane; k < a1; k += WAVE) { const int32_t j = A.ci[k]; s += B.rp[j + 1] - B.rp[j]; }
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
     if (lane == 0) ub[i] = s;
+    const unsigned long long c = (unsigned long long)(s < B.n ? s : B.n) + 1ull;
+    tot += c; longest = c > longest ? c : longest; rows[bin_of(s, a1 - a0)]++;
+  }
+  if (lane == 0) {
+    atomicAdd(&st->total, tot); atomicMax(&st->longest, longest);
+    for (int b = 0; b < 3; b++) if (rows[b]) atomicAdd(&st->rows[b], rows[b]);
   }
 }
+
+// the rows a kernel works on: an explicit list, or (rows == nullptr) every row of A whose bound puts it in `bin`
+struct RowSel { const int32_t* rows; int64_t nrows; const int64_t* ub; int bin; };
 
 // Table accessors.  LDS tables are touched with plain ds ops (one wave owns the table and the
 // wave executes its LDS instructions in order).  Global tables are touched only with relaxed
@@ -74,6 +97,12 @@ template <bool GLOBAL> struct Tab {
                                          GLOBAL ? __HIP_MEMORY_SCOPE_AGENT : __HIP_MEMORY_SCOPE_WAVEFRONT);
     return expected;   // EMPTY if we claimed the slot, else the resident key
   }
+  // vals[h] += x, one rounding.  LDS: ds_add_f64 without a return value - the wave does not wait for it, and since a
+  // wave's LDS instructions execute in order, additions to one slot land in the order they were issued.
+  __device__ __forceinline__ void add(int h, double x) const {
+    if (GLOBAL) stv(h, ldv(h) + x);
+    else (void)__hip_atomic_fetch_add(&vals[h], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  }
   __device__ __forceinline__ void sync() const {
     if (GLOBAL) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -85,29 +114,27 @@ template <bool GLOBAL> struct Tab {
 struct RowPool { unsigned long long* cursor; int64_t capacity; int32_t* ci; double* v; int64_t* row_pos; };
 constexpr int ROW_OK = 0, ROW_TABLE_OVERFLOW = 1, ROW_POOL_FULL = 2;
 
-// One output row by one wave.  tab: table of HT entries owned by this wave (HT power of two).
-// Stores the number of kept entries in *count_out, takes that many entries from the pool and writes the row there.
-// ROW_TABLE_OVERFLOW: the row must be redone with a larger table; ROW_POOL_FULL: with a fresh pool.
+// ---- accumulate, hash table: leaves the nu distinct columns of row i of A*B with their sums in tab[0, nu), sorted
+// by column; -1 = the table is too small for the row.  tab: HT slots owned by this wave (HT a power of two).
 template <bool GLOBAL>
-__device__ __forceinline__ int spgemm_row(const CsrView& A, const CsrView& B, int64_t i, const Tab<GLOBAL> tab, int HT,
-                                          const DropParams& dp, int64_t* count_out, const RowPool& pool) {
+__device__ __forceinline__ int hash_accumulate(const CsrView& A, const CsrView& B, int64_t i, const Tab<GLOBAL> tab, int HT, bool negate) {
 #pragma clang fp contract(off)   // a*b + c must round twice, as the host code does
-  constexpr bool FILL = true;
-  int32_t* __restrict__ out_ci = pool.ci; double* __restrict__ out_v = pool.v;
   const int lane = threadIdx.x & (WAVE - 1);
   const uint32_t mask = (uint32_t)HT - 1;
   const unsigned long long lt = (1ull << lane) - 1ull;
   for (int h = lane; h < HT; h += WAVE) { tab.stk(h, EMPTY); tab.stv(h, 0.0); }
   tab.sync();
   int unique = 0;
-  bool overflow = false;
+  const int limit = HT - HT / 8;
   const int64_t a0 = A.rp[i], a1 = A.rp[i + 1];
-  // The candidate stream of the row is consumed in "steps": one step = up to 64 consecutive
-  // entries of one row B(j,:) (distinct columns -> conflict-free lanes), steps ordered by k.
-  // The loads of PIPE steps are issued back to back before their insertions so that a wave keeps
-  // PIPE x 12 B x 64 in flight (the kernel is latency-bound otherwise: LDS limits the occupancy).
+  // The candidate stream of the row is consumed in "steps": one step = up to 64 consecutive entries of one row
+  // B(j,:) (distinct columns -> conflict-free lanes), steps ordered by k.  PIPE steps form a batch: their loads are
+  // issued back to back, then their slots are looked up TOGETHER (every probe round issues the compare-and-swaps of
+  // all pending steps before it waits - the kernel is bound by LDS latency, not by LDS bandwidth), then the products
+  // are added in step order.  Which step claims a new column first does not matter (the row is sorted afterwards);
+  // the order of the additions does, and that is the order of issue.
   constexpr int PIPE = 8;
-  for (int64_t kb = a0; kb < a1 && !overflow; kb += WAVE) {
+  for (int64_t kb = a0; kb < a1; kb += WAVE) {
     // a chunk of A(i,:): lane t holds entry k = kb + t and the extent of B(j_t,:)
     const int64_t kk = kb + lane;
     const bool valid = kk < a1;
@@ -118,50 +145,53 @@ __device__ __forceinline__ int spgemm_row(const CsrView& A, const CsrView& B, in
     int incl = nch;                                   // inclusive scan of the step counts
     for (int off = 1; off < WAVE; off <<= 1) { const int t = __shfl_up(incl, off, WAVE); if (lane >= off) incl += t; }
     const int total = __shfl(incl, WAVE - 1, WAVE);
-    for (int s0 = 0; s0 < total && !overflow; s0 += PIPE) {
-      int32_t cc[PIPE]; double bv[PIPE], av[PIPE]; bool act[PIPE];
+    for (int s0 = 0; s0 < total; s0 += PIPE) {
+      int32_t cc[PIPE]; double x[PIPE]; bool act[PIPE], pend[PIPE]; uint32_t hh[PIPE], inc[PIPE];
 #pragma unroll
       for (int d = 0; d < PIPE; d++) {
         const int st = s0 + d;
-        act[d] = false; cc[d] = 0; bv[d] = 0.0; av[d] = 0.0;
+        act[d] = false; cc[d] = 0; x[d] = 0.0;
         if (st < total) {
           const int t = __ffsll((long long)__ballot(incl > st)) - 1;     // owner of step st
           const int64_t tb0 = __shfl(b0, t, WAVE), tb1 = __shfl(b1, t, WAVE);
           const int first = __shfl(incl, t, WAVE) - __shfl(nch, t, WAVE);
           const int64_t q = tb0 + (int64_t)(st - first) * WAVE + lane;
-          av[d] = __shfl(al, t, WAVE);
+          const double av = __shfl(al, t, WAVE);
           act[d] = q < tb1;
-          if (act[d]) { cc[d] = B.ci[q]; bv[d] = B.v[q]; }
+          if (act[d]) { cc[d] = B.ci[q]; x[d] = av * B.v[q]; }
         }
       }
 #pragma unroll
       for (int d = 0; d < PIPE; d++) {
-        if (s0 + d >= total || overflow) continue;
-        bool claimed = false, failed = false;
-        if (act[d]) {
-          const int32_t c = cc[d];
-          const double x = av[d] * bv[d];
-          uint32_t h = hash_col(c) & mask;
-          int probes = 0;
-          for (;;) {
-            const int32_t old = tab.cas((int)h, c);
-            if (old == EMPTY) claimed = true;
-            if (old == EMPTY || old == c) {
-              // the columns of B(j,:) are distinct: no other lane touches this slot in this step
-              tab.stv((int)h, tab.ldv((int)h) + x);
-              break;
-            }
-            h = (h + 1) & mask;
-            if (++probes >= HT) { failed = true; break; }
+        const uint32_t g = (uint32_t)cc[d] * 2654435761u;
+        hh[d] = (g ^ (g >> 15)) & mask;
+        inc[d] = ((((uint32_t)cc[d] * 0x85EBCA6Bu) >> 8) | 1u) & mask;      // odd: the probe sequence visits every slot
+        pend[d] = act[d];
+      }
+      int rounds = 0;
+      for (;;) {
+        int32_t old[PIPE];
+#pragma unroll
+        for (int d = 0; d < PIPE; d++) old[d] = pend[d] ? tab.cas((int)hh[d], cc[d]) : 0;
+        bool more = false;
+#pragma unroll
+        for (int d = 0; d < PIPE; d++) {
+          const bool claimed = pend[d] && old[d] == EMPTY;
+          unique += __popcll(__ballot(claimed));
+          if (pend[d]) {
+            if (old[d] == EMPTY || old[d] == cc[d]) pend[d] = false;
+            else { hh[d] = (hh[d] + inc[d]) & mask; more = true; }
           }
         }
-        unique += __popcll(__ballot(claimed));
-        if (__any(failed) || unique > (HT - HT / 8)) overflow = true;
-        tab.sync();
+        if (!__any(more)) break;
+        if (++rounds > HT || unique > limit) return -1;
       }
+      if (unique > limit) return -1;
+#pragma unroll
+      for (int d = 0; d < PIPE; d++) if (act[d]) tab.add((int)hh[d], x[d]);
+      tab.sync();
     }
   }
-  if (overflow) return ROW_TABLE_OVERFLOW;
   // ---- compact the used slots to the front of the table (in place, chunk by chunk)
   int nu = 0;
   for (int base = 0; base < HT; base += WAVE) {
@@ -171,7 +201,7 @@ __device__ __forceinline__ int spgemm_row(const CsrView& A, const CsrView& B, in
     const unsigned long long bal = __ballot(used);
     const int pos = nu + __popcll(bal & lt);
     tab.sync();
-    if (used) { tab.stk(pos, k); tab.stv(pos, dp.negate ? -v : v); }
+    if (used) { tab.stk(pos, k); tab.stv(pos, negate ? -v : v); }
     nu += __popcll(bal);
     tab.sync();
   }
@@ -194,6 +224,75 @@ __device__ __forceinline__ int spgemm_row(const CsrView& A, const CsrView& B, in
       }
       tab.sync();
     }
+  return nu;
+}
+
+__device__ __forceinline__ int lane_i32(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ int64_t lane_i64(int64_t v, int l) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(v & 0xffffffffll), l);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), l);
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+// ---- accumulate, registers: a row with at most 64 candidates (and at most 64 entries in A(i,:)).  Lane c holds
+// candidate c of the sequential Gustavson sweep; a bitonic sort over the lanes by (column, c) brings equal columns
+// together in sweep order, the first lane of every run adds the run up from left to right - the order of the host
+// code - and the run heads go to tab[0, nu) (sorted).
+__device__ __forceinline__ int tiny_accumulate(const CsrView& A, const CsrView& B, int64_t i, const Tab<false> tab, bool negate) {
+#pragma clang fp contract(off)
+  const int lane = threadIdx.x & (WAVE - 1);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const int64_t a0 = A.rp[i];
+  const int na = (int)(A.rp[i + 1] - a0);
+  double al = 0.0; int64_t b0 = 0; int nb = 0;
+  if (lane < na) { const int32_t j = A.ci[a0 + lane]; al = A.v[a0 + lane]; b0 = B.rp[j]; nb = (int)(B.rp[j + 1] - b0); }
+  int incl = nb;
+  for (int off = 1; off < WAVE; off <<= 1) { const int t = __shfl_up(incl, off, WAVE); if (lane >= off) incl += t; }
+  const int excl = incl - nb;
+  int64_t q = -1; double a = 0.0;
+  for (int e = 0; e < na; e++) {          // e is wave-uniform: the owner's values come through readlane
+    const int se = lane_i32(excl, e), ne = lane_i32(nb, e);
+    const int64_t be = lane_i64(b0, e);
+    const double ae = __longlong_as_double(lane_i64(__double_as_longlong(al), e));
+    if (lane >= se && lane < se + ne) { q = be + (lane - se); a = ae; }
+  }
+  int32_t col = EMPTY; double x = 0.0;
+  if (q >= 0) { col = B.ci[q]; x = a * B.v[q]; }
+  uint64_t key = ((uint64_t)(uint32_t)col << 6) | (uint32_t)lane;          // distinct keys: no ties
+#pragma unroll
+  for (int size = 2; size <= WAVE; size <<= 1)
+#pragma unroll
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      const uint64_t ok = (uint64_t)__shfl_xor((long long)key, stride, WAVE);
+      const double ox = __shfl_xor(x, stride, WAVE);
+      const bool want_min = ((lane & stride) == 0) == ((lane & size) == 0);
+      if (want_min ? ok < key : ok > key) { key = ok; x = ox; }
+    }
+  col = (int32_t)(key >> 6);
+  const int32_t prev = __shfl_up(col, 1, WAVE);
+  const bool head = col != EMPTY && (lane == 0 || prev != col);
+  double s = 0.0 + x;                                   // the accumulator of the host code starts from +0
+  for (int r = 1; r < WAVE; r++) {
+    const int32_t cn = __shfl_down(col, r, WAVE);
+    const double xn = __shfl_down(x, r, WAVE);
+    const bool same = head && lane + r < WAVE && cn == col;
+    if (!__any(same)) break;                            // runs are contiguous: no run reaches further either
+    if (same) s = s + xn;
+  }
+  const unsigned long long bal = __ballot(head);
+  if (head) { const int pos = __popcll(bal & lt); tab.stk(pos, col); tab.stv(pos, negate ? -s : s); }
+  tab.sync();
+  return __popcll(bal);
+}
+
+// ---- filter and write: tab[0, nu) holds the sorted row.  Stores the number of kept entries in *count_out, takes that
+// many entries from the pool and writes the row there.  ROW_POOL_FULL: the row must be redone with a fresh pool.
+template <bool GLOBAL>
+__device__ __forceinline__ int finish_row(const Tab<GLOBAL> tab, int nu, int64_t i, const DropParams& dp, int64_t* count_out, const RowPool& pool) {
+#pragma clang fp contract(off)
+  int32_t* __restrict__ out_ci = pool.ci; double* __restrict__ out_v = pool.v;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const unsigned long long lt = (1ull << lane) - 1ull;
   // ---- filter (remove_small_from_sparse, relative to the row max incl. the diagonal)
   int64_t kept = nu;
   double dsum = 0.0; bool write_diag = false; double tol = 0.0;
@@ -217,7 +316,7 @@ __device__ __forceinline__ int spgemm_row(const CsrView& A, const CsrView& B, in
     }
     write_diag = have_diag || need_diag;
     kept = cnt + (write_diag ? 1 : 0);
-    if (write_diag && FILL) {
+    if (write_diag) {
       // kept diagonal value first, then the removed entries in column order, added one after the other so that
       // the result is bit-identical to the sequential host code.  The table is read 64 slots at a time; only the
       // additions are sequential (every lane performs them on broadcast values, so the sum stays wave-uniform).
@@ -290,22 +389,52 @@ __device__ __forceinline__ int spgemm_row(const CsrView& A, const CsrView& B, in
   return ROW_OK;
 }
 
+// a row that found no table / no place: cnt[i] = -status, and the launch's failure counters go up
+__device__ __forceinline__ void report(int st, int64_t i, int64_t* __restrict__ cnt, unsigned int* __restrict__ fail) {
+  if (st != ROW_OK && (threadIdx.x & (WAVE - 1)) == 0) { cnt[i] = -(int64_t)st; atomicAdd(&fail[st - 1], 1u); }
+}
+
+// the smallest table (>= 128 slots, <= cap) that the row cannot fill beyond 3/4
+__device__ __forceinline__ int table_for(int64_t ub, int cap) {
+  int ht = 128;
+  while (ht < cap && (int64_t)ht * 3 < ub * 4) ht <<= 1;
+  return ht;
+}
+
 template <int HT>
-__global__ __launch_bounds__(HT <= 1024 ? BLOCK : WAVE) void k_spgemm_lds(CsrView A, CsrView B, const int32_t* __restrict__ rows,
-                                                                            int64_t nrows, DropParams dp, int64_t* __restrict__ cnt,
-                                                                            RowPool pool, int32_t* __restrict__ status) {
+__global__ __launch_bounds__(HT <= 1024 ? BLOCK : WAVE) void k_spgemm_lds(CsrView A, CsrView B, RowSel sel, DropParams dp, int64_t* __restrict__ cnt,
+                                                                            RowPool pool, unsigned int* __restrict__ fail) {
   constexpr int WPB = HT <= 1024 ? WAVES_PER_BLOCK : 1;
   __shared__ int32_t keys_all[WPB][HT];
   __shared__ double vals_all[WPB][HT];
   const int wid = threadIdx.x >> 6;
-  const int64_t wave = (int64_t)blockIdx.x * WPB + wid;
   const int64_t nw = (int64_t)gridDim.x * WPB;
-  for (int64_t w = wave; w < nrows; w += nw) {
-    const int64_t i = rows[w];
-    const Tab<false> tab{keys_all[wid], vals_all[wid]};
-    const int st = spgemm_row<false>(A, B, i, tab, HT, dp, cnt + i, pool);
-    if (st != ROW_OK && (threadIdx.x & 63) == 0) status[w] = st;
+  const int64_t count = sel.rows ? sel.nrows : A.m;
+  const Tab<false> tab{keys_all[wid], vals_all[wid]};
+  for (int64_t w = (int64_t)blockIdx.x * WPB + wid; w < count; w += nw) {
+    const int64_t i = sel.rows ? (int64_t)sel.rows[w] : w;
+    const int64_t ubi = sel.ub[i];
+    if (!sel.rows && bin_of(ubi, A.rp[i + 1] - A.rp[i]) != sel.bin) continue;
+    const int nu = hash_accumulate<false>(A, B, i, tab, table_for(ubi, HT), dp.negate != 0);
+    report(nu < 0 ? ROW_TABLE_OVERFLOW : finish_row<false>(tab, nu, i, dp, cnt + i, pool), i, cnt, fail);
     __builtin_amdgcn_wave_barrier();
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_spgemm_tiny(CsrView A, CsrView B, RowSel sel, DropParams dp, int64_t* __restrict__ cnt, RowPool pool,
+                                                      unsigned int* __restrict__ fail) {
+  __shared__ int32_t keys_all[WAVES_PER_BLOCK][WAVE];
+  __shared__ double vals_all[WAVES_PER_BLOCK][WAVE];
+  const int wid = threadIdx.x >> 6;
+  const int64_t nw = (int64_t)gridDim.x * WAVES_PER_BLOCK;
+  const int64_t count = sel.rows ? sel.nrows : A.m;
+  const Tab<false> tab{keys_all[wid], vals_all[wid]};
+  for (int64_t w = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wid; w < count; w += nw) {
+    const int64_t i = sel.rows ? (int64_t)sel.rows[w] : w;
+    if (!sel.rows && bin_of(sel.ub[i], A.rp[i + 1] - A.rp[i]) != BIN_TINY) continue;
+    const int nu = tiny_accumulate(A, B, i, tab, dp.negate != 0);
+    report(finish_row<false>(tab, nu, i, dp, cnt + i, pool), i, cnt, fail);
+    tab.sync();
   }
 }
 
@@ -313,20 +442,23 @@ __global__ __launch_bounds__(HT <= 1024 ? BLOCK : WAVE) void k_spgemm_lds(CsrVie
 __global__ __launch_bounds__(BLOCK) void k_spgemm_glb(CsrView A, CsrView B, const int32_t* __restrict__ rows, int64_t nrows,
                                                      const int64_t* __restrict__ tab_off, const int32_t* __restrict__ tab_size,
                                                      int32_t* keys_pool, double* vals_pool, DropParams dp, int64_t* __restrict__ cnt,
-                                                     RowPool pool, int32_t* __restrict__ status) {
+                                                     RowPool pool, unsigned int* __restrict__ fail) {
   const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * BLOCK) >> 6;
   for (int64_t w = wave; w < nrows; w += nw) {
     const int64_t i = rows[w];
     const Tab<true> tab{keys_pool + tab_off[w], vals_pool + tab_off[w]};
-    const int st = spgemm_row<true>(A, B, i, tab, tab_size[w], dp, cnt + i, pool);
-    if (st != ROW_OK && (threadIdx.x & 63) == 0) status[w] = st;
+    const int nu = hash_accumulate<true>(A, B, i, tab, tab_size[w], dp.negate != 0);
+    report(nu < 0 ? ROW_TABLE_OVERFLOW : finish_row<true>(tab, nu, i, dp, cnt + i, pool), i, cnt, fail);
   }
 }
 
 template <class T> T* dmalloc(int64_t n) { T* p = nullptr; HIP_CHECK(hipMalloc(&p, sizeof(T) * (size_t)(n > 0 ? n : 1))); return p; }
 
 }  // namespace
+
+static int64_t g_pool_limit = 0;
+void spgemm_set_pool_limit(int64_t entries) { g_pool_limit = entries > 0 ? entries : 0; }
 
 void dcsr_free(DCsr& A) {
   if (A.rp) (void)hipFree(A.rp);
@@ -354,14 +486,6 @@ void dcsr_download(const DCsr& d, int64_t* rp, int32_t* ci, double* v) {
   }
 }
 
-// host-side exclusive scan of a downloaded count array (m int64: cheap next to the product itself)
-static int64_t scan_counts(std::vector<int64_t>& c) {
-  int64_t run = 0;
-  for (auto& x : c) { int64_t t = x; x = run; run += t; }
-  c.push_back(run);
-  return run;
-}
-
 // the finished rows from their places in a pool to row order; one wave per row
 __global__ __launch_bounds__(BLOCK) void k_gather_rows(int64_t nrows, const int32_t* __restrict__ rows, const int64_t* __restrict__ row_pos,
                                                       const int64_t* __restrict__ rp, const int32_t* __restrict__ pci,
@@ -378,8 +502,10 @@ __global__ __launch_bounds__(BLOCK) void k_gather_rows(int64_t nrows, const int3
 
 // One numeric pass (round 2; round 1 ran every product twice, once to count and once to fill): every wave computes
 // its row, takes as many entries as the row keeps from a pool (atomic bump allocator) and writes the sorted, filtered
-// row there; once all counts are known a gather pass puts the rows in row order.  The pool is sized generously from
-// the free device memory; if it still fills up, the rows that found no place are redone with a fresh pool.
+// row there; once all counts are known a gather pass puts the rows in row order.  Nothing per row crosses the bus on
+// the way: the bounds, the choice of accumulator and the counts stay on the device, the host reads a handful of
+// totals.  Only when rows fail (LDS table too small -> global table; pool exhausted -> another round with a fresh
+// pool) are the counts downloaded and the failed rows listed.
 DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, bool lump, bool negate, hipStream_t s,
                 SpgemmStats* stats) {
   if (A.n != B.m) throw std::runtime_error("dev_spgemm: shape mismatch");
@@ -392,107 +518,134 @@ DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, boo
   if (m == 0) { int64_t z = 0; HIP_CHECK(hipMemcpy(C.rp, &z, sizeof(int64_t), hipMemcpyHostToDevice)); return C; }
   const CsrView av = cview(A), bv = cview(B);
   const DropParams dp{drop_enabled ? 1 : 0, tol, lump ? 1 : 0, negate ? 1 : 0};
-  // ---- candidate upper bounds and binning (host side: m ints)
+  // ---- candidate upper bounds, and what they add up to
   int64_t* d_ub = dmalloc<int64_t>(m);
-  hipLaunchKernelGGL(k_row_ub, dim3(MAX_BLOCKS), dim3(BLOCK), 0, s, av, bv, d_ub);
-  std::vector<int64_t> ub(m);
-  HIP_CHECK(hipMemcpyAsync(ub.data(), d_ub, sizeof(int64_t) * (size_t)m, hipMemcpyDeviceToHost, s));
+  UbStats* d_us = dmalloc<UbStats>(1);
+  HIP_CHECK(hipMemsetAsync(d_us, 0, sizeof(UbStats), s));
+  hipLaunchKernelGGL(k_row_ub, dim3(MAX_BLOCKS), dim3(BLOCK), 0, s, av, bv, d_ub, d_us);
+  UbStats us;
+  HIP_CHECK(hipMemcpyAsync(&us, d_us, sizeof(UbStats), hipMemcpyDeviceToHost, s));
   HIP_CHECK(hipStreamSynchronize(s));
-  (void)hipFree(d_ub);
+  (void)hipFree(d_us);
   const double t_ub = now() - t_begin;
-  std::vector<int32_t> small, big, huge;
-  small.reserve(m);
-  int64_t ub_total = 0;
-  for (int64_t i = 0; i < m; i++) { (ub[i] <= 768 ? small : big).push_back((int32_t)i); ub_total += std::min<int64_t>(ub[i], B.n) + 1; }
+  const int64_t ub_total = (int64_t)us.total, longest = (int64_t)us.longest;
   int64_t* d_cnt = dmalloc<int64_t>(m + 1);
   int64_t* d_pos = dmalloc<int64_t>(m);
   unsigned long long* d_cursor = dmalloc<unsigned long long>(1);
-  auto grid_small = [&](size_t n) { int64_t b = ((int64_t)n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK; return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(b, 256 * 12))); };
-  auto grid_big = [&](size_t n) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)n, 256 * 3))); };
-  // run one list through a kernel and split it by outcome
-  auto run_list = [&](std::vector<int32_t>& rows, int kind, const RowPool& pool, std::vector<int32_t>& done, std::vector<int32_t>& overflow,
-                      std::vector<int32_t>& retry) {
-    if (rows.empty()) return;
-    int32_t* d_rows = dmalloc<int32_t>((int64_t)rows.size());
-    int32_t* d_st = dmalloc<int32_t>((int64_t)rows.size());
-    HIP_CHECK(hipMemcpyAsync(d_rows, rows.data(), sizeof(int32_t) * rows.size(), hipMemcpyHostToDevice, s));
-    HIP_CHECK(hipMemsetAsync(d_st, 0, sizeof(int32_t) * rows.size(), s));
-    int32_t* d_kpool = nullptr; double* d_vpool = nullptr; int64_t* d_toff = nullptr; int32_t* d_tsize = nullptr;
-    if (kind == 0) hipLaunchKernelGGL((k_spgemm_lds<1024>), grid_small(rows.size()), dim3(BLOCK), 0, s, av, bv, d_rows, (int64_t)rows.size(), dp, d_cnt, pool, d_st);
-    else if (kind == 1) hipLaunchKernelGGL((k_spgemm_lds<4096>), grid_big(rows.size()), dim3(WAVE), 0, s, av, bv, d_rows, (int64_t)rows.size(), dp, d_cnt, pool, d_st);
-    else {
-      std::vector<int64_t> toff(rows.size()); std::vector<int32_t> tsize(rows.size());
-      int64_t run = 0;
-      for (size_t w = 0; w < rows.size(); w++) {
-        const int64_t want = 2 * std::min<int64_t>(ub[rows[w]], B.n) + 64;
-        int64_t cap = 8192; while (cap < want) cap <<= 1;
-        if (cap > 0x40000000ll) throw std::runtime_error("dev_spgemm: row too long");
-        toff[w] = run; tsize[w] = (int32_t)cap; run += cap;
-      }
-      d_toff = dmalloc<int64_t>((int64_t)rows.size()); d_tsize = dmalloc<int32_t>((int64_t)rows.size());
-      d_kpool = dmalloc<int32_t>(run); d_vpool = dmalloc<double>(run);
-      HIP_CHECK(hipMemcpyAsync(d_toff, toff.data(), sizeof(int64_t) * rows.size(), hipMemcpyHostToDevice, s));
-      HIP_CHECK(hipMemcpyAsync(d_tsize, tsize.data(), sizeof(int32_t) * rows.size(), hipMemcpyHostToDevice, s));
-      HIP_CHECK(hipStreamSynchronize(s));
-      const unsigned gb = (unsigned)std::min<int64_t>(((int64_t)rows.size() + 3) / 4, 2048);
-      hipLaunchKernelGGL(k_spgemm_glb, dim3(gb), dim3(BLOCK), 0, s, av, bv, d_rows, (int64_t)rows.size(), d_toff, d_tsize, d_kpool, d_vpool, dp,
-                         d_cnt, pool, d_st);
-    }
-    std::vector<int32_t> st(rows.size());
-    HIP_CHECK(hipMemcpyAsync(st.data(), d_st, sizeof(int32_t) * st.size(), hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipStreamSynchronize(s));
-    for (size_t w = 0; w < rows.size(); w++) {
-      if (st[w] == ROW_OK) done.push_back(rows[w]);
-      else if (st[w] == ROW_TABLE_OVERFLOW) { if (kind == 2) throw std::runtime_error("dev_spgemm: global hash table overflow"); overflow.push_back(rows[w]); }
-      else retry.push_back(rows[w]);
-    }
-    (void)hipFree(d_rows); (void)hipFree(d_st);
-    if (d_kpool) { (void)hipFree(d_kpool); (void)hipFree(d_vpool); (void)hipFree(d_toff); (void)hipFree(d_tsize); }
+  unsigned int* d_fail = dmalloc<unsigned int>(2);
+  auto grid_tiny = [&](int64_t n) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 256 * 32))); };
+  auto grid_mid = [&](int64_t n) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 256 * 12))); };
+  auto grid_big = [&](int64_t n) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(n, 256 * 3))); };
+  // one accumulator kind over a row selection
+  auto launch = [&](int bin, const RowSel& sel, const RowPool& pool) {
+    const int64_t n = sel.rows ? sel.nrows : m;
+    if (bin == BIN_TINY) hipLaunchKernelGGL(k_spgemm_tiny, grid_tiny(n), dim3(BLOCK), 0, s, av, bv, sel, dp, d_cnt, pool, d_fail);
+    else if (bin == BIN_MID) hipLaunchKernelGGL((k_spgemm_lds<MID_HT>), grid_mid(n), dim3(BLOCK), 0, s, av, bv, sel, dp, d_cnt, pool, d_fail);
+    else hipLaunchKernelGGL((k_spgemm_lds<BIG_HT>), grid_big(n), dim3(WAVE), 0, s, av, bv, sel, dp, d_cnt, pool, d_fail);
   };
-  struct Round { int32_t* ci; double* v; std::vector<int32_t> done; };
+  // rows with an explicit list (second and later attempts)
+  struct List { std::vector<int32_t> rows; int32_t* d = nullptr; };
+  auto upload_list = [&](List& l) {
+    if (l.rows.empty()) return;
+    l.d = dmalloc<int32_t>((int64_t)l.rows.size());
+    HIP_CHECK(hipMemcpyAsync(l.d, l.rows.data(), sizeof(int32_t) * l.rows.size(), hipMemcpyHostToDevice, s));
+  };
+  std::vector<int64_t> ub_host;                         // only when some row needs a global table
+  auto launch_global = [&](List& l, const RowPool& pool, std::vector<void*>& scratch) {
+    if (ub_host.empty()) { ub_host.resize(m); HIP_CHECK(hipMemcpyAsync(ub_host.data(), d_ub, sizeof(int64_t) * (size_t)m, hipMemcpyDeviceToHost, s)); HIP_CHECK(hipStreamSynchronize(s)); }
+    const size_t n = l.rows.size();
+    std::vector<int64_t> toff(n); std::vector<int32_t> tsize(n);
+    int64_t run = 0;
+    for (size_t w = 0; w < n; w++) {
+      const int64_t want = 2 * std::min<int64_t>(ub_host[l.rows[w]], B.n) + 64;
+      int64_t cap = 8192; while (cap < want) cap <<= 1;
+      if (cap > 0x40000000ll) throw std::runtime_error("dev_spgemm: row too long");
+      toff[w] = run; tsize[w] = (int32_t)cap; run += cap;
+    }
+    int64_t* d_toff = dmalloc<int64_t>((int64_t)n); int32_t* d_tsize = dmalloc<int32_t>((int64_t)n);
+    int32_t* d_kpool = dmalloc<int32_t>(run); double* d_vpool = dmalloc<double>(run);
+    HIP_CHECK(hipMemcpyAsync(d_toff, toff.data(), sizeof(int64_t) * n, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(d_tsize, tsize.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));                  // toff / tsize are locals
+    const unsigned gb = (unsigned)std::min<int64_t>(((int64_t)n + 3) / 4, 2048);
+    hipLaunchKernelGGL(k_spgemm_glb, dim3(gb), dim3(BLOCK), 0, s, av, bv, l.d, (int64_t)n, d_toff, d_tsize, d_kpool, d_vpool, dp, d_cnt, pool, d_fail);
+    scratch.insert(scratch.end(), {d_toff, d_tsize, d_kpool, d_vpool});
+  };
+  struct Round { int32_t* ci; double* v; bool all_rows; std::vector<int32_t> done; };
   std::vector<Round> rounds;
-  int64_t n_small = (int64_t)small.size(), n_big = (int64_t)big.size(), n_huge = 0;
+  List todo[4];                                          // per accumulator kind; empty in the first round (= every row)
+  int64_t n_global = 0;
   double t_kern = 0;
-  int64_t longest = 0;
-  for (int64_t i = 0; i < m; i++) longest = std::max<int64_t>(longest, std::min<int64_t>(ub[i], B.n) + 1);
-  while (!small.empty() || !big.empty() || !huge.empty()) {
+  std::vector<int64_t> cnt_host;
+  for (bool first = true;; first = false) {
     // pool: a few times the inputs, never more than the sum of the bounds, never more than a third of the free memory
     size_t mem_free = 0, mem_total = 0;
     HIP_CHECK(hipMemGetInfo(&mem_free, &mem_total));
     int64_t capacity = std::max<int64_t>(4 * (A.nnz + B.nnz) + (1 << 20), 2 * longest);
     capacity = std::min<int64_t>(capacity, ub_total);
     capacity = std::min<int64_t>(capacity, (int64_t)(mem_free / 3 / 12));
+    if (g_pool_limit) capacity = std::max<int64_t>(longest, std::min<int64_t>(capacity, g_pool_limit));
     if (capacity < longest) throw std::runtime_error("dev_spgemm: not enough device memory for the output pool");
-    Round rd; rd.ci = dmalloc<int32_t>(capacity); rd.v = dmalloc<double>(capacity);
+    Round rd; rd.ci = dmalloc<int32_t>(capacity); rd.v = dmalloc<double>(capacity); rd.all_rows = false;
     HIP_CHECK(hipMemsetAsync(d_cursor, 0, sizeof(unsigned long long), s));
+    HIP_CHECK(hipMemsetAsync(d_fail, 0, 2 * sizeof(unsigned int), s));
     const RowPool pool{d_cursor, capacity, rd.ci, rd.v, d_pos};
     const double tk0 = now();
-    std::vector<int32_t> retry_s, retry_b, retry_h, over;
-    run_list(small, 0, pool, rd.done, over, retry_s);
-    run_list(big, 1, pool, rd.done, over, retry_b);
-    huge.insert(huge.end(), over.begin(), over.end());
-    n_huge += (int64_t)over.size();
-    std::vector<int32_t> over2;
-    run_list(huge, 2, pool, rd.done, over2, retry_h);
+    std::vector<void*> scratch;
+    if (first) {
+      for (int bin = 0; bin < 3; bin++) if (us.rows[bin]) launch(bin, RowSel{nullptr, 0, d_ub, bin}, pool);
+    } else {
+      for (int bin = 0; bin < 4; bin++) upload_list(todo[bin]);
+      for (int bin = 0; bin < 3; bin++) if (todo[bin].d) launch(bin, RowSel{todo[bin].d, (int64_t)todo[bin].rows.size(), d_ub, bin}, pool);
+      if (todo[BIN_GLOBAL].d) launch_global(todo[BIN_GLOBAL], pool, scratch);
+    }
+    unsigned int fail[2];
+    HIP_CHECK(hipMemcpyAsync(fail, d_fail, sizeof(fail), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    for (void* p : scratch) (void)hipFree(p);
     t_kern += now() - tk0;
-    const size_t left = retry_s.size() + retry_b.size() + retry_h.size();
-    if (left && rd.done.empty()) throw std::runtime_error("dev_spgemm: no progress (output pool too small)");
-    small.swap(retry_s); big.swap(retry_b); huge.swap(retry_h);
+    const bool clean = fail[0] == 0 && fail[1] == 0;
+    if (first && clean) { rd.all_rows = true; rounds.push_back(std::move(rd)); break; }
+    // ---- some rows failed (or this is a later round): sort the rows of this round by outcome
+    cnt_host.resize(m);
+    HIP_CHECK(hipMemcpyAsync(cnt_host.data(), d_cnt, sizeof(int64_t) * (size_t)m, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    List next[4];
+    auto outcome = [&](int32_t i, int bin) {
+      const int64_t c = cnt_host[i];
+      if (c >= 0) rd.done.push_back(i);
+      else if (c == -ROW_TABLE_OVERFLOW) {
+        if (bin == BIN_GLOBAL) throw std::runtime_error("dev_spgemm: global hash table overflow");
+        next[BIN_GLOBAL].rows.push_back(i); n_global++;
+      } else next[bin].rows.push_back(i);
+    };
+    if (first) {
+      if (ub_host.empty()) { ub_host.resize(m); HIP_CHECK(hipMemcpyAsync(ub_host.data(), d_ub, sizeof(int64_t) * (size_t)m, hipMemcpyDeviceToHost, s)); HIP_CHECK(hipStreamSynchronize(s)); }
+      std::vector<int64_t> arp(m + 1);
+      HIP_CHECK(hipMemcpyAsync(arp.data(), A.rp, sizeof(int64_t) * (size_t)(m + 1), hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+      for (int64_t i = 0; i < m; i++) outcome((int32_t)i, bin_of(ub_host[i], arp[i + 1] - arp[i]));
+    } else {
+      for (int bin = 0; bin < 4; bin++) for (int32_t i : todo[bin].rows) outcome(i, bin);
+    }
+    size_t left = 0;
+    for (int bin = 0; bin < 4; bin++) { if (todo[bin].d) (void)hipFree(todo[bin].d); left += next[bin].rows.size(); }
+    const bool progress = !rd.done.empty() || !next[BIN_GLOBAL].rows.empty();
     rounds.push_back(std::move(rd));
+    if (!left) break;
+    if (!progress) throw std::runtime_error("dev_spgemm: no progress (output pool too small)");
+    for (int bin = 0; bin < 4; bin++) { todo[bin].rows.swap(next[bin].rows); todo[bin].d = nullptr; }
   }
-  // ---- row pointers, then the rows of every round into row order
+  // ---- row pointers (device scan of the counts), then the rows of every round into row order
   const double tg0 = now();
-  std::vector<int64_t> cnt(m);
-  HIP_CHECK(hipMemcpyAsync(cnt.data(), d_cnt, sizeof(int64_t) * (size_t)m, hipMemcpyDeviceToHost, s));
-  HIP_CHECK(hipStreamSynchronize(s));
-  C.nnz = scan_counts(cnt);
-  HIP_CHECK(hipMemcpyAsync(C.rp, cnt.data(), sizeof(int64_t) * (size_t)(m + 1), hipMemcpyHostToDevice, s));
+  C.nnz = device_exclusive_scan(m, d_cnt, C.rp, s);
+  HIP_CHECK(hipMemcpyAsync(C.rp + m, &C.nnz, sizeof(int64_t), hipMemcpyHostToDevice, s));
   C.ci = dmalloc<int32_t>(C.nnz); C.v = dmalloc<double>(C.nnz);
   for (Round& rd : rounds) {
-    const int64_t nr = (int64_t)rd.done.size();
+    const int64_t nr = rd.all_rows ? m : (int64_t)rd.done.size();
     if (nr) {
       int32_t* d_rows = nullptr;
-      if (rounds.size() > 1) {
+      if (!rd.all_rows) {
         d_rows = dmalloc<int32_t>(nr);
         HIP_CHECK(hipMemcpyAsync(d_rows, rd.done.data(), sizeof(int32_t) * (size_t)nr, hipMemcpyHostToDevice, s));
       }
@@ -503,15 +656,17 @@ DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, boo
     }
     (void)hipFree(rd.ci); (void)hipFree(rd.v);
   }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) throw std::runtime_error(std::string("HIP error ") + hipGetErrorString(e) + " in the device SpGEMM");
   const double t_gather = now() - tg0;
-  (void)hipFree(d_cnt); (void)hipFree(d_pos); (void)hipFree(d_cursor);
+  (void)hipFree(d_ub); (void)hipFree(d_cnt); (void)hipFree(d_pos); (void)hipFree(d_cursor); (void)hipFree(d_fail);
   if (trace) {
-    std::printf("   [spgemm] m=%lld nnzA=%lld nnzB=%lld bound=%lld nnzC=%lld bins=%lld/%lld/%lld rounds=%zu  ub %.3f kernels %.3f gather %.3f total %.3f s\n",
-                (long long)m, (long long)A.nnz, (long long)B.nnz, (long long)ub_total, (long long)C.nnz, (long long)n_small, (long long)n_big,
-                (long long)n_huge, rounds.size(), t_ub, t_kern, t_gather, now() - t_begin);
+    std::printf("   [spgemm] m=%lld nnzA=%lld nnzB=%lld bound=%lld nnzC=%lld bins=%llu/%llu/%llu/%lld rounds=%zu  ub %.3f kernels %.3f gather %.3f total %.3f s\n",
+                (long long)m, (long long)A.nnz, (long long)B.nnz, (long long)ub_total, (long long)C.nnz, us.rows[0], us.rows[1], us.rows[2],
+                (long long)n_global, rounds.size(), t_ub, t_kern, t_gather, now() - t_begin);
     std::fflush(stdout);
   }
-  if (stats) { stats->rows_small = n_small; stats->rows_big = n_big; stats->rows_global = n_huge; }
+  if (stats) { stats->rows_tiny = (int64_t)us.rows[0]; stats->rows_small = (int64_t)us.rows[1]; stats->rows_big = (int64_t)us.rows[2]; stats->rows_global = n_global; }
   return C;
 }
 

@@ -13,7 +13,11 @@ struct DCsr {
   double* v = nullptr;
 };
 
-struct SpgemmStats { int64_t rows_small = 0, rows_big = 0, rows_global = 0; };
+// rows per accumulator kind: registers (<= 64 candidates), LDS 1k slots, LDS 4k slots, global-memory table
+struct SpgemmStats { int64_t rows_tiny = 0, rows_small = 0, rows_big = 0, rows_global = 0; };
+
+// test hook: cap of the output pool in entries (0 = automatic); a small cap forces the retry rounds
+void spgemm_set_pool_limit(int64_t entries);
 
 void dcsr_free(DCsr& A);
 DCsr dcsr_upload(int64_t m, int64_t n, const int64_t* rp, const int32_t* ci, const double* v);

@@ -19,7 +19,7 @@ def _spgemm(P, A, B, drop=False, tol=0.0, lump=False, negate=False, on_device=Tr
     fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     a, b = P.as_csr(A), P.as_csr(B)
     h = C.c_void_p()
-    stats = (C.c_int64 * 3)()
+    stats = (C.c_int64 * 4)()
     rc = fn(a.ref(), b.ref(), int(drop), float(tol), int(lump), int(negate), int(on_device), C.byref(h), stats)
     assert rc == 0, P.lib().airhip_last_error().decode()
     out = P.HostMat(h).csr()
@@ -49,10 +49,12 @@ def _same(c, d, what=""):
 
 
 SPGEMM_CASES = [
-    # m, k, n, nnz/row A, nnz/row B, expected path index with rows (0 small, 1 big, 2 global)
+    # m, k, n, nnz/row A, nnz/row B, accumulator kind that must see rows (0 registers, 1 LDS 1k, 2 LDS 4k, 3 global table)
     (500, 400, 600, 5, 6, 0),
-    (300, 300, 300, 40, 40, 1),
-    (64, 3000, 40000, 300, 30, 2),
+    (700, 90, 60, 8, 8, 0),             # 64 candidates on 60 columns: runs of equal columns in the register sort
+    (400, 400, 500, 12, 14, 1),
+    (300, 300, 300, 40, 40, 2),
+    (64, 3000, 40000, 300, 30, 3),
 ]
 
 
@@ -73,6 +75,49 @@ def test_device_spgemm_bitwise(gpu, m, k, n, pa, pb, path, mode):
         ref.sort_indices()
         assert np.array_equal(ref.indptr, dev.rowptr) and np.array_equal(ref.indices, dev.col)
         np.testing.assert_allclose(dev.val, ref.data, rtol=1e-12, atol=1e-12)
+
+
+def test_device_spgemm_many_short_rows_of_b(gpu):
+    """rows of A with more than 64 entries whose candidates still number <= 64 (rows of B with 0 or 1 entries) take the
+    hash path; rows with exactly 64 candidates the register path"""
+    import pflare_amd as P
+    rng = np.random.default_rng(5)
+    k = 500
+    B = sp.random(k, 300, density=0.002, random_state=3, format="csr", data_rvs=rng.standard_normal)   # 0.6 per row
+    B.sort_indices()
+    A = _rand(200, k, 90, 7)
+    for kw in ({}, dict(drop=True, tol=1e-1, lump=True)):
+        href, _ = _spgemm(P, A, B, on_device=False, **kw)
+        dev, stats = _spgemm(P, A, B, on_device=True, **kw)
+        assert stats[1] > 0, stats
+        _same(dev, href)
+    A64 = _rand(300, 64, 8, 11)
+    B8 = _rand(64, 1000, 8, 12)
+    assert int((A64 @ abs(B8)).getnnz(axis=1).max()) <= 64
+    href, _ = _spgemm(P, A64, B8, on_device=False, drop=True, tol=1e-2)
+    dev, stats = _spgemm(P, A64, B8, on_device=True, drop=True, tol=1e-2)
+    assert stats[0] == 300, stats
+    _same(dev, href)
+
+
+def test_device_spgemm_pool_exhaustion_takes_more_rounds(gpu):
+    """the output pool is a bump allocator; rows that find it full are redone with a fresh pool (airhip_set_tuning
+    "spgemm_pool_entries" shrinks it so that the case arises at test size), rows that overflow the 4k LDS table go to the
+    global table on the way"""
+    import pflare_amd as P
+    lib = P.lib()
+    cases = [(_rand(3000, 400, 5, 1), _rand(400, 600, 6, 2)), (_rand(600, 300, 40, 3), _rand(300, 300, 40, 4)),
+             (_rand(64, 3000, 300, 5), _rand(3000, 40000, 30, 6))]
+    try:
+        for A, B in cases:
+            for kw in ({}, dict(drop=True, tol=5e-2, lump=True)):
+                assert lib.airhip_set_tuning(b"spgemm_pool_entries", 0) == 0
+                href, _ = _spgemm(P, A, B, on_device=False, **kw)
+                assert lib.airhip_set_tuning(b"spgemm_pool_entries", max(1, href.val.size // 3)) == 0
+                dev, _ = _spgemm(P, A, B, on_device=True, **kw)
+                _same(dev, href)
+    finally:
+        lib.airhip_set_tuning(b"spgemm_pool_entries", 0)
 
 
 def test_device_spgemm_empty_rows_and_diagonal_creation(gpu):
