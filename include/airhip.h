@@ -100,8 +100,8 @@ int airhip_set_num_threads(int n, int* prev);
  * airhip_pcair_setup_host_only / airhip_pcinv_setup_host_only: build the hierarchy without touching a device (CPU-side
  *   tests of the setup, hierarchy export); apply / solve then fail with AIRHIP_ERR_STATE.
  * airhip_spgemm_filtered: C = filter(A*B) with the host (on_device = 0) or the device SpGEMM of the setup, drop / lump /
- *   negate as in the setup's Z and RAP products; stats[4] = rows per accumulator kind (registers, LDS 1k, LDS 4k,
- *   global-memory table). */
+ *   negate as in the setup's Z and RAP products; stats[5] = rows each accumulator kind worked on (registers, LDS tables
+ *   of 1k / 2k / 4k slots, global-memory table). */
 int airhip_set_tuning(const char* key, int value);
 
 /* ---------------------------------------------------------------- stand-alone CF splitting */

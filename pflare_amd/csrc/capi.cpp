@@ -223,8 +223,7 @@ int airhip_hostmat_get(airhip_hostmat A, airhip_csr* view) {
   API_END
 }
 // Inspection hook (declared in the header, not part of the stable ABI): C = filter(A*B) with the host or the device SpGEMM of
-// the setup; stats[4] = {rows accumulated in registers, rows in the 1k-entry LDS bin, rows in the 4k-entry LDS bin,
-// rows redone with a global-memory table}.
+// the setup; stats[5] = rows each accumulator kind worked on {registers, LDS 1k, LDS 2k, LDS 4k, global-memory table}.
 int airhip_spgemm_filtered(const airhip_csr* A, const airhip_csr* B, int drop, double tol, int lump, int negate,
                                    int on_device, airhip_hostmat* out, int64_t* stats) {
   API_BEGIN
@@ -242,7 +241,7 @@ int airhip_spgemm_filtered(const airhip_csr* A, const airhip_csr* B, int drop, d
     h->A.rp.alloc(dc.m + 1); h->A.ci.alloc(dc.nnz); h->A.v.alloc(dc.nnz);
     dcsr_download(dc, h->A.rp.data(), h->A.ci.data(), h->A.v.data());
     dcsr_free(da); dcsr_free(db); dcsr_free(dc);
-    if (stats) { stats[0] = st.rows_tiny; stats[1] = st.rows_small; stats[2] = st.rows_big; stats[3] = st.rows_global; }
+    if (stats) { stats[0] = st.rows_reg; stats[1] = st.rows_1k; stats[2] = st.rows_2k; stats[3] = st.rows_4k; stats[4] = st.rows_global; }
   }
   *out = h;
   API_END

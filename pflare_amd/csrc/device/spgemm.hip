@@ -37,23 +37,35 @@ static CsrView cview(const DCsr& A) { return CsrView{A.m, A.n, A.rp, A.ci, A.v};
 struct DropParams { int enabled; double tol; int lump; int negate; };
 
 // Accumulator kinds.  ub_i = sum_k nnz(B(k,:)) bounds the candidates of row i:
-//   TINY   ub <= 64 (and <= 64 entries in A(i,:)): the candidates sit one per lane and are sorted in registers
-//   MID    ub <= 768: LDS hash table of <= 1024 slots, four waves (rows) per workgroup
-//   BIG    LDS hash table of 4096 slots, one wave per workgroup; rows with more than 3584 distinct columns overflow to
-//   GLOBAL a hash table in device memory
-constexpr int BIN_TINY = 0, BIN_MID = 1, BIN_BIG = 2, BIN_GLOBAL = 3;
-constexpr int TINY_MAX = 64, MID_MAX = 768, MID_HT = 1024, BIG_HT = 4096;
-__host__ __device__ inline int bin_of(int64_t ub, int64_t na) { return (ub <= TINY_MAX && na <= TINY_MAX) ? BIN_TINY : ub <= MID_MAX ? BIN_MID : BIN_BIG; }
+//   REG    ub <= 64 (and <= 64 entries in A(i,:)): the candidates sit one per lane and are sorted in registers
+//   L1K    LDS hash table of 1024 slots, four waves (rows) per workgroup, 12 waves per CU
+//   L2K    2048 slots, two waves per workgroup, 6 waves per CU
+//   L4K    4096 slots, one wave per workgroup, 3 waves per CU
+//   GLOBAL a hash table in device memory (rows with more than 3584 distinct columns)
+// A table holds the DISTINCT columns of the row, and on the AIR operators those are 3-15 times fewer than the
+// candidates (the rows of B that one row of A meets overlap heavily).  Sizing by ub put nearly every row of the deep
+// levels into the 4k kernel, which runs at a quarter of the occupancy and pays for clearing, compacting and sorting
+// 4096 slots; so the ratio distinct / candidates is measured on a sample of rows first (k_spgemm_sample) and a row
+// goes to the smallest table that ub * ratio fits.  A row that overflows its table all the same moves up one kind
+// (1k -> 2k -> 4k through device lists, 4k -> GLOBAL through the host).
+constexpr int KIND_REG = 0, KIND_L1K = 1, KIND_L2K = 2, KIND_L4K = 3, KIND_GLOBAL = 4, NKIND = 5;
+constexpr int TINY_MAX = 64, L1K_MAX = 768, L2K_MAX = 1536;     // bounds a table of that kind cannot overflow on
+constexpr int L1K_FILL = 800, L2K_FILL = 1650;                  // distinct columns the tables are planned for (overflow: 896 / 1792)
+constexpr int MAX_HT = 4096;
+struct Plan { int64_t max1k, max2k; float ratio; };              // largest bounds the 1k / 2k tables take; distinct per candidate
+__host__ __device__ inline int kind_of(int64_t ub, int64_t na, const Plan& p) {
+  return (ub <= TINY_MAX && na <= TINY_MAX) ? KIND_REG : ub <= p.max1k ? KIND_L1K : ub <= p.max2k ? KIND_L2K : KIND_L4K;
+}
 
-// what the bounds add up to (decides the pool size and which kernels run; no per-row list leaves the device)
-struct UbStats { unsigned long long total, longest, rows[3]; };
+// what the bounds add up to (decides the pool size; no per-row list leaves the device)
+struct UbStats { unsigned long long total, longest, above_1k; };
 
 // per-row upper bound of candidates
 __global__ __launch_bounds__(BLOCK) void k_row_ub(CsrView A, CsrView B, int64_t* __restrict__ ub, UbStats* __restrict__ st) {
   const int lane = threadIdx.x & (WAVE - 1);
   const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * BLOCK) >> 6;
-  unsigned long long tot = 0, longest = 0, rows[3] = {0, 0, 0};
+  unsigned long long tot = 0, longest = 0, above = 0;
   for (int64_t i = wave; i < A.m; i += nw) {
     int64_t s = 0;
     const int64_t a0 = A.rp[i], a1 = A.rp[i + 1];
@@ -61,16 +73,16 @@ __global__ __launch_bounds__(BLOCK) void k_row_ub(CsrView A, CsrView B, int64_t*
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
     if (lane == 0) ub[i] = s;
     const unsigned long long c = (unsigned long long)(s < B.n ? s : B.n) + 1ull;
-    tot += c; longest = c > longest ? c : longest; rows[bin_of(s, a1 - a0)]++;
+    tot += c; longest = c > longest ? c : longest; above += s > L1K_MAX ? 1 : 0;
   }
-  if (lane == 0) {
-    atomicAdd(&st->total, tot); atomicMax(&st->longest, longest);
-    for (int b = 0; b < 3; b++) if (rows[b]) atomicAdd(&st->rows[b], rows[b]);
-  }
+  if (lane == 0) { atomicAdd(&st->total, tot); atomicMax(&st->longest, longest); if (above) atomicAdd(&st->above_1k, above); }
 }
 
-// the rows a kernel works on: an explicit list, or (rows == nullptr) every row of A whose bound puts it in `bin`
-struct RowSel { const int32_t* rows; int64_t nrows; const int64_t* ub; int bin; };
+// the rows a kernel works on: an explicit list, or (rows == nullptr) every row of A whose bound selects `kind`
+struct RowSel { const int32_t* rows; int64_t nrows; const int64_t* ub; int kind; Plan plan; };
+
+// rows that move up one accumulator kind, and the rows each kind has seen
+struct Escalation { int32_t* rows; unsigned int* count; };
 
 // Table accessors.  LDS tables are touched with plain ds ops (one wave owns the table and the
 // wave executes its LDS instructions in order).  Global tables are touched only with relaxed
@@ -114,58 +126,68 @@ template <bool GLOBAL> struct Tab {
 struct RowPool { unsigned long long* cursor; int64_t capacity; int32_t* ci; double* v; int64_t* row_pos; };
 constexpr int ROW_OK = 0, ROW_TABLE_OVERFLOW = 1, ROW_POOL_FULL = 2;
 
+// value of lane l (wave-uniform l) as a scalar
+__device__ __forceinline__ int lane_i32(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ int64_t lane_i64(int64_t v, int l) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(v & 0xffffffffll), l);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), l);
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
 // ---- accumulate, hash table: leaves the nu distinct columns of row i of A*B with their sums in tab[0, nu), sorted
 // by column; -1 = the table is too small for the row.  tab: HT slots owned by this wave (HT a power of two).
 template <bool GLOBAL>
-__device__ __forceinline__ int hash_accumulate(const CsrView& A, const CsrView& B, int64_t i, const Tab<GLOBAL> tab, int HT, bool negate) {
+__device__ __forceinline__ int hash_accumulate(const CsrView& A, const CsrView& B, int64_t i, const Tab<GLOBAL> tab, int HT, bool negate,
+                                               bool count_only = false) {
 #pragma clang fp contract(off)   // a*b + c must round twice, as the host code does
   const int lane = threadIdx.x & (WAVE - 1);
   const uint32_t mask = (uint32_t)HT - 1;
   const unsigned long long lt = (1ull << lane) - 1ull;
   for (int h = lane; h < HT; h += WAVE) { tab.stk(h, EMPTY); tab.stv(h, 0.0); }
   tab.sync();
-  int unique = 0;
-  const int limit = HT - HT / 8;
-  const int64_t a0 = A.rp[i], a1 = A.rp[i + 1];
+  const int64_t a0 = uniform64(A.rp[i]), a1 = uniform64(A.rp[i + 1]);
   // The candidate stream of the row is consumed in "steps": one step = up to 64 consecutive entries of one row
-  // B(j,:) (distinct columns -> conflict-free lanes), steps ordered by k.  PIPE steps form a batch: their loads are
-  // issued back to back, then their slots are looked up TOGETHER (every probe round issues the compare-and-swaps of
-  // all pending steps before it waits - the kernel is bound by LDS latency, not by LDS bandwidth), then the products
-  // are added in step order.  Which step claims a new column first does not matter (the row is sorted afterwards);
-  // the order of the additions does, and that is the order of issue.
+  // B(j,:) (distinct columns -> conflict-free lanes), steps ordered by k.  The walk over (entry of A, offset in its
+  // row of B) is scalar: lane e of a chunk holds entry kb + e of A(i,:) and the extent of B(j_e,:), the current
+  // entry's base / length / value sit in SGPRs (readlane), so a step costs a handful of vector instructions.  PIPE
+  // steps form a batch: their loads are issued back to back, then their slots are looked up TOGETHER (every probe
+  // round issues the compare-and-swaps of all pending steps before it waits), then the products are added in step
+  // order.  Which step claims a new column first does not matter (the row is sorted afterwards); the order of the
+  // additions does, and that is the order of issue.
   constexpr int PIPE = 8;
+  constexpr int MAX_PROBE_ROUNDS = 64;     // double hashing: a table filled to 3/4 needs more with probability 1e-8 per insert
   for (int64_t kb = a0; kb < a1; kb += WAVE) {
-    // a chunk of A(i,:): lane t holds entry k = kb + t and the extent of B(j_t,:)
-    const int64_t kk = kb + lane;
-    const bool valid = kk < a1;
-    const int32_t jl = valid ? A.ci[kk] : 0;
-    const double al = valid ? A.v[kk] : 0.0;
-    const int64_t b0 = valid ? B.rp[jl] : 0, b1 = valid ? B.rp[jl + 1] : 0;
-    const int nch = (int)((b1 - b0 + WAVE - 1) >> 6);
-    int incl = nch;                                   // inclusive scan of the step counts
-    for (int off = 1; off < WAVE; off <<= 1) { const int t = __shfl_up(incl, off, WAVE); if (lane >= off) incl += t; }
-    const int total = __shfl(incl, WAVE - 1, WAVE);
-    for (int s0 = 0; s0 < total; s0 += PIPE) {
-      int32_t cc[PIPE]; double x[PIPE]; bool act[PIPE], pend[PIPE]; uint32_t hh[PIPE], inc[PIPE];
+    const int nk = (int)(a1 - kb < WAVE ? a1 - kb : WAVE);
+    double al = 0.0; int64_t b0 = 0; int len = 0;
+    if (lane < nk) { const int32_t j = A.ci[kb + lane]; al = A.v[kb + lane]; b0 = B.rp[j]; len = (int)(B.rp[j + 1] - b0); }
+    const long long al_bits = __double_as_longlong(al);
+    int e = 0, off = 0;
+    int cur_len = lane_i32(len, 0);
+    int64_t cur_b0 = lane_i64(b0, 0);
+    double cur_a = __longlong_as_double(lane_i64(al_bits, 0));
+    while (e < nk) {
+      int32_t cc[PIPE]; double x[PIPE], av[PIPE]; bool act[PIPE], pend[PIPE]; uint32_t hh[PIPE], inc[PIPE];
 #pragma unroll
       for (int d = 0; d < PIPE; d++) {
-        const int st = s0 + d;
-        act[d] = false; cc[d] = 0; x[d] = 0.0;
-        if (st < total) {
-          const int t = __ffsll((long long)__ballot(incl > st)) - 1;     // owner of step st
-          const int64_t tb0 = __shfl(b0, t, WAVE), tb1 = __shfl(b1, t, WAVE);
-          const int first = __shfl(incl, t, WAVE) - __shfl(nch, t, WAVE);
-          const int64_t q = tb0 + (int64_t)(st - first) * WAVE + lane;
-          const double av = __shfl(al, t, WAVE);
-          act[d] = q < tb1;
-          if (act[d]) { cc[d] = B.ci[q]; x[d] = av * B.v[q]; }
+        act[d] = false; cc[d] = 0; x[d] = 0.0; av[d] = 0.0;
+        if (e < nk) {                                   // wave-uniform
+          const uint32_t o = (uint32_t)(off + lane);
+          act[d] = o < (uint32_t)cur_len;
+          av[d] = cur_a;
+          if (act[d]) { cc[d] = (B.ci + cur_b0)[o]; x[d] = (B.v + cur_b0)[o]; }   // no arithmetic: the batch's loads stay in flight together
+          off += WAVE;
+          if (off >= cur_len) {                         // next entry of A (an empty row of B costs one idle step)
+            e++; off = 0;
+            if (e < nk) { cur_len = lane_i32(len, e); cur_b0 = lane_i64(b0, e); cur_a = __longlong_as_double(lane_i64(al_bits, e)); }
+          }
         }
       }
 #pragma unroll
       for (int d = 0; d < PIPE; d++) {
+        x[d] = av[d] * x[d];
         const uint32_t g = (uint32_t)cc[d] * 2654435761u;
         hh[d] = (g ^ (g >> 15)) & mask;
-        inc[d] = ((((uint32_t)cc[d] * 0x85EBCA6Bu) >> 8) | 1u) & mask;      // odd: the probe sequence visits every slot
+        inc[d] = ((g >> 19) | 1u) & mask;               // odd: the probe sequence visits every slot
         pend[d] = act[d];
       }
       int rounds = 0;
@@ -176,17 +198,14 @@ __device__ __forceinline__ int hash_accumulate(const CsrView& A, const CsrView& 
         bool more = false;
 #pragma unroll
         for (int d = 0; d < PIPE; d++) {
-          const bool claimed = pend[d] && old[d] == EMPTY;
-          unique += __popcll(__ballot(claimed));
           if (pend[d]) {
             if (old[d] == EMPTY || old[d] == cc[d]) pend[d] = false;
             else { hh[d] = (hh[d] + inc[d]) & mask; more = true; }
           }
         }
         if (!__any(more)) break;
-        if (++rounds > HT || unique > limit) return -1;
+        if (++rounds > MAX_PROBE_ROUNDS) return -1;     // (nearly) full table
       }
-      if (unique > limit) return -1;
 #pragma unroll
       for (int d = 0; d < PIPE; d++) if (act[d]) tab.add((int)hh[d], x[d]);
       tab.sync();
@@ -205,6 +224,7 @@ __device__ __forceinline__ int hash_accumulate(const CsrView& A, const CsrView& 
     nu += __popcll(bal);
     tab.sync();
   }
+  if (count_only) return nu;
   int P2 = 64; while (P2 < nu) P2 <<= 1;
   for (int h = nu + lane; h < P2; h += WAVE) { tab.stk(h, EMPTY); tab.stv(h, 0.0); }
   tab.sync();
@@ -225,13 +245,6 @@ __device__ __forceinline__ int hash_accumulate(const CsrView& A, const CsrView& 
       tab.sync();
     }
   return nu;
-}
-
-__device__ __forceinline__ int lane_i32(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
-__device__ __forceinline__ int64_t lane_i64(int64_t v, int l) {
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(v & 0xffffffffll), l);
-  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), l);
-  return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
 // ---- accumulate, registers: a row with at most 64 candidates (and at most 64 entries in A(i,:)).  Lane c holds
@@ -394,47 +407,80 @@ __device__ __forceinline__ void report(int st, int64_t i, int64_t* __restrict__ 
   if (st != ROW_OK && (threadIdx.x & (WAVE - 1)) == 0) { cnt[i] = -(int64_t)st; atomicAdd(&fail[st - 1], 1u); }
 }
 
-// the smallest table (>= 128 slots, <= cap) that the row cannot fill beyond 3/4
-__device__ __forceinline__ int table_for(int64_t ub, int cap) {
+// the smallest table (>= 128 slots, <= cap) that `expect` distinct columns fill to 3/4 at most
+__device__ __forceinline__ int table_for(int64_t expect, int cap) {
   int ht = 128;
-  while (ht < cap && (int64_t)ht * 3 < ub * 4) ht <<= 1;
+  while (ht < cap && (int64_t)ht * 3 < expect * 4) ht <<= 1;
   return ht;
 }
 
+// HT = the wave's share of LDS.  A row starts with the table its expected number of distinct columns asks for (short
+// tables are cheaper to clear, compact and sort), and is redone with all HT slots if that overflows; a row that
+// overflows HT slots moves up (esc) or is reported.
 template <int HT>
-__global__ __launch_bounds__(HT <= 1024 ? BLOCK : WAVE) void k_spgemm_lds(CsrView A, CsrView B, RowSel sel, DropParams dp, int64_t* __restrict__ cnt,
-                                                                            RowPool pool, unsigned int* __restrict__ fail) {
-  constexpr int WPB = HT <= 1024 ? WAVES_PER_BLOCK : 1;
+__global__ __launch_bounds__(MAX_HT / HT * WAVE) void k_spgemm_lds(CsrView A, CsrView B, RowSel sel, DropParams dp, int64_t* __restrict__ cnt,
+                                                                  RowPool pool, unsigned int* __restrict__ fail, Escalation esc,
+                                                                  unsigned long long* __restrict__ seen) {
+  constexpr int WPB = MAX_HT / HT;
   __shared__ int32_t keys_all[WPB][HT];
   __shared__ double vals_all[WPB][HT];
-  const int wid = threadIdx.x >> 6;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t nw = (int64_t)gridDim.x * WPB;
   const int64_t count = sel.rows ? sel.nrows : A.m;
   const Tab<false> tab{keys_all[wid], vals_all[wid]};
+  unsigned long long mine = 0;
   for (int64_t w = (int64_t)blockIdx.x * WPB + wid; w < count; w += nw) {
     const int64_t i = sel.rows ? (int64_t)sel.rows[w] : w;
     const int64_t ubi = sel.ub[i];
-    if (!sel.rows && bin_of(ubi, A.rp[i + 1] - A.rp[i]) != sel.bin) continue;
-    const int nu = hash_accumulate<false>(A, B, i, tab, table_for(ubi, HT), dp.negate != 0);
-    report(nu < 0 ? ROW_TABLE_OVERFLOW : finish_row<false>(tab, nu, i, dp, cnt + i, pool), i, cnt, fail);
+    if (!sel.rows && kind_of(ubi, A.rp[i + 1] - A.rp[i], sel.plan) != sel.kind) continue;
+    mine++;
+    const int64_t expect = ubi <= L1K_MAX ? ubi : (int64_t)((float)ubi * sel.plan.ratio) + 64;
+    const int ht = table_for(expect < ubi ? expect : ubi, HT);
+    int nu = hash_accumulate<false>(A, B, i, tab, ht, dp.negate != 0);
+    if (nu < 0 && ht < HT) nu = hash_accumulate<false>(A, B, i, tab, HT, dp.negate != 0);
+    if (nu < 0 && esc.rows) {
+      if ((threadIdx.x & (WAVE - 1)) == 0) esc.rows[atomicAdd(esc.count, 1u)] = (int32_t)i;
+    } else {
+      report(nu < 0 ? ROW_TABLE_OVERFLOW : finish_row<false>(tab, nu, i, dp, cnt + i, pool), i, cnt, fail);
+    }
     __builtin_amdgcn_wave_barrier();
   }
+  if ((threadIdx.x & (WAVE - 1)) == 0 && mine) atomicAdd(seen, mine);
 }
 
 __global__ __launch_bounds__(BLOCK) void k_spgemm_tiny(CsrView A, CsrView B, RowSel sel, DropParams dp, int64_t* __restrict__ cnt, RowPool pool,
-                                                      unsigned int* __restrict__ fail) {
+                                                      unsigned int* __restrict__ fail, unsigned long long* __restrict__ seen) {
   __shared__ int32_t keys_all[WAVES_PER_BLOCK][WAVE];
   __shared__ double vals_all[WAVES_PER_BLOCK][WAVE];
-  const int wid = threadIdx.x >> 6;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t nw = (int64_t)gridDim.x * WAVES_PER_BLOCK;
   const int64_t count = sel.rows ? sel.nrows : A.m;
   const Tab<false> tab{keys_all[wid], vals_all[wid]};
+  unsigned long long mine = 0;
   for (int64_t w = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wid; w < count; w += nw) {
     const int64_t i = sel.rows ? (int64_t)sel.rows[w] : w;
-    if (!sel.rows && bin_of(sel.ub[i], A.rp[i + 1] - A.rp[i]) != BIN_TINY) continue;
+    if (!sel.rows && kind_of(sel.ub[i], A.rp[i + 1] - A.rp[i], sel.plan) != KIND_REG) continue;
+    mine++;
     const int nu = tiny_accumulate(A, B, i, tab, dp.negate != 0);
     report(finish_row<false>(tab, nu, i, dp, cnt + i, pool), i, cnt, fail);
     tab.sync();
+  }
+  if ((threadIdx.x & (WAVE - 1)) == 0 && mine) atomicAdd(seen, mine);
+}
+
+// distinct columns of a sample of the rows with more than L1K_MAX candidates: sample w looks at row w * m / nsamples
+// and stores its bound and its number of distinct columns (-1: more than the 4k table holds, -2: not such a row)
+__global__ __launch_bounds__(WAVE) void k_spgemm_sample(CsrView A, CsrView B, const int64_t* __restrict__ ub, int nsamples,
+                                                       int64_t* __restrict__ out_ub, int32_t* __restrict__ out_nu) {
+  __shared__ int32_t keys[MAX_HT];
+  __shared__ double vals[MAX_HT];
+  const Tab<false> tab{keys, vals};
+  for (int w = blockIdx.x; w < nsamples; w += gridDim.x) {
+    const int64_t i = ((int64_t)w * A.m) / nsamples;
+    const int64_t u = ub[i];
+    const int nu = u > L1K_MAX ? hash_accumulate<false>(A, B, i, tab, MAX_HT, false, true) : -2;
+    if (threadIdx.x == 0) { out_ub[w] = u; out_nu[w] = nu; }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -527,21 +573,66 @@ DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, boo
   HIP_CHECK(hipMemcpyAsync(&us, d_us, sizeof(UbStats), hipMemcpyDeviceToHost, s));
   HIP_CHECK(hipStreamSynchronize(s));
   (void)hipFree(d_us);
-  const double t_ub = now() - t_begin;
   const int64_t ub_total = (int64_t)us.total, longest = (int64_t)us.longest;
+  // ---- distinct columns per candidate on a sample of the long rows: which table each of them gets
+  Plan plan{L1K_MAX, L2K_MAX, 1.0f};
+  if (us.above_1k) {
+    const int ns = (int)std::min<int64_t>(m, 1536);
+    int64_t* d_sub = dmalloc<int64_t>(ns); int32_t* d_snu = dmalloc<int32_t>(ns);
+    hipLaunchKernelGGL(k_spgemm_sample, dim3((unsigned)std::min(ns, 768)), dim3(WAVE), 0, s, av, bv, d_ub, ns, d_sub, d_snu);
+    std::vector<int64_t> sub(ns); std::vector<int32_t> snu(ns);
+    HIP_CHECK(hipMemcpyAsync(sub.data(), d_sub, sizeof(int64_t) * (size_t)ns, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(snu.data(), d_snu, sizeof(int32_t) * (size_t)ns, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    (void)hipFree(d_sub); (void)hipFree(d_snu);
+    std::vector<double> r;
+    for (int w = 0; w < ns; w++) if (snu[w] != -2) r.push_back(snu[w] < 0 ? 1.0 : (double)snu[w] / (double)sub[w]);
+    if (!r.empty()) {
+      std::sort(r.begin(), r.end());
+      const double r90 = std::max(r[std::min(r.size() - 1, r.size() * 9 / 10)], 1e-3);
+      plan.ratio = (float)r90;
+      plan.max1k = std::max<int64_t>(L1K_MAX, (int64_t)(L1K_FILL / r90));
+      plan.max2k = std::max<int64_t>(L2K_MAX, (int64_t)(L2K_FILL / r90));
+    }
+  }
+  const double t_ub = now() - t_begin;
   int64_t* d_cnt = dmalloc<int64_t>(m + 1);
   int64_t* d_pos = dmalloc<int64_t>(m);
   unsigned long long* d_cursor = dmalloc<unsigned long long>(1);
-  unsigned int* d_fail = dmalloc<unsigned int>(2);
-  auto grid_tiny = [&](int64_t n) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 256 * 32))); };
-  auto grid_mid = [&](int64_t n) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 256 * 12))); };
-  auto grid_big = [&](int64_t n) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(n, 256 * 3))); };
-  // one accumulator kind over a row selection
-  auto launch = [&](int bin, const RowSel& sel, const RowPool& pool) {
-    const int64_t n = sel.rows ? sel.nrows : m;
-    if (bin == BIN_TINY) hipLaunchKernelGGL(k_spgemm_tiny, grid_tiny(n), dim3(BLOCK), 0, s, av, bv, sel, dp, d_cnt, pool, d_fail);
-    else if (bin == BIN_MID) hipLaunchKernelGGL((k_spgemm_lds<MID_HT>), grid_mid(n), dim3(BLOCK), 0, s, av, bv, sel, dp, d_cnt, pool, d_fail);
-    else hipLaunchKernelGGL((k_spgemm_lds<BIG_HT>), grid_big(n), dim3(WAVE), 0, s, av, bv, sel, dp, d_cnt, pool, d_fail);
+  unsigned int* d_fail = dmalloc<unsigned int>(4);       // [0] table overflow, [1] pool full, [2] / [3] rows moved up from 1k / 2k
+  unsigned long long* d_seen = dmalloc<unsigned long long>(NKIND);
+  int32_t* d_up1 = nullptr; int32_t* d_up2 = nullptr;    // rows that overflowed a 1k / 2k table
+  if (us.above_1k) { d_up1 = dmalloc<int32_t>(m); d_up2 = dmalloc<int32_t>(m); }
+  HIP_CHECK(hipMemsetAsync(d_seen, 0, NKIND * sizeof(unsigned long long), s));
+  const int resident = 256 * 3;                          // workgroups of 48 KB LDS the chip holds
+  auto grid_reg = [&](int64_t n) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 256 * 32))); };
+  auto grid_lds = [&](int64_t n, int wpb) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((n + wpb - 1) / wpb, 4 * resident))); };
+  auto launch_lds = [&](int kind, const int32_t* rows, int64_t nrows, const RowPool& pool, Escalation esc) {
+    const RowSel sel{rows, nrows, d_ub, kind, plan};
+    const int64_t n = rows ? nrows : m;
+    if (kind == KIND_L1K) hipLaunchKernelGGL((k_spgemm_lds<1024>), grid_lds(n, 4), dim3(4 * WAVE), 0, s, av, bv, sel, dp, d_cnt, pool, d_fail, esc, d_seen + kind);
+    else if (kind == KIND_L2K) hipLaunchKernelGGL((k_spgemm_lds<2048>), grid_lds(n, 2), dim3(2 * WAVE), 0, s, av, bv, sel, dp, d_cnt, pool, d_fail, esc, d_seen + kind);
+    else hipLaunchKernelGGL((k_spgemm_lds<4096>), grid_lds(n, 1), dim3(WAVE), 0, s, av, bv, sel, dp, d_cnt, pool, d_fail, esc, d_seen + kind);
+  };
+  auto read_u32 = [&](const unsigned int* d) {
+    unsigned int v = 0;
+    HIP_CHECK(hipMemcpyAsync(&v, d, sizeof(v), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    return v;
+  };
+  // all LDS kinds over their row selections (rows[k] == nullptr and all == true: the rows of A whose bound selects k),
+  // longest rows first (they run at the lowest occupancy), then the rows that moved up
+  auto run_tables = [&](const int32_t* const rows[NKIND], const int64_t nrows[NKIND], bool all, const RowPool& pool) {
+    auto wanted = [&](int k) { return all ? (k == KIND_L1K || us.above_1k > 0) : rows[k] != nullptr; };
+    const bool moving = d_up1 != nullptr;
+    if (moving) HIP_CHECK(hipMemsetAsync(d_fail + 2, 0, 2 * sizeof(unsigned int), s));
+    const Escalation none{nullptr, nullptr}, up1{d_up1, d_fail + 2}, up2{d_up2, d_fail + 3};
+    if (wanted(KIND_L4K)) launch_lds(KIND_L4K, rows[KIND_L4K], nrows[KIND_L4K], pool, none);
+    if (wanted(KIND_L2K)) launch_lds(KIND_L2K, rows[KIND_L2K], nrows[KIND_L2K], pool, moving ? up2 : none);
+    if (wanted(KIND_L1K)) launch_lds(KIND_L1K, rows[KIND_L1K], nrows[KIND_L1K], pool, moving ? up1 : none);
+    if (!moving) return;
+    if (const unsigned int n1 = read_u32(d_fail + 2)) launch_lds(KIND_L2K, d_up1, n1, pool, up2);
+    if (const unsigned int n2 = read_u32(d_fail + 3)) launch_lds(KIND_L4K, d_up2, n2, pool, none);
   };
   // rows with an explicit list (second and later attempts)
   struct List { std::vector<int32_t> rows; int32_t* d = nullptr; };
@@ -550,9 +641,15 @@ DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, boo
     l.d = dmalloc<int32_t>((int64_t)l.rows.size());
     HIP_CHECK(hipMemcpyAsync(l.d, l.rows.data(), sizeof(int32_t) * l.rows.size(), hipMemcpyHostToDevice, s));
   };
-  std::vector<int64_t> ub_host;                         // only when some row needs a global table
+  std::vector<int64_t> ub_host;                         // only when rows fail
+  auto need_ub_host = [&] {
+    if (!ub_host.empty()) return;
+    ub_host.resize(m);
+    HIP_CHECK(hipMemcpyAsync(ub_host.data(), d_ub, sizeof(int64_t) * (size_t)m, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+  };
   auto launch_global = [&](List& l, const RowPool& pool, std::vector<void*>& scratch) {
-    if (ub_host.empty()) { ub_host.resize(m); HIP_CHECK(hipMemcpyAsync(ub_host.data(), d_ub, sizeof(int64_t) * (size_t)m, hipMemcpyDeviceToHost, s)); HIP_CHECK(hipStreamSynchronize(s)); }
+    need_ub_host();
     const size_t n = l.rows.size();
     std::vector<int64_t> toff(n); std::vector<int32_t> tsize(n);
     int64_t run = 0;
@@ -573,7 +670,7 @@ DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, boo
   };
   struct Round { int32_t* ci; double* v; bool all_rows; std::vector<int32_t> done; };
   std::vector<Round> rounds;
-  List todo[4];                                          // per accumulator kind; empty in the first round (= every row)
+  List todo[NKIND];                                      // per accumulator kind; empty in the first round (= every row)
   int64_t n_global = 0;
   double t_kern = 0;
   std::vector<int64_t> cnt_host;
@@ -588,17 +685,19 @@ DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, boo
     if (capacity < longest) throw std::runtime_error("dev_spgemm: not enough device memory for the output pool");
     Round rd; rd.ci = dmalloc<int32_t>(capacity); rd.v = dmalloc<double>(capacity); rd.all_rows = false;
     HIP_CHECK(hipMemsetAsync(d_cursor, 0, sizeof(unsigned long long), s));
-    HIP_CHECK(hipMemsetAsync(d_fail, 0, 2 * sizeof(unsigned int), s));
+    HIP_CHECK(hipMemsetAsync(d_fail, 0, 4 * sizeof(unsigned int), s));
     const RowPool pool{d_cursor, capacity, rd.ci, rd.v, d_pos};
     const double tk0 = now();
     std::vector<void*> scratch;
-    if (first) {
-      for (int bin = 0; bin < 3; bin++) if (us.rows[bin]) launch(bin, RowSel{nullptr, 0, d_ub, bin}, pool);
-    } else {
-      for (int bin = 0; bin < 4; bin++) upload_list(todo[bin]);
-      for (int bin = 0; bin < 3; bin++) if (todo[bin].d) launch(bin, RowSel{todo[bin].d, (int64_t)todo[bin].rows.size(), d_ub, bin}, pool);
-      if (todo[BIN_GLOBAL].d) launch_global(todo[BIN_GLOBAL], pool, scratch);
+    const int32_t* lists[NKIND] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int64_t counts[NKIND] = {0, 0, 0, 0, 0};
+    if (!first) for (int k = 0; k < NKIND; k++) { upload_list(todo[k]); lists[k] = todo[k].d; counts[k] = (int64_t)todo[k].rows.size(); }
+    if (first || lists[KIND_REG]) {
+      const RowSel sel{lists[KIND_REG], counts[KIND_REG], d_ub, KIND_REG, plan};
+      hipLaunchKernelGGL(k_spgemm_tiny, grid_reg(first ? m : counts[KIND_REG]), dim3(BLOCK), 0, s, av, bv, sel, dp, d_cnt, pool, d_fail, d_seen + KIND_REG);
     }
+    run_tables(lists, counts, first, pool);
+    if (lists[KIND_GLOBAL]) launch_global(todo[KIND_GLOBAL], pool, scratch);
     unsigned int fail[2];
     HIP_CHECK(hipMemcpyAsync(fail, d_fail, sizeof(fail), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
@@ -610,31 +709,31 @@ DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, boo
     cnt_host.resize(m);
     HIP_CHECK(hipMemcpyAsync(cnt_host.data(), d_cnt, sizeof(int64_t) * (size_t)m, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
-    List next[4];
-    auto outcome = [&](int32_t i, int bin) {
+    List next[NKIND];
+    auto outcome = [&](int32_t i, int kind) {
       const int64_t c = cnt_host[i];
       if (c >= 0) rd.done.push_back(i);
       else if (c == -ROW_TABLE_OVERFLOW) {
-        if (bin == BIN_GLOBAL) throw std::runtime_error("dev_spgemm: global hash table overflow");
-        next[BIN_GLOBAL].rows.push_back(i); n_global++;
-      } else next[bin].rows.push_back(i);
+        if (kind == KIND_GLOBAL) throw std::runtime_error("dev_spgemm: global hash table overflow");
+        next[KIND_GLOBAL].rows.push_back(i); n_global++;
+      } else next[kind].rows.push_back(i);               // no place in the pool: same kind again (it moves up again if it must)
     };
     if (first) {
-      if (ub_host.empty()) { ub_host.resize(m); HIP_CHECK(hipMemcpyAsync(ub_host.data(), d_ub, sizeof(int64_t) * (size_t)m, hipMemcpyDeviceToHost, s)); HIP_CHECK(hipStreamSynchronize(s)); }
+      need_ub_host();
       std::vector<int64_t> arp(m + 1);
       HIP_CHECK(hipMemcpyAsync(arp.data(), A.rp, sizeof(int64_t) * (size_t)(m + 1), hipMemcpyDeviceToHost, s));
       HIP_CHECK(hipStreamSynchronize(s));
-      for (int64_t i = 0; i < m; i++) outcome((int32_t)i, bin_of(ub_host[i], arp[i + 1] - arp[i]));
+      for (int64_t i = 0; i < m; i++) outcome((int32_t)i, kind_of(ub_host[i], arp[i + 1] - arp[i], plan));
     } else {
-      for (int bin = 0; bin < 4; bin++) for (int32_t i : todo[bin].rows) outcome(i, bin);
+      for (int k = 0; k < NKIND; k++) for (int32_t i : todo[k].rows) outcome(i, k);
     }
     size_t left = 0;
-    for (int bin = 0; bin < 4; bin++) { if (todo[bin].d) (void)hipFree(todo[bin].d); left += next[bin].rows.size(); }
-    const bool progress = !rd.done.empty() || !next[BIN_GLOBAL].rows.empty();
+    for (int k = 0; k < NKIND; k++) { if (todo[k].d) (void)hipFree(todo[k].d); left += next[k].rows.size(); }
+    const bool progress = !rd.done.empty() || !next[KIND_GLOBAL].rows.empty();
     rounds.push_back(std::move(rd));
     if (!left) break;
     if (!progress) throw std::runtime_error("dev_spgemm: no progress (output pool too small)");
-    for (int bin = 0; bin < 4; bin++) { todo[bin].rows.swap(next[bin].rows); todo[bin].d = nullptr; }
+    for (int k = 0; k < NKIND; k++) { todo[k].rows.swap(next[k].rows); todo[k].d = nullptr; }
   }
   // ---- row pointers (device scan of the counts), then the rows of every round into row order
   const double tg0 = now();
@@ -659,14 +758,20 @@ DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, boo
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) throw std::runtime_error(std::string("HIP error ") + hipGetErrorString(e) + " in the device SpGEMM");
   const double t_gather = now() - tg0;
-  (void)hipFree(d_ub); (void)hipFree(d_cnt); (void)hipFree(d_pos); (void)hipFree(d_cursor); (void)hipFree(d_fail);
+  unsigned long long seen[NKIND];
+  HIP_CHECK(hipMemcpy(seen, d_seen, sizeof(seen), hipMemcpyDeviceToHost));
+  (void)hipFree(d_ub); (void)hipFree(d_cnt); (void)hipFree(d_pos); (void)hipFree(d_cursor); (void)hipFree(d_fail); (void)hipFree(d_seen);
+  if (d_up1) { (void)hipFree(d_up1); (void)hipFree(d_up2); }
   if (trace) {
-    std::printf("   [spgemm] m=%lld nnzA=%lld nnzB=%lld bound=%lld nnzC=%lld bins=%llu/%llu/%llu/%lld rounds=%zu  ub %.3f kernels %.3f gather %.3f total %.3f s\n",
-                (long long)m, (long long)A.nnz, (long long)B.nnz, (long long)ub_total, (long long)C.nnz, us.rows[0], us.rows[1], us.rows[2],
-                (long long)n_global, rounds.size(), t_ub, t_kern, t_gather, now() - t_begin);
+    std::printf("   [spgemm] m=%lld nnzA=%lld nnzB=%lld bound=%lld nnzC=%lld rows reg/1k/2k/4k/global=%llu/%llu/%llu/%llu/%lld ratio=%.3f rounds=%zu  plan %.3f kernels %.3f gather %.3f total %.3f s\n",
+                (long long)m, (long long)A.nnz, (long long)B.nnz, (long long)ub_total, (long long)C.nnz, seen[0], seen[1], seen[2], seen[3],
+                (long long)n_global, (double)plan.ratio, rounds.size(), t_ub, t_kern, t_gather, now() - t_begin);
     std::fflush(stdout);
   }
-  if (stats) { stats->rows_tiny = (int64_t)us.rows[0]; stats->rows_small = (int64_t)us.rows[1]; stats->rows_big = (int64_t)us.rows[2]; stats->rows_global = n_global; }
+  if (stats) {
+    stats->rows_reg = (int64_t)seen[KIND_REG]; stats->rows_1k = (int64_t)seen[KIND_L1K]; stats->rows_2k = (int64_t)seen[KIND_L2K];
+    stats->rows_4k = (int64_t)seen[KIND_L4K]; stats->rows_global = n_global;
+  }
   return C;
 }
 

@@ -13,8 +13,9 @@ struct DCsr {
   double* v = nullptr;
 };
 
-// rows per accumulator kind: registers (<= 64 candidates), LDS 1k slots, LDS 4k slots, global-memory table
-struct SpgemmStats { int64_t rows_tiny = 0, rows_small = 0, rows_big = 0, rows_global = 0; };
+// rows each accumulator kind has worked on: registers (<= 64 candidates), LDS tables of 1k / 2k / 4k slots, global-memory
+// table (a row that overflows a table is counted again by the next kind)
+struct SpgemmStats { int64_t rows_reg = 0, rows_1k = 0, rows_2k = 0, rows_4k = 0, rows_global = 0; };
 
 // test hook: cap of the output pool in entries (0 = automatic); a small cap forces the retry rounds
 void spgemm_set_pool_limit(int64_t entries);

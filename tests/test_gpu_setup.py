@@ -19,7 +19,7 @@ def _spgemm(P, A, B, drop=False, tol=0.0, lump=False, negate=False, on_device=Tr
     fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     a, b = P.as_csr(A), P.as_csr(B)
     h = C.c_void_p()
-    stats = (C.c_int64 * 4)()
+    stats = (C.c_int64 * 5)()
     rc = fn(a.ref(), b.ref(), int(drop), float(tol), int(lump), int(negate), int(on_device), C.byref(h), stats)
     assert rc == 0, P.lib().airhip_last_error().decode()
     out = P.HostMat(h).csr()
@@ -49,12 +49,14 @@ def _same(c, d, what=""):
 
 
 SPGEMM_CASES = [
-    # m, k, n, nnz/row A, nnz/row B, accumulator kind that must see rows (0 registers, 1 LDS 1k, 2 LDS 4k, 3 global table)
+    # m, k, n, nnz/row A, nnz/row B, accumulator kind that must see rows (0 registers, 1-3 LDS 1k / 2k / 4k, 4 global table)
     (500, 400, 600, 5, 6, 0),
     (700, 90, 60, 8, 8, 0),             # 64 candidates on 60 columns: runs of equal columns in the register sort
     (400, 400, 500, 12, 14, 1),
-    (300, 300, 300, 40, 40, 2),
-    (64, 3000, 40000, 300, 30, 3),
+    (300, 300, 300, 40, 40, 1),         # 1600 candidates on 300 columns: the sampled ratio sends the rows to the 1k tables
+    (300, 3000, 40000, 40, 40, 2),      # 1600 candidates, nearly all distinct
+    (200, 3000, 40000, 70, 40, 3),      # 2800
+    (64, 3000, 40000, 300, 30, 4),      # 9000
 ]
 
 
@@ -100,6 +102,31 @@ def test_device_spgemm_many_short_rows_of_b(gpu):
     _same(dev, href)
 
 
+def test_device_spgemm_rows_that_overflow_the_planned_table_move_up(gpu):
+    """the accumulator is chosen from the ratio distinct columns / candidates of a SAMPLE of rows; rows with far more
+    distinct columns than the sample promised overflow the 1k table and are redone with a 2k table, those that
+    overflow that with a 4k table (device lists)"""
+    import pflare_amd as P
+    rng = np.random.default_rng(21)
+    k, n, m = 2000, 50000, 1200
+    # rows 0..999 of B live on 300 columns, rows 1000..1999 anywhere
+    rows = np.repeat(np.arange(k), 40)
+    cols = np.where(rows < 1000, rng.integers(0, 300, size=rows.size), rng.integers(0, n, size=rows.size))
+    B = sp.csr_matrix((rng.standard_normal(rows.size), (rows, cols)), shape=(k, n)); B.sum_duplicates(); B.sort_indices()
+    # rows of A: 40 entries on the clustered rows of B; every 40th row 40 entries, every other 40th row 70 entries on the spread rows
+    length = np.where(np.arange(m) % 40 == 13, 70, 40)
+    arows = np.repeat(np.arange(m), length)
+    spread = np.isin(arows % 40, (7, 13))
+    acols = np.where(spread, rng.integers(1000, 2000, size=arows.size), rng.integers(0, 1000, size=arows.size))
+    A = sp.csr_matrix((rng.standard_normal(arows.size), (arows, acols)), shape=(m, k)); A.sum_duplicates(); A.sort_indices()
+    for kw in ({}, dict(drop=True, tol=1e-2, lump=True)):
+        href, _ = _spgemm(P, A, B, on_device=False, **kw)
+        dev, stats = _spgemm(P, A, B, on_device=True, **kw)
+        # every row tried the 1k table, both kinds of spread rows moved to 2k, the long ones on to 4k
+        assert stats[1] == m and stats[2] == 2 * (m // 40) and stats[3] == m // 40 and stats[4] == 0, stats
+        _same(dev, href)
+
+
 def test_device_spgemm_pool_exhaustion_takes_more_rounds(gpu):
     """the output pool is a bump allocator; rows that find it full are redone with a fresh pool (airhip_set_tuning
     "spgemm_pool_entries" shrinks it so that the case arises at test size), rows that overflow the 4k LDS table go to the
@@ -107,7 +134,7 @@ def test_device_spgemm_pool_exhaustion_takes_more_rounds(gpu):
     import pflare_amd as P
     lib = P.lib()
     cases = [(_rand(3000, 400, 5, 1), _rand(400, 600, 6, 2)), (_rand(600, 300, 40, 3), _rand(300, 300, 40, 4)),
-             (_rand(64, 3000, 300, 5), _rand(3000, 40000, 30, 6))]
+             (_rand(300, 3000, 40, 7), _rand(3000, 40000, 40, 8)), (_rand(64, 3000, 300, 5), _rand(3000, 40000, 30, 6))]
     try:
         for A, B in cases:
             for kw in ({}, dict(drop=True, tol=5e-2, lump=True)):

@@ -22,7 +22,7 @@ def device_spgemm(P, A, B, drop, tol, lump, negate):
     fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     a, b = P.as_csr(A), P.as_csr(B)
     h = C.c_void_p()
-    stats = (C.c_int64 * 4)()
+    stats = (C.c_int64 * 5)()
     t0 = time.perf_counter()
     rc = fn(a.ref(), b.ref(), int(drop), float(tol), int(lump), int(negate), 1, C.byref(h), stats)
     dt = time.perf_counter() - t0
@@ -46,6 +46,8 @@ if __name__ == "__main__":
     t0 = time.perf_counter()
     pc.setup(A)
     print(f"[lab] {size}^3: {pc.num_levels} levels, setup {time.perf_counter() - t0:.1f} s", flush=True)
+    if len(sys.argv) > 5:          # experiment switches of a lab build of the kernels (not in the committed library)
+        os.environ["AIRHIP_SPGEMM_LAB"] = sys.argv[5]
     for lv in range(first, min(first + count, pc.num_levels - 1)):
         s = pc.export_level(lv, copy=True)
         if "A_ff" not in s or "mat" not in s["inv_ff"]:
