@@ -21,9 +21,11 @@ struct DevSetupAccel final : SetupAccel {
   hipStream_t stream = nullptr;
   DCsr resident;                 // last R*A*P result
   const void* resident_key = nullptr;  // host row-pointer array it was downloaded into
+  DCsr inverse;                  // last assembled polynomial inverse (the B of the Z = -A_cf * M product that follows)
+  const void* inverse_key = nullptr;
   int64_t min_nnz = 200000;      // smaller products stay on the host: launch + sync overheads dominate
 
-  ~DevSetupAccel() override { dcsr_free(resident); }
+  ~DevSetupAccel() override { dcsr_free(resident); dcsr_free(inverse); spgemm_release_scratch(); }
 
   DCsr up(const Csr& A) {
     const double t0 = now_s();
@@ -42,7 +44,10 @@ struct DevSetupAccel final : SetupAccel {
 
   Csr spgemm(const Csr& A, const Csr& B, const SpgemmDrop& drop) override {
     if (A.nnz() + B.nnz() < min_nnz) return airhip::spgemm(A, B, drop);
-    DCsr dA = up(A), dB = up(B);
+    DCsr dA = up(A), dB;
+    if (inverse_key && inverse_key == (const void*)B.rp.data() && inverse.m == B.m && inverse.nnz == B.nnz()) { dB = inverse; inverse = DCsr(); }
+    else dB = up(B);
+    dcsr_free(inverse); inverse_key = nullptr;
     const double t0 = now_s();
     DCsr dC = dev_spgemm(dA, dB, drop.enabled, drop.tol, drop.lump, drop.negate, stream);
     t_compute += now_s() - t0;
@@ -67,7 +72,7 @@ struct DevSetupAccel final : SetupAccel {
     return true;
   }
 
-  bool poly_assemble(const Csr& A, const std::vector<double>& c, Csr& M) override {
+  bool poly_assemble(const Csr& A, const std::vector<double>& c, Csr& M, bool final_values) override {
     static const bool enabled = [] { const char* e = std::getenv("AIRHIP_DEVICE_POLY"); return !(e && e[0] == '0'); }();
     if (!enabled || A.nnz() < min_nnz || c.size() < 3) return false;
     DCsr dA = up(A), dM;
@@ -77,7 +82,9 @@ struct DevSetupAccel final : SetupAccel {
     dcsr_free(dA);
     if (!ok) return false;
     M = down(dM);
-    dcsr_free(dM);
+    dcsr_free(inverse); inverse_key = nullptr;
+    if (final_values) { inverse = dM; inverse_key = (const void*)M.rp.data(); }   // Arr moves keep the pointer
+    else dcsr_free(dM);
     return true;
   }
 

@@ -272,15 +272,25 @@ __device__ __forceinline__ int tiny_accumulate(const CsrView& A, const CsrView& 
   int32_t col = EMPTY; double x = 0.0;
   if (q >= 0) { col = B.ci[q]; x = a * B.v[q]; }
   uint64_t key = ((uint64_t)(uint32_t)col << 6) | (uint32_t)lane;          // distinct keys: no ties
+  // bitonic network over the first P lanes (P = the candidates rounded up to a power of two; the other lanes hold
+  // EMPTY, which sorts last anyway).  Partner values come through ds_bpermute with the lane address of the stride.
+  const int total = lane_i32(incl, WAVE - 1);
 #pragma unroll
-  for (int size = 2; size <= WAVE; size <<= 1)
+  for (int size = 2; size <= WAVE; size <<= 1) {
+    if (size / 2 >= total) break;                       // wave-uniform
 #pragma unroll
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      const uint64_t ok = (uint64_t)__shfl_xor((long long)key, stride, WAVE);
-      const double ox = __shfl_xor(x, stride, WAVE);
+      const int addr = (lane ^ stride) << 2;
+      const uint32_t klo = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)key);
+      const uint32_t khi = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)(key >> 32));
+      const long long xb = __double_as_longlong(x);
+      const uint32_t xlo = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)xb);
+      const uint32_t xhi = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)((unsigned long long)xb >> 32));
+      const uint64_t ok = ((uint64_t)khi << 32) | klo;
       const bool want_min = ((lane & stride) == 0) == ((lane & size) == 0);
-      if (want_min ? ok < key : ok > key) { key = ok; x = ox; }
+      if ((ok < key) == want_min) { key = ok; x = __longlong_as_double((long long)(((uint64_t)xhi << 32) | xlo)); }
     }
+  }
   col = (int32_t)(key >> 6);
   const int32_t prev = __shfl_up(col, 1, WAVE);
   const bool head = col != EMPTY && (lane == 0 || prev != col);
@@ -506,6 +516,19 @@ template <class T> T* dmalloc(int64_t n) { T* p = nullptr; HIP_CHECK(hipMalloc(&
 static int64_t g_pool_limit = 0;
 void spgemm_set_pool_limit(int64_t entries) { g_pool_limit = entries > 0 ? entries : 0; }
 
+// The output pool of one product is tens of GB on the large levels and hipMalloc / hipFree of such blocks costs
+// seconds (mapping the pages): the pool of the last product is kept and reused when it is large enough.
+namespace {
+struct PoolCache { int32_t* ci = nullptr; double* v = nullptr; int64_t capacity = 0; bool in_use = false; };
+PoolCache g_pool;
+}
+void spgemm_release_scratch() {
+  if (g_pool.in_use) return;
+  if (g_pool.ci) (void)hipFree(g_pool.ci);
+  if (g_pool.v) (void)hipFree(g_pool.v);
+  g_pool = PoolCache();
+}
+
 void dcsr_free(DCsr& A) {
   if (A.rp) (void)hipFree(A.rp);
   if (A.ci) (void)hipFree(A.ci);
@@ -668,22 +691,29 @@ DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, boo
     hipLaunchKernelGGL(k_spgemm_glb, dim3(gb), dim3(BLOCK), 0, s, av, bv, l.d, (int64_t)n, d_toff, d_tsize, d_kpool, d_vpool, dp, d_cnt, pool, d_fail);
     scratch.insert(scratch.end(), {d_toff, d_tsize, d_kpool, d_vpool});
   };
-  struct Round { int32_t* ci; double* v; bool all_rows; std::vector<int32_t> done; };
+  struct Round { int32_t* ci; double* v; bool all_rows; bool cached; std::vector<int32_t> done; };
   std::vector<Round> rounds;
   List todo[NKIND];                                      // per accumulator kind; empty in the first round (= every row)
   int64_t n_global = 0;
   double t_kern = 0;
   std::vector<int64_t> cnt_host;
   for (bool first = true;; first = false) {
-    // pool: a few times the inputs, never more than the sum of the bounds, never more than a third of the free memory
+    // pool: twice the inputs, never more than the sum of the bounds, never more than a third of the free memory
     size_t mem_free = 0, mem_total = 0;
     HIP_CHECK(hipMemGetInfo(&mem_free, &mem_total));
-    int64_t capacity = std::max<int64_t>(4 * (A.nnz + B.nnz) + (1 << 20), 2 * longest);
+    int64_t capacity = std::max<int64_t>(2 * (A.nnz + B.nnz) + (1 << 20), 2 * longest);
     capacity = std::min<int64_t>(capacity, ub_total);
     capacity = std::min<int64_t>(capacity, (int64_t)(mem_free / 3 / 12));
     if (g_pool_limit) capacity = std::max<int64_t>(longest, std::min<int64_t>(capacity, g_pool_limit));
     if (capacity < longest) throw std::runtime_error("dev_spgemm: not enough device memory for the output pool");
-    Round rd; rd.ci = dmalloc<int32_t>(capacity); rd.v = dmalloc<double>(capacity); rd.all_rows = false;
+    Round rd; rd.all_rows = false; rd.cached = false;
+    if (!g_pool.in_use && (g_pool.capacity >= capacity || (first && g_pool.capacity >= longest && g_pool.capacity >= capacity / 2))) {
+      rd.ci = g_pool.ci; rd.v = g_pool.v; capacity = g_pool.capacity; rd.cached = true; g_pool.in_use = true;   // (a little small: worth a try)
+    } else {
+      if (!g_pool.in_use) spgemm_release_scratch();
+      rd.ci = dmalloc<int32_t>(capacity); rd.v = dmalloc<double>(capacity);
+      if (!g_pool.in_use) { g_pool.ci = rd.ci; g_pool.v = rd.v; g_pool.capacity = capacity; g_pool.in_use = true; rd.cached = true; }
+    }
     HIP_CHECK(hipMemsetAsync(d_cursor, 0, sizeof(unsigned long long), s));
     HIP_CHECK(hipMemsetAsync(d_fail, 0, 4 * sizeof(unsigned int), s));
     const RowPool pool{d_cursor, capacity, rd.ci, rd.v, d_pos};
@@ -753,7 +783,7 @@ DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, boo
       HIP_CHECK(hipStreamSynchronize(s));
       if (d_rows) (void)hipFree(d_rows);
     }
-    (void)hipFree(rd.ci); (void)hipFree(rd.v);
+    if (rd.cached) g_pool.in_use = false; else { (void)hipFree(rd.ci); (void)hipFree(rd.v); }
   }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) throw std::runtime_error(std::string("HIP error ") + hipGetErrorString(e) + " in the device SpGEMM");

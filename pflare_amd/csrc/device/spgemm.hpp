@@ -20,6 +20,9 @@ struct SpgemmStats { int64_t rows_reg = 0, rows_1k = 0, rows_2k = 0, rows_4k = 0
 // test hook: cap of the output pool in entries (0 = automatic); a small cap forces the retry rounds
 void spgemm_set_pool_limit(int64_t entries);
 
+// frees the output pool kept between products (the end of a setup)
+void spgemm_release_scratch();
+
 void dcsr_free(DCsr& A);
 DCsr dcsr_upload(int64_t m, int64_t n, const int64_t* rp, const int32_t* ci, const double* v);
 void dcsr_download(const DCsr& d, int64_t* rp, int32_t* ci, double* v);

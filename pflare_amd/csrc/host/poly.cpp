@@ -575,7 +575,7 @@ static void build_gmres_polynomial_inverse(const OpView& A, int poly_order, cons
   } else if (sparsity_order < poly_order) {
     op.kind = InvOp::ASSEMBLED;
     // the default case (sparsity order 1) may run on the device, bit-identically (device/polyasm.hip)
-    if (!(sparsity_order == 1 && g_setup_accel && g_setup_accel->poly_assemble(*As, c, op.mat)))
+    if (!(sparsity_order == 1 && g_setup_accel && g_setup_accel->poly_assemble(*As, c, op.mat, !diag_scale)))
       op.mat = mat_mult_powers_share_sparsity(*As, c, sparsity_order);
   } else {
     // unconstrained: sum of true matrix powers

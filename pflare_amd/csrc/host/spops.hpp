@@ -64,8 +64,9 @@ struct SetupAccel {
     (void)A; (void)o; (void)markers; return false;
   }
   // Assembled GMRES polynomial with the sparsity of A (sparsity order 1): M = c0 I + c1 A + sum c_t [A^t]_P
-  // (host/poly.cpp::mat_mult_powers_share_sparsity).  Returns false when it declines.
-  virtual bool poly_assemble(const Csr& A, const std::vector<double>& c, Csr& M) { (void)A; (void)c; (void)M; return false; }
+  // (host/poly.cpp::mat_mult_powers_share_sparsity).  Returns false when it declines.  final_values: the caller will not
+  // change M afterwards (the accelerator may then keep its copy for the product that follows).
+  virtual bool poly_assemble(const Csr& A, const std::vector<double>& c, Csr& M, bool final_values) { (void)A; (void)c; (void)M; (void)final_values; return false; }
   double t_transfer = 0.0, t_compute = 0.0, t_cfsplit = 0.0, t_poly = 0.0;
 };
 // the accelerator the polynomial assembly may use (set by setup_air for its duration; null = host only)
