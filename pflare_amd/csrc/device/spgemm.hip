@@ -123,7 +123,11 @@ template <bool GLOBAL> struct Tab {
 
 // where the finished rows go: a pool with a bump allocator (the rows end up in completion order; a gather pass puts
 // them in row order once all counts are known)
-struct RowPool { unsigned long long* cursor; int64_t capacity; int32_t* ci; double* v; int64_t* row_pos; };
+// One atomic on the cursor per row caps the product at 80 M rows/s (same-address atomics take ~12 ns each at L2), which
+// is what the register kernel ran at on the fine levels whatever the rows held: a wave takes `chunk` entries at a time
+// and hands them out to its rows itself (the rest of its last chunk stays unused; the host sizes the pool for that).
+struct RowPool { unsigned long long* cursor; int64_t capacity; int32_t* ci; double* v; int64_t* row_pos; int chunk; };
+struct WaveAlloc { int64_t pos = 0, end = 0; };
 constexpr int ROW_OK = 0, ROW_TABLE_OVERFLOW = 1, ROW_POOL_FULL = 2;
 
 // value of lane l (wave-uniform l) as a scalar
@@ -311,7 +315,8 @@ __device__ __forceinline__ int tiny_accumulate(const CsrView& A, const CsrView& 
 // ---- filter and write: tab[0, nu) holds the sorted row.  Stores the number of kept entries in *count_out, takes that
 // many entries from the pool and writes the row there.  ROW_POOL_FULL: the row must be redone with a fresh pool.
 template <bool GLOBAL>
-__device__ __forceinline__ int finish_row(const Tab<GLOBAL> tab, int nu, int64_t i, const DropParams& dp, int64_t* count_out, const RowPool& pool) {
+__device__ __forceinline__ int finish_row(const Tab<GLOBAL> tab, int nu, int64_t i, const DropParams& dp, int64_t* count_out, const RowPool& pool,
+                                          WaveAlloc& wa) {
 #pragma clang fp contract(off)
   int32_t* __restrict__ out_ci = pool.ci; double* __restrict__ out_v = pool.v;
   const int lane = threadIdx.x & (WAVE - 1);
@@ -368,13 +373,19 @@ __device__ __forceinline__ int finish_row(const Tab<GLOBAL> tab, int nu, int64_t
     }
   }
   // ---- a place in the pool
-  unsigned long long base = 0;
-  if (lane == 0) base = atomicAdd(pool.cursor, (unsigned long long)kept);
-  base = (unsigned long long)uniform64((int64_t)base);
-  if ((int64_t)base + kept > pool.capacity) return ROW_POOL_FULL;
-  if (lane == 0) { *count_out = kept; pool.row_pos[i] = (int64_t)base; }
+  kept = uniform64(kept);
+  if (wa.pos + kept > wa.end) {
+    const int64_t want = kept > pool.chunk ? kept : (int64_t)pool.chunk;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(pool.cursor, (unsigned long long)want);
+    const int64_t b = uniform64((int64_t)base);
+    if (b + want > pool.capacity) return ROW_POOL_FULL;
+    wa.pos = b; wa.end = b + want;
+  }
+  int64_t o = wa.pos;
+  wa.pos += kept;
+  if (lane == 0) { *count_out = kept; pool.row_pos[i] = o; }
   // ---- write the row in column order
-  int64_t o = (int64_t)base;
   if (!dp.enabled) {
     for (int h = lane; h < nu; h += WAVE) { out_ci[o + h] = tab.ldk(h); out_v[o + h] = tab.ldv(h); }
     return ROW_OK;
@@ -439,6 +450,7 @@ __global__ __launch_bounds__(MAX_HT / HT * WAVE) void k_spgemm_lds(CsrView A, Cs
   const int64_t count = sel.rows ? sel.nrows : A.m;
   const Tab<false> tab{keys_all[wid], vals_all[wid]};
   unsigned long long mine = 0;
+  WaveAlloc wa;
   for (int64_t w = (int64_t)blockIdx.x * WPB + wid; w < count; w += nw) {
     const int64_t i = sel.rows ? (int64_t)sel.rows[w] : w;
     const int64_t ubi = sel.ub[i];
@@ -451,7 +463,7 @@ __global__ __launch_bounds__(MAX_HT / HT * WAVE) void k_spgemm_lds(CsrView A, Cs
     if (nu < 0 && esc.rows) {
       if ((threadIdx.x & (WAVE - 1)) == 0) esc.rows[atomicAdd(esc.count, 1u)] = (int32_t)i;
     } else {
-      report(nu < 0 ? ROW_TABLE_OVERFLOW : finish_row<false>(tab, nu, i, dp, cnt + i, pool), i, cnt, fail);
+      report(nu < 0 ? ROW_TABLE_OVERFLOW : finish_row<false>(tab, nu, i, dp, cnt + i, pool, wa), i, cnt, fail);
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -467,12 +479,13 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_tiny(CsrView A, CsrView B, Row
   const int64_t count = sel.rows ? sel.nrows : A.m;
   const Tab<false> tab{keys_all[wid], vals_all[wid]};
   unsigned long long mine = 0;
+  WaveAlloc wa;
   for (int64_t w = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wid; w < count; w += nw) {
     const int64_t i = sel.rows ? (int64_t)sel.rows[w] : w;
     if (!sel.rows && kind_of(sel.ub[i], A.rp[i + 1] - A.rp[i], sel.plan) != KIND_REG) continue;
     mine++;
     const int nu = tiny_accumulate(A, B, i, tab, dp.negate != 0);
-    report(finish_row<false>(tab, nu, i, dp, cnt + i, pool), i, cnt, fail);
+    report(finish_row<false>(tab, nu, i, dp, cnt + i, pool, wa), i, cnt, fail);
     tab.sync();
   }
   if ((threadIdx.x & (WAVE - 1)) == 0 && mine) atomicAdd(seen, mine);
@@ -501,11 +514,12 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_glb(CsrView A, CsrView B, cons
                                                      RowPool pool, unsigned int* __restrict__ fail) {
   const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * BLOCK) >> 6;
+  WaveAlloc wa;
   for (int64_t w = wave; w < nrows; w += nw) {
     const int64_t i = rows[w];
     const Tab<true> tab{keys_pool + tab_off[w], vals_pool + tab_off[w]};
     const int nu = hash_accumulate<true>(A, B, i, tab, tab_size[w], dp.negate != 0);
-    report(nu < 0 ? ROW_TABLE_OVERFLOW : finish_row<true>(tab, nu, i, dp, cnt + i, pool), i, cnt, fail);
+    report(nu < 0 ? ROW_TABLE_OVERFLOW : finish_row<true>(tab, nu, i, dp, cnt + i, pool, wa), i, cnt, fail);
   }
 }
 
@@ -514,7 +528,9 @@ template <class T> T* dmalloc(int64_t n) { T* p = nullptr; HIP_CHECK(hipMalloc(&
 }  // namespace
 
 static int64_t g_pool_limit = 0;
+static int g_pool_chunk = -1;          // -1: chunks of 2048 entries on the large products, none on the small ones
 void spgemm_set_pool_limit(int64_t entries) { g_pool_limit = entries > 0 ? entries : 0; }
+void spgemm_set_pool_chunk(int entries) { g_pool_chunk = entries; }
 
 // The output pool of one product is tens of GB on the large levels and hipMalloc / hipFree of such blocks costs
 // seconds (mapping the pages): the pool of the last product is kept and reused when it is large enough.
@@ -704,6 +720,12 @@ DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, boo
     int64_t capacity = std::max<int64_t>(2 * (A.nnz + B.nnz) + (1 << 20), 2 * longest);
     capacity = std::min<int64_t>(capacity, ub_total);
     capacity = std::min<int64_t>(capacity, (int64_t)(mem_free / 3 / 12));
+    // chunked hand-out: every wave may leave most of one chunk unused (at most ~70k waves over the kernels of a round)
+    // (only worth it - and only affordable - on the large products)
+    int chunk = g_pool_chunk >= 0 ? g_pool_chunk : 2048;
+    const int64_t slack = (int64_t)chunk * 72 * 1024;
+    if (!g_pool_limit && (g_pool_chunk >= 0 || capacity >= 2 * slack) && (int64_t)(mem_free / 3 / 12) > capacity + slack) capacity += slack;
+    else chunk = 0;
     if (g_pool_limit) capacity = std::max<int64_t>(longest, std::min<int64_t>(capacity, g_pool_limit));
     if (capacity < longest) throw std::runtime_error("dev_spgemm: not enough device memory for the output pool");
     Round rd; rd.all_rows = false; rd.cached = false;
@@ -716,7 +738,7 @@ DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, boo
     }
     HIP_CHECK(hipMemsetAsync(d_cursor, 0, sizeof(unsigned long long), s));
     HIP_CHECK(hipMemsetAsync(d_fail, 0, 4 * sizeof(unsigned int), s));
-    const RowPool pool{d_cursor, capacity, rd.ci, rd.v, d_pos};
+    const RowPool pool{d_cursor, capacity, rd.ci, rd.v, d_pos, chunk};
     const double tk0 = now();
     std::vector<void*> scratch;
     const int32_t* lists[NKIND] = {nullptr, nullptr, nullptr, nullptr, nullptr};

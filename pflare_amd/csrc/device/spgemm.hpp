@@ -19,6 +19,8 @@ struct SpgemmStats { int64_t rows_reg = 0, rows_1k = 0, rows_2k = 0, rows_4k = 0
 
 // test hook: cap of the output pool in entries (0 = automatic); a small cap forces the retry rounds
 void spgemm_set_pool_limit(int64_t entries);
+// test hook: entries a wave takes from the pool at a time (-1 = automatic: 2048 on large products, row by row on small ones)
+void spgemm_set_pool_chunk(int entries);
 
 // frees the output pool kept between products (the end of a setup)
 void spgemm_release_scratch();

@@ -147,6 +147,24 @@ def test_device_spgemm_pool_exhaustion_takes_more_rounds(gpu):
         lib.airhip_set_tuning(b"spgemm_pool_entries", 0)
 
 
+def test_device_spgemm_chunked_pool(gpu):
+    """on large products a wave takes 2048 pool entries at a time and places its rows itself; forced here at test size
+    (chunks of 100 entries: rows longer than a chunk, rows that straddle the end of one)"""
+    import pflare_amd as P
+    lib = P.lib()
+    cases = [(_rand(3000, 400, 5, 1), _rand(400, 600, 6, 2)), (_rand(600, 300, 40, 3), _rand(300, 300, 40, 4)),
+             (_rand(300, 3000, 40, 7), _rand(3000, 40000, 40, 8))]
+    try:
+        assert lib.airhip_set_tuning(b"spgemm_pool_chunk", 100) == 0
+        for A, B in cases:
+            for kw in ({}, dict(drop=True, tol=5e-2, lump=True)):
+                href, _ = _spgemm(P, A, B, on_device=False, **kw)
+                dev, _ = _spgemm(P, A, B, on_device=True, **kw)
+                _same(dev, href)
+    finally:
+        lib.airhip_set_tuning(b"spgemm_pool_chunk", -1)
+
+
 def test_device_spgemm_empty_rows_and_diagonal_creation(gpu):
     import pflare_amd as P
     # rows without entries, and rows whose diagonal only exists through lumping
