@@ -184,6 +184,12 @@ def main():
         st = pc.setup_times()
         cx = pc.complexities()
         log(f"[bench] setup {t_setup:.1f}s (host {st['host_setup_s']:.1f}s, upload {st['upload_s']:.1f}s) levels={pc.num_levels} {cx}")
+        if args.verbose:
+            try:
+                roll = {l.split(":")[0]: l.split(":")[1].strip() for l in open("/proc/self/smaps_rollup") if ":" in l}
+                log(f"[bench] host memory after setup: Rss {roll.get('Rss')}, AnonHugePages {roll.get('AnonHugePages')}")
+            except OSError:
+                pass
         info = dict(nnzA=nnzA, t_setup=t_setup, st=st, cx=cx, levels=pc.num_levels)
     parallelism = "single GPU"
     comm = None

@@ -721,16 +721,16 @@ DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, boo
     capacity = std::min<int64_t>(capacity, ub_total);
     capacity = std::min<int64_t>(capacity, (int64_t)(mem_free / 3 / 12));
     // chunked hand-out: every wave may leave most of one chunk unused (at most ~70k waves over the kernels of a round)
-    // (only worth it - and only affordable - on the large products)
+    // (only worth it on products with millions of rows)
     int chunk = g_pool_chunk >= 0 ? g_pool_chunk : 2048;
     const int64_t slack = (int64_t)chunk * 72 * 1024;
-    if (!g_pool_limit && (g_pool_chunk >= 0 || capacity >= 2 * slack) && (int64_t)(mem_free / 3 / 12) > capacity + slack) capacity += slack;
+    if (!g_pool_limit && (g_pool_chunk >= 0 || m >= (1 << 20)) && (int64_t)(mem_free / 3 / 12) > capacity + slack) capacity += slack;
     else chunk = 0;
     if (g_pool_limit) capacity = std::max<int64_t>(longest, std::min<int64_t>(capacity, g_pool_limit));
     if (capacity < longest) throw std::runtime_error("dev_spgemm: not enough device memory for the output pool");
     Round rd; rd.all_rows = false; rd.cached = false;
-    if (!g_pool.in_use && (g_pool.capacity >= capacity || (first && g_pool.capacity >= longest && g_pool.capacity >= capacity / 2))) {
-      rd.ci = g_pool.ci; rd.v = g_pool.v; capacity = g_pool.capacity; rd.cached = true; g_pool.in_use = true;   // (a little small: worth a try)
+    if (!g_pool.in_use && g_pool.capacity >= capacity) {
+      rd.ci = g_pool.ci; rd.v = g_pool.v; capacity = g_pool.capacity; rd.cached = true; g_pool.in_use = true;
     } else {
       if (!g_pool.in_use) spgemm_release_scratch();
       rd.ci = dmalloc<int32_t>(capacity); rd.v = dmalloc<double>(capacity);

@@ -180,6 +180,7 @@ static void coarse_solver(const Csr& A, const AirOptions& o, InvOp& op, bool fin
 
 std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o, SetupAccel* accel) {
   struct AccelScope { SetupAccel* prev; explicit AccelScope(SetupAccel* a) : prev(g_setup_accel) { g_setup_accel = a; } ~AccelScope() { g_setup_accel = prev; } } accel_scope(accel);
+  struct CacheScope { ~CacheScope() { trim_host_array_cache(true); } } cache_scope;   // released blocks wait for reuse during the setup only
   auto H = std::make_unique<Hierarchy>();
   H->opt = o;
   H->timers.assign(8, 0.0);
@@ -407,9 +408,10 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o, SetupAc
     }
     if (!any_c) { /* A_cf is only needed again for C smoothing; keep it anyway for export */ }
     if (o.print_stats_timings)
-      std::printf(" ~~~~~~~~~~~~ Level %d\n Global rows %lld Global F-points %lld Global C-points %lld  (nnz %lld, A_ff %s, t=%.2fs)\n",
+      std::printf(" ~~~~~~~~~~~~ Level %d\n Global rows %lld Global F-points %lld Global C-points %lld  (nnz %lld, A_ff %s, t=%.2fs, outside the timers %.2fs)\n",
                   our_level, (long long)n, (long long)n_f, (long long)n_c, (long long)L.nnz_A,
-                  L.aff_diag ? "diagonal" : "sparse", now_s() - t_setup);
+                  L.aff_diag ? "diagonal" : "sparse", now_s() - t_setup,
+                  now_s() - t_setup - (H->timers[0] + H->timers[1] + H->timers[2] + H->timers[3] + H->timers[4] + H->timers[5] + H->timers[6] + H->timers[7]));
     if (o.print_stats_timings)   // labels of print_timers() (src/Timers.F90:30-46): tools/parse_pflare_output.py reads them
       std::printf(" coarsen time     : %.6f\n extract time     : %.6f\n proc agglom time : %.6f\n inverse time     : %.6f\n"
                   " restrict time    : %.6f\n prolong time     : %.6f\n constrain time   : %.6f\n rap time         : %.6f\n"

@@ -15,26 +15,18 @@
 #include <algorithm>
 #include <chrono>
 #include <omp.h>
-#include <sys/mman.h>
 
 namespace airhip {
 
-// Large host arrays ask for transparent huge pages: with THP in "madvise" mode (the GPU box) the first touch of fresh
-// 4 KiB pages runs at 16 GB/s over 16 threads and hipMemcpy from such memory at 19 GB/s; with 2 MiB pages the same
-// box does 175 GB/s and 47 GB/s (profiles/r02_thp_probe.txt) - and the setup allocates and fills ~0.5 TB of arrays.
+// Memory of the host arrays (host/hostmem.cpp): blocks of 4 MiB and more are 2 MiB-aligned and advised as transparent
+// huge pages, blocks of 64 MiB and more wait in a bounded cache when they are released (returning tens of GB to the
+// kernel costs seconds).  free_host_array takes any pointer alloc_host_array returned; plain std::free is also valid
+// for such a pointer (the block then simply leaves the bookkeeping).
 constexpr size_t HUGE_ALIGN = 2u << 20;
-inline void* alloc_host_array(size_t bytes) {
-  void* p;
-  if (bytes >= 2 * HUGE_ALIGN) {
-    bytes = (bytes + HUGE_ALIGN - 1) / HUGE_ALIGN * HUGE_ALIGN;
-    p = std::aligned_alloc(HUGE_ALIGN, bytes);
-    if (p) (void)madvise(p, bytes, MADV_HUGEPAGE);     // advisory: failure leaves ordinary pages
-  } else {
-    p = std::aligned_alloc(64, (bytes + 63) / 64 * 64);
-  }
-  if (!p) throw std::bad_alloc();
-  return p;
-}
+void* alloc_host_array(size_t bytes);
+void free_host_array(void* p);
+// returns the cached blocks to the system (the end of a setup), optionally on a detached thread
+void trim_host_array_cache(bool in_background);
 
 // Uninitialised, 64-byte aligned array (std::vector would zero 5 GB arrays serially).
 template <class T>
@@ -52,7 +44,7 @@ struct Arr {
     return *this;
   }
   ~Arr() { release(); }
-  void release() { if (p && own) std::free(p); p = nullptr; n = 0; own = true; }
+  void release() { if (p && own) free_host_array(p); p = nullptr; n = 0; own = true; }
   void view(const T* ptr, int64_t n_) { release(); p = const_cast<T*>(ptr); n = n_; own = false; }
   void alloc(int64_t n_) {
     release();

@@ -88,12 +88,12 @@ OpHalo compute_halo(const Csr& X, const Space& R, const Space& C, int N) {
 
 struct OpRef { const Csr* X; const Space* R; const Space* C; OpHalo halo; };
 
-// hands the array's memory over to the archive (Arr memory comes from aligned_alloc -> free)
+// hands the array's memory over to the archive
 template <class T>
 void put_take(Archive& ar, const std::string& name, int dtype, Arr<T>& a, int64_t count) {
   if (!a.own || !a.p) { ar.add_copy(name, dtype, a.p, count); return; }
   Archive::Item it; it.name = name; it.dtype = dtype; it.count = count; it.ptr = a.p;
-  it.own = std::shared_ptr<void>((void*)a.p, std::free);
+  it.own = std::shared_ptr<void>((void*)a.p, free_host_array);
   a.p = nullptr; a.n = 0;
   ar.index[name] = (int)ar.items.size();
   ar.items.push_back(std::move(it));
