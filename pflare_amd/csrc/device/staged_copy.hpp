@@ -1,6 +1,7 @@
-// Large host <-> device copies of pageable host memory through two pinned bounce buffers: the DMA of chunk k+1
-// overlaps a multi-threaded memcpy of chunk k (a plain hipMemcpy of pageable memory ran at 13-15 GB/s on the test
-// box; the setup moves every level operator once in each direction).
+// Large host <-> device copies of pageable host memory (the setup moves every level operator once in each direction).
+// Arrays of 32 MiB and more are pinned in place for the copy (hipHostRegister; 57 GB/s); if that is refused, and for
+// AIRHIP_HOST_COPY=staged, the copy goes through two pinned bounce buffers, the DMA of chunk k+1 overlapping a
+// multi-threaded memcpy of chunk k (~30 GB/s); AIRHIP_HOST_COPY=plain is a bare hipMemcpy.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstddef>

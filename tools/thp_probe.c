@@ -38,6 +38,22 @@ int main(void) {
     t0 = now(); hipMemcpy(p, d, n, hipMemcpyDeviceToHost); t1 = now();
     printf(", D2H (untouched) %.2f GB/s\n", n / (t1 - t0) / 1e9);
     free(p);
+    // pinning in place: hipHostRegister of touched memory, copies to / from it, unregister
+    if (posix_memalign((void**)&p, 2u << 20, n)) return 1;
+    if (huge) madvise(p, n, MADV_HUGEPAGE);
+    touch(p, n);
+    t0 = now(); hipError_t e = hipHostRegister(p, n, hipHostRegisterDefault); t1 = now();
+    printf("               hipHostRegister %s %.2f GB/s", e == hipSuccess ? "ok" : "FAILED", n / (t1 - t0) / 1e9);
+    if (e == hipSuccess) {
+      t0 = now(); hipMemcpy(d, p, n, hipMemcpyHostToDevice); t1 = now();
+      printf(", H2D %.2f GB/s", n / (t1 - t0) / 1e9);
+      t0 = now(); hipMemcpy(p, d, n, hipMemcpyDeviceToHost); t1 = now();
+      printf(", D2H %.2f GB/s", n / (t1 - t0) / 1e9);
+      t0 = now(); hipHostUnregister(p); t1 = now();
+      printf(", unregister %.2f GB/s", n / (t1 - t0) / 1e9);
+    }
+    t0 = now(); free(p); t1 = now();
+    printf(", free %.2f GB/s\n", n / (t1 - t0) / 1e9);
   }
   return 0;
 }
