@@ -446,6 +446,7 @@ int airhip_pcair_setup(airhip_pcair pc, const airhip_csr* A) {
   pc->byo = false;
   pc->op_nnz_top = (double)pc->A_top.nnz();
   if (pc->device_upload) finish_device(pc);
+  trim_host_array_cache(true);   // blocks released during the setup waited for reuse; after the upload, so that the unmapping does not get in its way
   pc->A_top = Csr();   // drop the view of the caller's arrays
   if (pc->opt.print_stats_timings) {
     // print_stats (src/AIR_MG_Stats.F90:386-416); the format tools/parse_pflare_output.py reads
@@ -471,6 +472,7 @@ int airhip_pcair_setup_host_only(airhip_pcair pc, const airhip_csr* A) {
   ThreadScope threads(A->rowptr[A->m]);
   double t0 = now_s();
   pc->H = setup_air(view, pc->opt);
+  trim_host_array_cache(true);
   pc->host_setup_s = now_s() - t0;
   pc->op_nnz_top = (double)view.nnz();
   pc->byo = false;

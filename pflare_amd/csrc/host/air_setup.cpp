@@ -180,7 +180,6 @@ static void coarse_solver(const Csr& A, const AirOptions& o, InvOp& op, bool fin
 
 std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o, SetupAccel* accel) {
   struct AccelScope { SetupAccel* prev; explicit AccelScope(SetupAccel* a) : prev(g_setup_accel) { g_setup_accel = a; } ~AccelScope() { g_setup_accel = prev; } } accel_scope(accel);
-  struct CacheScope { ~CacheScope() { trim_host_array_cache(true); } } cache_scope;   // released blocks wait for reuse during the setup only
   auto H = std::make_unique<Hierarchy>();
   H->opt = o;
   H->timers.assign(8, 0.0);
