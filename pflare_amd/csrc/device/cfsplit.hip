@@ -15,6 +15,7 @@
 #include "rb.hpp"
 #include "spgemm.hpp"
 #include "cfsplit_dev.hpp"
+#include "devmem.hpp"
 #include <vector>
 #include <cmath>
 #include <algorithm>
@@ -203,8 +204,8 @@ __global__ __launch_bounds__(BLOCK) void k_ddc_flip(int64_t m, const double* __r
 
 struct Scratch {
   std::vector<void*> p;
-  ~Scratch() { for (void* q : p) if (q) (void)hipFree(q); }
-  template <class T> T* get(int64_t n) { void* q = nullptr; HIP_CHECK(hipMalloc(&q, sizeof(T) * (size_t)std::max<int64_t>(n, 1))); p.push_back(q); return (T*)q; }
+  ~Scratch() { for (void* q : p) dev_free(q); }
+  template <class T> T* get(int64_t n) { void* q = dev_alloc(sizeof(T) * (size_t)std::max<int64_t>(n, 1)); p.push_back(q); return (T*)q; }
 };
 
 }  // namespace

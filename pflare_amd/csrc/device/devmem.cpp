@@ -1,0 +1,88 @@
+#include "devmem.hpp"
+#include "dev.hpp"
+#include <cstdlib>
+#include <mutex>
+#include <stdexcept>
+#include <unordered_map>
+#include <vector>
+
+namespace airhip {
+
+namespace {
+
+constexpr size_t CACHE_MIN = 1u << 20;      // smaller blocks are not worth keeping
+
+struct DevCache {
+  std::mutex mu;
+  std::unordered_map<void*, size_t> live;
+  std::vector<std::pair<void*, size_t>> idle;
+  size_t idle_bytes = 0;
+  size_t limit = [] {
+    const char* e = std::getenv("AIRHIP_DEVICE_CACHE_GB");
+    return (size_t)(e ? std::atof(e) : 96.0) << 30;
+  }();
+};
+DevCache& cache() { static DevCache* c = new DevCache; return *c; }
+
+}  // namespace
+
+void* dev_alloc(size_t bytes) {
+  if (bytes == 0) bytes = 1;
+  DevCache& c = cache();
+  if (bytes >= CACHE_MIN) {
+    std::lock_guard<std::mutex> lock(c.mu);
+    int best = -1;          // smallest idle block that holds the request and is at most twice its size
+    for (int k = 0; k < (int)c.idle.size(); k++)
+      if (c.idle[k].second >= bytes && c.idle[k].second / 2 <= bytes && (best < 0 || c.idle[k].second < c.idle[best].second)) best = k;
+    if (best >= 0) {
+      const auto blk = c.idle[best];
+      c.idle.erase(c.idle.begin() + best);
+      c.idle_bytes -= blk.second;
+      c.live[blk.first] = blk.second;
+      return blk.first;
+    }
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) {                 // make room and try once more
+    (void)hipGetLastError();
+    dev_cache_trim();
+    e = hipMalloc(&p, bytes);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    throw std::runtime_error(std::string("hipMalloc of ") + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
+  }
+  if (bytes >= CACHE_MIN) { std::lock_guard<std::mutex> lock(c.mu); c.live[p] = bytes; }
+  return p;
+}
+
+void dev_free(void* p) {
+  if (!p) return;
+  DevCache& c = cache();
+  {
+    std::lock_guard<std::mutex> lock(c.mu);
+    auto it = c.live.find(p);
+    if (it != c.live.end()) {
+      const size_t bytes = it->second;
+      c.live.erase(it);
+      if (c.idle_bytes + bytes <= c.limit) { c.idle.emplace_back(p, bytes); c.idle_bytes += bytes; return; }
+    }
+  }
+  (void)hipFree(p);
+}
+
+void dev_cache_trim() {
+  DevCache& c = cache();
+  std::vector<std::pair<void*, size_t>> blocks;
+  { std::lock_guard<std::mutex> lock(c.mu); blocks.swap(c.idle); c.idle_bytes = 0; }
+  for (const auto& b : blocks) (void)hipFree(b.first);
+}
+
+size_t dev_cache_idle_bytes() {
+  DevCache& c = cache();
+  std::lock_guard<std::mutex> lock(c.mu);
+  return c.idle_bytes;
+}
+
+}  // namespace airhip

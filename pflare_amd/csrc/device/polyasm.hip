@@ -14,6 +14,7 @@
 #include "rb.hpp"
 #include "spgemm.hpp"
 #include "polyasm.hpp"
+#include "devmem.hpp"
 #include <vector>
 #include <stdexcept>
 #include <algorithm>
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(WPB * WAVE) void k_poly_rows(int64_t nrows, const i
   }
 }
 
-template <class T> T* dalloc(int64_t n) { T* p = nullptr; HIP_CHECK(hipMalloc(&p, sizeof(T) * (size_t)(n > 0 ? n : 1))); return p; }
+template <class T> T* dalloc(int64_t n) { return (T*)dev_alloc(sizeof(T) * (size_t)(n > 0 ? n : 1)); }
 
 }  // namespace
 
@@ -148,7 +149,7 @@ bool dev_poly_assemble(const DCsr& A, const double* c, int nterms, DCsr& M, hipS
   hipLaunchKernelGGL(k_poly_count, dim3(g1), dim3(BLOCK), 0, s, m, A.rp, A.ci, cnt);
   M.nnz = device_exclusive_scan(m, cnt, M.rp, s);
   HIP_CHECK(hipMemcpyAsync(M.rp + m, &M.nnz, sizeof(int64_t), hipMemcpyHostToDevice, s));
-  (void)hipFree(cnt);
+  dev_free(cnt);
   M.ci = dalloc<int32_t>(M.nnz); M.v = dalloc<double>(M.nnz);
   int32_t* d_small = dalloc<int32_t>((int64_t)small.size());
   int32_t* d_big = dalloc<int32_t>((int64_t)big.size());
@@ -166,7 +167,7 @@ bool dev_poly_assemble(const DCsr& A, const double* c, int nterms, DCsr& M, hipS
   }
   HIP_CHECK(hipStreamSynchronize(s));
   const hipError_t e = hipGetLastError();
-  (void)hipFree(d_small); (void)hipFree(d_big);
+  dev_free(d_small); dev_free(d_big);
   if (e != hipSuccess) throw std::runtime_error(std::string("HIP error ") + hipGetErrorString(e) + " in the device polynomial assembly");
   return true;
 }

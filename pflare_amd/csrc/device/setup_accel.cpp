@@ -7,6 +7,7 @@
 #include "spgemm.hpp"
 #include "cfsplit_dev.hpp"
 #include "polyasm.hpp"
+#include "devmem.hpp"
 #include "../host/air.hpp"
 #include <cmath>
 #include <cstdlib>
@@ -25,7 +26,7 @@ struct DevSetupAccel final : SetupAccel {
   const void* inverse_key = nullptr;
   int64_t min_nnz = 200000;      // smaller products stay on the host: launch + sync overheads dominate
 
-  ~DevSetupAccel() override { dcsr_free(resident); dcsr_free(inverse); spgemm_release_scratch(); }
+  ~DevSetupAccel() override { dcsr_free(resident); dcsr_free(inverse); spgemm_release_scratch(); dev_cache_trim(); }
 
   DCsr up(const Csr& A) {
     const double t0 = now_s();
@@ -100,8 +101,8 @@ struct DevSetupAccel final : SetupAccel {
     if (p < 1 || (int64_t)p + 1 > n) return false;
     struct Bufs {
       std::vector<void*> ptrs; DevMat M;
-      ~Bufs() { for (void* q : ptrs) if (q) (void)hipFree(q); devmat_free(M); }
-      double* alloc(size_t count) { void* q = nullptr; HIP_CHECK(hipMalloc(&q, sizeof(double) * std::max<size_t>(count, 1))); ptrs.push_back(q); return (double*)q; }
+      ~Bufs() { for (void* q : ptrs) dev_free(q); devmat_free(M); }
+      double* alloc(size_t count) { void* q = dev_alloc(sizeof(double) * std::max<size_t>(count, 1)); ptrs.push_back(q); return (double*)q; }
     } B;
     // the level operator: still resident from the previous level's R*A*P, or uploaded once
     {

@@ -18,6 +18,7 @@
 #include "rb.hpp"
 #include "spgemm.hpp"
 #include "staged_copy.hpp"
+#include "devmem.hpp"
 #include <stdexcept>
 #include <algorithm>
 #include <chrono>
@@ -523,7 +524,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_glb(CsrView A, CsrView B, cons
   }
 }
 
-template <class T> T* dmalloc(int64_t n) { T* p = nullptr; HIP_CHECK(hipMalloc(&p, sizeof(T) * (size_t)(n > 0 ? n : 1))); return p; }
+template <class T> T* dmalloc(int64_t n) { return (T*)dev_alloc(sizeof(T) * (size_t)(n > 0 ? n : 1)); }
 
 }  // namespace
 
@@ -540,15 +541,15 @@ PoolCache g_pool;
 }
 void spgemm_release_scratch() {
   if (g_pool.in_use) return;
-  if (g_pool.ci) (void)hipFree(g_pool.ci);
-  if (g_pool.v) (void)hipFree(g_pool.v);
+  if (g_pool.ci) dev_free(g_pool.ci);
+  if (g_pool.v) dev_free(g_pool.v);
   g_pool = PoolCache();
 }
 
 void dcsr_free(DCsr& A) {
-  if (A.rp) (void)hipFree(A.rp);
-  if (A.ci) (void)hipFree(A.ci);
-  if (A.v) (void)hipFree(A.v);
+  if (A.rp) dev_free(A.rp);
+  if (A.ci) dev_free(A.ci);
+  if (A.v) dev_free(A.v);
   A = DCsr();
 }
 
@@ -611,7 +612,7 @@ DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, boo
   UbStats us;
   HIP_CHECK(hipMemcpyAsync(&us, d_us, sizeof(UbStats), hipMemcpyDeviceToHost, s));
   HIP_CHECK(hipStreamSynchronize(s));
-  (void)hipFree(d_us);
+  dev_free(d_us);
   const int64_t ub_total = (int64_t)us.total, longest = (int64_t)us.longest;
   // ---- distinct columns per candidate on a sample of the long rows: which table each of them gets
   Plan plan{L1K_MAX, L2K_MAX, 1.0f};
@@ -623,7 +624,7 @@ DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, boo
     HIP_CHECK(hipMemcpyAsync(sub.data(), d_sub, sizeof(int64_t) * (size_t)ns, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipMemcpyAsync(snu.data(), d_snu, sizeof(int32_t) * (size_t)ns, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
-    (void)hipFree(d_sub); (void)hipFree(d_snu);
+    dev_free(d_sub); dev_free(d_snu);
     std::vector<double> r;
     for (int w = 0; w < ns; w++) if (snu[w] != -2) r.push_back(snu[w] < 0 ? 1.0 : (double)snu[w] / (double)sub[w]);
     if (!r.empty()) {
@@ -717,6 +718,7 @@ DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, boo
     // pool: twice the inputs, never more than the sum of the bounds, never more than a third of the free memory
     size_t mem_free = 0, mem_total = 0;
     HIP_CHECK(hipMemGetInfo(&mem_free, &mem_total));
+    mem_free += dev_cache_idle_bytes();      // released blocks are handed back when a request does not fit
     int64_t capacity = std::max<int64_t>(2 * (A.nnz + B.nnz) + (1 << 20), 2 * longest);
     capacity = std::min<int64_t>(capacity, ub_total);
     capacity = std::min<int64_t>(capacity, (int64_t)(mem_free / 3 / 12));
@@ -753,7 +755,7 @@ DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, boo
     unsigned int fail[2];
     HIP_CHECK(hipMemcpyAsync(fail, d_fail, sizeof(fail), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
-    for (void* p : scratch) (void)hipFree(p);
+    for (void* p : scratch) dev_free(p);
     t_kern += now() - tk0;
     const bool clean = fail[0] == 0 && fail[1] == 0;
     if (first && clean) { rd.all_rows = true; rounds.push_back(std::move(rd)); break; }
@@ -780,7 +782,7 @@ DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, boo
       for (int k = 0; k < NKIND; k++) for (int32_t i : todo[k].rows) outcome(i, k);
     }
     size_t left = 0;
-    for (int k = 0; k < NKIND; k++) { if (todo[k].d) (void)hipFree(todo[k].d); left += next[k].rows.size(); }
+    for (int k = 0; k < NKIND; k++) { if (todo[k].d) dev_free(todo[k].d); left += next[k].rows.size(); }
     const bool progress = !rd.done.empty() || !next[KIND_GLOBAL].rows.empty();
     rounds.push_back(std::move(rd));
     if (!left) break;
@@ -803,17 +805,17 @@ DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, boo
       const unsigned g = (unsigned)std::max<int64_t>(1, std::min<int64_t>((nr + 3) / 4, 8192));
       hipLaunchKernelGGL(k_gather_rows, dim3(g), dim3(BLOCK), 0, s, nr, d_rows, d_pos, C.rp, rd.ci, rd.v, C.ci, C.v);
       HIP_CHECK(hipStreamSynchronize(s));
-      if (d_rows) (void)hipFree(d_rows);
+      if (d_rows) dev_free(d_rows);
     }
-    if (rd.cached) g_pool.in_use = false; else { (void)hipFree(rd.ci); (void)hipFree(rd.v); }
+    if (rd.cached) g_pool.in_use = false; else { dev_free(rd.ci); dev_free(rd.v); }
   }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) throw std::runtime_error(std::string("HIP error ") + hipGetErrorString(e) + " in the device SpGEMM");
   const double t_gather = now() - tg0;
   unsigned long long seen[NKIND];
   HIP_CHECK(hipMemcpy(seen, d_seen, sizeof(seen), hipMemcpyDeviceToHost));
-  (void)hipFree(d_ub); (void)hipFree(d_cnt); (void)hipFree(d_pos); (void)hipFree(d_cursor); (void)hipFree(d_fail); (void)hipFree(d_seen);
-  if (d_up1) { (void)hipFree(d_up1); (void)hipFree(d_up2); }
+  dev_free(d_ub); dev_free(d_cnt); dev_free(d_pos); dev_free(d_cursor); dev_free(d_fail); dev_free(d_seen);
+  if (d_up1) { dev_free(d_up1); dev_free(d_up2); }
   if (trace) {
     std::printf("   [spgemm] m=%lld nnzA=%lld nnzB=%lld bound=%lld nnzC=%lld rows reg/1k/2k/4k/global=%llu/%llu/%llu/%llu/%lld ratio=%.3f rounds=%zu  plan %.3f kernels %.3f gather %.3f total %.3f s\n",
                 (long long)m, (long long)A.nnz, (long long)B.nnz, (long long)ub_total, (long long)C.nnz, seen[0], seen[1], seen[2], seen[3],
