@@ -190,6 +190,8 @@ int airhip_compute_cf_splitting_on_device(const airhip_csr* A, int symmetric, do
   Arr<int32_t> m;
   REQUIRE(accel->cf_splitting(view, o, m), AIRHIP_ERR_STATE, "the device CF splitting is disabled (AIRHIP_DEVICE_CFSPLIT=0)");
   for (int64_t i = 0; i < A->m; i++) markers[i] = m[i];
+  accel.reset();
+  dev_cache_trim();
   API_END
 }
 
@@ -448,6 +450,7 @@ int airhip_pcair_setup(airhip_pcair pc, const airhip_csr* A) {
   pc->byo = false;
   pc->op_nnz_top = (double)pc->A_top.nnz();
   if (pc->device_upload) finish_device(pc);
+  dev_cache_trim();
   trim_host_array_cache(true);   // blocks released during the setup waited for reuse; after the upload, so that the unmapping does not get in its way
   pc->A_top = Csr();   // drop the view of the caller's arrays
   if (pc->opt.print_stats_timings) {
@@ -1052,6 +1055,7 @@ int airhip_pcinv_setup(airhip_pcinv pc, const airhip_csr* A) {
   pcinv_build_host(pc, view, true);
   view_csr(A, pc->inner.A_top);
   finish_device(&pc->inner);
+  dev_cache_trim();
   pc->inner.A_top = Csr();
   API_END
 }
@@ -1101,6 +1105,7 @@ int airhip_mat_create(const airhip_csr* A, airhip_mat* out) {
   HIP_CHECK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
   Csr view; view_csr(A, view);
   upload_mat(view, nullptr, nullptr, m->A, m->stream);
+  dev_cache_trim();
   m->n = A->m;
   *out = m;
   API_END

@@ -57,6 +57,17 @@ void* dev_alloc(size_t bytes) {
   return p;
 }
 
+void* dev_alloc_exact(size_t bytes) {
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+  if (e != hipSuccess) { (void)hipGetLastError(); dev_cache_trim(); e = hipMalloc(&p, bytes ? bytes : 1); }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    throw std::runtime_error(std::string("hipMalloc of ") + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
+  }
+  return p;
+}
+
 void dev_free(void* p) {
   if (!p) return;
   DevCache& c = cache();

@@ -11,6 +11,8 @@
 namespace airhip {
 void* dev_alloc(size_t bytes);           // throws std::runtime_error when the device is out of memory even after a trim
 void dev_free(void* p);                  // any pointer dev_alloc returned (nullptr is ignored)
+// long-lived arrays: a plain hipMalloc of exactly that size (released with hipFree), after a trim if the device is full
+void* dev_alloc_exact(size_t bytes);
 void dev_cache_trim();
 size_t dev_cache_idle_bytes();
 }  // namespace airhip

@@ -11,12 +11,21 @@
 
 namespace airhip {
 
+// where the upload of a hierarchy spends its time (printed with -pc_air_print_stats_timings)
+static double g_t_h2d = 0.0, g_t_convert = 0.0;
+
 void upload_mat(const Csr& A, const int32_t* d_rowsrc, const int32_t* d_colmap, DevMat& out, hipStream_t s, int64_t n_ghost) {
-  DBuf<int64_t> rp; DBuf<int32_t> ci; DBuf<double> v;
-  rp.upload(A.rp.data(), A.m + 1);
-  ci.upload(A.ci.data(), A.nnz());
-  v.upload(A.v.data(), A.nnz());
-  devmat_from_csr_device(A.m, A.n, rp.p, ci.p, v.p, d_rowsrc, d_colmap, out, s, n_ghost);
+  // the CSR arrays are only staged on the device: blocks from the cache, back to it afterwards
+  struct Staged { void* p; explicit Staged(size_t bytes) : p(dev_alloc(bytes)) {} ~Staged() { dev_free(p); } };
+  const int64_t nnz = A.nnz();
+  Staged rp(sizeof(int64_t) * (size_t)(A.m + 1)), ci(sizeof(int32_t) * (size_t)std::max<int64_t>(nnz, 1)), v(sizeof(double) * (size_t)std::max<int64_t>(nnz, 1));
+  double t0 = now_s();
+  staged_h2d(rp.p, A.rp.data(), sizeof(int64_t) * (size_t)(A.m + 1));
+  if (nnz > 0) { staged_h2d(ci.p, A.ci.data(), sizeof(int32_t) * (size_t)nnz); staged_h2d(v.p, A.v.data(), sizeof(double) * (size_t)nnz); }
+  g_t_h2d += now_s() - t0;
+  t0 = now_s();
+  devmat_from_csr_device(A.m, A.n, (const int64_t*)rp.p, (const int32_t*)ci.p, (const double*)v.p, d_rowsrc, d_colmap, out, s, n_ghost);
+  g_t_convert += now_s() - t0;
 }
 
 double DevInv::alg_bytes() const {
@@ -196,6 +205,8 @@ void DevPCAIR::upload_inv(const InvOp& h, DevInv& d, const DevMat* Aop, const do
 
 void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy* dist, Comm* comm) {
   const int L = H.no_levels();
+  const double t_upload0 = now_s();
+  g_t_h2d = g_t_convert = 0.0;
   comm_ = dist ? comm : nullptr;
   if (dist && !comm) throw std::runtime_error("a distributed hierarchy needs a communicator");
   plans_.clear();
@@ -268,6 +279,7 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
     return ip;
   };
 
+  const double t_order = now_s() - t_upload0;
   // top-level operator in hierarchical ordering (outer Krylov works in that ordering)
   {
     std::vector<int32_t> ip = inverse(perm[0]);
@@ -454,6 +466,12 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
     else b_ptr_[l] = cb_.p + off_[l];
   }
   HIP_CHECK(hipStreamSynchronize(stream_));
+  dev_cache_trim();       // the staging blocks
+  if (H.opt.print_stats_timings) {
+    std::printf(" hierarchy to the device: %.2f s (orderings %.2f s, host -> device copies of the operators %.2f s, conversion to row blocks %.2f s)\n",
+                now_s() - t_upload0, t_order, g_t_h2d, g_t_convert);
+    std::fflush(stdout);
+  }
 }
 
 double DevPCAIR::storage_bytes() const {

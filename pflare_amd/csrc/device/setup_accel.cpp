@@ -26,7 +26,8 @@ struct DevSetupAccel final : SetupAccel {
   const void* inverse_key = nullptr;
   int64_t min_nnz = 200000;      // smaller products stay on the host: launch + sync overheads dominate
 
-  ~DevSetupAccel() override { dcsr_free(resident); dcsr_free(inverse); spgemm_release_scratch(); dev_cache_trim(); }
+  // (the block cache is not trimmed here: the upload of the hierarchy that usually follows stages through it)
+  ~DevSetupAccel() override { dcsr_free(resident); dcsr_free(inverse); spgemm_release_scratch(); }
 
   DCsr up(const Csr& A) {
     const double t0 = now_s();

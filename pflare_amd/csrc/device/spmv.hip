@@ -32,6 +32,7 @@
 #include "dev.hpp"
 #include "kcommon.hpp"
 #include "rb.hpp"
+#include "devmem.hpp"
 #include <stdexcept>
 #include <vector>
 #include <algorithm>
@@ -431,8 +432,7 @@ __global__ __launch_bounds__(BLOCK) void k_chunk_scan(int64_t n, const int64_t* 
 int64_t device_exclusive_scan(int64_t n, const int64_t* d_in, int64_t* d_out, hipStream_t s) {
   if (n == 0) return 0;
   const int64_t nchunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
-  int64_t* d_sums = nullptr;
-  HIP_CHECK(hipMalloc(&d_sums, sizeof(int64_t) * (size_t)nchunks));
+  int64_t* d_sums = (int64_t*)dev_alloc(sizeof(int64_t) * (size_t)nchunks);
   hipLaunchKernelGGL(k_chunk_sum, dim3((unsigned)nchunks), dim3(BLOCK), 0, s, n, d_in, d_sums);
   std::vector<int64_t> h(nchunks);
   HIP_CHECK(hipMemcpyAsync(h.data(), d_sums, sizeof(int64_t) * (size_t)nchunks, hipMemcpyDeviceToHost, s));
@@ -442,7 +442,7 @@ int64_t device_exclusive_scan(int64_t n, const int64_t* d_in, int64_t* d_out, hi
   HIP_CHECK(hipMemcpyAsync(d_sums, h.data(), sizeof(int64_t) * (size_t)nchunks, hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(k_chunk_scan, dim3((unsigned)nchunks), dim3(BLOCK), 0, s, n, d_in, d_sums, d_out);
   HIP_CHECK(hipStreamSynchronize(s));
-  (void)hipFree(d_sums);
+  dev_free(d_sums);
   return run;
 }
 
@@ -568,14 +568,13 @@ __global__ __launch_bounds__(BLOCK) void k_boundary_flags(int64_t nblocks, const
 void devmat_boundary_flags(const DevMat& A, std::vector<uint8_t>& flags, hipStream_t s) {
   flags.assign((size_t)A.nblocks, 0);
   if (A.nblocks == 0 || A.n_ghost == 0) return;
-  uint8_t* d = nullptr;
-  HIP_CHECK(hipMalloc(&d, (size_t)A.nblocks));
+  uint8_t* d = (uint8_t*)dev_alloc((size_t)A.nblocks);
   HIP_CHECK(hipMemsetAsync(d, 0, (size_t)A.nblocks, s));
   const int g = (int)std::min<int64_t>((A.nblocks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 4096);
   hipLaunchKernelGGL(k_boundary_flags, dim3(g < 1 ? 1 : g), dim3(BLOCK), 0, s, A.nblocks, A.blk, A.idx, (int32_t)(A.n - A.n_ghost), d);
   HIP_CHECK(hipMemcpyAsync(flags.data(), d, (size_t)A.nblocks, hipMemcpyDeviceToHost, s));
   HIP_CHECK(hipStreamSynchronize(s));
-  (void)hipFree(d);
+  dev_free(d);
 }
 
 static int grid1d(int64_t n) {
@@ -591,40 +590,38 @@ void devmat_from_csr_device(int64_t m, int64_t n, const int64_t* d_rp, const int
   out.m = m; out.n = n; out.n_ghost = n_ghost;
   if (m == 0) return;
   if (m >= (1ll << 29) || n >= (1ll << 29)) throw std::runtime_error("matrix dimension exceeds the 2^29 rows / columns of the 32-bit byte offsets");
-  int64_t *d_len = nullptr, *d_nrp = nullptr;
-  HIP_CHECK(hipMalloc(&d_len, sizeof(int64_t) * (size_t)m));
-  HIP_CHECK(hipMalloc(&d_nrp, sizeof(int64_t) * (size_t)(m + 1)));
+  // temporaries come from the block cache (device/devmem.hpp), the arrays of the matrix itself are exact allocations
+  int64_t* d_len = (int64_t*)dev_alloc(sizeof(int64_t) * (size_t)m);
+  int64_t* d_nrp = (int64_t*)dev_alloc(sizeof(int64_t) * (size_t)(m + 1));
   hipLaunchKernelGGL(k_row_len, dim3(grid1d(m)), dim3(BLOCK), 0, s, m, d_rp, d_rowsrc, d_len);
   out.nnz = device_exclusive_scan(m, d_len, d_nrp, s);
   HIP_CHECK(hipMemcpyAsync(d_nrp + m, &out.nnz, sizeof(int64_t), hipMemcpyHostToDevice, s));
-  (void)hipFree(d_len);
+  dev_free(d_len);
   // entries in the new row order (plain columns), then packed per block
-  int32_t* tcol = nullptr; double* tval = nullptr;
-  HIP_CHECK(hipMalloc(&tcol, sizeof(int32_t) * (size_t)(out.nnz + 1)));
-  HIP_CHECK(hipMalloc(&tval, sizeof(double) * (size_t)(out.nnz + 1)));
+  int32_t* tcol = (int32_t*)dev_alloc(sizeof(int32_t) * (size_t)(out.nnz + 1));
+  double* tval = (double*)dev_alloc(sizeof(double) * (size_t)(out.nnz + 1));
   hipLaunchKernelGGL(k_copy_rows, dim3(MAX_BLOCKS), dim3(BLOCK), 0, s, m, d_rp, d_ci, d_v, d_rowsrc, d_colmap,
                      (int32_t)(n - n_ghost), d_nrp, tcol, tval);
   // row blocks: count per chunk, scan, fill
   const int64_t nchunks = (m + CHUNK_ROWS - 1) / CHUNK_ROWS;
-  int64_t *d_cnt = nullptr, *d_first = nullptr;
-  HIP_CHECK(hipMalloc(&d_cnt, sizeof(int64_t) * (size_t)nchunks));
-  HIP_CHECK(hipMalloc(&d_first, sizeof(int64_t) * (size_t)nchunks));
+  int64_t* d_cnt = (int64_t*)dev_alloc(sizeof(int64_t) * (size_t)nchunks);
+  int64_t* d_first = (int64_t*)dev_alloc(sizeof(int64_t) * (size_t)nchunks);
   hipLaunchKernelGGL((k_chunk_blocks<false>), dim3(grid1d(nchunks)), dim3(BLOCK), 0, s, m, d_nrp, d_cnt, nullptr, nullptr, nullptr);
   out.nblocks = device_exclusive_scan(nchunks, d_cnt, d_first, s);
-  HIP_CHECK(hipMalloc(&out.blk, sizeof(BlkDesc) * (size_t)(out.nblocks + 1)));
-  HIP_CHECK(hipMalloc(&out.roff, sizeof(uint16_t) * (size_t)m));
+  out.blk = (BlkDesc*)dev_alloc_exact(sizeof(BlkDesc) * (size_t)(out.nblocks + 1));
+  out.roff = (uint16_t*)dev_alloc_exact(sizeof(uint16_t) * (size_t)m);
   hipLaunchKernelGGL((k_chunk_blocks<true>), dim3(grid1d(nchunks)), dim3(BLOCK), 0, s, m, d_nrp, d_cnt, d_first, out.blk, out.roff);
   const BlkDesc end{out.nnz, (int32_t)m, 0};
   HIP_CHECK(hipMemcpyAsync(out.blk + out.nblocks, &end, sizeof(BlkDesc), hipMemcpyHostToDevice, s));
-  HIP_CHECK(hipMalloc(&out.idx, sizeof(uint32_t) * (size_t)(out.nnz + 1)));
-  HIP_CHECK(hipMalloc(&out.val, sizeof(double) * (size_t)(out.nnz + 1)));
+  out.idx = (uint32_t*)dev_alloc_exact(sizeof(uint32_t) * (size_t)(out.nnz + 1));
+  out.val = (double*)dev_alloc_exact(sizeof(double) * (size_t)(out.nnz + 1));
   HIP_CHECK(hipMemsetAsync(out.idx + out.nnz, 0, sizeof(uint32_t), s));
   HIP_CHECK(hipMemsetAsync(out.val + out.nnz, 0, sizeof(double), s));
   const int g = (int)std::min<int64_t>((out.nblocks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 4096);
   hipLaunchKernelGGL(k_block_pack, dim3(g < 1 ? 1 : g), dim3(BLOCK), 0, s, out.nblocks, out.blk, tcol, tval, out.idx, out.val);
   HIP_CHECK(hipStreamSynchronize(s));
   check_launch("row-block conversion");
-  (void)hipFree(d_nrp); (void)hipFree(d_cnt); (void)hipFree(d_first); (void)hipFree(tcol); (void)hipFree(tval);
+  dev_free(d_nrp); dev_free(d_cnt); dev_free(d_first); dev_free(tcol); dev_free(tval);
 }
 
 void devmat_free(DevMat& A) {
