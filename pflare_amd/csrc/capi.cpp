@@ -451,6 +451,7 @@ int airhip_pcair_setup(airhip_pcair pc, const airhip_csr* A) {
   pc->op_nnz_top = (double)pc->A_top.nnz();
   if (pc->device_upload) finish_device(pc);
   dev_cache_trim();
+  if (pc->opt.print_stats_timings) { std::printf(" %s\n", host_array_cache_report().c_str()); std::fflush(stdout); }
   trim_host_array_cache(true);   // blocks released during the setup waited for reuse; after the upload, so that the unmapping does not get in its way
   pc->A_top = Csr();   // drop the view of the caller's arrays
   if (pc->opt.print_stats_timings) {

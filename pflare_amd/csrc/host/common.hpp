@@ -27,6 +27,7 @@ void* alloc_host_array(size_t bytes);
 void free_host_array(void* p);
 // returns the cached blocks to the system (the end of a setup), optionally on a detached thread
 void trim_host_array_cache(bool in_background);
+std::string host_array_cache_report();   // since the last trim
 
 // Uninitialised, 64-byte aligned array (std::vector would zero 5 GB arrays serially).
 template <class T>

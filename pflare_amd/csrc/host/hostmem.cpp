@@ -8,6 +8,7 @@
 // slowly from level to level, so each generation takes over the blocks of the one before last).
 #include "common.hpp"
 #include <sys/mman.h>
+#include <cstdio>
 #include <mutex>
 #include <thread>
 #include <unordered_map>
@@ -23,6 +24,8 @@ struct HostCache {
   std::unordered_map<void*, size_t> live;            // big blocks handed out: true size
   std::vector<std::pair<void*, size_t>> idle;        // released, waiting for reuse
   size_t idle_bytes = 0;
+  // statistics since the last trim (GB): requests served from the cache / by the system, blocks kept / given back
+  double reused = 0, fresh = 0, kept = 0, returned = 0;
   size_t limit = [] {
     const char* e = std::getenv("AIRHIP_HOST_CACHE_GB");
     return (size_t)(e ? std::atof(e) : 32.0) << 30;
@@ -51,13 +54,14 @@ void* alloc_host_array(size_t bytes) {
       c.idle.erase(c.idle.begin() + best);
       c.idle_bytes -= blk.second;
       c.live[blk.first] = blk.second;
+      c.reused += blk.second * 1e-9;
       return blk.first;
     }
   }
   void* p = std::aligned_alloc(HUGE_ALIGN, bytes);
   if (!p) throw std::bad_alloc();
   (void)madvise(p, bytes, MADV_HUGEPAGE);            // advisory: failure leaves ordinary pages
-  if (bytes >= CACHE_MIN) { std::lock_guard<std::mutex> lock(c.mu); c.live[p] = bytes; }
+  if (bytes >= CACHE_MIN) { std::lock_guard<std::mutex> lock(c.mu); c.live[p] = bytes; c.fresh += bytes * 1e-9; }
   return p;
 }
 
@@ -70,16 +74,26 @@ void free_host_array(void* p) {
     if (it != c.live.end()) {
       const size_t bytes = it->second;
       c.live.erase(it);
-      if (c.idle_bytes + bytes <= c.limit) { c.idle.emplace_back(p, bytes); c.idle_bytes += bytes; return; }
-    }
+      if (c.idle_bytes + bytes <= c.limit) { c.idle.emplace_back(p, bytes); c.idle_bytes += bytes; c.kept += bytes * 1e-9; return; }
+      c.returned += bytes * 1e-9;      // (a helper thread for these was tried: the unmapping then slows the page faults of the
+    }                                  // working threads down by as much as it saves)
   }
   std::free(p);
+}
+
+std::string host_array_cache_report() {
+  HostCache& c = cache();
+  std::lock_guard<std::mutex> lock(c.mu);
+  char buf[256];
+  std::snprintf(buf, sizeof buf, "large host arrays: %.1f GB from released blocks, %.1f GB fresh; %.1f GB of released blocks kept, %.1f GB returned at once, %.1f GB idle",
+                c.reused, c.fresh, c.kept, c.returned, c.idle_bytes * 1e-9);
+  return buf;
 }
 
 void trim_host_array_cache(bool in_background) {
   HostCache& c = cache();
   std::vector<std::pair<void*, size_t>> blocks;
-  { std::lock_guard<std::mutex> lock(c.mu); blocks.swap(c.idle); c.idle_bytes = 0; }
+  { std::lock_guard<std::mutex> lock(c.mu); blocks.swap(c.idle); c.idle_bytes = 0; c.reused = c.fresh = c.kept = c.returned = 0; }
   if (blocks.empty()) return;
   auto work = [blocks] { for (const auto& b : blocks) std::free(b.first); };
   if (in_background) std::thread(work).detach(); else work();
