@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--recipe", default="trunc", choices=sorted(RECIPES))
     ap.add_argument("--max-levels", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=4, help="Krylov iterations of the CPU baseline sample (about 4 s each at 464^3 on 32 threads)")
+    ap.add_argument("--cpu-iters", type=int, default=8, help="Krylov iterations of the CPU baseline sample (about 2 s each at 464^3 on 32 threads)")
     ap.add_argument("--graph", type=int, default=0)
     ap.add_argument("--profile-kernels", type=int, default=1)
     ap.add_argument("--variants", default="", help="diagnostic: ';'-separated kernel tunings to time on the same "
