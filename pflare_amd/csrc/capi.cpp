@@ -441,7 +441,8 @@ int airhip_pcair_setup(airhip_pcair pc, const airhip_csr* A) {
     if (accel) {
       pc->accel_transfer_s = accel->t_transfer; pc->accel_compute_s = accel->t_compute;
       if (pc->opt.print_stats_timings) {
-        std::printf(" setup products on device: transfers %.2f s, SpGEMM %.2f s\n", accel->t_transfer, accel->t_compute);
+        std::printf(" setup products on device: transfers %.2f s, SpGEMM %.2f s, CF splitting %.2f s, polynomial assembly %.2f s, block extraction %.2f s\n",
+                    accel->t_transfer, accel->t_compute, accel->t_cfsplit, accel->t_poly, accel->t_extract);
         std::fflush(stdout);
       }
     }

@@ -1,0 +1,99 @@
+// Sub-matrix extraction on the device; see extract.hpp.  One wave per source row: a counting pass, four exclusive scans,
+// a filling pass in which the lanes of a 64-entry chunk find their places with ballots (the order inside a row is kept).
+#include "extract.hpp"
+#include "dev.hpp"
+#include "kcommon.hpp"
+#include "rb.hpp"
+#include "devmem.hpp"
+#include <stdexcept>
+
+namespace airhip {
+
+namespace {
+
+constexpr uint32_t FBIT = 0x80000000u;
+
+struct Src { int64_t m; const int64_t* rp; const int32_t* ci; const double* v; };
+struct Block { int64_t* rp; int32_t* ci; double* v; };      // rp doubles as the count array of the first pass
+
+__global__ __launch_bounds__(BLOCK) void k_split_count(Src A, const uint32_t* __restrict__ code, Block ff, Block fc, Block cf, Block cc) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * BLOCK) >> 6;
+  for (int64_t i = wave; i < A.m; i += nw) {
+    const int64_t a0 = A.rp[i], a1 = A.rp[i + 1];
+    int nf = 0;
+    for (int64_t k = a0 + lane; k < a0 + ((a1 - a0 + WAVE - 1) / WAVE) * WAVE; k += WAVE) {
+      const bool f = k < a1 && (code[A.ci[k]] & FBIT);
+      nf += __popcll(__ballot(f));
+    }
+    if (lane == 0) {
+      const uint32_t c = code[i];
+      const int64_t r = c & ~FBIT, tot = a1 - a0;
+      if (c & FBIT) { ff.rp[r] = nf; fc.rp[r] = tot - nf; }
+      else { cf.rp[r] = nf; if (cc.rp) cc.rp[r] = tot - nf; }
+    }
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_split_fill(Src A, const uint32_t* __restrict__ code, Block ff, Block fc, Block cf, Block cc) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * BLOCK) >> 6;
+  for (int64_t i = wave; i < A.m; i += nw) {
+    const int64_t a0 = A.rp[i], a1 = A.rp[i + 1];
+    const uint32_t ci = code[i];
+    const int64_t r = ci & ~FBIT;
+    const Block& X = (ci & FBIT) ? ff : cf;      // F columns of this row
+    const Block& Y = (ci & FBIT) ? fc : cc;      // C columns
+    int64_t ox = X.rp[r], oy = Y.rp ? Y.rp[r] : 0;
+    for (int64_t k = a0 + lane; k < a0 + ((a1 - a0 + WAVE - 1) / WAVE) * WAVE; k += WAVE) {
+      const bool valid = k < a1;
+      uint32_t c = 0; double v = 0.0;
+      if (valid) { c = code[A.ci[k]]; v = A.v[k]; }
+      const bool f = valid && (c & FBIT), g = valid && !(c & FBIT);
+      const unsigned long long bf = __ballot(f), bg = __ballot(g);
+      if (f) { const int64_t o = ox + __popcll(bf & lt); X.ci[o] = (int32_t)(c & ~FBIT); X.v[o] = v; }
+      if (g && Y.rp) { const int64_t o = oy + __popcll(bg & lt); Y.ci[o] = (int32_t)c; Y.v[o] = v; }
+      ox += __popcll(bf); oy += __popcll(bg);
+    }
+  }
+}
+
+template <class T> T* dalloc(int64_t n) { return (T*)dev_alloc(sizeof(T) * (size_t)(n > 0 ? n : 1)); }
+
+}  // namespace
+
+void dev_split_fc(const DCsr& A, const uint32_t* d_code, int64_t n_f, int64_t n_c, DCsr& A_ff, DCsr& A_fc, DCsr& A_cf, DCsr* A_cc,
+                  hipStream_t s) {
+  if (A.m != A.n || n_f + n_c != A.m) throw std::runtime_error("dev_split_fc: shape mismatch");
+  const Src src{A.m, A.rp, A.ci, A.v};
+  struct Out { DCsr* d; int64_t m, n; int64_t* cnt; } outs[4] = {{&A_ff, n_f, n_f, nullptr}, {&A_fc, n_f, n_c, nullptr}, {&A_cf, n_c, n_f, nullptr},
+                                                              {A_cc, n_c, n_c, nullptr}};
+  Block blk[4] = {};
+  for (int b = 0; b < 4; b++) {
+    if (!outs[b].d) continue;
+    *outs[b].d = DCsr(); outs[b].d->m = outs[b].m; outs[b].d->n = outs[b].n;
+    outs[b].cnt = dalloc<int64_t>(outs[b].m);
+    blk[b].rp = outs[b].cnt;
+  }
+  hipLaunchKernelGGL(k_split_count, dim3(MAX_BLOCKS), dim3(BLOCK), 0, s, src, d_code, blk[0], blk[1], blk[2], blk[3]);
+  for (int b = 0; b < 4; b++) {
+    if (!outs[b].d) continue;
+    DCsr& X = *outs[b].d;
+    X.rp = dalloc<int64_t>(X.m + 1);
+    X.nnz = device_exclusive_scan(X.m, outs[b].cnt, X.rp, s);
+    HIP_CHECK(hipMemcpyAsync(X.rp + X.m, &X.nnz, sizeof(int64_t), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));                     // &X.nnz is read by the copy
+    dev_free(outs[b].cnt);
+    X.ci = dalloc<int32_t>(X.nnz); X.v = dalloc<double>(X.nnz);
+    blk[b] = Block{X.rp, X.ci, X.v};
+  }
+  hipLaunchKernelGGL(k_split_fill, dim3(MAX_BLOCKS), dim3(BLOCK), 0, s, src, d_code, blk[0], blk[1], blk[2], blk[3]);
+  HIP_CHECK(hipStreamSynchronize(s));
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) throw std::runtime_error(std::string("HIP error ") + hipGetErrorString(e) + " in the device sub-matrix extraction");
+}
+
+}  // namespace airhip

@@ -1,13 +1,17 @@
 // Device implementation of the SetupAccel interface (host/spops.hpp): the sparse products of
 // the PCAIR setup run as HIP SpGEMMs (device/spgemm.hip).  The coarse operator produced by
-// one level's R*A*P stays resident and is reused as the A of the next level, so each level
-// operator crosses PCIe once (device -> host, for the host-side CF splitting / extraction).
+// one level's R*A*P stays resident: the next level's truncation test, CF splitting, F / C block
+// extraction and R*A*P read it where it is, and it only crosses PCIe if a host routine asks for
+// it (materialize; the coarsest operator always does).  What goes to the host per level are the
+// blocks A_ff, A_fc, A_cf (A_cc only with C smoothing), the assembled inverse, Z and the counts.
 #include "setup_accel.hpp"
 #include "dev.hpp"
 #include "spgemm.hpp"
 #include "cfsplit_dev.hpp"
 #include "polyasm.hpp"
+#include "extract.hpp"
 #include "devmem.hpp"
+#include "staged_copy.hpp"
 #include "../host/air.hpp"
 #include <cmath>
 #include <cstdlib>
@@ -20,14 +24,25 @@ namespace {
 
 struct DevSetupAccel final : SetupAccel {
   hipStream_t stream = nullptr;
-  DCsr resident;                 // last R*A*P result
-  const void* resident_key = nullptr;  // host row-pointer array it was downloaded into
+  DCsr resident;                 // last R*A*P result (or the top-level operator)
+  const void* resident_key = nullptr;  // host row-pointer array it was downloaded into / uploaded from
+  uint64_t resident_tag = 0;     // Csr::device_tag of the operator it is
+  DCsr res_ff, res_cf;           // blocks of the last extraction: the A of the polynomial assembly, the A of Z = -A_cf M
+  uint64_t ff_tag = 0, cf_tag = 0;
+  uint64_t next_tag = 0;
   DCsr inverse;                  // last assembled polynomial inverse (the B of the Z = -A_cf * M product that follows)
   const void* inverse_key = nullptr;
   int64_t min_nnz = 200000;      // smaller products stay on the host: launch + sync overheads dominate
 
   // (the block cache is not trimmed here: the upload of the hierarchy that usually follows stages through it)
-  ~DevSetupAccel() override { dcsr_free(resident); dcsr_free(inverse); spgemm_release_scratch(); }
+  ~DevSetupAccel() override { dcsr_free(resident); dcsr_free(inverse); dcsr_free(res_ff); dcsr_free(res_cf); spgemm_release_scratch(); }
+
+  bool is_resident(const Csr& A) const {
+    if (!resident.rp || resident.m != A.m || resident.nnz != A.nnz()) return false;
+    if (A.device_tag && A.device_tag == resident_tag) return true;
+    return A.on_host() && resident_key && resident_key == (const void*)A.rp.data();
+  }
+  void drop_resident() { dcsr_free(resident); resident_key = nullptr; resident_tag = 0; }
 
   DCsr up(const Csr& A) {
     const double t0 = now_s();
@@ -46,7 +61,9 @@ struct DevSetupAccel final : SetupAccel {
 
   Csr spgemm(const Csr& A, const Csr& B, const SpgemmDrop& drop) override {
     if (A.nnz() + B.nnz() < min_nnz) return airhip::spgemm(A, B, drop);
-    DCsr dA = up(A), dB;
+    DCsr dA, dB;
+    if (A.device_tag && A.device_tag == cf_tag && res_cf.rp && res_cf.nnz == A.nnz()) { dA = res_cf; res_cf = DCsr(); cf_tag = 0; }
+    else dA = up(A);
     if (inverse_key && inverse_key == (const void*)B.rp.data() && inverse.m == B.m && inverse.nnz == B.nnz()) { dB = inverse; inverse = DCsr(); }
     else dB = up(B);
     dcsr_free(inverse); inverse_key = nullptr;
@@ -64,8 +81,7 @@ struct DevSetupAccel final : SetupAccel {
   bool cf_splitting(const Csr& A, const AirOptions& o, Arr<int32_t>& markers) override {
     static const bool enabled = [] { const char* e = std::getenv("AIRHIP_DEVICE_CFSPLIT"); return !(e && e[0] == '0'); }();
     if (!enabled || o.cf_splitting_type != 0 || A.nnz() < min_nnz) return false;
-    const bool have = resident_key && resident_key == (const void*)A.rp.data() && resident.m == A.m && resident.nnz == A.nnz();
-    if (!have) { dcsr_free(resident); resident = up(A); resident_key = (const void*)A.rp.data(); }
+    if (!is_resident(A)) { drop_resident(); resident = up(A); resident_key = (const void*)A.rp.data(); }
     const double t0 = now_s();
     markers.alloc(A.m);
     dev_cf_splitting_pmisr_ddc(resident, o.strong_threshold, !o.symmetric, o.max_luby_steps, rng_key(o.seed), o.ddc_its,
@@ -77,7 +93,9 @@ struct DevSetupAccel final : SetupAccel {
   bool poly_assemble(const Csr& A, const std::vector<double>& c, Csr& M, bool final_values) override {
     static const bool enabled = [] { const char* e = std::getenv("AIRHIP_DEVICE_POLY"); return !(e && e[0] == '0'); }();
     if (!enabled || A.nnz() < min_nnz || c.size() < 3) return false;
-    DCsr dA = up(A), dM;
+    DCsr dA, dM;
+    if (A.device_tag && A.device_tag == ff_tag && res_ff.rp && res_ff.nnz == A.nnz()) { dA = res_ff; res_ff = DCsr(); ff_tag = 0; }
+    else dA = up(A);
     const double t0 = now_s();
     const bool ok = dev_poly_assemble(dA, c.data(), (int)c.size(), dM, stream);
     t_poly += now_s() - t0;
@@ -107,7 +125,8 @@ struct DevSetupAccel final : SetupAccel {
     } B;
     // the level operator: still resident from the previous level's R*A*P, or uploaded once
     {
-      const bool have = resident_key && resident_key == (const void*)A.rp.data() && resident.m == A.m && resident.nnz == A.nnz();
+      const bool have = is_resident(A);
+      if (!have && !A.on_host()) return false;
       DCsr dA = have ? resident : up(A);
       devmat_from_csr_device(dA.m, dA.n, dA.rp, dA.ci, dA.v, nullptr, nullptr, B.M, stream);
       HIP_CHECK(hipStreamSynchronize(stream));
@@ -203,20 +222,21 @@ struct DevSetupAccel final : SetupAccel {
     return true;
   }
 
-  Csr rap(const Csr& R, const Csr& A, const Csr& P, const SpgemmDrop& drop) override {
+  Csr rap(const Csr& R, const Csr& A, const Csr& P, const SpgemmDrop& drop, bool device_only) override {
     if (A.nnz() < min_nnz) {
-      dcsr_free(resident); resident_key = nullptr;
+      if (!A.on_host()) throw std::logic_error("rap: a small operator that is not on the host");
+      drop_resident();
       Csr AP = airhip::spgemm(A, P);
       return airhip::spgemm(R, AP, drop);
     }
     DCsr dA;
-    if (resident_key && resident_key == (const void*)A.rp.data() && resident.m == A.m && resident.nnz == A.nnz()) {
-      dA = resident; resident = DCsr();
-    } else {
+    if (is_resident(A)) { dA = resident; resident = DCsr(); }
+    else {
+      if (!A.on_host()) throw std::logic_error("rap: the device copy of the level operator is gone");
       dcsr_free(resident);
       dA = up(A);
     }
-    resident_key = nullptr;
+    resident_key = nullptr; resident_tag = 0;
     DCsr dP = up(P);
     double t0 = now_s();
     DCsr dAP = dev_spgemm(dA, dP, false, 0.0, false, false, stream);
@@ -227,10 +247,50 @@ struct DevSetupAccel final : SetupAccel {
     DCsr dC = dev_spgemm(dR, dAP, drop.enabled, drop.tol, drop.lump, drop.negate, stream);
     t_compute += now_s() - t0;
     dcsr_free(dR); dcsr_free(dAP);
-    Csr C = down(dC);
+    Csr C;
+    // a coarse operator below the device threshold goes to the host at once: the next level works there
+    if (device_only && dC.nnz >= min_nnz) { C.m = dC.m; C.n = dC.n; C.stub_nnz = dC.nnz; }
+    else C = down(dC);
     resident = dC;
-    resident_key = (const void*)C.rp.data();   // Arr moves keep the pointer
+    resident_tag = C.device_tag = ++next_tag;
+    resident_key = C.on_host() ? (const void*)C.rp.data() : nullptr;   // Arr moves keep the pointer
     return C;
+  }
+
+  void materialize(Csr& A) override {
+    if (A.on_host()) return;
+    if (!is_resident(A)) throw std::logic_error("materialize: the device copy of the operator is gone");
+    const uint64_t tag = A.device_tag;
+    A = down(resident);
+    A.device_tag = tag;
+    resident_key = (const void*)A.rp.data();
+  }
+
+  // the F / C blocks of the resident level operator
+  bool split_fc(const Csr& A, const Arr<int32_t>& markers, const Arr<int32_t>& newidx, int64_t n_f, int64_t n_c,
+                Csr& A_ff, Csr& A_fc, Csr& A_cf, Csr* A_cc) override {
+    if (!is_resident(A)) return false;
+    const int64_t n = A.m;
+    Arr<uint32_t> code(n);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) code[i] = (uint32_t)newidx[i] | (markers[i] == F_POINT ? 0x80000000u : 0u);
+    double t0 = now_s();
+    uint32_t* d_code = (uint32_t*)dev_alloc(sizeof(uint32_t) * (size_t)n);
+    staged_h2d(d_code, code.data(), sizeof(uint32_t) * (size_t)n);
+    t_transfer += now_s() - t0;
+    t0 = now_s();
+    DCsr dff, dfc, dcf, dcc;
+    dev_split_fc(resident, d_code, n_f, n_c, dff, dfc, dcf, A_cc ? &dcc : nullptr, stream);
+    dev_free(d_code);
+    t_extract += now_s() - t0;
+    A_ff = down(dff); A_fc = down(dfc); A_cf = down(dcf);
+    dcsr_free(dfc);
+    if (A_cc) { *A_cc = down(dcc); dcsr_free(dcc); }
+    // A_ff feeds the polynomial assembly, A_cf the Z product: they stay
+    dcsr_free(res_ff); dcsr_free(res_cf);
+    res_ff = dff; ff_tag = A_ff.device_tag = ++next_tag;
+    res_cf = dcf; cf_tag = A_cf.device_tag = ++next_tag;
+    return true;
   }
 };
 

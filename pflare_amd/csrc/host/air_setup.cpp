@@ -185,6 +185,8 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o, SetupAc
   H->timers.assign(8, 0.0);
   Csr owned;              // level operators below the top are owned here
   const Csr* cur = &A0;
+  // with an accelerator the level operators below the top stay on it until a host routine asks for one
+  auto on_host = [&]() -> const Csr& { if (!cur->on_host()) accel->materialize(owned); return *cur; };
   const bool any_c = o.any_c_smooths();
   bool auto_truncated = false;
   const double t_setup = now_s();
@@ -205,7 +207,7 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o, SetupAc
                           accel->truncation_ratio(*cur, o.coarsest_inverse_type, o.coarsest_poly_order, o.seed, dev_ratio);
       bool decided = dev_ok && dev_ratio > 2.0 * o.auto_truncate_tol;        // clearly not yet: carry on coarsening
       if (!decided) {
-        coarse_solver(*cur, o, cop);
+        coarse_solver(on_host(), o, cop);
         if (dev_ok && dev_ratio < 0.5 * o.auto_truncate_tol) {                // clearly good enough: truncate here
           auto_truncated = true; H->coarse_inv = std::move(cop); decided = true;
         }
@@ -229,7 +231,7 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o, SetupAc
     int64_t n_f = 0, n_c = 0;
     if (!auto_truncated) {
       double t0 = now_s();
-      if (!(accel && accel->cf_splitting(*cur, o, markers))) compute_cf_splitting(*cur, o, markers);
+      if (!(accel && accel->cf_splitting(*cur, o, markers))) compute_cf_splitting(on_host(), o, markers);
 #pragma omp parallel for schedule(static) reduction(+ : n_f)
       for (int64_t i = 0; i < n; i++) n_f += (markers[i] == F_POINT) ? 1 : 0;
       n_c = n - n_f;
@@ -256,7 +258,8 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o, SetupAc
         else { newidx[i] = (int32_t)(i - pre[i]); L.C[i - pre[i]] = (int32_t)i; }
       }
     }
-    split_fc(*cur, markers.data(), newidx.data(), L.F, L.C, L.A_ff, L.A_fc, L.A_cf, any_c ? &L.A_cc : nullptr);
+    if (!(accel && accel->split_fc(*cur, markers, newidx, n_f, n_c, L.A_ff, L.A_fc, L.A_cf, any_c ? &L.A_cc : nullptr)))
+      split_fc(on_host(), markers.data(), newidx.data(), L.F, L.C, L.A_ff, L.A_fc, L.A_cf, any_c ? &L.A_cc : nullptr);
     H->timers[1] += now_s() - t0;
 
     for (int i = 0; i < 10; i++) L.smooth_order[i] = o.smooth_order[i];
@@ -277,7 +280,7 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o, SetupAc
     const bool r_dropped = o.strong_r_threshold != 0.0;
     if (r_dropped) {
       t0 = now_s();
-      Csr Ad = remove_small(*cur, o.strong_r_threshold, 1, false, 0);
+      Csr Ad = remove_small(on_host(), o.strong_r_threshold, 1, false, 0);
       H->timers[6] += now_s() - t0;
       t0 = now_s();
       split_fc(Ad, markers.data(), newidx.data(), L.F, L.C, Aff_drop, Afc_drop, Acf_drop, nullptr);
@@ -296,7 +299,7 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o, SetupAc
       throw std::runtime_error("improve_z / improve_w are not available with full up / down smoothing");
     // the smoother: A_ff^-1, or with full smoothing an inverse of the whole level operator (AIR_Operators_Setup.F90:113-119)
     OpView sm = aff;
-    if (full) { sm = OpView(); sm.A = cur; sm.n = n; }
+    if (full) { sm = OpView(); sm.A = &on_host(); sm.n = n; }
     build_inverse(sm, inv_type_aff, o.poly_order, sparsity_aff, o.matrix_free_polys, o.diag_scale_polys,
                   o.seed, L.inv_ff, (product_z && !r_dropped && !full) ? &inv_asm : nullptr);
     if (product_z && (r_dropped || full)) {
@@ -398,7 +401,7 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o, SetupAc
       Csr P = build_P(L);
       Csr R = build_R(L.Z, L.F, L.C, n);
       SpgemmDrop d; d.enabled = true; d.tol = o.a_drop; d.lump = o.a_lump;
-      if (accel) coarse = accel->rap(R, *cur, P, d);
+      if (accel) coarse = accel->rap(R, *cur, P, d, true);
       else {
         Csr AP = spgemm(*cur, P);
         coarse = spgemm(R, AP, d);      // drop / lump fused into the product (timer: RAP)
@@ -428,7 +431,7 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o, SetupAc
   }
 
   // ---- coarse grid solver (AIR_MG_Setup.F90:933-962, 1110-1136)
-  if (cur == &A0) H->coarse_A = A0.clone(); else H->coarse_A = std::move(owned);
+  if (cur == &A0) H->coarse_A = A0.clone(); else { on_host(); H->coarse_A = std::move(owned); }
   if (!auto_truncated) {
     double t0 = now_s();
     if (H->levels.empty() && !o.coarse_lu) {

@@ -78,9 +78,16 @@ struct Csr {
   Arr<int64_t> rp;
   Arr<int32_t> ci;
   Arr<double> v;
-  int64_t nnz() const { return m > 0 && rp.p ? rp[m] : 0; }
+  // Bookkeeping of the setup accelerator (host/spops.hpp: SetupAccel): device_tag names the copy of this operator the
+  // accelerator holds (0 = none); stub_nnz >= 0 means the arrays are NOT on the host yet - only the sizes are - and
+  // SetupAccel::materialize() brings them over when a host routine needs them.  Moves keep both, clone() drops both.
+  uint64_t device_tag = 0;
+  int64_t stub_nnz = -1;
+  int64_t nnz() const { return stub_nnz >= 0 ? stub_nnz : (m > 0 && rp.p ? rp[m] : 0); }
+  bool on_host() const { return stub_nnz < 0; }
   bool empty() const { return rp.p == nullptr; }
   Csr clone() const {
+    if (!on_host()) throw std::logic_error("clone of an operator that is not on the host");
     Csr c; c.m = m; c.n = n; c.rp = rp.clone(); c.ci = ci.clone(); c.v = v.clone();
     return c;
   }

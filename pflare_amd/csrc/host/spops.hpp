@@ -49,8 +49,17 @@ struct SetupAccel {
   virtual ~SetupAccel() = default;
   virtual Csr spgemm(const Csr& A, const Csr& B, const SpgemmDrop& drop) = 0;
   // filter(R * (A * P)); the implementation may keep the result resident and recognise it when
-  // it comes back as the A of the next level
-  virtual Csr rap(const Csr& R, const Csr& A, const Csr& P, const SpgemmDrop& drop) = 0;
+  // it comes back as the A of the next level.  device_only: the caller can work with a result whose arrays stay on
+  // the accelerator (Csr::stub_nnz >= 0) and will call materialize() before any host routine reads it.
+  virtual Csr rap(const Csr& R, const Csr& A, const Csr& P, const SpgemmDrop& drop, bool device_only = false) = 0;
+  // brings the arrays of a device-only operator to the host (no-op for an operator that is there already)
+  virtual void materialize(Csr& A) { if (!A.on_host()) throw std::logic_error("this accelerator holds no device-only operators"); }
+  // the four F / C blocks of the level operator (host/spops.cpp: split_fc) extracted where the operator is; A_cc only
+  // when asked for.  Returns false when it declines (the operator is not resident on the accelerator).
+  virtual bool split_fc(const Csr& A, const Arr<int32_t>& markers, const Arr<int32_t>& newidx, int64_t n_f, int64_t n_c,
+                        Csr& A_ff, Csr& A_fc, Csr& A_cf, Csr* A_cc) {
+    (void)A; (void)markers; (void)newidx; (void)n_f; (void)n_c; (void)A_ff; (void)A_fc; (void)A_cf; (void)A_cc; return false;
+  }
   // Auto-truncation test (src/AIR_MG_Setup.F90:158-256) evaluated by the accelerator: ||A M r - r|| / ||r|| for the
   // matrix-free Newton coarse solver M built from `seed`.  Returns false when it cannot do it (the host then does).
   // The value is only used to DECIDE (with a safety margin, see air_setup.cpp); the solver that ends up in the
@@ -67,7 +76,7 @@ struct SetupAccel {
   // (host/poly.cpp::mat_mult_powers_share_sparsity).  Returns false when it declines.  final_values: the caller will not
   // change M afterwards (the accelerator may then keep its copy for the product that follows).
   virtual bool poly_assemble(const Csr& A, const std::vector<double>& c, Csr& M, bool final_values) { (void)A; (void)c; (void)M; (void)final_values; return false; }
-  double t_transfer = 0.0, t_compute = 0.0, t_cfsplit = 0.0, t_poly = 0.0;
+  double t_transfer = 0.0, t_compute = 0.0, t_cfsplit = 0.0, t_poly = 0.0, t_extract = 0.0;
 };
 // the accelerator the polynomial assembly may use (set by setup_air for its duration; null = host only)
 extern thread_local SetupAccel* g_setup_accel;

@@ -206,7 +206,9 @@ def test_device_setup_equals_host_setup(gpu, case):
     for lv in range(pd.num_levels - 1):
         d, h = pd.export_level(lv), ph.export_level(lv)
         assert np.array_equal(d["F"], h["F"]) and np.array_equal(d["C"], h["C"])
-        for k in ("Z", "A_fc", "A_cf", "A_ff"):
+        # (A_ff, A_fc, A_cf and - with C smoothing - A_cc come from the device extraction of the resident level operator)
+        for k in ("Z", "W", "A_fc", "A_cf", "A_ff", "A_cc"):
+            assert (k in d) == (k in h), k
             if k in h:
                 _same(d[k], h[k], f"level {lv} {k}")
     (Ad, invd), (Ah, invh) = pd.export_coarse(), ph.export_coarse()
