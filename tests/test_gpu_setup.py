@@ -178,6 +178,12 @@ def test_device_spgemm_empty_rows_and_diagonal_creation(gpu):
 
 SETUP_CASES = {
     "adv2d_60": (dict(dim=2, M=60, N=60), {}),
+    # options whose host routines need the level operator itself: it stays on the device after R*A*P and must come
+    # over on demand (SetupAccel::materialize) - full smoothing, the strong-R threshold, lAIR, a host-only CF splitting
+    "adv2d_40_full": (dict(dim=2, M=40, N=40), dict(full_smoothing_up_and_down=True)),
+    "advdiff2d_40_strong_r": (dict(dim=2, M=40, N=40, alpha=0.05), dict(strong_r_threshold=0.05)),
+    "adv3d_12_lair_rthr": (dict(dim=3, M=12, N=12, P=12), dict(z_type="lair", strong_r_threshold=0.01, inverse_type="power")),
+    "diff2d_30_diag_dom": (dict(dim=2, M=30, N=30, u=0, v=0, alpha=1.0), dict(cf_splitting_type="diag_dom", strong_threshold=0.6)),
     "adv3d_20_lump": (dict(dim=3, M=20, N=20, P=20), dict(a_lump=True)),
     "diff2d_40": (dict(dim=2, M=40, N=40, u=0, v=0, alpha=1.0), {}),
     "advdiff2d_50_order4": (dict(dim=2, M=50, N=50, alpha=0.1), dict(poly_order=4, inverse_sparsity_order=2)),
