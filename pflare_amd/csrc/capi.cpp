@@ -245,7 +245,7 @@ int airhip_spgemm_filtered(const airhip_csr* A, const airhip_csr* B, int drop, d
     h->A.rp.alloc(dc.m + 1); h->A.ci.alloc(dc.nnz); h->A.v.alloc(dc.nnz);
     dcsr_download(dc, h->A.rp.data(), h->A.ci.data(), h->A.v.data());
     dcsr_free(da); dcsr_free(db); dcsr_free(dc);
-    spgemm_release_scratch(); dev_cache_trim();
+    dev_cache_trim();
     if (stats) { stats[0] = st.rows_reg; stats[1] = st.rows_1k; stats[2] = st.rows_2k; stats[3] = st.rows_4k; stats[4] = st.rows_global; }
   }
   *out = h;

@@ -35,7 +35,7 @@ struct DevSetupAccel final : SetupAccel {
   int64_t min_nnz = 200000;      // smaller products stay on the host: launch + sync overheads dominate
 
   // (the block cache is not trimmed here: the upload of the hierarchy that usually follows stages through it)
-  ~DevSetupAccel() override { dcsr_free(resident); dcsr_free(inverse); dcsr_free(res_ff); dcsr_free(res_cf); spgemm_release_scratch(); }
+  ~DevSetupAccel() override { dcsr_free(resident); dcsr_free(inverse); dcsr_free(res_ff); dcsr_free(res_cf); }
 
   bool is_resident(const Csr& A) const {
     if (!resident.rp || resident.m != A.m || resident.nnz != A.nnz()) return false;

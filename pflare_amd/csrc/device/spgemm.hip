@@ -533,19 +533,6 @@ static int g_pool_chunk = -1;          // -1: chunks of 2048 entries on the larg
 void spgemm_set_pool_limit(int64_t entries) { g_pool_limit = entries > 0 ? entries : 0; }
 void spgemm_set_pool_chunk(int entries) { g_pool_chunk = entries; }
 
-// The output pool of one product is tens of GB on the large levels and hipMalloc / hipFree of such blocks costs
-// seconds (mapping the pages): the pool of the last product is kept and reused when it is large enough.
-namespace {
-struct PoolCache { int32_t* ci = nullptr; double* v = nullptr; int64_t capacity = 0; bool in_use = false; };
-PoolCache g_pool;
-}
-void spgemm_release_scratch() {
-  if (g_pool.in_use) return;
-  if (g_pool.ci) dev_free(g_pool.ci);
-  if (g_pool.v) dev_free(g_pool.v);
-  g_pool = PoolCache();
-}
-
 void dcsr_free(DCsr& A) {
   if (A.rp) dev_free(A.rp);
   if (A.ci) dev_free(A.ci);
@@ -708,7 +695,7 @@ DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, boo
     hipLaunchKernelGGL(k_spgemm_glb, dim3(gb), dim3(BLOCK), 0, s, av, bv, l.d, (int64_t)n, d_toff, d_tsize, d_kpool, d_vpool, dp, d_cnt, pool, d_fail);
     scratch.insert(scratch.end(), {d_toff, d_tsize, d_kpool, d_vpool});
   };
-  struct Round { int32_t* ci; double* v; bool all_rows; bool cached; std::vector<int32_t> done; };
+  struct Round { int32_t* ci; double* v; bool all_rows; std::vector<int32_t> done; };
   std::vector<Round> rounds;
   List todo[NKIND];                                      // per accumulator kind; empty in the first round (= every row)
   int64_t n_global = 0;
@@ -730,14 +717,9 @@ DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, boo
     else chunk = 0;
     if (g_pool_limit) capacity = std::max<int64_t>(longest, std::min<int64_t>(capacity, g_pool_limit));
     if (capacity < longest) throw std::runtime_error("dev_spgemm: not enough device memory for the output pool");
-    Round rd; rd.all_rows = false; rd.cached = false;
-    if (!g_pool.in_use && g_pool.capacity >= capacity) {
-      rd.ci = g_pool.ci; rd.v = g_pool.v; capacity = g_pool.capacity; rd.cached = true; g_pool.in_use = true;
-    } else {
-      if (!g_pool.in_use) spgemm_release_scratch();
-      rd.ci = dmalloc<int32_t>(capacity); rd.v = dmalloc<double>(capacity);
-      if (!g_pool.in_use) { g_pool.ci = rd.ci; g_pool.v = rd.v; g_pool.capacity = capacity; g_pool.in_use = true; rd.cached = true; }
-    }
+    // (tens of GB on the large levels: the block cache of device/devmem.hpp hands the previous product's pool back)
+    Round rd; rd.all_rows = false;
+    rd.ci = dmalloc<int32_t>(capacity); rd.v = dmalloc<double>(capacity);
     HIP_CHECK(hipMemsetAsync(d_cursor, 0, sizeof(unsigned long long), s));
     HIP_CHECK(hipMemsetAsync(d_fail, 0, 4 * sizeof(unsigned int), s));
     const RowPool pool{d_cursor, capacity, rd.ci, rd.v, d_pos, chunk};
@@ -807,7 +789,7 @@ DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, boo
       HIP_CHECK(hipStreamSynchronize(s));
       if (d_rows) dev_free(d_rows);
     }
-    if (rd.cached) g_pool.in_use = false; else { dev_free(rd.ci); dev_free(rd.v); }
+    dev_free(rd.ci); dev_free(rd.v);
   }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) throw std::runtime_error(std::string("HIP error ") + hipGetErrorString(e) + " in the device SpGEMM");

@@ -22,9 +22,6 @@ void spgemm_set_pool_limit(int64_t entries);
 // test hook: entries a wave takes from the pool at a time (-1 = automatic: 2048 on large products, row by row on small ones)
 void spgemm_set_pool_chunk(int entries);
 
-// frees the output pool kept between products (the end of a setup)
-void spgemm_release_scratch();
-
 void dcsr_free(DCsr& A);
 DCsr dcsr_upload(int64_t m, int64_t n, const int64_t* rp, const int32_t* ci, const double* v);
 void dcsr_download(const DCsr& d, int64_t* rp, int32_t* ci, double* v);
