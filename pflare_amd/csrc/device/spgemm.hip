@@ -139,9 +139,127 @@ __device__ __forceinline__ int64_t lane_i64(int64_t v, int l) {
   return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
+// ---- sort of an LDS table's nu compacted (column, value) pairs by column, sample sort instead of the bitonic network
+// (which costs ~25 nu log^2 nu / 64 instructions per wave and was 25-40 % of the table kernels on the deep levels):
+//   4 NB sampled columns are sorted in registers, every fourth becomes a splitter (NB = 64 or 128 buckets of ~nu / NB
+//   columns, twice that in practice); every pair - all held in registers, CAP / 64 per lane - finds its bucket by
+//   binary search and takes a place in it (LDS counter); the columns are regrouped by bucket in place; the rank of a
+//   pair is its bucket's offset plus the number of smaller columns in its bucket, counted by reading the bucket
+//   through; the pairs are stored at their ranks.  ~3 nu instructions per wave for nu ~ 1000.
+// Returns false (table untouched) when the scratch words at the end of the key array are not free or a bucket holds
+// more than BUCKET_MAX columns; the caller then runs the bitonic network.  CAP = slots of the wave's table region.
+template <int CAP>
+__device__ __forceinline__ bool lds_bucket_sort(const Tab<false> tab, int nu) {
+  constexpr int E = CAP / WAVE;                      // pairs per lane
+  constexpr int NB = CAP >= 2048 ? 128 : 64;         // buckets
+  constexpr int Q = NB / WAVE;                       // buckets per lane in the scan
+  constexpr int S = 4 * Q;                           // samples per lane (4 NB in all)
+  constexpr int BUCKET_MAX = 192;
+  if (nu > CAP - 3 * NB) return false;
+  const int lane = threadIdx.x & (WAVE - 1);
+  int32_t* spl = tab.keys + (CAP - 3 * NB);          // splitters | counters | offsets
+  int32_t* cnt = spl + NB;
+  int32_t* off = cnt + NB;
+  // ---- samples, blocked over the lanes (element S * lane + r), bitonic on 32-bit keys: min / max only
+  int32_t sm[S];
+#pragma unroll
+  for (int r = 0; r < S; r++) sm[r] = tab.ldk((int)(((long long)(lane * S + r) * nu) / (WAVE * S)));
+  const int e0 = lane * S;
+#pragma unroll
+  for (int size = 2; size <= WAVE * S; size <<= 1)
+#pragma unroll
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      if (stride < S) {
+#pragma unroll
+        for (int r = 0; r < S; r++) {
+          if (r & stride) continue;
+          const bool asc = (((e0 + r) & size) == 0);
+          const int32_t x = sm[r], y = sm[r | stride];
+          const int32_t lo = x < y ? x : y, hi = x < y ? y : x;
+          sm[r] = asc ? lo : hi; sm[r | stride] = asc ? hi : lo;
+        }
+      } else {
+        const int addr = (lane ^ (stride / S)) << 2;
+        const bool want_min = ((e0 & stride) == 0) == ((e0 & size) == 0);
+#pragma unroll
+        for (int r = 0; r < S; r++) {
+          const int32_t o = __builtin_amdgcn_ds_bpermute(addr, sm[r]);
+          const int32_t lo = sm[r] < o ? sm[r] : o, hi = sm[r] < o ? o : sm[r];
+          sm[r] = want_min ? lo : hi;
+        }
+      }
+    }
+  // splitter j = sample 4 j + 3 = lane j / Q, register 4 (j % Q) + 3; the last bucket is open-ended
+#pragma unroll
+  for (int q = 0; q < Q; q++) {
+    const int j = lane * Q + q;
+    spl[j] = j < NB - 1 ? sm[4 * q + 3] : 0x7fffffff;
+    cnt[j] = 0;
+  }
+  tab.sync();
+  // ---- every pair into registers, its bucket and its place in the bucket
+  int32_t k[E]; double v[E]; int place[E];           // place = bucket << 16 | index in the bucket, then the rank
+#pragma unroll
+  for (int r = 0; r < E; r++) {
+    k[r] = 0; v[r] = 0.0; place[r] = 0;
+    if (r * WAVE >= nu) continue;                    // wave-uniform
+    const int e = r * WAVE + lane;
+    if (e < nu) {
+      k[r] = tab.ldk(e); v[r] = tab.ldv(e);
+      int b = 0;                                     // number of splitters < k: branch-free binary search
+#pragma unroll
+      for (int step = NB / 2; step > 0; step >>= 1) b += (spl[b + step - 1] < k[r]) ? step : 0;
+      const int li = (int)__hip_atomic_fetch_add((unsigned int*)&cnt[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      place[r] = (b << 16) | li;
+    }
+  }
+  tab.sync();
+  // ---- bucket offsets (exclusive scan); a bucket that outgrew BUCKET_MAX columns sends the row to the network
+  int c[Q], mine = 0, longest = 0;
+#pragma unroll
+  for (int q = 0; q < Q; q++) { c[q] = cnt[lane * Q + q]; mine += c[q]; longest = c[q] > longest ? c[q] : longest; }
+  for (int d = 32; d > 0; d >>= 1) { const int t = __shfl_xor(longest, d, WAVE); longest = t > longest ? t : longest; }
+  longest = __builtin_amdgcn_readfirstlane(longest);
+  if (longest > BUCKET_MAX) return false;            // nothing has been moved yet
+  int incl = mine;
+  for (int d = 1; d < WAVE; d <<= 1) { const int t = __shfl_up(incl, d, WAVE); if (lane >= d) incl += t; }
+  int run = incl - mine;
+#pragma unroll
+  for (int q = 0; q < Q; q++) { off[lane * Q + q] = run; run += c[q]; }
+  tab.sync();
+  // ---- columns regrouped by bucket, in place (every column is in a register by now)
+#pragma unroll
+  for (int r = 0; r < E; r++) {
+    if (r * WAVE >= nu) continue;
+    if (r * WAVE + lane < nu) tab.stk(off[place[r] >> 16] + (place[r] & 0xffff), k[r]);
+  }
+  tab.sync();
+  // ---- rank = bucket offset + smaller columns in the bucket
+#pragma unroll
+  for (int r = 0; r < E; r++) {
+    if (r * WAVE >= nu) continue;
+    const bool in = r * WAVE + lane < nu;
+    const int b = place[r] >> 16;
+    const int o = in ? off[b] : 0, n = in ? cnt[b] : 0;
+    int rank = o;
+    for (int j = 0; j < longest; j++) rank += (j < n && tab.ldk(o + j) < k[r]) ? 1 : 0;
+    place[r] = rank;
+  }
+  tab.sync();
+  // ---- the pairs at their ranks
+#pragma unroll
+  for (int r = 0; r < E; r++) {
+    if (r * WAVE >= nu) continue;
+    if (r * WAVE + lane < nu) { tab.stk(place[r], k[r]); tab.stv(place[r], v[r]); }
+  }
+  tab.sync();
+  return true;
+}
+
 // ---- accumulate, hash table: leaves the nu distinct columns of row i of A*B with their sums in tab[0, nu), sorted
 // by column; -1 = the table is too small for the row.  tab: HT slots owned by this wave (HT a power of two).
-template <bool GLOBAL>
+// CAP: slots of the wave's LDS region (0: no sample sort - global tables, counting only).
+template <bool GLOBAL, int CAP>
 __device__ __forceinline__ int hash_accumulate(const CsrView& A, const CsrView& B, int64_t i, const Tab<GLOBAL> tab, int HT, bool negate,
                                                bool count_only = false) {
 #pragma clang fp contract(off)   // a*b + c must round twice, as the host code does
@@ -230,6 +348,9 @@ __device__ __forceinline__ int hash_accumulate(const CsrView& A, const CsrView& 
     tab.sync();
   }
   if (count_only) return nu;
+  if constexpr (!GLOBAL && CAP > 0) {
+    if (nu > 128 && lds_bucket_sort<CAP>(tab, nu)) return nu;
+  }
   int P2 = 64; while (P2 < nu) P2 <<= 1;
   for (int h = nu + lane; h < P2; h += WAVE) { tab.stk(h, EMPTY); tab.stv(h, 0.0); }
   tab.sync();
@@ -459,8 +580,8 @@ __global__ __launch_bounds__(MAX_HT / HT * WAVE) void k_spgemm_lds(CsrView A, Cs
     mine++;
     const int64_t expect = ubi <= L1K_MAX ? ubi : (int64_t)((float)ubi * sel.plan.ratio) + 64;
     const int ht = table_for(expect < ubi ? expect : ubi, HT);
-    int nu = hash_accumulate<false>(A, B, i, tab, ht, dp.negate != 0);
-    if (nu < 0 && ht < HT) nu = hash_accumulate<false>(A, B, i, tab, HT, dp.negate != 0);
+    int nu = hash_accumulate<false, HT>(A, B, i, tab, ht, dp.negate != 0);
+    if (nu < 0 && ht < HT) nu = hash_accumulate<false, HT>(A, B, i, tab, HT, dp.negate != 0);
     if (nu < 0 && esc.rows) {
       if ((threadIdx.x & (WAVE - 1)) == 0) esc.rows[atomicAdd(esc.count, 1u)] = (int32_t)i;
     } else {
@@ -502,7 +623,7 @@ __global__ __launch_bounds__(WAVE) void k_spgemm_sample(CsrView A, CsrView B, co
   for (int w = blockIdx.x; w < nsamples; w += gridDim.x) {
     const int64_t i = ((int64_t)w * A.m) / nsamples;
     const int64_t u = ub[i];
-    const int nu = u > L1K_MAX ? hash_accumulate<false>(A, B, i, tab, MAX_HT, false, true) : -2;
+    const int nu = u > L1K_MAX ? hash_accumulate<false, 0>(A, B, i, tab, MAX_HT, false, true) : -2;
     if (threadIdx.x == 0) { out_ub[w] = u; out_nu[w] = nu; }
     __builtin_amdgcn_wave_barrier();
   }
@@ -519,7 +640,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_glb(CsrView A, CsrView B, cons
   for (int64_t w = wave; w < nrows; w += nw) {
     const int64_t i = rows[w];
     const Tab<true> tab{keys_pool + tab_off[w], vals_pool + tab_off[w]};
-    const int nu = hash_accumulate<true>(A, B, i, tab, tab_size[w], dp.negate != 0);
+    const int nu = hash_accumulate<true, 0>(A, B, i, tab, tab_size[w], dp.negate != 0);
     report(nu < 0 ? ROW_TABLE_OVERFLOW : finish_row<true>(tab, nu, i, dp, cnt + i, pool, wa), i, cnt, fail);
   }
 }
@@ -702,11 +823,14 @@ DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, boo
   double t_kern = 0;
   std::vector<int64_t> cnt_host;
   for (bool first = true;; first = false) {
-    // pool: twice the inputs, never more than the sum of the bounds, never more than a third of the free memory
+    // pool: twice the inputs (more when nothing will be dropped), never more than the sum of the bounds, never more than
+    // a third of the free memory
     size_t mem_free = 0, mem_total = 0;
     HIP_CHECK(hipMemGetInfo(&mem_free, &mem_total));
     mem_free += dev_cache_idle_bytes();      // released blocks are handed back when a request does not fit
     int64_t capacity = std::max<int64_t>(2 * (A.nnz + B.nnz) + (1 << 20), 2 * longest);
+    // nothing is dropped: the rows keep all their distinct columns, which the sample has an estimate of
+    if ((!drop_enabled || tol == 0.0) && plan.ratio < 1.0f) capacity = std::max<int64_t>(capacity, (int64_t)(1.1 * (double)plan.ratio * (double)ub_total));
     capacity = std::min<int64_t>(capacity, ub_total);
     capacity = std::min<int64_t>(capacity, (int64_t)(mem_free / 3 / 12));
     // chunked hand-out: every wave may leave most of one chunk unused (at most ~70k waves over the kernels of a round)
