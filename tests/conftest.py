@@ -41,7 +41,7 @@ if ROOT not in sys.path:
 
 # parity proper first; anything that starts other processes last
 _ORDER = ["test_gpu_parity.py", "test_gpu_kernel_paths.py", "test_golden.py", "test_gpu_streams.py", "test_gpu_setup.py", "test_capi.py",
-          "test_reference_data.py", "test_gpu_baseline_configs.py", "test_gpu_large.py"]
+          "test_reference_data.py", "test_gpu_baseline_configs.py", "test_gpu_large.py", "test_gpu_full_size.py"]
 _LAST = ["test_c_example.py", "test_gpu_dist.py", "test_bench_contract.py"]
 
 

@@ -1,0 +1,72 @@
+"""BASELINE configs 3/4 at their FULL size on the GPU: 3D upwind advection 464^3 = 99 897 344 DoF with bench.py's recipe
+(-pc_air_a_lump + the truncation recipe of docs/gpus.md:34-38, 16^3-brick layout hint).  The C/OpenMP oracle
+(oracle/air_oracle.c, the same code as bench.py's cpu_baseline leg) applies one V-cycle on the same hierarchy in a
+few seconds on the box's host cores, so the V-cycle is checked against it at full size; linearity and the true
+residual of the GMRES solution are the size-independent properties on top."""
+import numpy as np
+import pytest
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
+
+M = 464
+
+
+def _lcg(n, shift=12345):
+    i = np.arange(n, dtype=np.uint64)
+    return ((np.uint64(1103515245) * (i + np.uint64(shift))) % np.uint64(2 ** 31)).astype(np.float64) / 2.0 ** 30 - 1.0
+
+
+def test_config3_464_vcycle_against_the_c_oracle_linearity_and_true_residual(gpu):
+    import torch
+    import pflare_amd as P
+    from oracle import c_oracle
+    free, _ = torch.cuda.mem_get_info()
+    if free < 200 * 2 ** 30:
+        pytest.skip("needs ~200 GB of device memory")
+    A = P.HostMat.adv_diff_fd(dim=3, M=M, N=M, P=M)
+    n = A.shape[0]
+    assert n == 99897344
+    pc = P.PCAIR(a_lump=True, auto_truncate_start_level=1, auto_truncate_tol=1e-1, coarsest_inverse_type="newton",
+                 coarsest_matrix_free_polys=True, coarsest_poly_order=10)
+    # bench.py's layout hint: grid points grouped in 16^3 bricks (the operator keeps the reference numbering)
+    B = 16
+    nbk = (M + B - 1) // B
+    ax = np.arange(M, dtype=np.int64)
+    bi, li = ax // B, ax % B
+    key = ((bi[:, None, None] * nbk + bi[None, :, None]) * nbk + bi[None, None, :]) * B ** 3 \
+        + (li[:, None, None] * B + li[None, :, None]) * B + li[None, None, :]
+    pc.set_ordering_hint(key.reshape(-1))
+    del key
+    pc.setup(A)
+    assert 12 <= pc.num_levels <= 18                   # 15 with the committed setup (bit-reproducible)
+    # ---- one V-cycle against the oracle on the same hierarchy
+    ch = c_oracle.CHierarchy(pc, copy=False)
+    x = _lcg(n)
+    dx = torch.from_numpy(x).cuda()
+    z = torch.empty(n, dtype=torch.float64, device="cuda")
+    pc.apply(dx, z)
+    zr = ch.vcycle(x)
+    zh = z.cpu().numpy()
+    assert np.linalg.norm(zh - zr) <= 1e-10 * np.linalg.norm(zr)
+    del zr, ch
+    # ---- linearity of PCApply
+    y = _lcg(n, shift=777)
+    dy = torch.from_numpy(y).cuda()
+    w = torch.empty_like(z); s = torch.empty_like(z)
+    pc.apply(dy, w)
+    pc.apply(2.0 * dx - 3.0 * dy, s)
+    lin = 2.0 * z - 3.0 * w
+    assert float((s - lin).norm()) <= 1e-12 * float(lin.norm())
+    del dy, w, s, lin, dx, z
+    # ---- GMRES(30), right preconditioning, rtol 1e-10 from x0 = 1 to b = 0: converges in the bench's 12 iterations
+    # and the true residual ||b - A x|| agrees with the recurrence's
+    b = torch.zeros(n, dtype=torch.float64, device="cuda"); sol = torch.ones_like(b)
+    res = P.KSP("gmres", pc_side="right", rtol=1e-10, atol=1e-50, max_it=30).solve(b, sol, pc=pc)
+    assert res["reason"] > 0 and 10 <= res["its"] <= 14, res
+    dA = P.DeviceMat(A)
+    r = torch.empty_like(b); r0 = torch.empty_like(b)
+    dA.mult(sol, r)
+    dA.mult(torch.ones_like(b), r0)
+    true_rel = float(r.norm()) / float(r0.norm())
+    assert true_rel <= 1.05e-10, true_rel
+    assert abs(float(r.norm()) - res["rnorm"]) <= 1e-3 * float(r0.norm()) * 1e-10 + 0.05 * res["rnorm"]
