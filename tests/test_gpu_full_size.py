@@ -1,8 +1,9 @@
 """BASELINE configs 3/4 at their FULL size on the GPU: 3D upwind advection 464^3 = 99 897 344 DoF with bench.py's recipe
 (-pc_air_a_lump + the truncation recipe of docs/gpus.md:34-38, 16^3-brick layout hint).  The C/OpenMP oracle
 (oracle/air_oracle.c, the same code as bench.py's cpu_baseline leg) applies one V-cycle on the same hierarchy in a
-few seconds on the box's host cores, so the V-cycle is checked against it at full size; linearity and the true
-residual of the GMRES solution are the size-independent properties on top."""
+few seconds on the box's host cores, so the V-cycle AND the whole GMRES solve (12 iterations, about half a minute) are
+checked against it at full size; linearity and the true residual of the solution are the size-independent properties
+on top."""
 import numpy as np
 import pytest
 
@@ -48,7 +49,10 @@ def test_config3_464_vcycle_against_the_c_oracle_linearity_and_true_residual(gpu
     zr = ch.vcycle(x)
     zh = z.cpu().numpy()
     assert np.linalg.norm(zh - zr) <= 1e-10 * np.linalg.norm(zr)
-    del zr, ch
+    del zr, zh
+    # ---- the whole solve on the host cores: GMRES(30), right preconditioning, rtol 1e-10, x0 = 1, b = 0
+    _, its_cpu, reason_cpu, rn_cpu, _ = ch.ksp(A, np.zeros(n), np.ones(n), "gmres", "right", rtol=1e-10, atol=1e-50, max_it=30)
+    del ch
     # ---- linearity of PCApply
     y = _lcg(n, shift=777)
     dy = torch.from_numpy(y).cuda()
@@ -63,6 +67,9 @@ def test_config3_464_vcycle_against_the_c_oracle_linearity_and_true_residual(gpu
     b = torch.zeros(n, dtype=torch.float64, device="cuda"); sol = torch.ones_like(b)
     res = P.KSP("gmres", pc_side="right", rtol=1e-10, atol=1e-50, max_it=30).solve(b, sol, pc=pc)
     assert res["reason"] > 0 and 10 <= res["its"] <= 14, res
+    # identical iteration count and convergence reason, final residual norms agreeing to 2 digits (SURVEY 8d parity gate)
+    assert res["its"] == its_cpu and res["reason"] == reason_cpu, (res, its_cpu, reason_cpu)
+    assert abs(res["rnorm"] - rn_cpu) <= 0.05 * rn_cpu, (res["rnorm"], rn_cpu)
     dA = P.DeviceMat(A)
     r = torch.empty_like(b); r0 = torch.empty_like(b)
     dA.mult(sol, r)
