@@ -254,7 +254,7 @@ def main():
         ch = c_oracle.CHierarchy(pc, copy=False)
         b0 = np.zeros(n); x1 = np.ones(n)
         tc = time.time()
-        _, its_c, _, _, _ = ch.ksp(hm, b0, x1, "gmres", "right", rtol=1e-300, atol=1e-300, max_it=args.cpu_iters)
+        _, its_c, _, _, hist_c = ch.ksp(hm, b0, x1, "gmres", "right", rtol=1e-300, atol=1e-300, max_it=args.cpu_iters)
         dt = time.time() - tc
         cpu = {"value": its_c / dt, "unit": "KSP iterations/s", "cores": cores, "kind": "port",
                "sample": f"{its_c} right-preconditioned GMRES iterations (SpMV + AIR V-cycle + CGS) of the same "
@@ -280,6 +280,13 @@ def main():
     res0 = ksp.solve(b, x, pc=pc)
     log(f"[bench] converged solve: its={res0['its']} reason={res0['reason_name']} rnorm={res0['rnorm']:.3e} {res0['solve_ms']:.1f} ms")
     its_conv = max(res0["its"], 1)
+    if cpu is not None and its_c > 0:
+        # the oracle as the checker: residual norms of the CPU sample's iterations against the GPU solve's (same system,
+        # same hierarchy, same Krylov method)
+        k = min(len(hist_c), len(res0["history"]))
+        d = max(abs(res0["history"][i] - hist_c[i]) / max(abs(hist_c[i]), 1e-300) for i in range(k)) if k else None
+        cpu["check"] = {"residual_norms_compared": k, "max_rel_diff_gpu_vs_cpu": d}
+        log(f"[bench] residual norms GPU vs CPU oracle over {k} entries: max relative difference {d}")
 
     def run_iterations(k):
         """exactly k Krylov iterations over consecutive solves of the reference problem"""
