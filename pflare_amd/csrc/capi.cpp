@@ -49,6 +49,7 @@ int airhip_set_tuning(const char* key, int value) {
   REQUIRE(key, AIRHIP_ERR_ARG, "null argument");
   if (std::string(key) == "spgemm_pool_entries") airhip::spgemm_set_pool_limit(value);
   else if (std::string(key) == "spgemm_pool_chunk") airhip::spgemm_set_pool_chunk(value);
+  else if (std::string(key) == "block_order_min_blocks") airhip::set_block_order_min(value);
   else if (airhip::spmv_set_tuning(key, value) != 0) { g_err = std::string("unknown tuning key ") + key; return AIRHIP_ERR_ARG; }
   API_END
 }

@@ -41,6 +41,10 @@ struct DevMat {
   // the interior blocks run while the neighbour exchange is in flight
   int32_t* list_int = nullptr; int32_t* list_bnd = nullptr;
   int64_t n_int = 0, n_bnd = 0;
+  // optional processing order of the row blocks (all nblocks of them): operators whose rows run through the sections
+  // of a hierarchical vector are swept in the spatial order of their rows, so that the blocks of different sections
+  // that gather the same neighbourhood of x run close together in time (DevPCAIR::upload)
+  int32_t* list_ord = nullptr;
   bool valid() const { return blk != nullptr; }
   // algorithmic bytes of one SpMV with this operator: S(X) of SURVEY 8(d)
   double s_bytes() const { return 12.0 * nnz + 4.0 * (m + 1) + 8.0 * m + 8.0 * n; }

@@ -28,6 +28,27 @@ void upload_mat(const Csr& A, const int32_t* d_rowsrc, const int32_t* d_colmap, 
   g_t_convert += now_s() - t0;
 }
 
+// Processing order of an operator's row blocks by the locality key of each block's first row (host arrays:
+// dev_row_to_host[r] = host row stored as device row r, key[host row]).  See DevMat::list_ord.
+static int64_t g_block_order_min = 4096;      // smaller operators sit in the caches anyway
+void set_block_order_min(int64_t nblocks) { g_block_order_min = nblocks > 0 ? nblocks : 1; }
+
+static void order_blocks_by_key(DevMat& M, const int32_t* dev_row_to_host, const int64_t* key, hipStream_t s) {
+  if (M.nblocks < g_block_order_min || M.list_ord) return;
+  std::vector<BlkDesc> blk((size_t)M.nblocks);
+  HIP_CHECK(hipMemcpyAsync(blk.data(), M.blk, sizeof(BlkDesc) * (size_t)M.nblocks, hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  std::vector<std::pair<int64_t, int32_t>> kb((size_t)M.nblocks);
+#pragma omp parallel for schedule(static)
+  for (int64_t b = 0; b < M.nblocks; b++) kb[(size_t)b] = {key[dev_row_to_host ? dev_row_to_host[blk[(size_t)b].row] : blk[(size_t)b].row], (int32_t)b};
+  __gnu_parallel::sort(kb.begin(), kb.end());
+  std::vector<int32_t> ord((size_t)M.nblocks);
+#pragma omp parallel for schedule(static)
+  for (int64_t b = 0; b < M.nblocks; b++) ord[(size_t)b] = kb[(size_t)b].second;
+  M.list_ord = (int32_t*)dev_alloc_exact(sizeof(int32_t) * (size_t)M.nblocks);
+  HIP_CHECK(hipMemcpy(M.list_ord, ord.data(), sizeof(int32_t) * (size_t)M.nblocks, hipMemcpyHostToDevice));
+}
+
 double DevInv::alg_bytes() const {
   if (kind == InvOp::ASSEMBLED) return mat.s_bytes();
   if (kind == InvOp::DIAG) return 12.0 * n + 4.0 * (n + 1) + 8.0 * n + 8.0 * n;
@@ -228,6 +249,27 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
   if (use_key && (int64_t)hint_.size() != n_) throw std::runtime_error("ordering hint has the wrong length");
   std::vector<std::vector<int32_t>> fpos(L > 0 ? L - 1 : 0);
   std::vector<int32_t> cpos;       // coarsest level: natural index -> position (empty = identity)
+  std::vector<std::vector<int64_t>> level_keys;   // locality key of every point of every level (level-local numbering)
+  const bool order_blocks = !dist && !(std::getenv("AIRHIP_BLOCK_ORDER") && std::atoi(std::getenv("AIRHIP_BLOCK_ORDER")) == 0);
+  // level_keys[l][i]: locality key of point i of level l (level-local numbering) - the caller's hint on the top level, the
+  // row's own index without one (the reference numbering is lexicographic, which is a locality key as well); a coarse
+  // point inherits the key of its parent C point.  Used for the layout (with a hint) and for the processing order of
+  // the row blocks of operators whose rows run through several sections (DevMat::list_ord).
+  {
+    level_keys.resize(L);
+    std::vector<int64_t> key;
+    if (use_key) key = hint_;
+    else { key.resize((size_t)n_); for (int64_t i = 0; i < n_; i++) key[(size_t)i] = i; }
+    for (int l = 0; l + 1 < L; l++) {
+      const Level& Lv = *H.levels[l];
+      std::vector<int64_t> nxt((size_t)Lv.n_c);
+#pragma omp parallel for schedule(static)
+      for (int64_t j = 0; j < Lv.n_c; j++) nxt[(size_t)j] = key[Lv.C[j]];
+      level_keys[l] = std::move(key);
+      key = std::move(nxt);
+    }
+    level_keys[L - 1] = std::move(key);
+  }
   if (use_key) {
     auto rank_by = [](const std::vector<int64_t>& k) {
       const int64_t n = (int64_t)k.size();
@@ -239,18 +281,15 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
       for (int64_t r = 0; r < n; r++) pos[ord[r]] = (int32_t)r;
       return pos;
     };
-    std::vector<int64_t> key(hint_), nxt, kf;
+    std::vector<int64_t> kf;
     for (int l = 0; l + 1 < L; l++) {
       const Level& Lv = *H.levels[l];
-      kf.resize(Lv.n_f); nxt.resize(Lv.n_c);
+      kf.resize(Lv.n_f);
 #pragma omp parallel for schedule(static)
-      for (int64_t i = 0; i < Lv.n_f; i++) kf[i] = key[Lv.F[i]];
-#pragma omp parallel for schedule(static)
-      for (int64_t j = 0; j < Lv.n_c; j++) nxt[j] = key[Lv.C[j]];
+      for (int64_t i = 0; i < Lv.n_f; i++) kf[i] = level_keys[l][Lv.F[i]];
       fpos[l] = rank_by(kf);
-      key.swap(nxt);
     }
-    cpos = rank_by(key);
+    cpos = rank_by(level_keys[L - 1]);
   }
   // hierarchical permutations, coarsest level first: perm[l][i] = position of natural
   // index i of level l inside the level-l vector [F_l | level l+1 ...]
@@ -287,6 +326,7 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
     iperm_.upload(ip.data(), n_);
     upload_mat(A_top, iperm_.p, perm_.p, A_perm_, stream_, ng(dist ? &dist->h_top : nullptr));
     attach_halo(A_perm_, dist ? &dist->h_top : nullptr, perm[0].data());
+    if (order_blocks) order_blocks_by_key(A_perm_, ip.data(), level_keys[0].data(), stream_);
   }
 
   cycle_bytes_ = 0.0;
@@ -326,6 +366,7 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
       std::vector<int32_t> ipv = inverse(perm[l]);
       pl.upload(perm[l].data(), h.n); ipl.upload(ipv.data(), h.n);
       upload_mat(h.A_full, ipl.p, pl.p, d.A_full, stream_);
+      if (order_blocks) order_blocks_by_key(d.A_full, ipv.data(), level_keys[l].data(), stream_);
       std::vector<double> dg;
       if ((h.inv_ff.kind == InvOp::HORNER || h.inv_ff.kind == InvOp::NEWTON) && h.inv_ff.diag_scale) {
         std::vector<double> nat(h.n); get_diagonal(h.A_full, nat.data());
@@ -334,7 +375,9 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
       }
       upload_inv(h.inv_ff, d.inv_ff, &d.A_full, dg.empty() ? nullptr : dg.data(), nullptr, ipl.p, pl.p, perm[l].data());
       d.inv_ff.n = h.n;
+      if (order_blocks && d.inv_ff.kind == InvOp::ASSEMBLED) order_blocks_by_key(d.inv_ff.mat, ipv.data(), level_keys[l].data(), stream_);
       upload_mat(h.Z, ipc.p, Fcol, d.Z, stream_);
+      if (order_blocks) order_blocks_by_key(d.Z, ipn.data(), level_keys[l + 1].data(), stream_);
       // the prolongator always as a matrix here (x_f += W e)
       d.one_point = false;
       if (h.one_point) {
@@ -358,6 +401,7 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
     attach_halo(d.A_fc, hl ? &hl->A_fc : nullptr, perm[l + 1].data());
     upload_mat(h.Z, ipc.p, Fcol, d.Z, stream_, ng(hl ? &hl->Z : nullptr));           // rows permuted coarse, cols F block
     attach_halo(d.Z, hl ? &hl->Z : nullptr, fph);
+    if (order_blocks) order_blocks_by_key(d.Z, ipn.data(), level_keys[l + 1].data(), stream_);
     std::vector<double> affd_host;
     bool mf = (h.inv_ff.kind == InvOp::HORNER || h.inv_ff.kind == InvOp::NEWTON);
     if (h.aff_diag) {
@@ -390,13 +434,16 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
     if (any_c_) {
       upload_mat(h.A_cf, ipc.p, Fcol, d.A_cf, stream_, ng(hl ? &hl->A_cf : nullptr));
       attach_halo(d.A_cf, hl ? &hl->A_cf : nullptr, fph);
+      if (order_blocks) order_blocks_by_key(d.A_cf, ipn.data(), level_keys[l + 1].data(), stream_);
       upload_mat(h.A_cc, ipc.p, pc.p, d.A_cc, stream_, ng(hl ? &hl->A_cc : nullptr));
       attach_halo(d.A_cc, hl ? &hl->A_cc : nullptr, perm[l + 1].data());
+      if (order_blocks) order_blocks_by_key(d.A_cc, ipn.data(), level_keys[l + 1].data(), stream_);
       // inverse of A_cc lives in the permuted coarse numbering as well
       if (h.inv_cc.kind == InvOp::ASSEMBLED) {
         d.inv_cc.kind = InvOp::ASSEMBLED; d.inv_cc.n = h.n_c;
         upload_mat(h.inv_cc.mat, ipc.p, pc.p, d.inv_cc.mat, stream_, ng(hl ? &hl->M_cc : nullptr));
         attach_halo(d.inv_cc.mat, hl ? &hl->M_cc : nullptr, perm[l + 1].data());
+        if (order_blocks) order_blocks_by_key(d.inv_cc.mat, ipn.data(), level_keys[l + 1].data(), stream_);
       } else if (h.inv_cc.kind == InvOp::DIAG) {
         std::vector<double> dd(h.n_c);
         for (int64_t j = 0; j < h.n_c; j++) dd[perm[l + 1][j]] = h.inv_cc.d[j];

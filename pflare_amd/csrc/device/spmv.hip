@@ -343,6 +343,7 @@ void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t
                  const int32_t* blk_list, int64_t nlist) {
   if (A.m == 0 || (blk_list && nlist == 0)) return;
   RbView v = view_of(A);
+  if (!blk_list && A.list_ord) { blk_list = A.list_ord; nlist = A.nblocks; }
   v.blk_list = blk_list; v.nlist = nlist;
   const int64_t nb = blk_list ? nlist : A.nblocks;
   if (A.n == 0) x = A.val;     // no columns: blocks of empty rows still read element 0 of "x"
@@ -631,6 +632,7 @@ void devmat_free(DevMat& A) {
   if (A.val) (void)hipFree(A.val);
   if (A.list_int) (void)hipFree(A.list_int);
   if (A.list_bnd) (void)hipFree(A.list_bnd);
+  if (A.list_ord) (void)hipFree(A.list_ord);
   A = DevMat();
 }
 

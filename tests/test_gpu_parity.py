@@ -207,3 +207,41 @@ def test_ordering_hint_changes_layout_not_results(torch_mod, case):
     x0 = torch.ones_like(x); r0 = ksp.solve(b, x0, pc=pc0)
     x1 = torch.ones_like(x); r1 = ksp.solve(b, x1, pc=pc1)
     assert r0["its"] == r1["its"] and r0["reason"] == r1["reason"]
+
+
+@pytest.mark.parametrize("case", ["adv3d_12_lump", "adv2d_16_fcf", "adv2d_24_full", "adv3d_10_lair_rthr", "diff2d_16_neumann_mf"])
+@pytest.mark.parametrize("hint", [False, True])
+def test_spatial_block_order_is_bitwise_neutral(torch_mod, case, hint):
+    """Operators whose rows run through several sections of a hierarchical vector (R = [Z I], the outer operator,
+    A_cf / A_cc, the level operator of full smoothing) are swept in the spatial order of their row blocks
+    (DevMat::list_ord; only from 4096 blocks on by default - forced here).  The order of the blocks must not change a
+    bit of PCApply, with and without a layout hint, and the V-cycle must still match the oracle."""
+    torch = torch_mod
+    import pflare_amd as P
+    from oracle import air_ref as R, bridge
+    gen, opts = CASES[case]
+    hm = P.HostMat.adv_diff_fd(**gen)
+    A = bridge.to_scipy(hm.csr())
+    n = A.shape[0]
+    x = lcg_vector(n)
+    key = np.random.default_rng(9).permutation(n) if hint else None
+    out = []
+    lib = P.lib()
+    try:
+        for min_blocks in (1 << 30, 1):              # never / always
+            assert lib.airhip_set_tuning(b"block_order_min_blocks", min_blocks) == 0
+            pc = P.PCAIR(**opts)
+            if key is not None:
+                pc.set_ordering_hint(key)
+            pc.setup(A)
+            z = torch.empty(n, dtype=torch.float64, device="cuda")
+            pc.apply(dev(torch, x), z)
+            b = torch.zeros(n, dtype=torch.float64, device="cuda"); sol = torch.ones_like(b)
+            res = P.KSP("gmres", pc_side="right", rtol=1e-10, atol=1e-50, max_it=40).solve(b, sol, pc=pc)
+            out.append((z, res["its"], res["rnorm"], pc))
+    finally:
+        lib.airhip_set_tuning(b"block_order_min_blocks", 4096)
+    assert torch.equal(out[0][0], out[1][0])
+    assert out[0][1] == out[1][1] and out[0][2] == out[1][2]
+    H = bridge.hierarchy_from_product(out[1][3], A)
+    assert relerr(out[1][0].cpu().numpy(), R.vcycle(H, x)) <= TOL_CYCLE
