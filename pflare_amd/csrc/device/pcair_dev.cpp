@@ -47,6 +47,17 @@ static void order_blocks_by_key(DevMat& M, const int32_t* dev_row_to_host, const
   for (int64_t b = 0; b < M.nblocks; b++) ord[(size_t)b] = kb[(size_t)b].second;
   M.list_ord = (int32_t*)dev_alloc_exact(sizeof(int32_t) * (size_t)M.nblocks);
   HIP_CHECK(hipMemcpy(M.list_ord, ord.data(), sizeof(int32_t) * (size_t)M.nblocks, hipMemcpyHostToDevice));
+  if (M.list_int && M.list_bnd) {
+    // distributed operand with the interior / boundary split: both lists in the same spatial order
+    std::vector<int32_t> lb((size_t)M.n_bnd);
+    if (M.n_bnd) HIP_CHECK(hipMemcpy(lb.data(), M.list_bnd, sizeof(int32_t) * (size_t)M.n_bnd, hipMemcpyDeviceToHost));
+    std::vector<uint8_t> bnd((size_t)M.nblocks, 0);
+    for (int32_t b : lb) bnd[(size_t)b] = 1;
+    std::vector<int32_t> li; li.reserve((size_t)M.n_int); lb.clear();
+    for (int32_t b : ord) (bnd[(size_t)b] ? lb : li).push_back(b);
+    if (!li.empty()) HIP_CHECK(hipMemcpy(M.list_int, li.data(), sizeof(int32_t) * li.size(), hipMemcpyHostToDevice));
+    if (!lb.empty()) HIP_CHECK(hipMemcpy(M.list_bnd, lb.data(), sizeof(int32_t) * lb.size(), hipMemcpyHostToDevice));
+  }
 }
 
 double DevInv::alg_bytes() const {
@@ -250,7 +261,7 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
   std::vector<std::vector<int32_t>> fpos(L > 0 ? L - 1 : 0);
   std::vector<int32_t> cpos;       // coarsest level: natural index -> position (empty = identity)
   std::vector<std::vector<int64_t>> level_keys;   // locality key of every point of every level (level-local numbering)
-  const bool order_blocks = !dist && !(std::getenv("AIRHIP_BLOCK_ORDER") && std::atoi(std::getenv("AIRHIP_BLOCK_ORDER")) == 0);
+  const bool order_blocks = !(std::getenv("AIRHIP_BLOCK_ORDER") && std::atoi(std::getenv("AIRHIP_BLOCK_ORDER")) == 0);
   // level_keys[l][i]: locality key of point i of level l (level-local numbering) - the caller's hint on the top level, the
   // row's own index without one (the reference numbering is lexicographic, which is a locality key as well); a coarse
   // point inherits the key of its parent C point.  Used for the layout (with a hint) and for the processing order of
