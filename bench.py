@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--hint-brick", type=int, default=16,
                     help="locality hint for the device layout: grid points grouped in BxBxB bricks (0: none, -1: Morton "
                          "order of the bricks of size 4); the operator keeps the reference numbering")
+    ap.add_argument("--hint-morton", type=int, default=0, help="diagnostic: with --hint-brick B > 0, number the bricks along a Morton curve instead of lexicographically")
     ap.add_argument("--brick", type=int, default=0, help="diagnostic: renumber the grid in BxBxB bricks before the setup (locality experiment; not the reference numbering)")
     ap.add_argument("--threads", type=int, default=0, help="host threads for setup + CPU baseline (0: cores / ranks, capped at 32 - measured best on the GPU box)")
     ap.add_argument("--device-trunc", type=int, default=1,
@@ -170,8 +171,17 @@ def main():
             nbk = (M + B - 1) // B
             ax = np.arange(M, dtype=np.int64)
             bi, li = ax // B, ax % B
-            key = ((bi[:, None, None] * nbk + bi[None, :, None]) * nbk + bi[None, None, :]) * B ** 3 \
-                + (li[:, None, None] * B + li[None, :, None]) * B + li[None, None, :]      # [k, j, i]
+            if args.hint_morton:
+                def spread3(v):
+                    r = np.zeros_like(v)
+                    for bit in range(10):
+                        r |= ((v >> bit) & 1) << (3 * bit)
+                    return r
+                sb = spread3(bi)
+                bkey = (sb[:, None, None] << 2) | (sb[None, :, None] << 1) | sb[None, None, :]
+            else:
+                bkey = (bi[:, None, None] * nbk + bi[None, :, None]) * nbk + bi[None, None, :]
+            key = bkey * B ** 3 + (li[:, None, None] * B + li[None, :, None]) * B + li[None, None, :]      # [k, j, i]
             pc.set_ordering_hint(key.reshape(-1))
             del key
         if dist_mode:
