@@ -71,6 +71,48 @@ __global__ __launch_bounds__(BLOCK) void k_strength_fill(int64_t m, const int64_
   }
 }
 
+// The same two passes with one WAVE per row, for operators with long rows (the deep levels have hundreds of entries
+// per row: a thread per row reads them uncoalesced).  Maximum and count are order-free; the strong entries keep their
+// column order through ballot prefixes.
+__global__ __launch_bounds__(BLOCK) void k_strength_count_w(int64_t m, const int64_t* __restrict__ rp, const int32_t* __restrict__ ci,
+                                                           const double* __restrict__ v, double theta, double* __restrict__ thr,
+                                                           int64_t* __restrict__ cnt) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * BLOCK) >> 6;
+  for (int64_t i = wave; i < m; i += nw) {
+    const int64_t a0 = rp[i], a1 = rp[i + 1];
+    double mx = -1.7976931348623157e308;
+    for (int64_t k = a0 + lane; k < a1; k += 64) if (ci[k] != i) mx = fmax(mx, fabs(v[k]));
+    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+    const double t = theta * mx;
+    int c = 0;
+    for (int64_t k = a0 + lane; k < a1; k += 64) c += (ci[k] != i && fabs(v[k]) >= t) ? 1 : 0;
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+    if (lane == 0) { thr[i] = t; cnt[i] = c; }
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_strength_fill_w(int64_t m, const int64_t* __restrict__ rp, const int32_t* __restrict__ ci,
+                                                          const double* __restrict__ v, const double* __restrict__ thr,
+                                                          const int64_t* __restrict__ srp, int32_t* __restrict__ sci,
+                                                          unsigned long long* __restrict__ tcnt) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * BLOCK) >> 6;
+  for (int64_t i = wave; i < m; i += nw) {
+    const int64_t a0 = rp[i], a1 = rp[i + 1];
+    int64_t o = srp[i];
+    const double t = thr[i];
+    for (int64_t kb = a0; kb < a1; kb += 64) {
+      const int64_t k = kb + lane;
+      const bool strong = k < a1 && ci[k] != i && fabs(v[k]) >= t;
+      const unsigned long long b = __ballot(strong);
+      if (strong) { const int32_t c = ci[k]; sci[o + __popcll(b & lt)] = c; if (tcnt) atomicAdd(&tcnt[c], 1ull); }
+      o += __popcll(b);
+    }
+  }
+}
+
 // S^T adjacency (any order inside a row) and, per row, how many of its S entries have the reverse edge in S
 __global__ __launch_bounds__(BLOCK) void k_transpose_fill(int64_t m, const int64_t* __restrict__ srp, const int32_t* __restrict__ sci,
                                                          unsigned long long* __restrict__ cursor, int32_t* __restrict__ tci,
@@ -196,6 +238,35 @@ __global__ __launch_bounds__(BLOCK) void k_ddc_ratio(int64_t m, const int64_t* _
   }
 }
 
+// one wave per row; the off-diagonal sum is taken in column order like the host's (the F-F entries of a 64-entry chunk
+// are added one after the other by all lanes on broadcast values), so the ratios and with them the histogram are the same
+__global__ __launch_bounds__(BLOCK) void k_ddc_ratio_w(int64_t m, const int64_t* __restrict__ rp, const int32_t* __restrict__ ci,
+                                                      const double* __restrict__ v, const int32_t* __restrict__ markers,
+                                                      double* __restrict__ ratio, unsigned long long* __restrict__ bins) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * BLOCK) >> 6;
+  for (int64_t i = wave; i < m; i += nw) {
+    double r = 0.0;
+    if (markers[i] == F_POINT_D) {
+      const int64_t a0 = rp[i], a1 = rp[i + 1];
+      double diag = 0.0, off = 0.0;
+      for (int64_t kb = a0; kb < a1; kb += 64) {
+        const int64_t k = kb + lane;
+        int32_t c = -1; double av = 0.0;
+        if (k < a1) { c = ci[k]; av = fabs(v[k]); }
+        const bool ff = c >= 0 && markers[c] == F_POINT_D;
+        const unsigned long long bd = __ballot(ff && c == (int32_t)i);
+        if (bd) diag = __shfl(av, __ffsll((long long)bd) - 1, 64);
+        unsigned long long b = __ballot(ff && c != (int32_t)i);
+        while (b) { const int t = __ffsll((long long)b) - 1; off += __shfl(av, t, 64); b &= b - 1; }
+      }
+      if (diag != 0.0) r = off / diag;
+      if (lane == 0) atomicAdd(&bins[ddc_bin(r)], 1ull);
+    }
+    if (lane == 0) ratio[i] = r;
+  }
+}
+
 __global__ __launch_bounds__(BLOCK) void k_ddc_flip(int64_t m, const double* __restrict__ ratio, double swap_val, int32_t* __restrict__ markers) {
   const int64_t stride = (int64_t)gridDim.x * BLOCK;
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < m; i += stride)
@@ -218,7 +289,10 @@ void dev_cf_splitting_pmisr_ddc(const DCsr& A, double strong_threshold, bool sym
   double* thr = S.get<double>(m);
   int64_t* cnt = S.get<int64_t>(m);
   int64_t* srp = S.get<int64_t>(m + 1);
-  hipLaunchKernelGGL(k_strength_count, dim3(grid1(m)), dim3(BLOCK), 0, s, m, A.rp, A.ci, A.v, strong_threshold, thr, cnt);
+  const bool long_rows = A.nnz >= 12 * m;            // one wave per row pays from a dozen entries per row on
+  const int gw = (int)std::min<int64_t>((m + 3) / 4 > 0 ? (m + 3) / 4 : 1, 65535 * 16);
+  if (long_rows) hipLaunchKernelGGL(k_strength_count_w, dim3(gw), dim3(BLOCK), 0, s, m, A.rp, A.ci, A.v, strong_threshold, thr, cnt);
+  else hipLaunchKernelGGL(k_strength_count, dim3(grid1(m)), dim3(BLOCK), 0, s, m, A.rp, A.ci, A.v, strong_threshold, thr, cnt);
   const int64_t snnz = device_exclusive_scan(m, cnt, srp, s);
   HIP_CHECK(hipMemcpyAsync(srp + m, &snnz, sizeof(int64_t), hipMemcpyHostToDevice, s));
   int32_t* sci = S.get<int32_t>(snnz);
@@ -228,7 +302,8 @@ void dev_cf_splitting_pmisr_ddc(const DCsr& A, double strong_threshold, bool sym
     tcnt = S.get<unsigned long long>(m);
     HIP_CHECK(hipMemsetAsync(tcnt, 0, sizeof(unsigned long long) * (size_t)m, s));
   }
-  hipLaunchKernelGGL(k_strength_fill, dim3(grid1(m)), dim3(BLOCK), 0, s, m, A.rp, A.ci, A.v, thr, srp, sci, tcnt);
+  if (long_rows) hipLaunchKernelGGL(k_strength_fill_w, dim3(gw), dim3(BLOCK), 0, s, m, A.rp, A.ci, A.v, thr, srp, sci, tcnt);
+  else hipLaunchKernelGGL(k_strength_fill, dim3(grid1(m)), dim3(BLOCK), 0, s, m, A.rp, A.ci, A.v, thr, srp, sci, tcnt);
   if (symmetrize) {
     trp = S.get<int64_t>(m + 1);
     static_assert(sizeof(unsigned long long) == sizeof(int64_t), "");
@@ -269,7 +344,8 @@ void dev_cf_splitting_pmisr_ddc(const DCsr& A, double strong_threshold, bool sym
     unsigned long long* bins = S.get<unsigned long long>(1001);
     for (int it = 0; it < ddc_its; it++) {
       HIP_CHECK(hipMemsetAsync(bins, 0, sizeof(unsigned long long) * 1001, s));
-      hipLaunchKernelGGL(k_ddc_ratio, dim3(grid1(m)), dim3(BLOCK), 0, s, m, A.rp, A.ci, A.v, markers, ratio, bins);
+      if (long_rows) hipLaunchKernelGGL(k_ddc_ratio_w, dim3(gw), dim3(BLOCK), 0, s, m, A.rp, A.ci, A.v, markers, ratio, bins);
+      else hipLaunchKernelGGL(k_ddc_ratio, dim3(grid1(m)), dim3(BLOCK), 0, s, m, A.rp, A.ci, A.v, markers, ratio, bins);
       unsigned long long hb[1001];
       HIP_CHECK(hipMemcpyAsync(hb, bins, sizeof(hb), hipMemcpyDeviceToHost, s));
       HIP_CHECK(hipStreamSynchronize(s));
