@@ -57,6 +57,8 @@ SPGEMM_CASES = [
     (300, 3000, 40000, 40, 40, 2),      # 1600 candidates, nearly all distinct
     (200, 3000, 40000, 70, 40, 3),      # 2800
     (64, 3000, 40000, 300, 30, 4),      # 9000
+    (64, 4000, 200000, 128, 30, 3),     # ~3800 distinct columns: the 4k table nearly full (no room for the sample sort's
+                                        # scratch words -> bitonic network, or too many probe rounds -> global table)
 ]
 
 
