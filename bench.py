@@ -50,9 +50,8 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=8, help="Krylov iterations of the CPU baseline sample (about 2 s each at 464^3 on 32 threads)")
     ap.add_argument("--graph", type=int, default=0)
     ap.add_argument("--profile-kernels", type=int, default=1)
-    ap.add_argument("--variants", default="", help="diagnostic: ';'-separated kernel tunings to time on the same "
-                    "hierarchy, each a ','-separated list of key=value for airhip_set_tuning (e.g. "
-                    "'spmv_pipeline=0;spmv_occupancy=4,spmv_wg_per_cu=3')")
+    ap.add_argument("--variants", default="", help="diagnostic: ';'-separated tunings to time on the same hierarchy, each a "
+                    "','-separated list of key=value for airhip_set_tuning (keys: include/airhip.h)")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--hint-brick", type=int, default=16,
                     help="locality hint for the device layout: grid points grouped in BxBxB bricks (0: none, -1: Morton "
