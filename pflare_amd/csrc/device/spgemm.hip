@@ -259,14 +259,18 @@ __device__ __forceinline__ bool lds_bucket_sort(const Tab<false> tab, int nu) {
 // ---- accumulate, hash table: leaves the nu distinct columns of row i of A*B with their sums in tab[0, nu), sorted
 // by column; -1 = the table is too small for the row.  tab: HT slots owned by this wave (HT a power of two).
 // CAP: slots of the wave's LDS region (0: no sample sort - global tables, counting only).
+// dummy (LDS tables): first of 64 slots outside the table that stay EMPTY, one per lane (same-address LDS atomics
+// serialise) - a lane without a candidate aims its compare-and-swaps and its additions of 0 at its own, so that the
+// probe rounds need no per-step exec masks.
 template <bool GLOBAL, int CAP>
 __device__ __forceinline__ int hash_accumulate(const CsrView& A, const CsrView& B, int64_t i, const Tab<GLOBAL> tab, int HT, bool negate,
-                                               bool count_only = false) {
+                                               bool count_only = false, int dummy = 0) {
 #pragma clang fp contract(off)   // a*b + c must round twice, as the host code does
   const int lane = threadIdx.x & (WAVE - 1);
   const uint32_t mask = (uint32_t)HT - 1;
   const unsigned long long lt = (1ull << lane) - 1ull;
   for (int h = lane; h < HT; h += WAVE) { tab.stk(h, EMPTY); tab.stv(h, 0.0); }
+  if (!GLOBAL) { tab.stk(dummy + lane, EMPTY); tab.stv(dummy + lane, 0.0); }
   tab.sync();
   const int64_t a0 = uniform64(A.rp[i]), a1 = uniform64(A.rp[i + 1]);
   // The candidate stream of the row is consumed in "steps": one step = up to 64 consecutive entries of one row
@@ -314,23 +318,46 @@ __device__ __forceinline__ int hash_accumulate(const CsrView& A, const CsrView& 
         pend[d] = act[d];
       }
       int rounds = 0;
-      for (;;) {
-        int32_t old[PIPE];
+      if constexpr (GLOBAL) {
+        for (;;) {
+          int32_t old[PIPE];
 #pragma unroll
-        for (int d = 0; d < PIPE; d++) old[d] = pend[d] ? tab.cas((int)hh[d], cc[d]) : 0;
-        bool more = false;
+          for (int d = 0; d < PIPE; d++) old[d] = pend[d] ? tab.cas((int)hh[d], cc[d]) : 0;
+          bool more = false;
 #pragma unroll
-        for (int d = 0; d < PIPE; d++) {
-          if (pend[d]) {
-            if (old[d] == EMPTY || old[d] == cc[d]) pend[d] = false;
-            else { hh[d] = (hh[d] + inc[d]) & mask; more = true; }
+          for (int d = 0; d < PIPE; d++) {
+            if (pend[d]) {
+              if (old[d] == EMPTY || old[d] == cc[d]) pend[d] = false;
+              else { hh[d] = (hh[d] + inc[d]) & mask; more = true; }
+            }
           }
+          if (!__any(more)) break;
+          if (++rounds > MAX_PROBE_ROUNDS) return -1;     // (nearly) full table
         }
-        if (!__any(more)) break;
-        if (++rounds > MAX_PROBE_ROUNDS) return -1;     // (nearly) full table
-      }
 #pragma unroll
-      for (int d = 0; d < PIPE; d++) if (act[d]) tab.add((int)hh[d], x[d]);
+        for (int d = 0; d < PIPE; d++) if (act[d]) tab.add((int)hh[d], x[d]);
+      } else {
+        // branch-free rounds: a lane that has found its slot repeats the compare-and-swap there (it returns its own
+        // column), a lane without a candidate works on the dummy slot
+#pragma unroll
+        for (int d = 0; d < PIPE; d++) if (!act[d]) { cc[d] = EMPTY; hh[d] = (uint32_t)(dummy + lane); inc[d] = 0; x[d] = 0.0; }
+        for (;;) {
+          int32_t old[PIPE];
+#pragma unroll
+          for (int d = 0; d < PIPE; d++) old[d] = tab.cas((int)hh[d], cc[d]);
+          bool more = false;
+#pragma unroll
+          for (int d = 0; d < PIPE; d++) {
+            const bool miss = old[d] != EMPTY && old[d] != cc[d];
+            hh[d] = miss ? ((hh[d] + inc[d]) & mask) : hh[d];
+            more |= miss;
+          }
+          if (!__any(more)) break;
+          if (++rounds > MAX_PROBE_ROUNDS) return -1;     // (nearly) full table
+        }
+#pragma unroll
+        for (int d = 0; d < PIPE; d++) tab.add((int)hh[d], x[d]);
+      }
       tab.sync();
     }
   }
@@ -565,8 +592,8 @@ __global__ __launch_bounds__(MAX_HT / HT * WAVE) void k_spgemm_lds(CsrView A, Cs
                                                                   RowPool pool, unsigned int* __restrict__ fail, Escalation esc,
                                                                   unsigned long long* __restrict__ seen) {
   constexpr int WPB = MAX_HT / HT;
-  __shared__ int32_t keys_all[WPB][HT];
-  __shared__ double vals_all[WPB][HT];
+  __shared__ int32_t keys_all[WPB][HT + WAVE];       // + the dummy slots (hash_accumulate)
+  __shared__ double vals_all[WPB][HT + WAVE];
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t nw = (int64_t)gridDim.x * WPB;
   const int64_t count = sel.rows ? sel.nrows : A.m;
@@ -580,8 +607,8 @@ __global__ __launch_bounds__(MAX_HT / HT * WAVE) void k_spgemm_lds(CsrView A, Cs
     mine++;
     const int64_t expect = ubi <= L1K_MAX ? ubi : (int64_t)((float)ubi * sel.plan.ratio) + 64;
     const int ht = table_for(expect < ubi ? expect : ubi, HT);
-    int nu = hash_accumulate<false, HT>(A, B, i, tab, ht, dp.negate != 0);
-    if (nu < 0 && ht < HT) nu = hash_accumulate<false, HT>(A, B, i, tab, HT, dp.negate != 0);
+    int nu = hash_accumulate<false, HT>(A, B, i, tab, ht, dp.negate != 0, false, HT);
+    if (nu < 0 && ht < HT) nu = hash_accumulate<false, HT>(A, B, i, tab, HT, dp.negate != 0, false, HT);
     if (nu < 0 && esc.rows) {
       if ((threadIdx.x & (WAVE - 1)) == 0) esc.rows[atomicAdd(esc.count, 1u)] = (int32_t)i;
     } else {
@@ -617,13 +644,13 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_tiny(CsrView A, CsrView B, Row
 // and stores its bound and its number of distinct columns (-1: more than the 4k table holds, -2: not such a row)
 __global__ __launch_bounds__(WAVE) void k_spgemm_sample(CsrView A, CsrView B, const int64_t* __restrict__ ub, int nsamples,
                                                        int64_t* __restrict__ out_ub, int32_t* __restrict__ out_nu) {
-  __shared__ int32_t keys[MAX_HT];
-  __shared__ double vals[MAX_HT];
+  __shared__ int32_t keys[MAX_HT + WAVE];
+  __shared__ double vals[MAX_HT + WAVE];
   const Tab<false> tab{keys, vals};
   for (int w = blockIdx.x; w < nsamples; w += gridDim.x) {
     const int64_t i = ((int64_t)w * A.m) / nsamples;
     const int64_t u = ub[i];
-    const int nu = u > L1K_MAX ? hash_accumulate<false, 0>(A, B, i, tab, MAX_HT, false, true) : -2;
+    const int nu = u > L1K_MAX ? hash_accumulate<false, 0>(A, B, i, tab, MAX_HT, false, true, MAX_HT) : -2;
     if (threadIdx.x == 0) { out_ub[w] = u; out_nu[w] = nu; }
     __builtin_amdgcn_wave_barrier();
   }
