@@ -219,6 +219,7 @@ void DevPCAIR::upload_inv(const InvOp& h, DevInv& d, const DevMat* Aop, const do
     d.n = h.d.size();
     if (pos_host) {
       std::vector<double> dd(d.n);
+#pragma omp parallel for schedule(static)
       for (int64_t i = 0; i < d.n; i++) dd[pos_host[i]] = h.d[i];
       d.d.upload(dd.data(), d.n);
     } else d.d.upload(h.d.data(), h.d.size());
@@ -228,6 +229,7 @@ void DevPCAIR::upload_inv(const InvOp& h, DevInv& d, const DevMat* Aop, const do
     d.t1.alloc(d.n); d.t2.alloc(d.n); d.t3.alloc(d.n);
     if (h.diag_scale) {
       std::vector<double> di(d.n);
+#pragma omp parallel for schedule(static)
       for (int64_t i = 0; i < d.n; i++) di[i] = 1.0 / host_diag_of_op[i];
       d.dinv.upload(di.data(), d.n);
       d.rhs.alloc(d.n);
@@ -308,6 +310,7 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
   {
     const int64_t nL = H.coarse_A.m;
     perm[L - 1].resize(nL);
+#pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < nL; i++) perm[L - 1][i] = use_key ? cpos[i] : (int32_t)i;
     for (int l = L - 2; l >= 0; l--) {
       const Level& Lv = *H.levels[l];
@@ -366,6 +369,7 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
     const int32_t* Fcol = use_key ? fpd.p : nullptr;    // host F column c becomes Fcol[c]
     auto fperm_vec = [&](const double* v) {             // host F-indexed vector -> device order
       std::vector<double> o(h.n_f);
+#pragma omp parallel for schedule(static)
       for (int64_t i = 0; i < h.n_f; i++) o[fph ? fph[i] : i] = v[i];
       return o;
     };
@@ -402,7 +406,12 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
       d.rfull.alloc(h.n);
       auto S = [](double nnz, double m, double n) { return 12.0 * nnz + 4.0 * (m + 1) + 8.0 * m + 8.0 * n; };
       double nnzW = h.one_point ? 0.0 : (double)h.W.nnz();
-      if (h.one_point) for (int64_t i = 0; i < h.n_f; i++) nnzW += h.wcol[i] >= 0 ? 1 : 0;
+      if (h.one_point) {
+      int64_t cntw = 0;
+#pragma omp parallel for schedule(static) reduction(+ : cntw)
+      for (int64_t i = 0; i < h.n_f; i++) cntw += h.wcol[i] >= 0 ? 1 : 0;
+      nnzW += (double)cntw;
+    }
       cycle_bytes_ += S((double)h.Z.nnz() + h.n_c, h.n_c, h.n) + S(nnzW + h.n_c, h.n, h.n_c)
                     + 2.0 * (d.A_full.s_bytes() + d.inv_ff.alg_bytes());
       levels_.push_back(std::move(dl));
@@ -435,6 +444,7 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
       std::vector<int32_t> wc(h.n_f);
       const int32_t* pn = perm[l + 1].data();
       // distributed: columns >= n_c are ghost columns of A_fc and keep their index
+#pragma omp parallel for schedule(static)
       for (int64_t i = 0; i < h.n_f; i++) { const int32_t c = h.wcol[i]; wc[fph ? fph[i] : i] = c < 0 ? -1 : (c < h.n_c ? pn[c] : c); }
       d.wcol.upload(wc.data(), h.n_f);
     } else {
@@ -474,7 +484,12 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
     // reference counts them
     auto S = [](double nnz, double m, double n) { return 12.0 * nnz + 4.0 * (m + 1) + 8.0 * m + 8.0 * n; };
     double nnzW = h.one_point ? 0.0 : (double)h.W.nnz();
-    if (h.one_point) for (int64_t i = 0; i < h.n_f; i++) nnzW += h.wcol[i] >= 0 ? 1 : 0;
+    if (h.one_point) {
+      int64_t cntw = 0;
+#pragma omp parallel for schedule(static) reduction(+ : cntw)
+      for (int64_t i = 0; i < h.n_f; i++) cntw += h.wcol[i] >= 0 ? 1 : 0;
+      nnzW += (double)cntw;
+    }
     cycle_bytes_ += S((double)h.Z.nnz() + h.n_c, h.n_c, h.n) + S(nnzW + h.n_c, h.n, h.n_c);
     int g = 0, sf = 0, gc = 0, sc = 0;
     for (int i = 0; i < 10; i++) { int s = h.smooth_order[i]; if (s > 0) { g++; sf += s; } else if (s < 0) { gc++; sc += -s; } }

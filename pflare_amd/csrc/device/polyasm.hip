@@ -42,29 +42,49 @@ __global__ __launch_bounds__(BLOCK) void k_poly_count(int64_t m, const int64_t* 
   }
 }
 
+__device__ __forceinline__ int lane_i32(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ int64_t lane_i64(int64_t v, int l) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(v & 0xffffffffll), l);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), l);
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
 // CAP: longest row the bin handles; HT = 2 * CAP hash slots.  WPB waves per workgroup.
+// The sweep over (j in P(i), 64-entry chunk of row j of A) is a scalar walk - lane e of a chunk of P(i) holds the
+// extent of row cols[e] and prev[e], the current row's base / length / factor come through readlane - and PIPE steps
+// form a batch: their loads are issued together, their columns are looked up in the hash map together (read-only
+// probes), then the products are added with ds_add_f64 in step order, which is the order of the host code.
 template <int CAP, int WPB>
 __global__ __launch_bounds__(WPB * WAVE) void k_poly_rows(int64_t nrows, const int32_t* __restrict__ rows, const int64_t* __restrict__ rp,
                                                          const int32_t* __restrict__ ci, const double* __restrict__ v, Coefs cf,
                                                          const int64_t* __restrict__ orp, int32_t* __restrict__ oci, double* __restrict__ ov) {
 #pragma clang fp contract(off)   // a*b + c rounds twice, as the host code does
   constexpr int HT = 2 * CAP;
+  constexpr int PIPE = 8;
   __shared__ int32_t s_cols[WPB][CAP];
   __shared__ int32_t s_hkey[WPB][HT];
   __shared__ uint16_t s_hpos[WPB][HT];
-  __shared__ double s_prev[WPB][CAP], s_cur[WPB][CAP], s_acc[WPB][CAP];
-  const int wid = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1);
+  __shared__ int64_t s_rb0[WPB][CAP];
+  __shared__ int32_t s_rlen[WPB][CAP];
+  __shared__ double s_prev[WPB][CAP], s_cur[WPB][CAP + WAVE], s_acc[WPB][CAP];
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & (WAVE - 1);
   int32_t* cols = s_cols[wid]; int32_t* hkey = s_hkey[wid]; uint16_t* hpos = s_hpos[wid];
+  int64_t* rb0 = s_rb0[wid]; int32_t* rlen = s_rlen[wid];
   double* prev = s_prev[wid]; double* cur = s_cur[wid]; double* acc = s_acc[wid];
   auto sync = [] { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
   const int64_t nw = (int64_t)gridDim.x * WPB;
   for (int64_t w = (int64_t)blockIdx.x * WPB + wid; w < nrows; w += nw) {
     const int64_t i = rows[w];
-    const int64_t p0 = rp[i];
-    const int nc = (int)(rp[i + 1] - p0);
-    // P(i), the previous power (= the row of A itself), the accumulator, the hash map
+    const int64_t p0 = uniform64(rp[i]);
+    const int nc = (int)(uniform64(rp[i + 1]) - p0);
+    // P(i), the extents of the rows it names, the previous power (= the row of A itself), the accumulator, the hash map
     for (int h = lane; h < HT; h += WAVE) hkey[h] = EMPTYK;
-    for (int q = lane; q < nc; q += WAVE) { cols[q] = ci[p0 + q]; prev[q] = v[p0 + q]; acc[q] = 0.0; }
+    for (int q = lane; q < nc; q += WAVE) {
+      const int32_t c = ci[p0 + q];
+      cols[q] = c; prev[q] = v[p0 + q]; acc[q] = 0.0;
+      const int64_t b = rp[c];
+      rb0[q] = b; rlen[q] = (int32_t)(rp[c + 1] - b);
+    }
     sync();
     for (int q = lane; q < nc; q += WAVE) {
       const int32_t c = cols[q];
@@ -78,23 +98,58 @@ __global__ __launch_bounds__(WPB * WAVE) void k_poly_rows(int64_t nrows, const i
     }
     sync();
     for (int term = 2; term < cf.n; term++) {
-      for (int q = lane; q < nc; q += WAVE) cur[q] = 0.0;
+      for (int q = lane; q < nc + WAVE; q += WAVE) cur[q] = 0.0;       // [nc, nc + 64): the dump slots of lanes without a hit
       sync();
-      for (int j = 0; j < nc; j++) {
-        const double pj = prev[j];
-        const int64_t r = cols[j];
-        const int64_t a0 = rp[r], a1 = rp[r + 1];
-        for (int64_t a = a0 + lane; a < a1; a += WAVE) {
-          const int32_t c = ci[a];
-          uint32_t h = hcol(c) & (HT - 1);
-          for (;;) {
-            const int32_t k = hkey[h];
-            if (k == c) { const int b = hpos[h]; cur[b] += pj * v[a]; break; }
-            if (k == EMPTYK) break;
-            h = (h + 1) & (HT - 1);
+      for (int jb = 0; jb < nc; jb += WAVE) {
+        const int nk = nc - jb < WAVE ? nc - jb : WAVE;
+        int64_t b0 = 0; int len = 0; double pj = 0.0;
+        if (lane < nk) { b0 = rb0[jb + lane]; len = rlen[jb + lane]; pj = prev[jb + lane]; }
+        const long long pj_bits = __double_as_longlong(pj);
+        int e = 0, off = 0;
+        int cur_len = lane_i32(len, 0);
+        int64_t cur_b0 = lane_i64(b0, 0);
+        double cur_p = __longlong_as_double(lane_i64(pj_bits, 0));
+        while (e < nk) {
+          int32_t cc[PIPE]; double x[PIPE], pv[PIPE]; bool act[PIPE]; uint32_t hh[PIPE]; int pos[PIPE];
+#pragma unroll
+          for (int d = 0; d < PIPE; d++) {
+            act[d] = false; cc[d] = EMPTYK; x[d] = 0.0; pv[d] = 0.0;
+            if (e < nk) {                                   // wave-uniform
+              const uint32_t o = (uint32_t)(off + lane);
+              act[d] = o < (uint32_t)cur_len;
+              pv[d] = cur_p;
+              if (act[d]) { cc[d] = (ci + cur_b0)[o]; x[d] = (v + cur_b0)[o]; }
+              off += WAVE;
+              if (off >= cur_len) {
+                e++; off = 0;
+                if (e < nk) { cur_len = lane_i32(len, e); cur_b0 = lane_i64(b0, e); cur_p = __longlong_as_double(lane_i64(pj_bits, e)); }
+              }
+            }
           }
+#pragma unroll
+          for (int d = 0; d < PIPE; d++) { x[d] = pv[d] * x[d]; hh[d] = hcol(cc[d]) & (HT - 1); pos[d] = nc + lane; }
+          // read-only probes of all steps together; a lane without an entry carries EMPTYK, which ends its probe at once
+          for (;;) {
+            int32_t k[PIPE];
+#pragma unroll
+            for (int d = 0; d < PIPE; d++) k[d] = hkey[hh[d]];
+            bool more = false;
+#pragma unroll
+            for (int d = 0; d < PIPE; d++) {
+              const bool hit = k[d] == cc[d] && act[d];
+              const bool miss = k[d] != cc[d] && k[d] != EMPTYK && act[d];
+              if (hit) pos[d] = hpos[hh[d]];
+              act[d] = act[d] && miss;                      // still looking
+              hh[d] = miss ? ((hh[d] + 1) & (HT - 1)) : hh[d];
+              more |= miss;
+            }
+            if (!__any(more)) break;
+          }
+#pragma unroll
+          for (int d = 0; d < PIPE; d++)
+            (void)__hip_atomic_fetch_add(&cur[pos[d]], pos[d] < nc ? x[d] : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          sync();
         }
-        sync();    // the next j may hit the same positions
       }
       const double ct = cf.c[term];
       if (ct != 0.0) for (int q = lane; q < nc; q += WAVE) acc[q] += ct * cur[q];
