@@ -188,12 +188,16 @@ bool dev_poly_assemble(const DCsr& A, const double* c, int nterms, DCsr& M, hipS
   std::vector<int64_t> rp(m + 1);
   HIP_CHECK(hipMemcpyAsync(rp.data(), A.rp, sizeof(int64_t) * (size_t)(m + 1), hipMemcpyDeviceToHost, s));
   HIP_CHECK(hipStreamSynchronize(s));
-  std::vector<int32_t> small, big;
-  small.reserve(m);
+  // rows by length: the longer the row, the larger its wave's share of LDS and the fewer waves a CU holds (20 / 10 / 6 / 3)
+  constexpr int NBIN = 4;
+  const int cap[NBIN] = {128, 256, 512, 1024};
+  std::vector<int32_t> bin[NBIN];
+  bin[0].reserve(m);
   for (int64_t i = 0; i < m; i++) {
     const int64_t len = rp[i + 1] - rp[i];
-    if (len > 1024) return false;
-    (len <= 128 ? small : big).push_back((int32_t)i);
+    if (len > cap[NBIN - 1]) return false;
+    int k = 0; while (len > cap[k]) k++;
+    bin[k].push_back((int32_t)i);
   }
   Coefs cf; cf.n = nterms;
   for (int k = 0; k < MAXC; k++) cf.c[k] = k < nterms ? c[k] : 0.0;
@@ -206,23 +210,19 @@ bool dev_poly_assemble(const DCsr& A, const double* c, int nterms, DCsr& M, hipS
   HIP_CHECK(hipMemcpyAsync(M.rp + m, &M.nnz, sizeof(int64_t), hipMemcpyHostToDevice, s));
   dev_free(cnt);
   M.ci = dalloc<int32_t>(M.nnz); M.v = dalloc<double>(M.nnz);
-  int32_t* d_small = dalloc<int32_t>((int64_t)small.size());
-  int32_t* d_big = dalloc<int32_t>((int64_t)big.size());
-  if (!small.empty()) HIP_CHECK(hipMemcpyAsync(d_small, small.data(), sizeof(int32_t) * small.size(), hipMemcpyHostToDevice, s));
-  if (!big.empty()) HIP_CHECK(hipMemcpyAsync(d_big, big.data(), sizeof(int32_t) * big.size(), hipMemcpyHostToDevice, s));
-  if (!small.empty()) {
-    const int64_t wgs = std::min<int64_t>(((int64_t)small.size() + 3) / 4, 256 * 16);
-    hipLaunchKernelGGL((k_poly_rows<128, 4>), dim3((unsigned)wgs), dim3(4 * WAVE), 0, s, (int64_t)small.size(), d_small, A.rp, A.ci, A.v, cf,
-                       M.rp, M.ci, M.v);
+  int32_t* d_rows[NBIN];
+  for (int k = 0; k < NBIN; k++) {
+    d_rows[k] = dalloc<int32_t>((int64_t)bin[k].size());
+    if (!bin[k].empty()) HIP_CHECK(hipMemcpyAsync(d_rows[k], bin[k].data(), sizeof(int32_t) * bin[k].size(), hipMemcpyHostToDevice, s));
   }
-  if (!big.empty()) {
-    const int64_t wgs = std::min<int64_t>((int64_t)big.size(), 256 * 4);
-    hipLaunchKernelGGL((k_poly_rows<1024, 1>), dim3((unsigned)wgs), dim3(WAVE), 0, s, (int64_t)big.size(), d_big, A.rp, A.ci, A.v, cf, M.rp,
-                       M.ci, M.v);
-  }
+  auto grid = [](size_t rows, int wpb, int per_cu) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(((int64_t)rows + wpb - 1) / wpb, 256 * per_cu * 4))); };
+  if (!bin[0].empty()) hipLaunchKernelGGL((k_poly_rows<128, 4>), grid(bin[0].size(), 4, 5), dim3(4 * WAVE), 0, s, (int64_t)bin[0].size(), d_rows[0], A.rp, A.ci, A.v, cf, M.rp, M.ci, M.v);
+  if (!bin[1].empty()) hipLaunchKernelGGL((k_poly_rows<256, 2>), grid(bin[1].size(), 2, 5), dim3(2 * WAVE), 0, s, (int64_t)bin[1].size(), d_rows[1], A.rp, A.ci, A.v, cf, M.rp, M.ci, M.v);
+  if (!bin[2].empty()) hipLaunchKernelGGL((k_poly_rows<512, 1>), grid(bin[2].size(), 1, 6), dim3(WAVE), 0, s, (int64_t)bin[2].size(), d_rows[2], A.rp, A.ci, A.v, cf, M.rp, M.ci, M.v);
+  if (!bin[3].empty()) hipLaunchKernelGGL((k_poly_rows<1024, 1>), grid(bin[3].size(), 1, 3), dim3(WAVE), 0, s, (int64_t)bin[3].size(), d_rows[3], A.rp, A.ci, A.v, cf, M.rp, M.ci, M.v);
   HIP_CHECK(hipStreamSynchronize(s));
   const hipError_t e = hipGetLastError();
-  dev_free(d_small); dev_free(d_big);
+  for (int k = 0; k < NBIN; k++) dev_free(d_rows[k]);
   if (e != hipSuccess) throw std::runtime_error(std::string("HIP error ") + hipGetErrorString(e) + " in the device polynomial assembly");
   return true;
 }
