@@ -340,6 +340,7 @@ def main():
     if args.profile_kernels:
         pc.profile(True)
         pc.profile_reset()
+    comm0 = comm.stats() if dist_mode else None
     barrier()
     t0 = time.perf_counter()
     ms_dev = run_iterations(args.steps)
@@ -353,6 +354,7 @@ def main():
     pc.profile(False)
     if dist_mode:
         info["comm"] = comm.stats()
+        info["comm_timed"] = {k: info["comm"][k] - comm0[k] for k in comm0}      # the timed iterations only
         cab = torch.tensor([pc.cycle_alg_bytes()], dtype=torch.float64, device="cpu" if staged else "cuda")
         dist.all_reduce(cab)
         cx = dict(cx); cx["cycle_alg_bytes"] = float(cab.item())
@@ -429,6 +431,9 @@ def main():
         out["config"]["distribute_s"] = info["t_distribute"]
         out["config"]["halo_exchanges_rank0"] = info["comm"]["exchanges"]
         out["config"]["allreduces_rank0"] = info["comm"]["allreduces"]
+        ct = info["comm_timed"]
+        out["config"]["per_iteration_rank0"] = {"halo_exchanges": ct["exchanges"] / args.steps, "halo_messages_sent": ct["messages_sent"] / args.steps,
+                                                "halo_bytes_sent": ct["bytes_sent"] / args.steps, "allreduces": ct["allreduces"] / args.steps}
         if out["roofline"] is not None:
             out["roofline"]["note"] = "kernel timings of rank 0"
     print(json.dumps(out), flush=True)

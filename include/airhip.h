@@ -256,6 +256,9 @@ int airhip_comm_create_rccl(int rank, int size, const void* unique_id128, airhip
 int airhip_comm_create_staged(int rank, int size, airhip_exchange_fn ex, airhip_allreduce_fn ar, void* user,
                               airhip_comm* out);
 int airhip_comm_stats(airhip_comm c, int64_t* exchanges, int64_t* allreduces);
+/* halo traffic this rank has sent since the communicator was created (or its last self-test): bytes, and messages
+ * (one per peer with something to send per exchange) */
+int airhip_comm_traffic(airhip_comm c, int64_t* bytes_sent, int64_t* messages_sent);
 /* collective check of a transport before it is trusted with a solve: every rank sends `count` doubles of a
  * known pattern to every other rank (device buffers, twice) and sums a value over the ranks; *ok = 1 if
  * everything arrived intact on this rank */

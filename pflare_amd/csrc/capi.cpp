@@ -958,6 +958,13 @@ int airhip_comm_stats(airhip_comm c, int64_t* exchanges, int64_t* allreduces) {
   if (allreduces) *allreduces = c->c->n_allreduces;
   API_END
 }
+int airhip_comm_traffic(airhip_comm c, int64_t* bytes_sent, int64_t* messages_sent) {
+  API_BEGIN
+  REQUIRE(c, AIRHIP_ERR_ARG, "null argument");
+  if (bytes_sent) *bytes_sent = c->c->bytes_sent;
+  if (messages_sent) *messages_sent = c->c->messages_sent;
+  API_END
+}
 int airhip_comm_selftest(airhip_comm c, int64_t count, int* ok) {
   API_BEGIN
   REQUIRE(c && ok, AIRHIP_ERR_ARG, "null argument");

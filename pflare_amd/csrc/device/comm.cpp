@@ -27,6 +27,8 @@ struct StagedComm final : Comm {
   }
   void exchange(const HaloPlan& p, hipStream_t s) override {
     n_exchanges++;
+    bytes_sent += 8 * p.n_send;
+    for (size_t k = 0; k + 1 < p.send_off.size(); k++) messages_sent += p.send_off[k + 1] > p.send_off[k] ? 1 : 0;
     ensure(p.n_send, p.n_ghost);
     if (p.n_send) HIP_CHECK(hipMemcpyAsync(hs, p.sendbuf, sizeof(double) * (size_t)p.n_send, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
@@ -94,6 +96,8 @@ struct RcclComm final : Comm {
   ~RcclComm() override { if (comm) (void)rccl().CommDestroy(comm); }
   void exchange(const HaloPlan& p, hipStream_t s) override {
     n_exchanges++;
+    bytes_sent += 8 * p.n_send;
+    for (size_t k = 0; k + 1 < p.send_off.size(); k++) messages_sent += p.send_off[k + 1] > p.send_off[k] ? 1 : 0;
     Rccl& r = rccl();
     RCCL_CHECK(r.GroupStart());
     for (size_t k = 0; k < p.peers.size(); k++) {
@@ -171,6 +175,7 @@ bool comm_selftest(Comm& c, int64_t count) {
   HIP_CHECK(hipStreamSynchronize(s));
   (void)hipStreamDestroy(s);
   c.n_exchanges = c.n_allreduces = 0;
+  c.bytes_sent = c.messages_sent = 0;
   return ok;
 }
 

@@ -33,6 +33,7 @@ struct Comm {
   // stream is synchronised
   virtual void allreduce_sum(double* d_vals, double* h_vals, int n, hipStream_t s) = 0;
   int64_t n_exchanges = 0, n_allreduces = 0;
+  int64_t bytes_sent = 0, messages_sent = 0;     // halo traffic this rank has sent (8 bytes per ghost value)
 };
 
 typedef int (*exchange_cb)(void* user, int npeers, const int* peers, const double* send, const int64_t* send_off,

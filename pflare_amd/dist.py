@@ -193,7 +193,9 @@ class StagedComm:
     def stats(self):
         a, b = C.c_int64(), C.c_int64()
         check(lib().airhip_comm_stats(self._h, C.byref(a), C.byref(b)))
-        return dict(exchanges=a.value, allreduces=b.value)
+        c, d = C.c_int64(), C.c_int64()
+        check(lib().airhip_comm_traffic(self._h, C.byref(c), C.byref(d)))
+        return dict(exchanges=a.value, allreduces=b.value, bytes_sent=c.value, messages_sent=d.value)
 
     def selftest(self, count=4096):
         """Collective: all-pairs exchange of a known pattern + an all-reduce; True if intact on this rank."""
