@@ -301,3 +301,29 @@ def test_standalone_cf_splitting_matches_oracle(cf, thr):
     assert isf.size + isc.size == A.shape[0] and isf.size > 0 and isc.size > 0
     with pytest.raises(P.AirhipError):
         P.compute_cf_splitting(A, False, 0.5, -1, 4, 1, 0.1)        # aggregation: not built
+
+
+def test_reference_cf_splitting_driver_on_its_data_file():
+    """tests/Makefile:153 (`./ex6_cf_splitting -f data/mat_stream_2364`): the reference's stand-alone CF splitting driver
+    (tests/ex6_cf_splitting.c) on its own matrix - PMISR+DDC with the default arguments, diag_dom with strong_threshold
+    0.5 and CR with target rate 0.1 must each return a partition of the rows (CheckSplitting, :20-73), and the F-F block
+    of the diag_dom splitting must be diagonally dominant to the ratio asked for (CheckDiagDomSubmatrix, :77-135:
+    max over rows of sum |offdiag| / |diag| <= 0.5 + 1e-12 + 1e-10 * max(0.5, observed))."""
+    import os
+    from pflare_amd.petscio import load_mat_vec
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_data", "mat_stream_2364")
+    A = load_mat_vec(root)[0].tocsr()
+    n = A.shape[0]
+    for cf, thr in ((P.CF_PMISR_DDC, 0.5), (P.CF_DIAG_DOM, 0.5), (P.CF_CR, 0.1)):
+        isf, isc = P.compute_cf_splitting(A, False, thr, -1, cf, 1, 0.1)
+        seen = np.zeros(n, dtype=np.int64)
+        np.add.at(seen, isf, 1); np.add.at(seen, isc, 1)
+        assert isf.size + isc.size == n and np.all(seen == 1), cf
+        assert np.all(np.diff(isf) > 0) and np.all(np.diff(isc) > 0)
+        if cf == P.CF_DIAG_DOM:
+            Aff = A[isf][:, isf].tocsr()
+            d = np.abs(Aff.diagonal())
+            off = np.asarray(abs(Aff).sum(axis=1)).ravel() - d
+            ratio = np.where(d != 0.0, off / np.where(d != 0.0, d, 1.0), 0.0)
+            mx = float(ratio.max())
+            assert mx <= 0.5 + 1e-12 + 1e-10 * max(0.5, mx), mx

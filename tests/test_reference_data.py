@@ -176,3 +176,46 @@ def test_product_pflareinv_meets_reference_bounds(gpu, label, opts, bound):
     bd = torch.from_numpy(b).cuda(); xd = torch.from_numpy(x0.copy()).cuda()
     res = ksp.solve(bd, xd, pc=pc, A=P.DeviceMat(A))
     assert res["reason"] > 0 and res["its"] <= bound, (label, res)
+
+
+def _two_airg_problem():
+    A, _ = load_mat_vec(os.path.join(DATA, "mat_stream_2364"))
+    return A, np.random.default_rng(11).random(A.shape[0])       # tests/ex6_two_airg.c:97-99: random right-hand side
+
+
+def test_oracle_two_concurrent_airg_solves():
+    """tests/Makefile:103 (`./ex6_two_airg -f data/mat_stream_2364`): two PCAIR hierarchies on the same matrix with
+    strong thresholds 0.3 and 0.8 (different CF splittings), GMRES rtol 1e-6, <= 100 iterations: both must converge"""
+    A, b = _two_airg_problem()
+    for thr in (0.3, 0.8):
+        H = R.setup_air(A, _oracle_opts(dict(strong_threshold=thr)))
+        _, its, reason, _ = R.ksp_gmres(A, lambda r: R.vcycle(H, r), b, np.zeros(A.shape[0]), rtol=1e-6, max_it=100, pc_side="left")
+        assert reason > 0 and its <= 100, (thr, its, reason)
+
+
+@pytest.mark.gpu
+def test_product_two_concurrent_airg_solves(gpu):
+    """tests/Makefile:103: BOTH preconditioners are set up before either is applied (tests/ex6_two_airg.c:101-106: state
+    shared between two PCAIR objects would show here); both solves converge, and each equals the solve of the same
+    preconditioner built alone"""
+    import torch
+    import pflare_amd as P
+    A, b = _two_airg_problem()
+    n = A.shape[0]
+    dA = P.DeviceMat(A)
+    bd = torch.from_numpy(b).cuda()
+    ksp = P.KSP("gmres", pc_side="left", rtol=1e-6, max_it=100)
+    pc1 = P.PCAIR(strong_threshold=0.3).setup(A)
+    pc2 = P.PCAIR(strong_threshold=0.8).setup(A)
+    assert pc1.num_levels != pc2.num_levels or not np.array_equal(pc1.export_level(0)["F"], pc2.export_level(0)["F"])
+    out = []
+    for pc in (pc1, pc2):
+        x = torch.zeros(n, dtype=torch.float64, device="cuda")
+        res = ksp.solve(bd, x, pc=pc, A=dA)
+        assert res["reason"] > 0 and res["its"] <= 100, res
+        out.append((res["its"], x.clone()))
+    for thr, (its, x) in zip((0.3, 0.8), out):
+        alone = P.PCAIR(strong_threshold=thr).setup(A)
+        xa = torch.zeros(n, dtype=torch.float64, device="cuda")
+        ra = ksp.solve(bd, xa, pc=alone, A=dA)
+        assert ra["its"] == its and torch.equal(xa, x), thr
