@@ -169,7 +169,25 @@ def test_rccl_transport_loads_and_reduces(gpu, tmp_path):
     assert r["stats"]["allreduces"] > 0
 
 
-def _refdata_worker(rank, world, port, out):
+# the reference's parallel PCAIR load tests (tests/Makefile:212-279, `run_tests_load_parallel`, all with -n 2) that need
+# nothing but options this build has (the PCPFLAREINV ones, :229 / :232, have no distributed loader here)
+PAR_LOAD_CASES = {
+    "217-218 power matrix-free smoothers": ("mat_stream_2364", True, dict(a_drop=1e-3, inverse_type="power", matrix_free_polys=True),
+                                            dict(ksp_type="gmres", pc_side="left"), 5),
+    "235-239 exact solver, Newton-60 coarse": ("mat_stream_2364", True,
+                                               dict(strong_threshold=0.0, a_drop=0.0, r_drop=0.0, inverse_type="jacobi", max_levels=10,
+                                                    coarsest_poly_order=60, coarsest_matrix_free_polys=True, coarsest_inverse_type="newton",
+                                                    max_luby_steps=3),
+                                               dict(ksp_type="richardson", norm_type="unpreconditioned"), 1),
+    "254 indefinite, zero diagonals": ("e05r0100_petsc", False, dict(a_drop=1e-3, inverse_type="power"), dict(ksp_type="gmres", pc_side="left"), 26),
+    "258 assembled newton order 2": ("mat_stream_2364", True, dict(inverse_type="newton", poly_order=2), dict(ksp_type="gmres", pc_side="left"), 5),
+    "260 assembled newton order 3": ("mat_stream_2364", True, dict(inverse_type="newton", poly_order=3), dict(ksp_type="gmres", pc_side="left"), 5),
+    "278 newton matrix-free smoothers": ("mat_stream_2364", True, dict(a_drop=1e-3, inverse_type="newton", matrix_free_polys=True),
+                                         dict(ksp_type="gmres", pc_side="left"), 5),
+}
+
+
+def _refdata_worker(rank, world, port, out, case):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import proc_util
     proc_util.init_rank_env(rank, world, port)
@@ -182,18 +200,23 @@ def _refdata_worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=proc_util.pg_timeout())
     try:
         torch.cuda.set_device(0)
-        A, b = load_mat_vec(os.path.join(ROOT, "tests", "golden", "reference_data", "mat_stream_2364"))
+        fname, b_in_f, opts, kkw, bound = PAR_LOAD_CASES[case]
+        A, b = load_mat_vec(os.path.join(ROOT, "tests", "golden", "reference_data", fname))
         n = A.shape[0]
+        if b_in_f:
+            x0 = np.zeros(n)
+        else:                                   # tests/ex6.c:148-152: random initial guess, zero right-hand side
+            b = np.zeros(n); x0 = np.random.default_rng(0).random(n)
         pcg = owner = Ag = None
         if rank == 0:
             Ag = A
             owner = D.block_owner(n, world)
-            pcg = P.PCAIR(device_upload=False, a_drop=1e-3, inverse_type="power", matrix_free_polys=True)
+            pcg = P.PCAIR(device_upload=False, **opts)
             pcg.setup(A)
         comm = D.StagedComm()
         pc, gid = D.distribute(pcg, Ag, owner, comm)
-        ksp = P.KSP("gmres", pc_side="left", rtol=1e-5, max_it=5)
-        bd = torch.from_numpy(b[gid]).cuda(); xd = torch.zeros_like(bd)
+        ksp = P.KSP(rtol=1e-5, max_it=bound, **kkw)
+        bd = torch.from_numpy(b[gid]).cuda(); xd = torch.from_numpy(x0[gid].copy()).cuda()
         res = ksp.solve(bd, xd, pc=pc)
         if rank == 0:
             got = [(gid, xd.cpu().numpy(), res["its"], res["reason"])]
@@ -202,9 +225,9 @@ def _refdata_worker(rank, world, port, out):
             x = np.empty(n)
             for g, xx, *_ in got:
                 x[g] = xx
-            rel = float(np.linalg.norm(b - A @ x) / np.linalg.norm(b))
+            r0 = float(np.linalg.norm(b - A @ x0)); r1 = float(np.linalg.norm(b - A @ x))
             with open(out, "w") as f:
-                f.write(repr(dict(its=[g[2] for g in got], reasons=[g[3] for g in got], rel=rel)))
+                f.write(repr(dict(its=[g[2] for g in got], reasons=[g[3] for g in got], rel=r1 / r0)))
         else:
             dist.send_object_list([(gid, xd.cpu().numpy(), res["its"], res["reason"])], dst=0)
         dist.barrier()
@@ -213,12 +236,14 @@ def _refdata_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_reference_parallel_load_test_two_ranks(gpu, tmp_path):
-    """tests/Makefile:217-218 (`$(MPIEXEC) -n 2 ./ex6 -f data/mat_stream_2364 -pc_air_a_drop 1e-3
-    -pc_air_inverse_type power -pc_air_matrix_free_polys -ksp_max_it 5`): the distributed product must converge
-    within the reference's bound (row-block ownership instead of the reference's graph partition)."""
+@pytest.mark.parametrize("case", sorted(PAR_LOAD_CASES))
+def test_reference_parallel_load_test_two_ranks(gpu, tmp_path, case):
+    """tests/Makefile:212-279 (`$(MPIEXEC) -n 2 ./ex6 ...` / `./ex12f ...` on the reference's data files): the distributed
+    product must converge within the reference's bound on two ranks (row-block ownership instead of the reference's graph
+    partition), every rank with the same iteration count"""
     out = str(tmp_path / "r.txt")
-    proc_util.spawn(_refdata_worker, (2, _free_port(), out), 2)
+    proc_util.spawn(_refdata_worker, (2, _free_port(), out, case), 2)
     r = eval(open(out).read())
-    assert all(x > 0 for x in r["reasons"]) and max(r["its"]) <= 5 and len(set(r["its"])) == 1, r
+    bound = PAR_LOAD_CASES[case][4]
+    assert all(x > 0 for x in r["reasons"]) and max(r["its"]) <= bound and len(set(r["its"])) == 1, r
     assert r["rel"] <= 1e-3, r
