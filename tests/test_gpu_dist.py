@@ -184,6 +184,14 @@ PAR_LOAD_CASES = {
     "260 assembled newton order 3": ("mat_stream_2364", True, dict(inverse_type="newton", poly_order=3), dict(ksp_type="gmres", pc_side="left"), 5),
     "278 newton matrix-free smoothers": ("mat_stream_2364", True, dict(a_drop=1e-3, inverse_type="newton", matrix_free_polys=True),
                                          dict(ksp_type="gmres", pc_side="left"), 5),
+    # `$(MPIEXEC) -n 2 ./adv_diff_fd ...` (tests/Makefile:747-758): the generator's problem (b = 0, x0 = 1) on two DMDA boxes
+    "749 adv 8x8 fc smoothing": (dict(dim=2, M=8, N=8), None, dict(smooth_type="fc"), dict(ksp_type="gmres", pc_side="left"), 3),
+    "752 adv 8x8 fc, diagonal-sparsity C smoother": (dict(dim=2, M=8, N=8), None, dict(smooth_type="fc", c_inverse_sparsity_order=0),
+                                                    dict(ksp_type="gmres", pc_side="left"), 3),
+    "755 adv 10x10 diag_dom 0.9": (dict(dim=2, M=10, N=10), None, dict(cf_splitting_type="diag_dom", strong_threshold=0.9),
+                                   dict(ksp_type="gmres", pc_side="left"), 4),
+    "758 adv 10x10 compatible relaxation 0.1": (dict(dim=2, M=10, N=10), None, dict(cf_splitting_type="cr", strong_threshold=0.1),
+                                                dict(ksp_type="gmres", pc_side="left"), 4),
 }
 
 
@@ -201,16 +209,22 @@ def _refdata_worker(rank, world, port, out, case):
     try:
         torch.cuda.set_device(0)
         fname, b_in_f, opts, kkw, bound = PAR_LOAD_CASES[case]
-        A, b = load_mat_vec(os.path.join(ROOT, "tests", "golden", "reference_data", fname))
-        n = A.shape[0]
-        if b_in_f:
-            x0 = np.zeros(n)
-        else:                                   # tests/ex6.c:148-152: random initial guess, zero right-hand side
-            b = np.zeros(n); x0 = np.random.default_rng(0).random(n)
+        if isinstance(fname, dict):             # tests/adv_diff_fd.c: b = 0, x0 = 1
+            from oracle import bridge
+            hm = P.HostMat.adv_diff_fd(**fname)
+            A = bridge.to_scipy(hm.csr()); n = A.shape[0]
+            b = np.zeros(n); x0 = np.ones(n)
+        else:
+            A, b = load_mat_vec(os.path.join(ROOT, "tests", "golden", "reference_data", fname))
+            n = A.shape[0]
+            if b_in_f:
+                x0 = np.zeros(n)
+            else:                               # tests/ex6.c:148-152: random initial guess, zero right-hand side
+                b = np.zeros(n); x0 = np.random.default_rng(0).random(n)
         pcg = owner = Ag = None
         if rank == 0:
             Ag = A
-            owner = D.block_owner(n, world)
+            owner = D.box_owner(fname["M"], fname["N"], 1, world) if isinstance(fname, dict) else D.block_owner(n, world)
             pcg = P.PCAIR(device_upload=False, **opts)
             pcg.setup(A)
         comm = D.StagedComm()
