@@ -171,6 +171,9 @@ def test_rccl_transport_loads_and_reduces(gpu, tmp_path):
 
 # the reference's parallel PCAIR load tests (tests/Makefile:212-279, `run_tests_load_parallel`, all with -n 2) that need
 # nothing but options this build has (the PCPFLAREINV ones, :229 / :232, have no distributed loader here)
+_DIFF8 = dict(dim=2, M=8, N=8, u=0, v=0, alpha=1.0)
+_GL = dict(ksp_type="gmres", pc_side="left")
+_GR10 = dict(ksp_type="gmres", pc_side="right", rtol=1e-10, atol=1e-50)
 PAR_LOAD_CASES = {
     "217-218 power matrix-free smoothers": ("mat_stream_2364", True, dict(a_drop=1e-3, inverse_type="power", matrix_free_polys=True),
                                             dict(ksp_type="gmres", pc_side="left"), 5),
@@ -192,6 +195,34 @@ PAR_LOAD_CASES = {
                                    dict(ksp_type="gmres", pc_side="left"), 4),
     "758 adv 10x10 compatible relaxation 0.1": (dict(dim=2, M=10, N=10), None, dict(cf_splitting_type="cr", strong_threshold=0.1),
                                                 dict(ksp_type="gmres", pc_side="left"), 4),
+    # diffusion 8x8 (`-u 0 -v 0 -alpha 1.0`, tests/Makefile:834-876)
+    "836 diffusion power a_drop": (_DIFF8, None, dict(a_drop=1e-3, inverse_type="power"), _GL, 5),
+    "839 diffusion arnoldi": (_DIFF8, None, dict(inverse_type="arnoldi", coarsest_inverse_type="arnoldi"), _GL, 5),
+    "842 diffusion lAIR": (_DIFF8, None, dict(z_type="lair", a_drop=1e-3, inverse_type="power"), _GL, 4),
+    "851 diffusion neumann": (_DIFF8, None, dict(inverse_type="neumann", a_drop=1e-3), _GL, 5),
+    "853 diffusion neumann matrix-free": (_DIFF8, None, dict(inverse_type="neumann", matrix_free_polys=True, a_drop=1e-3), _GL, 5),
+    "858 diffusion SAI": (_DIFF8, None, dict(inverse_type="sai", a_drop=1e-3), _GL, 5),
+    "862 diffusion ISAI": (_DIFF8, None, dict(inverse_type="isai", a_drop=1e-3), _GL, 5),
+    "866 diffusion weighted jacobi": (_DIFF8, None, dict(inverse_type="wjacobi", a_drop=1e-3), _GL, 8),
+    "870 diffusion jacobi": (_DIFF8, None, dict(inverse_type="jacobi", a_drop=1e-3), _GL, 5),
+    "874-876 diffusion exact solver": (_DIFF8, None, dict(strong_threshold=0.0, a_drop=0.0, r_drop=0.0, inverse_type="jacobi", mg_coarse_ksp_max_it=10),
+                                       dict(ksp_type="richardson", norm_type="unpreconditioned"), 1),
+    "880-883 adv 10x10 auto truncation": (dict(dim=2, M=10, N=10), None,
+                                          dict(coarsest_inverse_type="newton", coarsest_poly_order=10, coarsest_matrix_free_polys=True,
+                                               auto_truncate_start_level=1, auto_truncate_tol=1e-2, a_drop=1e-3, inverse_type="power"),
+                                          dict(ksp_type="richardson"), 3),
+    # rtol 1e-10, right preconditioning (KSP_RTOL of a double-precision build, tests/Makefile:34)
+    "971-973 adv_1d n=1000": (dict(kind="adv_1d", n=1000), None,
+                              dict(coarsest_inverse_type="newton", coarsest_poly_order=10, coarsest_matrix_free_polys=True, a_drop=1e-3, inverse_type="power"),
+                              _GR10, 10),
+    "977-978 adv 3D 10^3 a_lump": (dict(dim=3, M=10, N=10, P=10), None, dict(a_lump=True), _GR10, 4),
+    "1037-1040 adv 100x100 diag_dom 0.50001": (dict(dim=2, M=100, N=100), None,
+                                              dict(a_lump=True, a_drop=1e-4, cf_splitting_type="diag_dom", strong_threshold=0.50001, inverse_type="power"), _GR10, 7),
+    "1056-1059 adv 100x100 compatible relaxation": (dict(dim=2, M=100, N=100), None,
+                                                   dict(a_lump=True, a_drop=1e-4, cf_splitting_type="cr", strong_threshold=0.1, inverse_type="power"), _GR10, 12),
+    "1089-1090 adv 50x50 improve Z": (dict(dim=2, M=50, N=50), None, dict(improve_z_its=3, a_drop=1e-3, inverse_type="power"), _GL, 3),
+    "1094-1095 adv 50x50 improve W": (dict(dim=2, M=50, N=50), None,
+                                      dict(one_point_classical_prolong=False, improve_w_its=3, a_drop=1e-3, inverse_type="power"), _GL, 4),
 }
 
 
@@ -211,7 +242,7 @@ def _refdata_worker(rank, world, port, out, case):
         fname, b_in_f, opts, kkw, bound = PAR_LOAD_CASES[case]
         if isinstance(fname, dict):             # tests/adv_diff_fd.c: b = 0, x0 = 1
             from oracle import bridge
-            hm = P.HostMat.adv_diff_fd(**fname)
+            hm = P.HostMat.adv_1d(fname["n"]) if fname.get("kind") == "adv_1d" else P.HostMat.adv_diff_fd(**fname)
             A = bridge.to_scipy(hm.csr()); n = A.shape[0]
             b = np.zeros(n); x0 = np.ones(n)
         else:
@@ -224,12 +255,13 @@ def _refdata_worker(rank, world, port, out, case):
         pcg = owner = Ag = None
         if rank == 0:
             Ag = A
-            owner = D.box_owner(fname["M"], fname["N"], 1, world) if isinstance(fname, dict) else D.block_owner(n, world)
+            owner = (D.box_owner(fname["M"], fname["N"], fname.get("P", 1), world) if isinstance(fname, dict) and "M" in fname
+                     else D.block_owner(n, world))
             pcg = P.PCAIR(device_upload=False, **opts)
             pcg.setup(A)
         comm = D.StagedComm()
         pc, gid = D.distribute(pcg, Ag, owner, comm)
-        ksp = P.KSP(rtol=1e-5, max_it=bound, **kkw)
+        ksp = P.KSP(**{**dict(rtol=1e-5, max_it=bound), **kkw})
         bd = torch.from_numpy(b[gid]).cuda(); xd = torch.from_numpy(x0[gid].copy()).cuda()
         res = ksp.solve(bd, xd, pc=pc)
         if rank == 0:
