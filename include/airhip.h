@@ -278,6 +278,9 @@ int airhip_spgemm_filtered(const airhip_csr* A, const airhip_csr* B, int drop, d
                            int on_device, airhip_hostmat* out, int64_t* stats);
 int airhip_pcinv_apply(airhip_pcinv pc, const double* d_x, double* d_y);      /* PCApply_PFLAREINV_c, src/PCPFLAREINV.c:618-626 */
 int airhip_pcinv_apply_on_stream(airhip_pcinv pc, const double* d_x, double* d_y, void* stream);
+/* the zero-level PCAIR object a PCPFLAREINV is built on - BORROWED, valid while pc is; what airhip_partition_create takes
+ * to cut a PCPFLAREINV for a multi-GPU run (the per-rank objects are then PCAIR objects loaded from the pieces) */
+int airhip_pcinv_as_pcair(airhip_pcinv pc, airhip_pcair* out);
 int airhip_pcinv_sync(airhip_pcinv pc);
 int airhip_pcinv_get_inv(airhip_pcinv pc, airhip_invop* inv);
 int airhip_pcinv_destroy(airhip_pcinv* pc);

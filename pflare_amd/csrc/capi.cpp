@@ -1082,6 +1082,13 @@ int airhip_pcinv_apply(airhip_pcinv pc, const double* d_x, double* d_y) {
   REQUIRE(pc, AIRHIP_ERR_ARG, "null argument");
   return airhip_pcair_apply(&pc->inner, d_x, d_y);
 }
+// the zero-level PCAIR object a PCPFLAREINV is built on (borrowed: it lives and dies with pc)
+int airhip_pcinv_as_pcair(airhip_pcinv pc, airhip_pcair* out) {
+  API_BEGIN
+  REQUIRE(pc && out, AIRHIP_ERR_ARG, "null argument");
+  *out = &pc->inner;
+  API_END
+}
 int airhip_pcinv_apply_on_stream(airhip_pcinv pc, const double* d_x, double* d_y, void* stream) {
   REQUIRE(pc, AIRHIP_ERR_ARG, "null argument");
   return airhip_pcair_apply_on_stream(&pc->inner, d_x, d_y, stream);

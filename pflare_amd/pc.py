@@ -458,6 +458,16 @@ class PCPFLAREINV:
         check(lib().airhip_pcinv_get_inv(self._h, C.byref(inv)))
         return _invop_to_dict(inv, n)
 
+    def as_pcair(self):
+        """The zero-level PCAIR this object is built on, as something pflare_amd.dist.distribute can cut for a
+        multi-GPU run (borrowed handle: keeps this object alive, is never destroyed itself)."""
+        h = C.c_void_p()
+        check(lib().airhip_pcinv_as_pcair(self._h, C.byref(h)))
+        view = type("_BorrowedPCAIR", (), {})()
+        view._h = h
+        view._owner = self
+        return view
+
     def __del__(self):
         try:
             if self._h:

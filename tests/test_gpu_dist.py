@@ -169,14 +169,19 @@ def test_rccl_transport_loads_and_reduces(gpu, tmp_path):
     assert r["stats"]["allreduces"] > 0
 
 
-# the reference's parallel PCAIR load tests (tests/Makefile:212-279, `run_tests_load_parallel`, all with -n 2) that need
-# nothing but options this build has (the PCPFLAREINV ones, :229 / :232, have no distributed loader here)
+# the reference's parallel load tests (tests/Makefile:212-279, `run_tests_load_parallel`, all with -n 2) that need nothing but
+# options this build has.  opts with "pflareinv": a PCPFLAREINV, cut through the zero-level PCAIR it is built on.
 _DIFF8 = dict(dim=2, M=8, N=8, u=0, v=0, alpha=1.0)
 _GL = dict(ksp_type="gmres", pc_side="left")
 _GR10 = dict(ksp_type="gmres", pc_side="right", rtol=1e-10, atol=1e-50)
 PAR_LOAD_CASES = {
     "217-218 power matrix-free smoothers": ("mat_stream_2364", True, dict(a_drop=1e-3, inverse_type="power", matrix_free_polys=True),
                                             dict(ksp_type="gmres", pc_side="left"), 5),
+    "229 pflareinv power": ("mat_stream_2364", True, dict(pflareinv=dict(type="power")), dict(ksp_type="gmres", pc_side="left"), 21),
+    "232 pflareinv newton matrix-free": ("mat_stream_2364", True, dict(pflareinv=dict(type="newton", matrix_free=True)),
+                                         dict(ksp_type="gmres", pc_side="left"), 13),
+    "847 diffusion pflareinv power": (dict(dim=2, M=8, N=8, u=0, v=0, alpha=1.0), None, dict(pflareinv=dict(type="power")),
+                                      dict(ksp_type="gmres", pc_side="left"), 8),
     "235-239 exact solver, Newton-60 coarse": ("mat_stream_2364", True,
                                                dict(strong_threshold=0.0, a_drop=0.0, r_drop=0.0, inverse_type="jacobi", max_levels=10,
                                                     coarsest_poly_order=60, coarsest_matrix_free_polys=True, coarsest_inverse_type="newton",
@@ -257,8 +262,12 @@ def _refdata_worker(rank, world, port, out, case):
             Ag = A
             owner = (D.box_owner(fname["M"], fname["N"], fname.get("P", 1), world) if isinstance(fname, dict) and "M" in fname
                      else D.block_owner(n, world))
-            pcg = P.PCAIR(device_upload=False, **opts)
-            pcg.setup(A)
+            if "pflareinv" in opts:
+                inv = P.PCPFLAREINV(**opts["pflareinv"]).setup_host_only(A)
+                pcg = inv.as_pcair()
+            else:
+                pcg = P.PCAIR(device_upload=False, **opts)
+                pcg.setup(A)
         comm = D.StagedComm()
         pc, gid = D.distribute(pcg, Ag, owner, comm)
         ksp = P.KSP(**{**dict(rtol=1e-5, max_it=bound), **kkw})
