@@ -133,6 +133,10 @@ int airhip_gen_adv_diff_fd(int dim, int64_t M, int64_t N, int64_t P, double u, d
 int airhip_hostmat_from_csr(const airhip_csr* A, airhip_hostmat* out); /* deep copy */
 int airhip_hostmat_get(airhip_hostmat A, airhip_csr* view);
 int airhip_hostmat_destroy(airhip_hostmat* A);
+/* compute_diag_dom_submatrix(Mat, PetscReal max_dd_ratio, Mat* output)  (include/pflare.h:114, src/MatDiagDomSubmatrix.F90:17-76):
+ * A(F, F) for the diag_dom splitting with strong_threshold = max_dd_ratio, 0 < max_dd_ratio < 1; release with
+ * airhip_hostmat_destroy */
+int airhip_compute_diag_dom_submatrix(const airhip_csr* A, double max_dd_ratio, airhip_hostmat* out);
 
 /* ---------------------------------------------------------------------------- PCAIR */
 int airhip_pcair_create(airhip_pcair* pc);

@@ -51,7 +51,7 @@ DECLARED_SYMBOLS = [
     "airhip_partition_create", "airhip_partition_extract", "airhip_partition_destroy",
     "airhip_archive_create", "airhip_archive_add", "airhip_archive_count", "airhip_archive_item",
     "airhip_archive_destroy", "airhip_comm_rccl_unique_id", "airhip_comm_create_rccl",
-    "airhip_comm_create_staged", "airhip_comm_stats", "airhip_comm_traffic", "airhip_pcinv_as_pcair", "airhip_comm_selftest", "airhip_compute_cf_splitting", "airhip_compute_cf_splitting_on_device", "airhip_comm_destroy", "airhip_pcair_load_distributed",
+    "airhip_comm_create_staged", "airhip_comm_stats", "airhip_comm_traffic", "airhip_pcinv_as_pcair", "airhip_comm_selftest", "airhip_compute_cf_splitting", "airhip_compute_cf_splitting_on_device", "airhip_compute_diag_dom_submatrix", "airhip_comm_destroy", "airhip_pcair_load_distributed",
 ]
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double),
@@ -155,6 +155,7 @@ def lib():
         "airhip_comm_selftest": [vp, C.c_int64, pint],
         "airhip_compute_cf_splitting": [pcsr, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int32)],
         "airhip_compute_cf_splitting_on_device": [pcsr, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int32)],
+        "airhip_compute_diag_dom_submatrix": [pcsr, C.c_double, pvp],
         "airhip_comm_destroy": [pvp],
         "airhip_pcair_load_distributed": [vp, vp, vp],
     }

@@ -175,6 +175,45 @@ int airhip_compute_cf_splitting(const airhip_csr* A, int symmetric, double stron
   API_END
 }
 
+// compute_diag_dom_submatrix (include/pflare.h:114, src/MatDiagDomSubmatrix.F90:17-76): the F-F block of a diag_dom CF
+// splitting whose strong threshold is the ratio asked for - every row of it has sum |offdiag| / |diag| < max_dd_ratio
+int airhip_compute_diag_dom_submatrix(const airhip_csr* A, double max_dd_ratio, airhip_hostmat* out) {
+  API_BEGIN
+  REQUIRE(A && out, AIRHIP_ERR_ARG, "null argument");
+  REQUIRE_CSR(A, true);
+  REQUIRE(max_dd_ratio > 0.0 && max_dd_ratio < 1.0, AIRHIP_ERR_ARG, "max_dd_ratio input to compute_diag_dom_submatrix must be (0.0, 1.0)");
+  AirOptions o;
+  o.symmetric = false; o.strong_threshold = max_dd_ratio; o.max_luby_steps = -1; o.ddc_its = 0; o.ddc_fraction = 0.0;
+  o.cf_splitting_type = 1;
+  Csr view; view_csr(A, view);
+  ThreadScope threads(A->rowptr[A->m]);
+  Arr<int32_t> m;
+  compute_cf_splitting(view, o, m);
+  const int64_t n = view.m;
+  int64_t nf = 0;
+  Arr<int32_t> newidx(n);
+  for (int64_t i = 0; i < n; i++) newidx[i] = m[i] == F_POINT ? (int32_t)nf++ : -1;
+  auto* h = new airhip_hostmat_s;
+  Csr& S = h->A; S.m = S.n = nf; S.rp.alloc(nf + 1);
+  S.rp[0] = 0;
+  for (int64_t i = 0; i < n; i++) {
+    if (m[i] != F_POINT) continue;
+    int64_t c = 0;
+    for (int64_t k = view.rp[i]; k < view.rp[i + 1]; k++) c += m[view.ci[k]] == F_POINT ? 1 : 0;
+    S.rp[newidx[i] + 1] = S.rp[newidx[i]] + c;
+  }
+  S.ci.alloc(S.rp[nf]); S.v.alloc(S.rp[nf]);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; i++) {
+    if (m[i] != F_POINT) continue;
+    int64_t o2 = S.rp[newidx[i]];
+    for (int64_t k = view.rp[i]; k < view.rp[i + 1]; k++)
+      if (m[view.ci[k]] == F_POINT) { S.ci[o2] = newidx[view.ci[k]]; S.v[o2] = view.v[k]; o2++; }
+  }
+  *out = h;
+  API_END
+}
+
 // the same splitting computed by the device kernels (device/cfsplit.hip); PMISR + DDC only
 int airhip_compute_cf_splitting_on_device(const airhip_csr* A, int symmetric, double strong_threshold, int max_luby_steps,
                                           int ddc_its, double fraction_swap, int32_t* markers) {

@@ -189,6 +189,15 @@ def compute_cf_splitting(A, symmetric=False, strong_threshold=0.5, max_luby_step
     return np.flatnonzero(markers == -1), np.flatnonzero(markers != -1)
 
 
+def compute_diag_dom_submatrix(A, max_dd_ratio):
+    """pflare.compute_diag_dom_submatrix (include/pflare.h:114): the diagonally dominant submatrix A(F, F) of the diag_dom
+    CF splitting with that ratio, as a HostMat"""
+    a = as_csr(A)
+    h = C.c_void_p()
+    check(lib().airhip_compute_diag_dom_submatrix(a.ref(), float(max_dd_ratio), C.byref(h)))
+    return HostMat(h)
+
+
 class _InvHolder:
     """keeps the numpy arrays of an airhip_invop alive"""
 

@@ -9,7 +9,7 @@ replaced.  Options outside this build's scope raise `AirhipError` when set to a 
 """
 from enum import IntEnum
 
-from .pc import PCAIR, PCPFLAREINV, compute_cf_splitting  # noqa: F401
+from .pc import PCAIR, PCPFLAREINV, compute_cf_splitting, compute_diag_dom_submatrix  # noqa: F401
 
 
 class CFSplittingType(IntEnum):

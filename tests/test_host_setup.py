@@ -320,10 +320,19 @@ def test_reference_cf_splitting_driver_on_its_data_file():
         np.add.at(seen, isf, 1); np.add.at(seen, isc, 1)
         assert isf.size + isc.size == n and np.all(seen == 1), cf
         assert np.all(np.diff(isf) > 0) and np.all(np.diff(isc) > 0)
-        if cf == P.CF_DIAG_DOM:
-            Aff = A[isf][:, isf].tocsr()
-            d = np.abs(Aff.diagonal())
-            off = np.asarray(abs(Aff).sum(axis=1)).ravel() - d
-            ratio = np.where(d != 0.0, off / np.where(d != 0.0, d, 1.0), 0.0)
-            mx = float(ratio.max())
-            assert mx <= 0.5 + 1e-12 + 1e-10 * max(0.5, mx), mx
+    # compute_diag_dom_submatrix(A, 0.5) and the driver's check of it
+    import scipy.sparse as sp
+    c = P.compute_diag_dom_submatrix(A, 0.5).csr()
+    Add = sp.csr_matrix((c.val, c.col, c.rowptr), shape=c.shape)
+    assert 0 < Add.shape[0] < n and Add.shape[0] == Add.shape[1]
+    d = np.abs(Add.diagonal())
+    off = np.asarray(abs(Add).sum(axis=1)).ravel() - d
+    ratio = np.where(d != 0.0, off / np.where(d != 0.0, d, 1.0), 0.0)
+    mx = float(ratio.max())
+    assert mx <= 0.5 + 1e-12 + 1e-10 * max(0.5, mx), mx
+    # it is A(F, F) of the diag_dom splitting with that threshold (src/MatDiagDomSubmatrix.F90:44-72: ddc arguments ignored)
+    isf, _ = P.compute_cf_splitting(A, False, 0.5, -1, P.CF_DIAG_DOM, 0, 0.0)
+    ref = A[isf][:, isf].tocsr(); ref.sort_indices()
+    assert (abs(ref - Add)).nnz == 0
+    with pytest.raises(P.AirhipError):
+        P.compute_diag_dom_submatrix(A, 1.0)
