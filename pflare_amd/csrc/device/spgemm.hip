@@ -79,8 +79,17 @@ __global__ __launch_bounds__(BLOCK) void k_row_ub(CsrView A, CsrView B, int64_t*
   if (lane == 0) { atomicAdd(&st->total, tot); atomicMax(&st->longest, longest); if (above) atomicAdd(&st->above_1k, above); }
 }
 
+// longest row of a CSR matrix (is B a matrix of single-entry rows?)
+__global__ __launch_bounds__(BLOCK) void k_longest_row(int64_t m, const int64_t* __restrict__ rp, unsigned long long* __restrict__ out) {
+  unsigned long long mx = 0;
+  const int64_t stride = (int64_t)gridDim.x * BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < m; i += stride) { const unsigned long long l = (unsigned long long)(rp[i + 1] - rp[i]); mx = l > mx ? l : mx; }
+  for (int off = 32; off > 0; off >>= 1) { const unsigned long long t = __shfl_xor(mx, off, WAVE); mx = t > mx ? t : mx; }
+  if ((threadIdx.x & (WAVE - 1)) == 0 && mx) atomicMax(out, mx);
+}
+
 // the rows a kernel works on: an explicit list, or (rows == nullptr) every row of A whose bound selects `kind`
-struct RowSel { const int32_t* rows; int64_t nrows; const int64_t* ub; int kind; Plan plan; };
+struct RowSel { const int32_t* rows; int64_t nrows; const int64_t* ub; int kind; Plan plan; int b_single; };   // b_single: no row of B has more than one entry
 
 // rows that move up one accumulator kind, and the rows each kind has seen
 struct Escalation { int32_t* rows; unsigned int* count; };
@@ -264,7 +273,7 @@ __device__ __forceinline__ bool lds_bucket_sort(const Tab<false> tab, int nu) {
 // probe rounds need no per-step exec masks.
 template <bool GLOBAL, int CAP>
 __device__ __forceinline__ int hash_accumulate(const CsrView& A, const CsrView& B, int64_t i, const Tab<GLOBAL> tab, int HT, bool negate,
-                                               bool count_only = false, int dummy = 0) {
+                                               bool count_only = false, int dummy = 0, bool b_single = false) {
 #pragma clang fp contract(off)   // a*b + c must round twice, as the host code does
   const int lane = threadIdx.x & (WAVE - 1);
   const uint32_t mask = (uint32_t)HT - 1;
@@ -283,6 +292,44 @@ __device__ __forceinline__ int hash_accumulate(const CsrView& A, const CsrView& 
   // additions does, and that is the order of issue.
   constexpr int PIPE = 8;
   constexpr int MAX_PROBE_ROUNDS = 64;     // double hashing: a table filled to 3/4 needs more with probability 1e-8 per insert
+  if (b_single) {
+    // Every row of B has at most one entry (A * P with a one-point prolongator: the product is A with its columns
+    // relabelled and merged).  The walk above would spend a whole step on each entry of A; here 64 entries of A form
+    // a step: the slots are claimed together, and since several lanes of a step may carry the same column, the
+    // additions are made one lane after the other, in the order of the entries of A - the Gustavson order.
+    for (int64_t kb = a0; kb < a1; kb += WAVE) {
+      const int64_t kk = kb + lane;
+      int32_t c = EMPTY; double x = 0.0;
+      if (kk < a1) {
+        const int32_t j = A.ci[kk];
+        const int64_t b0 = B.rp[j];
+        if (B.rp[j + 1] > b0) { c = B.ci[b0]; x = A.v[kk] * B.v[b0]; }
+      }
+      const bool act = c != EMPTY;
+      uint32_t h = 0;
+      if (act) {
+        const uint32_t g = (uint32_t)c * 2654435761u;
+        h = (g ^ (g >> 15)) & mask;
+        const uint32_t inc = ((g >> 19) | 1u) & mask;
+        bool failed = false;
+        for (int rounds = 0;; rounds++) {
+          const int32_t old = tab.cas((int)h, c);
+          if (old == EMPTY || old == c) break;
+          h = (h + inc) & mask;
+          if (rounds > MAX_PROBE_ROUNDS) { failed = true; break; }
+        }
+        if (failed) h = 0xffffffffu;
+      }
+      if (__any(act && h == 0xffffffffu)) return -1;      // (nearly) full table
+      unsigned long long todo = __ballot(act);
+      while (todo) {
+        const int l = __ffsll((long long)todo) - 1;
+        if (lane == l) tab.add((int)h, x);
+        todo &= todo - 1;
+      }
+      tab.sync();
+    }
+  } else
   for (int64_t kb = a0; kb < a1; kb += WAVE) {
     const int nk = (int)(a1 - kb < WAVE ? a1 - kb : WAVE);
     double al = 0.0; int64_t b0 = 0; int len = 0;
@@ -607,8 +654,8 @@ __global__ __launch_bounds__(MAX_HT / HT * WAVE) void k_spgemm_lds(CsrView A, Cs
     mine++;
     const int64_t expect = ubi <= L1K_MAX ? ubi : (int64_t)((float)ubi * sel.plan.ratio) + 64;
     const int ht = table_for(expect < ubi ? expect : ubi, HT);
-    int nu = hash_accumulate<false, HT>(A, B, i, tab, ht, dp.negate != 0, false, HT);
-    if (nu < 0 && ht < HT) nu = hash_accumulate<false, HT>(A, B, i, tab, HT, dp.negate != 0, false, HT);
+    int nu = hash_accumulate<false, HT>(A, B, i, tab, ht, dp.negate != 0, false, HT, sel.b_single != 0);
+    if (nu < 0 && ht < HT) nu = hash_accumulate<false, HT>(A, B, i, tab, HT, dp.negate != 0, false, HT, sel.b_single != 0);
     if (nu < 0 && esc.rows) {
       if ((threadIdx.x & (WAVE - 1)) == 0) esc.rows[atomicAdd(esc.count, 1u)] = (int32_t)i;
     } else {
@@ -643,14 +690,14 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_tiny(CsrView A, CsrView B, Row
 // distinct columns of a sample of the rows with more than L1K_MAX candidates: sample w looks at row w * m / nsamples
 // and stores its bound and its number of distinct columns (-1: more than the 4k table holds, -2: not such a row)
 __global__ __launch_bounds__(WAVE) void k_spgemm_sample(CsrView A, CsrView B, const int64_t* __restrict__ ub, int nsamples,
-                                                       int64_t* __restrict__ out_ub, int32_t* __restrict__ out_nu) {
+                                                       int64_t* __restrict__ out_ub, int32_t* __restrict__ out_nu, int b_single) {
   __shared__ int32_t keys[MAX_HT + WAVE];
   __shared__ double vals[MAX_HT + WAVE];
   const Tab<false> tab{keys, vals};
   for (int w = blockIdx.x; w < nsamples; w += gridDim.x) {
     const int64_t i = ((int64_t)w * A.m) / nsamples;
     const int64_t u = ub[i];
-    const int nu = u > L1K_MAX ? hash_accumulate<false, 0>(A, B, i, tab, MAX_HT, false, true, MAX_HT) : -2;
+    const int nu = u > L1K_MAX ? hash_accumulate<false, 0>(A, B, i, tab, MAX_HT, false, true, MAX_HT, b_single != 0) : -2;
     if (threadIdx.x == 0) { out_ub[w] = u; out_nu[w] = nu; }
     __builtin_amdgcn_wave_barrier();
   }
@@ -749,12 +796,24 @@ DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, boo
   HIP_CHECK(hipStreamSynchronize(s));
   dev_free(d_us);
   const int64_t ub_total = (int64_t)us.total, longest = (int64_t)us.longest;
+  // B with at most one entry per row (A * P with a one-point prolongator): 64 entries of A per step (hash_accumulate)
+  int b_single = 0;
+  if (B.nnz <= B.m) {
+    unsigned long long* d_lr = dmalloc<unsigned long long>(1);
+    unsigned long long lr = 0;
+    HIP_CHECK(hipMemsetAsync(d_lr, 0, sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(k_longest_row, dim3(MAX_BLOCKS), dim3(BLOCK), 0, s, B.m, B.rp, d_lr);
+    HIP_CHECK(hipMemcpyAsync(&lr, d_lr, sizeof(lr), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    dev_free(d_lr);
+    b_single = lr <= 1 ? 1 : 0;
+  }
   // ---- distinct columns per candidate on a sample of the long rows: which table each of them gets
   Plan plan{L1K_MAX, L2K_MAX, 1.0f};
   if (us.above_1k) {
     const int ns = (int)std::min<int64_t>(m, 1536);
     int64_t* d_sub = dmalloc<int64_t>(ns); int32_t* d_snu = dmalloc<int32_t>(ns);
-    hipLaunchKernelGGL(k_spgemm_sample, dim3((unsigned)std::min(ns, 768)), dim3(WAVE), 0, s, av, bv, d_ub, ns, d_sub, d_snu);
+    hipLaunchKernelGGL(k_spgemm_sample, dim3((unsigned)std::min(ns, 768)), dim3(WAVE), 0, s, av, bv, d_ub, ns, d_sub, d_snu, b_single);
     std::vector<int64_t> sub(ns); std::vector<int32_t> snu(ns);
     HIP_CHECK(hipMemcpyAsync(sub.data(), d_sub, sizeof(int64_t) * (size_t)ns, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipMemcpyAsync(snu.data(), d_snu, sizeof(int32_t) * (size_t)ns, hipMemcpyDeviceToHost, s));
@@ -783,7 +842,7 @@ DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, boo
   auto grid_reg = [&](int64_t n) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 256 * 32))); };
   auto grid_lds = [&](int64_t n, int wpb) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((n + wpb - 1) / wpb, 4 * resident))); };
   auto launch_lds = [&](int kind, const int32_t* rows, int64_t nrows, const RowPool& pool, Escalation esc) {
-    const RowSel sel{rows, nrows, d_ub, kind, plan};
+    const RowSel sel{rows, nrows, d_ub, kind, plan, b_single};
     const int64_t n = rows ? nrows : m;
     if (kind == KIND_L1K) hipLaunchKernelGGL((k_spgemm_lds<1024>), grid_lds(n, 4), dim3(4 * WAVE), 0, s, av, bv, sel, dp, d_cnt, pool, d_fail, esc, d_seen + kind);
     else if (kind == KIND_L2K) hipLaunchKernelGGL((k_spgemm_lds<2048>), grid_lds(n, 2), dim3(2 * WAVE), 0, s, av, bv, sel, dp, d_cnt, pool, d_fail, esc, d_seen + kind);
@@ -880,7 +939,7 @@ DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, boo
     int64_t counts[NKIND] = {0, 0, 0, 0, 0};
     if (!first) for (int k = 0; k < NKIND; k++) { upload_list(todo[k]); lists[k] = todo[k].d; counts[k] = (int64_t)todo[k].rows.size(); }
     if (first || lists[KIND_REG]) {
-      const RowSel sel{lists[KIND_REG], counts[KIND_REG], d_ub, KIND_REG, plan};
+      const RowSel sel{lists[KIND_REG], counts[KIND_REG], d_ub, KIND_REG, plan, b_single};
       hipLaunchKernelGGL(k_spgemm_tiny, grid_reg(first ? m : counts[KIND_REG]), dim3(BLOCK), 0, s, av, bv, sel, dp, d_cnt, pool, d_fail, d_seen + KIND_REG);
     }
     run_tables(lists, counts, first, pool);

@@ -149,6 +149,23 @@ def test_device_spgemm_pool_exhaustion_takes_more_rounds(gpu):
         lib.airhip_set_tuning(b"spgemm_pool_entries", 0)
 
 
+def test_device_spgemm_single_entry_rows_of_b(gpu):
+    """A * P with a one-point prolongator: no row of B has more than one entry, many entries of a row of A land on
+    the same column.  The kernel then takes 64 entries of A per step and adds lane by lane (the Gustavson order)."""
+    import pflare_amd as P
+    rng = np.random.default_rng(17)
+    for (m, k, n, per_row) in ((300, 5000, 40, 70), (200, 6000, 900, 300), (100, 9000, 3000, 2000)):
+        A = _rand(m, k, per_row, 3)
+        rows = np.flatnonzero(rng.random(k) < 0.9)                       # a tenth of the rows of B are empty
+        B = sp.csr_matrix((rng.standard_normal(rows.size), (rows, rng.integers(0, n, size=rows.size))), shape=(k, n))
+        assert int(B.getnnz(axis=1).max()) == 1
+        for kw in ({}, dict(drop=True, tol=1e-2, lump=True), dict(drop=True, tol=1e-3, negate=True)):
+            href, _ = _spgemm(P, A, B, on_device=False, **kw)
+            dev, stats = _spgemm(P, A, B, on_device=True, **kw)
+            assert sum(stats[1:4]) >= m, stats                           # the table kernels, not the register path
+            _same(dev, href)
+
+
 def test_device_spgemm_chunked_pool(gpu):
     """on large products a wave takes 2048 pool entries at a time and places its rows itself; forced here at test size
     (chunks of 100 entries: rows longer than a chunk, rows that straddle the end of one)"""
