@@ -45,14 +45,18 @@ extern "C" {
 #define AIRHIP_ERR_UNSUPPORTED (-4)
 #define AIRHIP_ERR_INTERNAL (-5)
 
-/* PCPFLAREINVType (include/pflare.h of the reference) */
+/* PCPFLAREINVType: same enumerators and values as the reference's enum (include/pflare.h:36-46), so that a C
+ * caller can pass a PCPFLAREINVType straight through.  tests/test_capi.py parses both headers and compares them.
+ * The options themselves travel as strings (airhip_pcair_set_option "inverse_type" "newton" ...). */
 #define AIRHIP_INV_POWER 0
 #define AIRHIP_INV_ARNOLDI 1
 #define AIRHIP_INV_NEWTON 2
-#define AIRHIP_INV_NEUMANN 3
-#define AIRHIP_INV_WJACOBI 6
-#define AIRHIP_INV_JACOBI 7
-#define AIRHIP_INV_NEWTON_NO_EXTRA 8
+#define AIRHIP_INV_NEWTON_NO_EXTRA 3
+#define AIRHIP_INV_NEUMANN 4
+#define AIRHIP_INV_SAI 5
+#define AIRHIP_INV_ISAI 6
+#define AIRHIP_INV_WJACOBI 7
+#define AIRHIP_INV_JACOBI 8
 
 /* kinds of approximate inverse as applied in the solve phase */
 #define AIRHIP_OP_NONE 0

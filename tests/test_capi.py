@@ -159,3 +159,24 @@ def test_setup_can_be_repeated_on_the_same_object():
     for lv in range(pc.num_levels - 1):
         a, b = pc.export_level(lv), fresh.export_level(lv)
         assert np.array_equal(a["F"], b["F"]) and np.array_equal(a["Z"].val, b["Z"].val)
+
+
+def test_inverse_type_constants_equal_the_reference_enum():
+    """include/airhip.h's AIRHIP_INV_* = PCPFLAREINVType of the reference's include/pflare.h:36-46, value for value
+    (fixture tests/golden/reference_enums.json; re-derived from the reference header when it is present)."""
+    import json
+    import importlib.util
+    gold = os.path.join(ROOT, "tests", "golden")
+    ref = json.load(open(os.path.join(gold, "reference_enums.json")))["enums"]
+    if os.path.exists("/root/reference/include/pflare.h"):
+        spec = importlib.util.spec_from_file_location("make_reference_enums", os.path.join(gold, "make_reference_enums.py"))
+        mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+        assert mod.parse_enums("/root/reference/include/pflare.h") == ref
+    txt = open(os.path.join(ROOT, "include", "airhip.h")).read()
+    mine = {k: int(v) for k, v in re.findall(r"#define\s+AIRHIP_INV_(\w+)\s+(\d+)", txt)}
+    want = {k[len("PFLAREINV_"):]: v for k, v in ref["PCPFLAREINVType"].items()}
+    assert mine == want
+    # the Python mirror of the plugin surface uses the same numbers
+    from pflare_amd import pflare
+    for k, v in ref["PCPFLAREINVType"].items():
+        assert int(getattr(pflare.PCPFLAREINVType, k)) == v

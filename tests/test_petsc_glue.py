@@ -7,7 +7,7 @@ import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = open(os.path.join(ROOT, "pflare_amd", "csrc", "petsc_glue.c")).read()
-HDR = open(os.path.join(ROOT, "include", "airhip.h")).read()
+HDR = open(os.path.join(ROOT, "include", "airhip.h")).read() + open(os.path.join(ROOT, "include", "airhip_mpi.h")).read()
 
 
 def test_exports_the_references_plugin_symbols():
@@ -22,7 +22,7 @@ def test_exports_the_references_plugin_symbols():
 
 
 def test_calls_only_declared_abi_functions():
-    called = set(re.findall(r"\b(airhip_[a-z0-9_]+)\s*\(", SRC)) - {"airhip_push_option", "airhip_make_handle"}
+    called = set(re.findall(r"\b(airhip_[a-z0-9_]+)\s*\(", SRC)) - {"airhip_push_option", "airhip_make_handle", "airhip_complexity"}
     declared = set(re.findall(r"\b(airhip_[a-z0-9_]+)\s*\(", HDR))
     assert called and called <= declared, called - declared
     # the apply path goes through the stream-ordered entry points (no host synchronisation per PCApply)
@@ -47,3 +47,41 @@ def test_make_target_needs_petsc():
     r = subprocess.run(["make", "-C", os.path.join(ROOT, "pflare_amd", "csrc"), "petsc_glue", "PETSC_DIR="],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "PETSC_DIR" in (r.stdout + r.stderr)
+
+
+def test_typed_entry_points_follow_the_reference_header():
+    """every PCAIRSet* / PCAIRGet* / PCPFLAREINVSet* the glue defines exists in the reference's include/pflare.h with the
+    same parameter list (names committed in tests/golden/reference_prototypes.json), and the option each setter stores
+    is one the library accepts"""
+    import json
+    import pflare_amd as P
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_prototypes.json")))["prototypes"]
+    setters = re.findall(r"AIRHIP_SETTER\((\w+), (\w+), \"(\w+)\"", SRC)
+    enums = re.findall(r"AIRHIP_ENUM_SETTER\((\w+), \"(\w+)\"", SRC)
+    assert len(setters) >= 30 and len(enums) == 5
+    for fn, typ, opt in setters:
+        assert fn in ref, fn
+        assert ref[fn][0] == "PC" and len(ref[fn]) == 2, (fn, ref[fn])
+        want = ref[fn][1]
+        assert typ == want or (typ == "int" and want in ("CFSplittingType",)), (fn, typ, want)
+    for fn, opt in enums:
+        assert fn in ref and ref[fn][1] in ("PCPFLAREINVType", "PCAIRZType"), fn
+    for fn in ("PCAIRGetNumLevels", "PCAIRGetGridComplexity", "PCAIRGetOperatorComplexity", "PCAIRGetCycleComplexity",
+               "PCAIRGetStorageComplexity", "PCAIRSetSmoothType"):
+        assert fn in ref and re.search(r"PETSC_EXTERN PetscErrorCode %s\(" % fn, SRC), fn
+    sample = {"cf_splitting_type": "0"}
+    pc, pi = P.PCAIR(), P.PCPFLAREINV()
+    for fn, typ, opt in setters:
+        (pi if fn.startswith("PCPFLAREINV") else pc).set_option(opt, sample.get(opt, "1"))
+    # the enum tables are the reference's enumerators in order
+    enums_ref = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_enums.json")))["enums"]
+    names = re.search(r"airhip_inv_names\[\]\s*=\s*\{(.*?)\}", SRC, re.S).group(1)
+    mine = re.findall(r'"(\w+)"', names)
+    want = [k[len("PFLAREINV_"):].lower() for k, v in sorted(enums_ref["PCPFLAREINVType"].items(), key=lambda kv: kv[1])]
+    assert mine == want
+
+
+def test_mpi_path_is_wired():
+    assert "airhip_mpi_pcair_setup" in SRC and "MatMPIAIJGetSeqAIJ" in SRC
+    assert "PETSC_VERSION_GE(3, 23, 0)" in SRC          # PetscOptionItems by value only from 3.23 on
+    assert "hipDeviceSynchronize" in SRC                 # no stream handle: synchronise instead of assuming the NULL stream

@@ -1,0 +1,318 @@
+// Block-structured stream probe (gfx950): what limits a kernel of the shape of k_rb_spmv - one wave per block of 512
+// (index word, value) pairs, four waves per workgroup, as many waves as blocks - when the stream really comes from HBM.
+// Variants (compile-time): width of the value / index loads, one interleaved blob per block against two arrays,
+// a dependent descriptor load in front, the x gather (window size = locality), the LDS staging + row sums.
+//   hipcc -O3 --offload-arch=gfx950 tools/block_probe.hip -o /tmp/block_probe && /tmp/block_probe [GB]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <vector>
+#include <algorithm>
+
+#define CHECK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { std::printf("HIP error %s at line %d\n", hipGetErrorString(_e), __LINE__); std::exit(1); } } while (0)
+
+constexpr int NNZ = 512, WAVE = 64, EPL = 8;
+
+struct Desc { int64_t p0; int32_t row, cbase; };
+
+struct Args {
+  const uint32_t* idx; const double* val;     // two arrays (BLOB = 0)
+  const char* blob;                            // BLOB = 1: per block [val 4 KB][idx 2 KB]
+  const Desc* desc; const double* x; double* y; int64_t nblocks; int rows_per_block;
+};
+
+// VW: 2 = 8 x dwordx2 value loads, 4 = 4 x dwordx4 (pairs of rounds interleaved in memory)
+// IW: 1 = 8 x dword index loads, 4 = 2 x dwordx4
+template <int VW, int IW, int BLOB, int DESC, int GATHER, int LDS, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_block(Args a) {
+  __shared__ double lds_all[WAVES][NNZ + 2];
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int g = blockIdx.x & 7;
+  const int64_t bi = blockIdx.x >> 3;
+  const int64_t lo = a.nblocks * g / 8, hi = a.nblocks * (g + 1) / 8;
+  const int64_t b = lo + bi * WAVES + wid;
+  if (b >= hi) return;
+  int64_t p0 = b * NNZ;
+  if (DESC) {
+    const Desc __attribute__((address_space(4)))* dp = (const Desc __attribute__((address_space(4)))*)(uintptr_t)a.desc;
+    p0 = dp[b].p0;
+  }
+  const uint32_t* ip; const double* vp;
+  if (BLOB) { vp = (const double*)(a.blob + p0 * 12); ip = (const uint32_t*)(a.blob + p0 * 12 + NNZ * 8); }
+  else { ip = a.idx + p0; vp = a.val + p0; }
+  uint32_t ix[EPL]; double vv[EPL];
+  if (IW == 1) {
+#pragma unroll
+    for (int u = 0; u < EPL; u++) ix[u] = ip[u * WAVE + lane];
+  } else {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const uint4 q = ((const uint4*)ip)[h * WAVE + lane];
+      ix[4 * h] = q.x; ix[4 * h + 1] = q.y; ix[4 * h + 2] = q.z; ix[4 * h + 3] = q.w;
+    }
+  }
+  if (VW == 2) {
+#pragma unroll
+    for (int u = 0; u < EPL; u++) vv[u] = vp[u * WAVE + lane];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const double2 q = ((const double2*)vp)[i * WAVE + lane];
+      vv[2 * i] = q.x; vv[2 * i + 1] = q.y;
+    }
+  }
+  double acc = 0.0;
+  if (GATHER) {
+    double xx[EPL];
+#pragma unroll
+    for (int u = 0; u < EPL; u++) xx[u] = *(const double*)((const char*)a.x + ((size_t)ix[u] << 3));
+#pragma unroll
+    for (int u = 0; u < EPL; u++) vv[u] *= xx[u];
+  } else {
+#pragma unroll
+    for (int u = 0; u < EPL; u++) vv[u] += (double)ix[u];
+  }
+  if (LDS) {
+    double* lds = lds_all[wid];
+#pragma unroll
+    for (int u = 0; u < EPL; u++) lds[u * WAVE + lane + 1] = vv[u];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int R = a.rows_per_block, L = NNZ / R;     // rows of equal length
+    if (R > 32) { if (lane < R) { for (int j = 0; j < L; j++) acc += lds[lane * L + j + 1]; a.y[b * R + lane] = acc; } }
+    else {
+      const int T = 64 / R, gq = lane / T, t = lane % T;          // R is a power of two here
+      for (int j = t; j < L; j += T) acc += lds[gq * L + j + 1];
+      for (int off = T >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+      const double srow = __shfl(acc, (lane * T) & 63, 64);
+      if (lane < R) a.y[b * R + lane] = srow;
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < EPL; u++) acc += vv[u];
+    a.y[b * 64 + lane] = acc;            // every lane stores: no load is dead
+  }
+}
+
+
+// NB consecutive blocks per wave; the stream of block i+1 is requested before block i is processed (NB = 1: the
+// one-block-per-wave structure again, same code path as a cross-check).  val 4 x dwordx4, idx 8 x dword, two arrays.
+template <int NB, int IW, int WAVES, int MINW>
+__global__ __launch_bounds__(WAVES * 64, MINW) void k_multi(Args a) {
+  __shared__ double lds_all[WAVES][NNZ + 2];
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int g = blockIdx.x & 7;
+  const int64_t bi = blockIdx.x >> 3;
+  const int64_t nsuper = a.nblocks / NB;
+  const int64_t lo = nsuper * g / 8, hi = nsuper * (g + 1) / 8;
+  const int64_t sb = lo + bi * WAVES + wid;
+  if (sb >= hi) return;
+  double* lds = lds_all[wid];
+  uint32_t ix[2][EPL]; double vv[2][EPL];
+  auto load = [&](int64_t b, int slot) {
+    const uint32_t* ip = a.idx + b * NNZ; const double* vp = a.val + b * NNZ;
+    if (IW == 1) {
+#pragma unroll
+      for (int u = 0; u < EPL; u++) ix[slot][u] = ip[u * WAVE + lane];
+    } else {
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const uint4 q = ((const uint4*)ip)[h * WAVE + lane];
+        ix[slot][4 * h] = q.x; ix[slot][4 * h + 1] = q.y; ix[slot][4 * h + 2] = q.z; ix[slot][4 * h + 3] = q.w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const double2 q = ((const double2*)vp)[i * WAVE + lane]; vv[slot][2 * i] = q.x; vv[slot][2 * i + 1] = q.y; }
+  };
+  load(sb * NB, 0);
+#pragma unroll
+  for (int i = 0; i < NB; i++) {
+    const int cur = i & 1;
+    const int64_t b = sb * NB + i;
+    if (i + 1 < NB) load(b + 1, cur ^ 1);
+    double xx[EPL];
+#pragma unroll
+    for (int u = 0; u < EPL; u++) xx[u] = *(const double*)((const char*)a.x + ((size_t)ix[cur][u] << 3));
+#pragma unroll
+    for (int u = 0; u < EPL; u++) lds[u * WAVE + lane + 1] = vv[cur][u] * xx[u];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int R = a.rows_per_block, L = NNZ / R;
+    const int T = 64 / R, gq = lane / T, t = lane % T;
+    double acc = 0.0;
+    for (int j = t; j < L; j += T) acc += lds[gq * L + j + 1];
+    for (int off = T >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    const double srow = __shfl(acc, (lane * T) & 63, 64);
+    if (lane < R) a.y[b * R + lane] = srow;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+// persistent waves: the grid is what fits on the chip (PER_CU workgroups per CU), wave w of the grid takes the blocks
+// w, w + nwaves, ... ; the next block's stream is requested before the current one is processed
+template <int IW, int WAVES, int MINW>
+__global__ __launch_bounds__(WAVES * 64, MINW) void k_loop(Args a) {
+  __shared__ double lds_all[WAVES][NNZ + 2];
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  double* lds = lds_all[wid];
+  const int64_t nw = (int64_t)gridDim.x * WAVES;
+  int64_t b = (int64_t)blockIdx.x * WAVES + wid;
+  uint32_t ix[EPL], nix[EPL]; double vv[EPL], nvv[EPL];
+  auto load = [&](int64_t bb, uint32_t (&qi)[EPL], double (&qv)[EPL]) {
+    const uint32_t* ip = a.idx + bb * NNZ; const double* vp = a.val + bb * NNZ;
+    if (IW == 1) {
+#pragma unroll
+      for (int u = 0; u < EPL; u++) qi[u] = ip[u * WAVE + lane];
+    } else {
+#pragma unroll
+      for (int h = 0; h < 2; h++) { const uint4 q = ((const uint4*)ip)[h * WAVE + lane]; qi[4 * h] = q.x; qi[4 * h + 1] = q.y; qi[4 * h + 2] = q.z; qi[4 * h + 3] = q.w; }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const double2 q = ((const double2*)vp)[i * WAVE + lane]; qv[2 * i] = q.x; qv[2 * i + 1] = q.y; }
+  };
+  if (b < a.nblocks) load(b, ix, vv);
+  for (; b < a.nblocks; b += nw) {
+    const int64_t nb = b + nw;
+    if (nb < a.nblocks) load(nb, nix, nvv);
+    double xx[EPL];
+#pragma unroll
+    for (int u = 0; u < EPL; u++) xx[u] = *(const double*)((const char*)a.x + ((size_t)ix[u] << 3));
+#pragma unroll
+    for (int u = 0; u < EPL; u++) lds[u * WAVE + lane + 1] = vv[u] * xx[u];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int R = a.rows_per_block, L = NNZ / R;
+    const int T = 64 / R, gq = lane / T, t = lane % T;
+    double acc = 0.0;
+    for (int j = t; j < L; j += T) acc += lds[gq * L + j + 1];
+    for (int off = T >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    const double srow = __shfl(acc, (lane * T) & 63, 64);
+    if (lane < R) a.y[b * R + lane] = srow;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int u = 0; u < EPL; u++) { ix[u] = nix[u]; vv[u] = nvv[u]; }
+  }
+}
+
+// plain streaming read (float4 per lane, grid-stride) for reference
+__global__ __launch_bounds__(256) void k_stream(const double2* __restrict__ p, int64_t n, double* out) {
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) { const double2 q = p[i]; s += q.x + q.y; }
+  if (s == 1.2345e300) out[0] = s;
+}
+
+__global__ void k_blob_idx(const uint32_t* __restrict__ idx, char* __restrict__ blob, int64_t nnz) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * 256)
+    ((uint32_t*)(blob + (i / NNZ) * NNZ * 12 + NNZ * 8))[i % NNZ] = idx[i];
+}
+
+template <class F>
+static double time_ms(F f, int rep = 7) {
+  hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+  f(); CHECK(hipDeviceSynchronize());
+  float best = 1e30f;
+  for (int r = 0; r < rep; r++) {
+    CHECK(hipEventRecord(a)); f(); CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+    float ms; CHECK(hipEventElapsedTime(&ms, a, b)); if (ms < best) best = ms;
+  }
+  return best;
+}
+
+int main(int argc, char** argv) {
+  const double gb = argc > 1 ? std::atof(argv[1]) : 3.0;
+  const int64_t nblocks = (int64_t)(gb * 1e9 / (NNZ * 12)) / 32 * 32;
+  const int64_t nnz = nblocks * NNZ;
+  std::printf("blocks %lld, stream %.2f GB\n", (long long)nblocks, nnz * 12e-9);
+  uint32_t* idx; double* val; char* blob; Desc* desc; double* x; double* y;
+  CHECK(hipMalloc(&idx, nnz * 4)); CHECK(hipMalloc(&val, nnz * 8)); CHECK(hipMalloc(&blob, nnz * 12)); CHECK(hipMalloc(&desc, (nblocks + 1) * sizeof(Desc)));
+  const int64_t nx = nblocks * 64;                       // 64 rows per block at most
+  CHECK(hipMalloc(&x, nx * 8)); CHECK(hipMalloc(&y, nx * 8));
+  CHECK(hipMemset(val, 0, nnz * 8)); CHECK(hipMemset(x, 0, nx * 8));
+  std::vector<Desc> hd(nblocks + 1);
+  for (int64_t b = 0; b <= nblocks; b++) hd[b] = Desc{b * NNZ, (int32_t)(b * 16), 0};
+  CHECK(hipMemcpy(desc, hd.data(), (nblocks + 1) * sizeof(Desc), hipMemcpyHostToDevice));
+  double* out; CHECK(hipMalloc(&out, 64));
+  auto fill_idx = [&](int window, int rows) {
+    // window > 0: columns of block b pseudo-random inside a window of `window` columns around the block's rows.
+    // window < 0: a stencil - row i has the columns i + off[k] with NNZ / rows fixed sorted offsets inside -window
+    // columns (consecutive rows gather neighbouring entries, as the operators of the hierarchy do)
+    std::vector<uint32_t> h((size_t)nnz);
+    uint64_t s = 88172645463325252ull;
+    if (window > 0) {
+      for (int64_t b = 0; b < nblocks; b++) {
+        const int64_t base = std::max<int64_t>(0, std::min<int64_t>(b * rows - window / 2, nx - window));
+        for (int k = 0; k < NNZ; k++) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; h[(size_t)(b * NNZ + k)] = (uint32_t)(base + (int64_t)(s % (uint64_t)window)); }
+      }
+    } else {
+      const int L = NNZ / rows, W = -window;
+      std::vector<int> off(L);
+      for (int k = 0; k < L; k++) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; off[k] = (int)(s % (uint64_t)W); }
+      std::sort(off.begin(), off.end());
+      for (int64_t b = 0; b < nblocks; b++)
+        for (int r = 0; r < rows; r++)
+          for (int k = 0; k < L; k++) {
+            const int64_t c = std::min<int64_t>(nx - 1, b * rows + r + off[k]);
+            h[(size_t)(b * NNZ + r * L + k)] = (uint32_t)c;
+          }
+    }
+    CHECK(hipMemcpy(idx, h.data(), nnz * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_blob_idx, dim3(4096), dim3(256), 0, 0, idx, blob, nnz);   // blob copies of the index words
+    CHECK(hipDeviceSynchronize());
+  };
+  CHECK(hipMemset(blob, 0, nnz * 12));
+  const double stream_bytes = nnz * 12.0;
+  {
+    const double ms = time_ms([&] { hipLaunchKernelGGL(k_stream, dim3(256 * 16), dim3(256), 0, 0, (const double2*)val, nnz / 2, out); });
+    std::printf("%-64s %8.3f ms  %7.1f GB/s\n", "plain streaming read of the value array (float4, grid-stride)", ms, nnz * 8.0 / ms * 1e-6);
+  }
+  auto run = [&](const char* name, auto kern, int waves, int rows) {
+    Args a{idx, val, blob, desc, x, y, nblocks, rows};
+    const int64_t per_class = (nblocks + 7) / 8;
+    const unsigned grid = (unsigned)(8 * ((per_class + waves - 1) / waves));
+    const double ms = time_ms([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(waves * 64), 0, 0, a); });
+    const double bytes = stream_bytes + nblocks * rows * 8.0;   // rows = doubles stored per block
+    std::printf("%-64s %8.3f ms  %7.1f GB/s (stream + y)\n", name, ms, bytes / ms * 1e-6);
+  };
+  auto run_multi = [&](const char* name, auto kern, int waves, int nbper) {
+    Args a{idx, val, blob, desc, x, y, nblocks, 16};
+    const int64_t per_class = (nblocks / nbper + 7) / 8;
+    const unsigned grid = (unsigned)(8 * ((per_class + waves - 1) / waves));
+    const double ms = time_ms([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(waves * 64), 0, 0, a); });
+    std::printf("%-64s %8.3f ms  %7.1f GB/s (stream + y)\n", name, ms, (stream_bytes + nblocks * 16 * 8.0) / ms * 1e-6);
+  };
+  auto run_loop = [&](const char* name, auto kern, int waves, int wg_per_cu) {
+    Args a{idx, val, blob, desc, x, y, nblocks, 16};
+    const double ms = time_ms([&] { hipLaunchKernelGGL(kern, dim3(256 * wg_per_cu), dim3(waves * 64), 0, 0, a); });
+    std::printf("%-64s %8.3f ms  %7.1f GB/s (stream + y)\n", name, ms, (stream_bytes + nblocks * 16 * 8.0) / ms * 1e-6);
+  };
+  for (int window : {-256, -2048}) {
+    fill_idx(window, 16);
+    std::printf("-- gather + LDS row sums, stencil inside %d columns, 16 rows per block: blocks per wave / persistent waves\n", -window);
+    run("reference: one block per wave, val 4 x dwordx4, idx 8 x dword", k_block<4, 1, 0, 1, 1, 1, 4>, 4, 16);
+    run_multi("k_multi NB=1 idx dword", k_multi<1, 1, 4, 1>, 4, 1);
+    run_multi("k_multi NB=2 idx dword", k_multi<2, 1, 4, 1>, 4, 2);
+    run_multi("k_multi NB=4 idx dword", k_multi<4, 1, 4, 1>, 4, 4);
+    run_multi("k_multi NB=8 idx dword", k_multi<8, 1, 4, 1>, 4, 8);
+    run_multi("k_multi NB=2 idx x4", k_multi<2, 4, 4, 1>, 4, 2);
+    run_multi("k_multi NB=4 idx x4", k_multi<4, 4, 4, 1>, 4, 4);
+    run_multi("k_multi NB=4 idx dword, 5 waves/SIMD forced", k_multi<4, 1, 4, 5>, 4, 4);
+    run_multi("k_multi NB=4 idx dword, 6 waves/SIMD forced", k_multi<4, 1, 4, 6>, 4, 4);
+    run_multi("k_multi NB=2 idx dword, 2 waves per workgroup", k_multi<2, 1, 2, 1>, 2, 2);
+    run_multi("k_multi NB=4 idx dword, 8 waves per workgroup", k_multi<4, 1, 8, 1>, 8, 4);
+    for (int wgcu : {3, 4, 5, 6, 8}) {
+      char nm[96]; std::snprintf(nm, 96, "k_loop persistent, %d workgroups of 4 waves per CU, idx dword", wgcu);
+      run_loop(nm, k_loop<1, 4, 1>, 4, wgcu);
+    }
+    run_loop("k_loop persistent, 5 wg/CU, idx x4", k_loop<4, 4, 1>, 4, 5);
+    run_loop("k_loop persistent, 6 wg/CU, 6 waves/SIMD forced", k_loop<1, 4, 6>, 4, 6);
+  }
+  return 0;
+}
