@@ -20,6 +20,12 @@
 //     round trips with SQ_WAIT_ANY at 82 %; here the descriptor is a scalar load, every vector the block needs
 //     (index words, values, row offsets, epilogue inputs) is requested before the first wait, and the gather is
 //     the only second round trip;
+//   * a block's 512 logical slots are 8 ROUNDS of 64 (slot 64 u + lane = register u of that lane).  Index words are stored
+//     in slot order (8 coalesced dword loads).  VALUES are stored with every pair of full rounds (2i, 2i+1) interleaved -
+//     memory position 128 i + 2 lane + t holds slot 64 (2i + t) + lane - so that one 16-byte load per lane fetches both
+//     rounds: a dwordx4 load costs the address path what a dwordx2 load does (tools/ta_probe.hip), and the value stream is
+//     the largest load of a block (tools/block_probe.hip: +5 % on a gather-bound block kernel).  Rounds that a block does
+//     not have are not issued at all (a 425-entry row of the coarse operator issues 7 rounds, not 8);
 //   * every per-block array is read through a buffer resource with the block's extent: the hardware range check
 //     returns 0 past the end (and drops stores), which replaces clamps, exec-mask branches and 64-bit addresses;
 //   * phase 1: products to LDS at their row-major positions (4 KB per wave); phase 2: lane l sums the LDS
@@ -101,14 +107,38 @@ __device__ __forceinline__ void buf_store_f64(rsrc_t r, int voff, double v) {
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((__vector_size__(2 * sizeof(unsigned int)))) unsigned int, v), r, voff, 0, 0);
 }
 
-// the block's first 512 (index, value) pairs into registers
+// Rounds of a block (see the header): NF full rounds, then one more that is partial (or, when the block's size is a
+// multiple of 64, empty: the hardware range check then returns zeros and the lanes park a zero product in the dummy
+// slot).  NF is a compile-time constant - one straight-line variant of the block code per value (rb_block dispatches) -
+// because wave-uniform branches around the single loads cost more than they save (256^3: restriction -10 %).
+template <int NF> struct Rounds {
+  static constexpr int nu = NF < EPL ? NF + 1 : EPL;      // rounds issued
+  static constexpr int npair = NF >> 1;                   // interleaved value pairs
+  __device__ __forceinline__ static constexpr bool has(int u) { return u < nu; }
+};
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// the block's first 512 (index, value) pairs into registers: index words round by round, values pair by pair
+template <int NF>
 __device__ __forceinline__ void issue_stream(const RbView& A, const BlkInfo& d, int lane, uint32_t (&ix)[EPL], double (&vv)[EPL]) {
+  typedef Rounds<NF> R;
   const int n = d.nb < BLK_NNZ ? d.nb : BLK_NNZ;
   const rsrc_t ri = make_rsrc(A.idx + d.p0, (int64_t)n * 4), rv = make_rsrc(A.val + d.p0, (int64_t)n * 8);
 #pragma unroll
-  for (int u = 0; u < EPL; u++) ix[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(ri, lane * 4, u * WAVE * 4, 0);
+  for (int u = 0; u < EPL; u++) { ix[u] = 0; if (R::has(u)) ix[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(ri, lane * 4, u * WAVE * 4, 0); }
 #pragma unroll
-  for (int u = 0; u < EPL; u++) vv[u] = buf_f64(rv, lane * 8, u * WAVE * 8);
+  for (int i = 0; i < EPL / 2; i++) {
+    if (i < R::npair) {
+      const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rv, lane * 16, i * 2 * WAVE * 8, 0);
+      vv[2 * i] = __builtin_bit_cast(double, (unsigned long long)q.x | ((unsigned long long)q.y << 32));
+      vv[2 * i + 1] = __builtin_bit_cast(double, (unsigned long long)q.z | ((unsigned long long)q.w << 32));
+    } else {
+      vv[2 * i] = 0.0; vv[2 * i + 1] = 0.0;
+      if (R::has(2 * i)) vv[2 * i] = buf_f64(rv, lane * 8, 2 * i * WAVE * 8);
+      if (R::has(2 * i + 1)) vv[2 * i + 1] = buf_f64(rv, lane * 8, (2 * i + 1) * WAVE * 8);
+    }
+  }
 }
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -117,20 +147,13 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Epi interface (r0 = first row of the block, nr = its rows, lr = this lane's local row, may be >= nr):
-//   Early early(r0, nr, lr)            loads whose result feeds another load (issued with the stream)
-//   Pre   load(r0, nr, lr, Early)      the epilogue's inputs, issued before the gather is waited for
-//   void  store(r0, nr, lr, acc, Pre)  after the row sum is known; rows past the block's end are dropped
-template <bool DIST, class Epi>
-__device__ __forceinline__ void rb_block(const RbView& A, const XVec<DIST> x, double* __restrict__ lds, const Epi& epi) {
-  const int lane = threadIdx.x & (WAVE - 1);
-  const int64_t bi = my_block(A.blk_list ? A.nlist : A.nblocks);
-  if (bi < 0) return;
-  const BlkInfo d = load_blk(A, bi);
+template <int NF, bool DIST, class Epi>
+__device__ __forceinline__ void rb_body(const RbView& A, const BlkInfo& d, const XVec<DIST> x, double* __restrict__ lds, const Epi& epi, int lane) {
   const int nb = d.nb, nr = d.nr;
   const bool sorted = d.cbase >= 0;
+  typedef Rounds<NF> R;
   uint32_t ix[EPL]; double vv[EPL];
-  issue_stream(A, d, lane, ix, vv);
+  issue_stream<NF>(A, d, lane, ix, vv);
   // row offsets and epilogue inputs of this lane's (at most two) rows
   typename Epi::Early early[2];
   int ra[2], re[2];
@@ -150,16 +173,16 @@ __device__ __forceinline__ void rb_block(const RbView& A, const XVec<DIST> x, do
       re[q] = (r + 1 < nr) ? rnext : (r < nr ? nb : 0);       // no row: ra = re = 0, nothing to sum
     }
   }
-  // gather x for the whole block
+  // gather x for the rounds the block has
   double xx[EPL];
   if (sorted) {
     // packed block: the word's upper 22 bits are the byte offset of the column from the block's base column
     const XVec<DIST> xb = x.shifted(d.cbase);
 #pragma unroll
-    for (int u = 0; u < EPL; u++) xx[u] = xb.at_byte_offset(ix[u] >> POS_BITS);
+    for (int u = 0; u < EPL; u++) { xx[u] = 0.0; if (R::has(u)) xx[u] = xb.at_byte_offset(ix[u] >> POS_BITS); }
   } else {
 #pragma unroll
-    for (int u = 0; u < EPL; u++) xx[u] = x.at_byte_offset(ix[u] << 3);           // raw block: absolute columns
+    for (int u = 0; u < EPL; u++) { xx[u] = 0.0; if (R::has(u)) xx[u] = x.at_byte_offset(ix[u] << 3); }           // raw block: absolute columns
   }
   pre[0] = epi.load(d.r0, nr, lane, early[0]);
   pre[1] = pre[0];
@@ -168,10 +191,10 @@ __device__ __forceinline__ void rb_block(const RbView& A, const XVec<DIST> x, do
     // phase 1: products to their row-major positions (1-based; position 0 is the dummy slot of padding lanes)
     if (sorted) {
 #pragma unroll
-      for (int u = 0; u < EPL; u++) lds[ix[u] & POS_MASK] = vv[u] * xx[u];
+      for (int u = 0; u < EPL; u++) if (R::has(u)) lds[ix[u] & POS_MASK] = vv[u] * xx[u];
     } else {
 #pragma unroll
-      for (int u = 0; u < EPL; u++) { const int k = lane + u * WAVE; lds[k < nb ? k + 1 : 0] = vv[u] * xx[u]; }
+      for (int u = 0; u < EPL; u++) if (R::has(u)) { const int k = lane + u * WAVE; lds[k < nb ? k + 1 : 0] = vv[u] * xx[u]; }
     }
     wave_lds_sync();
     if (nr > 32) {
@@ -198,7 +221,7 @@ __device__ __forceinline__ void rb_block(const RbView& A, const XVec<DIST> x, do
     }
   } else {
     // one long row: the whole wave reduces it.  The first 512 entries are already in registers (stream and
-    // gather above); the rest is read with four independent chains per lane
+    // gather above: all eight rounds exist); the rest is read with four independent chains per lane
     const uint32_t* __restrict__ ip = A.idx + d.p0;
     const double* __restrict__ vp = A.val + d.p0;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -218,6 +241,29 @@ __device__ __forceinline__ void rb_block(const RbView& A, const XVec<DIST> x, do
     double s = (s0 + s1) + (s2 + s3);
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
     epi.store(d.r0, nr, lane, s, pre[0]);      // nr = 1: only lane 0 is inside the block
+  }
+}
+
+// Epi interface (r0 = first row of the block, nr = its rows, lr = this lane's local row, may be >= nr):
+//   Early early(r0, nr, lr)            loads whose result feeds another load (issued with the stream)
+//   Pre   load(r0, nr, lr, Early)      the epilogue's inputs, issued before the gather is waited for
+//   void  store(r0, nr, lr, acc, Pre)  after the row sum is known; rows past the block's end are dropped
+template <bool DIST, class Epi>
+__device__ __forceinline__ void rb_block(const RbView& A, const XVec<DIST> x, double* __restrict__ lds, const Epi& epi) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t bi = my_block(A.blk_list ? A.nlist : A.nblocks);
+  if (bi < 0) return;
+  const BlkInfo d = load_blk(A, bi);
+  switch ((d.nb < BLK_NNZ ? d.nb : BLK_NNZ) >> 6) {     // full rounds: one straight-line variant each (every long row: 8)
+    case 8: rb_body<8, DIST>(A, d, x, lds, epi, lane); break;
+    case 7: rb_body<7, DIST>(A, d, x, lds, epi, lane); break;
+    case 6: rb_body<6, DIST>(A, d, x, lds, epi, lane); break;
+    case 5: rb_body<5, DIST>(A, d, x, lds, epi, lane); break;
+    case 4: rb_body<4, DIST>(A, d, x, lds, epi, lane); break;
+    case 3: rb_body<3, DIST>(A, d, x, lds, epi, lane); break;
+    case 2: rb_body<2, DIST>(A, d, x, lds, epi, lane); break;
+    case 1: rb_body<1, DIST>(A, d, x, lds, epi, lane); break;
+    default: rb_body<0, DIST>(A, d, x, lds, epi, lane); break;
   }
 }
 
@@ -264,7 +310,9 @@ __global__ __launch_bounds__(SPMV_BLOCK) void k_rb_spmv_setup(RbView A, XVec<fal
 }
 
 // Fused first stage of an F-point relaxation with a one-point prolongator (see dev.hpp)
-template <bool DIST>
+// DIAG: A_ff and its inverse are diagonal and the whole F smooth rides along (a compile-time switch: the split mode must
+// not carry the registers of the two diagonal vectors)
+template <bool DIST, bool DIAG>
 struct EpiFcFirst {
   const int32_t* __restrict__ wcol; const double* __restrict__ b_f; XVec<DIST> x_c;
   const double* __restrict__ aff_d; const double* __restrict__ minv;
@@ -282,13 +330,13 @@ struct EpiFcFirst {
     p.x0 = x_c.at_byte_offset((uint32_t)(ea.wc >= 0 ? ea.wc : 0) << 3);
     if (ea.wc < 0) p.x0 = 0.0;
     p.ad = 0.0; p.mi = 0.0;
-    if (aff_d) { p.ad = buf_f64(make_rsrc(aff_d + r0, ext), lr * 8); p.mi = buf_f64(make_rsrc(minv + r0, ext), lr * 8); }
+    if constexpr (DIAG) { p.ad = buf_f64(make_rsrc(aff_d + r0, ext), lr * 8); p.mi = buf_f64(make_rsrc(minv + r0, ext), lr * 8); }
     return p;
   }
   __device__ __forceinline__ void store(int32_t r0, int nr, int lr, double acc, const Pre& p) const {
     const double t4 = p.b + (-1.0) * acc;
     const int64_t ext = (int64_t)nr * 8;
-    if (aff_d) {
+    if constexpr (DIAG) {
       // one F smooth with diagonal A_ff and diagonal inverse (src/FC_Smooth.F90:541-559)
       double t3 = p.ad * p.x0;
       t3 = t4 + (-1.0) * t3;
@@ -300,8 +348,8 @@ struct EpiFcFirst {
   }
 };
 
-template <bool DIST>
-__global__ __launch_bounds__(SPMV_BLOCK) void k_rb_fc_first(RbView A, XVec<DIST> x_c, EpiFcFirst<DIST> epi) {
+template <bool DIST, bool DIAG>
+__global__ __launch_bounds__(SPMV_BLOCK) void k_rb_fc_first(RbView A, XVec<DIST> x_c, EpiFcFirst<DIST, DIAG> epi) {
   __shared__ double lds_all[SPMV_WAVES][LDS_SLOTS];
   rb_block<DIST>(A, x_c, lds_all[threadIdx.x >> 6], epi);
 }
@@ -359,8 +407,12 @@ void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t
 }
 
 template <bool DIST>
-static void launch_fc_first_d(const RbView& v, const XVec<DIST>& xv, const EpiFcFirst<DIST>& epi, int64_t nb, hipStream_t s) {
-  hipLaunchKernelGGL((k_rb_fc_first<DIST>), dim3(grid_for(nb)), dim3(SPMV_BLOCK), 0, s, v, xv, epi);
+static void launch_fc_first_d(const RbView& v, const XVec<DIST>& xv, const int32_t* wcol, const double* b_f, const double* aff_d,
+                              const double* minv, double* t4_out, double* x_f, int64_t nb, hipStream_t s) {
+  if (aff_d) hipLaunchKernelGGL((k_rb_fc_first<DIST, true>), dim3(grid_for(nb)), dim3(SPMV_BLOCK), 0, s, v, xv,
+                                EpiFcFirst<DIST, true>{wcol, b_f, xv, aff_d, minv, t4_out, x_f});
+  else hipLaunchKernelGGL((k_rb_fc_first<DIST, false>), dim3(grid_for(nb)), dim3(SPMV_BLOCK), 0, s, v, xv,
+                          EpiFcFirst<DIST, false>{wcol, b_f, xv, aff_d, minv, t4_out, x_f});
 }
 
 void launch_fc_first(const DevMat& A_fc, const int32_t* wcol, const double* b_f, const double* x_c,
@@ -369,16 +421,17 @@ void launch_fc_first(const DevMat& A_fc, const int32_t* wcol, const double* b_f,
   if (A_fc.m == 0 || (blk_list && nlist == 0)) return;
   if (A_fc.n == 0) x_c = A_fc.val;
   RbView v = view_of(A_fc);
+  if (!blk_list && A_fc.list_ord) { blk_list = A_fc.list_ord; nlist = A_fc.nblocks; }
   v.blk_list = blk_list; v.nlist = nlist;
   const int64_t nb = blk_list ? nlist : A_fc.nblocks;
   if (A_fc.n_ghost > 0) {
     if (!x_ghost) throw std::runtime_error("launch_fc_first: distributed operand without ghost values");
     const int32_t nl = (int32_t)(A_fc.n - A_fc.n_ghost);
     const XVec<true> xv{x_c, x_ghost - nl, nl};
-    launch_fc_first_d<true>(v, xv, EpiFcFirst<true>{wcol, b_f, xv, aff_d, minv, t4_out, x_f}, nb, s);
+    launch_fc_first_d<true>(v, xv, wcol, b_f, aff_d, minv, t4_out, x_f, nb, s);
   } else {
     const XVec<false> xv{x_c, nullptr, 0};
-    launch_fc_first_d<false>(v, xv, EpiFcFirst<false>{wcol, b_f, xv, aff_d, minv, t4_out, x_f}, nb, s);
+    launch_fc_first_d<false>(v, xv, wcol, b_f, aff_d, minv, t4_out, x_f, nb, s);
   }
   check_launch("k_rb_fc_first");
 }
@@ -498,6 +551,14 @@ __global__ __launch_bounds__(BLOCK) void k_chunk_blocks(int64_t m, const int64_t
   }
 }
 
+// Memory position of the value of logical slot s inside a block of n (<= 512) entries: every pair of full rounds
+// (2i, 2i+1) is interleaved lane by lane, the rest stays in slot order (see the header; issue_stream reads it back)
+__device__ __forceinline__ int val_slot(int s, int n) {
+  const int npair = (n >> 6) >> 1;
+  if (s >= 2 * WAVE * npair) return s;
+  return (s >> 7) * (2 * WAVE) + 2 * (s & (WAVE - 1)) + ((s >> 6) & 1);
+}
+
 // One wave per block: blocks of <= BLK_NNZ entries whose columns span less than 2^COL_BITS are sorted by
 // column (bitonic sort of (column << 16 | position) keys in LDS) and get packed index words; the others
 // keep row-major order and absolute columns (cbase stays -1).
@@ -517,7 +578,13 @@ __global__ __launch_bounds__(BLOCK) void k_block_pack(int64_t nblocks, BlkDesc* 
     for (int off = 32; off > 0; off >>= 1) { cmin = min(cmin, __shfl_xor(cmin, off, WAVE)); cmax = max(cmax, __shfl_xor(cmax, off, WAVE)); }
     const bool pack = nbl > 0 && nbl <= BLK_NNZ && (int64_t)cmax - (int64_t)cmin < (int64_t)(1u << COL_BITS);
     if (!pack) {
-      for (int64_t k = p0 + lane; k < p1; k += WAVE) { oidx[k] = (uint32_t)col[k]; oval[k] = val[k]; }
+      // row-major order, absolute columns; the first 512 values in the interleaved placement (a long row has more)
+      const int n512 = (int)(nbl < BLK_NNZ ? nbl : BLK_NNZ);
+      for (int64_t k = p0 + lane; k < p1; k += WAVE) {
+        oidx[k] = (uint32_t)col[k];
+        const int64_t s = k - p0;
+        oval[s < n512 ? p0 + val_slot((int)s, n512) : k] = val[k];
+      }
       continue;
     }
     const int nb = (int)nbl;
@@ -542,7 +609,7 @@ __global__ __launch_bounds__(BLOCK) void k_block_pack(int64_t nblocks, BlkDesc* 
       const unsigned long long k = keys[i];
       const int pos = (int)(k & 0xffffull);
       oidx[p0 + i] = ((uint32_t)((int32_t)(k >> 16) - cmin) << (POS_BITS + 3)) | (uint32_t)(pos + 1);
-      oval[p0 + i] = val[p0 + pos];
+      oval[p0 + val_slot(i, nb)] = val[p0 + pos];
     }
     if (lane == 0) blk[b].cbase = cmin;
     __builtin_amdgcn_wave_barrier();
