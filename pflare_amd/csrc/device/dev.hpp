@@ -17,11 +17,12 @@
 
 namespace airhip {
 
-// One row block: 16 bytes, read with one scalar load.  cbase >= 0: the block's entries are stored SORTED BY
-// COLUMN, every index word holds ((column - cbase) * 8) << 10 | (row-major position + 1).  cbase < 0 ("raw" block: a
-// column span of 2^19 or more, or a single row longer than 512): entries in row-major order, index word =
-// absolute column.
-struct BlkDesc { int64_t p0; int32_t row; int32_t cbase; };
+// One row block: a self-contained 32-byte descriptor, read with ONE scalar load (s_load_dwordx8).  cbase >= 0: the
+// block's entries are stored SORTED BY COLUMN, every index word holds ((column - cbase) * 8) << 10 | (row-major
+// position + 1).  cbase < 0 ("raw" block: a column span of 2^19 or more, or a single row longer than 512): entries in
+// row-major order, index word = absolute column.  nb / nr: the block's non-zeros and rows (round 2 derived them from
+// the next descriptor, and a launch over a list of blocks read the list first: two dependent scalar loads more).
+struct alignas(32) BlkDesc { int64_t p0; int32_t row; int32_t cbase; int32_t nb; int32_t nr; int32_t pad[2]; };
 
 // Row-block CSR.  One wavefront streams a block's (index word, value) pairs with coalesced loads, gathers x,
 // stages the products a_ij * x_j in LDS at their row-major positions and then sums every row's LDS segment
@@ -33,23 +34,24 @@ struct DevMat {
   struct HaloPlan* halo = nullptr;   // how to obtain them (not owned)
   int64_t nnz = 0;
   int64_t nblocks = 0;
-  BlkDesc* blk = nullptr;        // [nblocks+1]; the last entry holds {nnz, m, 0}
+  BlkDesc* blk = nullptr;        // [nblocks] in storage order
   uint16_t* roff = nullptr;      // [m] start of row r relative to its block's first non-zero
   uint32_t* idx = nullptr;       // [nnz+1] index words (one readable padding entry)
   double* val = nullptr;         // [nnz+1]
-  // distributed operand: the row blocks that touch no ghost column (interior) / at least one (boundary);
-  // the interior blocks run while the neighbour exchange is in flight
-  int32_t* list_int = nullptr; int32_t* list_bnd = nullptr;
+  // distributed operand: the row blocks that touch no ghost column (interior) / at least one (boundary), as
+  // descriptor arrays of their own; the interior blocks run while the neighbour exchange is in flight
+  BlkDesc* desc_int = nullptr; BlkDesc* desc_bnd = nullptr;
   int64_t n_int = 0, n_bnd = 0;
   // optional processing order of the row blocks (all nblocks of them): operators whose rows run through the sections
   // of a hierarchical vector are swept in the spatial order of their rows, so that the blocks of different sections
-  // that gather the same neighbourhood of x run close together in time (DevPCAIR::upload)
-  int32_t* list_ord = nullptr;
+  // that gather the same neighbourhood of x run close together in time (DevPCAIR::upload): the descriptors again,
+  // in that order
+  BlkDesc* desc_ord = nullptr;
   bool valid() const { return blk != nullptr; }
   // algorithmic bytes of one SpMV with this operator: S(X) of SURVEY 8(d)
   double s_bytes() const { return 12.0 * nnz + 4.0 * (m + 1) + 8.0 * m + 8.0 * n; }
   // bytes the format actually holds
-  double stored_bytes() const { return 12.0 * (nnz + 1) + 2.0 * m + 16.0 * (nblocks + 1); }
+  double stored_bytes() const { return 12.0 * (nnz + 1) + 2.0 * m + 32.0 * nblocks * (desc_ord ? 2 : 1); }
 };
 
 // out_i = alpha * s_i + beta * z_i + gamma * w_i,  s = (A x)_i [ * dscale_i ]
@@ -67,9 +69,9 @@ struct SpmvEpi {
 };
 
 // x_ghost: the received ghost values of a distributed operand (A.n_ghost entries), else null
-// blk_list / nlist: restrict the launch to these row blocks (null = all)
+// blks / nblks: restrict the launch to these row blocks (descriptor array; null = all, in A.desc_ord's order if present)
 void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t s, const double* x_ghost = nullptr,
-                 const int32_t* blk_list = nullptr, int64_t nlist = 0);
+                 const BlkDesc* blks = nullptr, int64_t nblks = 0);
 
 // Fused first stage of an F-point relaxation with a one-point prolongator:
 //   acc = (A_fc x_c)_i ; t4 = b_f_i - acc ; x0 = x_c[wcol_i] (0 if wcol_i < 0)
@@ -77,9 +79,11 @@ void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t
 //   split mode                     :  t4_out_i = t4 ; x_f_i = x0
 void launch_fc_first(const DevMat& A_fc, const int32_t* wcol, const double* b_f, const double* x_c,
                      const double* aff_d, const double* minv, double* t4_out, double* x_f, hipStream_t s,
-                     const double* x_ghost = nullptr, const int32_t* blk_list = nullptr, int64_t nlist = 0);
+                     const double* x_ghost = nullptr, const BlkDesc* blks = nullptr, int64_t nblks = 0);
 // host flags (one per row block): does the block reference a ghost column?
 void devmat_boundary_flags(const DevMat& A, std::vector<uint8_t>& flags, hipStream_t s);
+// a descriptor array holding the blocks order[0 .. n) of A (device memory, released with hipFree)
+BlkDesc* devmat_desc_list(const DevMat& A, const int32_t* order_host, int64_t n, hipStream_t s);
 
 // vector kernels (n elements)
 void launch_axpby(int64_t n, double a, const double* x, double b, const double* y, double* out, hipStream_t s);  // out = a x + b y

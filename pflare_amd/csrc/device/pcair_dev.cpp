@@ -29,12 +29,12 @@ void upload_mat(const Csr& A, const int32_t* d_rowsrc, const int32_t* d_colmap, 
 }
 
 // Processing order of an operator's row blocks by the locality key of each block's first row (host arrays:
-// dev_row_to_host[r] = host row stored as device row r, key[host row]).  See DevMat::list_ord.
+// dev_row_to_host[r] = host row stored as device row r, key[host row]).  See DevMat::desc_ord.
 static int64_t g_block_order_min = 4096;      // smaller operators sit in the caches anyway
 void set_block_order_min(int64_t nblocks) { g_block_order_min = nblocks > 0 ? nblocks : 1; }
 
 static void order_blocks_by_key(DevMat& M, const int32_t* dev_row_to_host, const int64_t* key, hipStream_t s) {
-  if (M.nblocks < g_block_order_min || M.list_ord) return;
+  if (M.nblocks < g_block_order_min || M.desc_ord) return;
   std::vector<BlkDesc> blk((size_t)M.nblocks);
   HIP_CHECK(hipMemcpyAsync(blk.data(), M.blk, sizeof(BlkDesc) * (size_t)M.nblocks, hipMemcpyDeviceToHost, s));
   HIP_CHECK(hipStreamSynchronize(s));
@@ -42,21 +42,20 @@ static void order_blocks_by_key(DevMat& M, const int32_t* dev_row_to_host, const
 #pragma omp parallel for schedule(static)
   for (int64_t b = 0; b < M.nblocks; b++) kb[(size_t)b] = {key[dev_row_to_host ? dev_row_to_host[blk[(size_t)b].row] : blk[(size_t)b].row], (int32_t)b};
   __gnu_parallel::sort(kb.begin(), kb.end());
-  std::vector<int32_t> ord((size_t)M.nblocks);
+  // the descriptors themselves in that order (a launch reads them front to back: no index list in between)
+  std::vector<BlkDesc> ord((size_t)M.nblocks);
 #pragma omp parallel for schedule(static)
-  for (int64_t b = 0; b < M.nblocks; b++) ord[(size_t)b] = kb[(size_t)b].second;
-  M.list_ord = (int32_t*)dev_alloc_exact(sizeof(int32_t) * (size_t)M.nblocks);
-  HIP_CHECK(hipMemcpy(M.list_ord, ord.data(), sizeof(int32_t) * (size_t)M.nblocks, hipMemcpyHostToDevice));
-  if (M.list_int && M.list_bnd) {
+  for (int64_t b = 0; b < M.nblocks; b++) ord[(size_t)b] = blk[(size_t)kb[(size_t)b].second];
+  M.desc_ord = (BlkDesc*)dev_alloc_exact(sizeof(BlkDesc) * (size_t)M.nblocks);
+  HIP_CHECK(hipMemcpy(M.desc_ord, ord.data(), sizeof(BlkDesc) * (size_t)M.nblocks, hipMemcpyHostToDevice));
+  if (M.desc_int && M.desc_bnd) {
     // distributed operand with the interior / boundary split: both lists in the same spatial order
-    std::vector<int32_t> lb((size_t)M.n_bnd);
-    if (M.n_bnd) HIP_CHECK(hipMemcpy(lb.data(), M.list_bnd, sizeof(int32_t) * (size_t)M.n_bnd, hipMemcpyDeviceToHost));
-    std::vector<uint8_t> bnd((size_t)M.nblocks, 0);
-    for (int32_t b : lb) bnd[(size_t)b] = 1;
-    std::vector<int32_t> li; li.reserve((size_t)M.n_int); lb.clear();
-    for (int32_t b : ord) (bnd[(size_t)b] ? lb : li).push_back(b);
-    if (!li.empty()) HIP_CHECK(hipMemcpy(M.list_int, li.data(), sizeof(int32_t) * li.size(), hipMemcpyHostToDevice));
-    if (!lb.empty()) HIP_CHECK(hipMemcpy(M.list_bnd, lb.data(), sizeof(int32_t) * lb.size(), hipMemcpyHostToDevice));
+    std::vector<uint8_t> fl;
+    devmat_boundary_flags(M, fl, s);
+    std::vector<BlkDesc> li, lb; li.reserve((size_t)M.n_int); lb.reserve((size_t)M.n_bnd);
+    for (int64_t b = 0; b < M.nblocks; b++) { const int32_t q = kb[(size_t)b].second; (fl[(size_t)q] ? lb : li).push_back(blk[(size_t)q]); }
+    if (!li.empty()) HIP_CHECK(hipMemcpy(M.desc_int, li.data(), sizeof(BlkDesc) * li.size(), hipMemcpyHostToDevice));
+    if (!lb.empty()) HIP_CHECK(hipMemcpy(M.desc_bnd, lb.data(), sizeof(BlkDesc) * lb.size(), hipMemcpyHostToDevice));
   }
 }
 
@@ -131,9 +130,9 @@ void DevPCAIR::spmv(const DevMat& A, const double* x, const SpmvEpi& e, const ch
   if (profile_) { id = stat_id(name, level, bytes_override >= 0 ? bytes_override : A.s_bytes()); stats_[id].kernel = "k_rb_spmv"; }
   if (begin_exchange(A, x)) {
     if (profile_) begin_kernel(id);
-    launch_spmv(A, x, e, stream_, A.halo->recvbuf, A.list_int, A.n_int);   // rows that read no ghost value
+    launch_spmv(A, x, e, stream_, A.halo->recvbuf, A.desc_int, A.n_int);   // rows that read no ghost value
     wait_exchange();
-    launch_spmv(A, x, e, stream_, A.halo->recvbuf, A.list_bnd, A.n_bnd);
+    launch_spmv(A, x, e, stream_, A.halo->recvbuf, A.desc_bnd, A.n_bnd);
     if (profile_) end_kernel();
     return;
   }
@@ -149,7 +148,7 @@ void DevPCAIR::spmv(const DevMat& A, const double* x, const SpmvEpi& e, const ch
 // boundary launch on the compute stream, so a plan's buffers are never rewritten while still in use.
 bool DevPCAIR::begin_exchange(const DevMat& A, const double* x) {
   // worth it only when the interior part runs longer than an exchange takes (~20 us ~ 50 MB of matrix)
-  if (!A.halo || !overlap_ || !A.list_int || A.n_int < overlap_min_blocks_) return false;
+  if (!A.halo || !overlap_ || !A.desc_int || A.n_int < overlap_min_blocks_) return false;
   HaloPlan& p = *A.halo;
   if (p.n_send) launch_gather(p.n_send, p.send_idx, x, p.sendbuf, stream_);
   HIP_CHECK(hipEventRecord(ev_pack_, stream_));
@@ -184,10 +183,8 @@ void DevPCAIR::attach_halo(DevMat& M, const HaloHost* h, const int32_t* host_col
     std::vector<int32_t> li, lb;
     for (int64_t b = 0; b < M.nblocks; b++) (fl[b] ? lb : li).push_back((int32_t)b);
     M.n_int = (int64_t)li.size(); M.n_bnd = (int64_t)lb.size();
-    HIP_CHECK(hipMalloc(&M.list_int, sizeof(int32_t) * std::max<size_t>(li.size(), 1)));
-    HIP_CHECK(hipMalloc(&M.list_bnd, sizeof(int32_t) * std::max<size_t>(lb.size(), 1)));
-    if (!li.empty()) HIP_CHECK(hipMemcpy(M.list_int, li.data(), sizeof(int32_t) * li.size(), hipMemcpyHostToDevice));
-    if (!lb.empty()) HIP_CHECK(hipMemcpy(M.list_bnd, lb.data(), sizeof(int32_t) * lb.size(), hipMemcpyHostToDevice));
+    M.desc_int = devmat_desc_list(M, li.data(), M.n_int, stream_);
+    M.desc_bnd = devmat_desc_list(M, lb.data(), M.n_bnd, stream_);
   }
 }
 
@@ -267,7 +264,7 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
   // level_keys[l][i]: locality key of point i of level l (level-local numbering) - the caller's hint on the top level, the
   // row's own index without one (the reference numbering is lexicographic, which is a locality key as well); a coarse
   // point inherits the key of its parent C point.  Used for the layout (with a hint) and for the processing order of
-  // the row blocks of operators whose rows run through several sections (DevMat::list_ord).
+  // the row blocks of operators whose rows run through several sections (DevMat::desc_ord).
   {
     level_keys.resize(L);
     std::vector<int64_t> key;
@@ -655,9 +652,9 @@ void DevPCAIR::f_smooths(DevLevel& L, int li, bool first, int its) {
     const double* ad = full ? L.aff_d.p : nullptr; const double* mi = full ? L.inv_ff.d.p : nullptr;
     if (begin_exchange(L.A_fc, x_c)) {
       if (profile_) begin_kernel(id);
-      launch_fc_first(L.A_fc, L.wcol.p, b_f, x_c, ad, mi, L.t4.p, x_f, stream_, L.A_fc.halo->recvbuf, L.A_fc.list_int, L.A_fc.n_int);
+      launch_fc_first(L.A_fc, L.wcol.p, b_f, x_c, ad, mi, L.t4.p, x_f, stream_, L.A_fc.halo->recvbuf, L.A_fc.desc_int, L.A_fc.n_int);
       wait_exchange();
-      launch_fc_first(L.A_fc, L.wcol.p, b_f, x_c, ad, mi, L.t4.p, x_f, stream_, L.A_fc.halo->recvbuf, L.A_fc.list_bnd, L.A_fc.n_bnd);
+      launch_fc_first(L.A_fc, L.wcol.p, b_f, x_c, ad, mi, L.t4.p, x_f, stream_, L.A_fc.halo->recvbuf, L.A_fc.desc_bnd, L.A_fc.n_bnd);
     } else {
       const double* xg = halo_update(L.A_fc, x_c);
       if (profile_) begin_kernel(id);

@@ -26,7 +26,7 @@ struct DBuf {
   void upload(const T* h, int64_t n_) { alloc(n_); if (n_ > 0) staged_h2d(p, h, sizeof(T) * (size_t)n_); }
 };
 
-// test hook: operators with at least this many row blocks get a spatial processing order (DevMat::list_ord); default 4096
+// test hook: operators with at least this many row blocks get a spatial processing order (DevMat::desc_ord); default 4096
 void set_block_order_min(int64_t nblocks);
 
 // Upload a host CSR and convert it to SELL-64 on the device (rows/cols optionally permuted).

@@ -15,18 +15,22 @@ constexpr int CHUNK_ROWS = 512;     // the block partition is greedy inside chun
 constexpr int POS_BITS = 10;
 constexpr uint32_t POS_MASK = (1u << POS_BITS) - 1u;
 constexpr int COL_BITS = 32 - POS_BITS - 3;   // 19: a packed block's columns span less than 2^19
-constexpr int LDS_SLOTS = BLK_NNZ + 2;   // products staged per wave: slot 0 is the dummy slot of padding lanes
+// products staged per wave: slot 0 is the dummy slot of padding lanes; the row sums (four entries per trip, up to 32
+// lanes per row) read up to 3 * 32 slots past a row's end and discard what they find there
+constexpr int LDS_SLOTS = BLK_NNZ + 2 + 96;
 
 struct RbView {
-  int64_t m, nblocks, nnz;
-  const BlkDesc* __restrict__ blk;
+  const BlkDesc* __restrict__ blk;        // the blocks this launch processes, in processing order
   const uint16_t* __restrict__ roff;
   const uint32_t* __restrict__ idx;
   const double* __restrict__ val;
-  const int32_t* __restrict__ blk_list;   // optional: process only these blocks (interior / boundary split)
-  int64_t nlist;
+  int32_t nblocks;                        // how many
+  int32_t per_class;                      // ceil(nblocks / 8): the blocks of one XCD class (see my_block)
 };
-inline RbView view_of(const DevMat& A) { return RbView{A.m, A.nblocks, A.nnz, A.blk, A.roff, A.idx, A.val, nullptr, 0}; }
+inline RbView view_of(const DevMat& A, const BlkDesc* blks, int64_t nblks) {
+  if (!blks) { blks = A.desc_ord ? A.desc_ord : A.blk; nblks = A.nblocks; }
+  return RbView{blks, A.roff, A.idx, A.val, (int32_t)nblks, (int32_t)((nblks + 7) / 8)};
+}
 
 // Input vector of an SpMV.  Single device: DIST = false, plain x[c].  Row-block distributed
 // (one rank per GPU): columns < nl index the rank's own segment, columns >= nl the ghost values

@@ -56,14 +56,14 @@ constexpr int SPMV_BLOCK = SPMV_WAVES * WAVE;
 
 // XCD-aware assignment of row blocks to waves (gridDim.x is a multiple of 8): workgroup w of residue class
 // g = blockIdx & 7 (one XCD under round-robin dispatch; a speed assumption only) takes SPMV_WAVES consecutive
-// blocks of the g-th eighth of the matrix.  Returns -1 when the wave has no block.
-__device__ __forceinline__ int64_t my_block(int64_t nblocks) {
+// blocks of the g-th run of per_class = ceil(nblocks / 8) blocks.  Returns -1 when the wave has no block.
+// 32-bit scalar arithmetic: round 2's 64-bit nblocks * g / 8 was 25 scalar instructions in front of the first load.
+__device__ __forceinline__ int my_block(const RbView& A) {
   const int g = blockIdx.x & 7;
-  const int64_t bi = blockIdx.x >> 3;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int64_t lo = nblocks * g / 8, hi = nblocks * (g + 1) / 8;
-  const int64_t b = lo + bi * SPMV_WAVES + wid;
-  return b < hi ? b : -1;
+  const int k = (int)(blockIdx.x >> 3) * SPMV_WAVES + wid;          // position inside the class
+  const int b = g * A.per_class + k;
+  return (k < A.per_class && b < A.nblocks) ? b : -1;
 }
 
 // ---- tuning knobs (airhip_set_tuning): none at present; the hook stays for experiments
@@ -71,22 +71,19 @@ int spmv_set_tuning(const char*, int) { return -1; }
 
 struct BlkInfo { int64_t p0; int32_t r0, cbase, nb, nr; };
 
-// Block descriptors are read through the constant address space: the address is wave-uniform, so the
-// compiler emits scalar loads (s_load_dwordx4, counted by lgkmcnt) instead of vector loads whose wait
-// (vmcnt is in order) would drain the prefetched stream.  The arrays are never written by these kernels.
+// The block descriptor is read through the constant address space: the address is wave-uniform, so the compiler
+// emits one scalar load (s_load_dwordx8, counted by lgkmcnt) instead of vector loads whose wait (vmcnt is in order)
+// would drain the prefetched stream.  The arrays are never written by these kernels.
 typedef const BlkDesc __attribute__((address_space(4))) * BlkDescConstPtr;
-typedef const int32_t __attribute__((address_space(4))) * I32ConstPtr;
 
-__device__ __forceinline__ BlkInfo load_blk(const RbView& A, int64_t i) {
-  int64_t b = i;
-  if (A.blk_list) b = (int64_t)((I32ConstPtr)(uintptr_t)A.blk_list)[i];
+__device__ __forceinline__ BlkInfo load_blk(const RbView& A, int b) {
   BlkDescConstPtr bp = (BlkDescConstPtr)(uintptr_t)A.blk;
   BlkInfo o;
   o.p0 = bp[b].p0;
   o.r0 = bp[b].row;
   o.cbase = bp[b].cbase;
-  o.nb = (int)(bp[b + 1].p0 - o.p0);
-  o.nr = bp[b + 1].row - o.r0;
+  o.nb = bp[b].nb;
+  o.nr = bp[b].nr;
   return o;
 }
 
@@ -99,6 +96,10 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ rsrc_t make_rsrc(const void* base, int64_t bytes) {
   const int nrec = bytes > 0x7fffffffll ? 0x7fffffff : (int)bytes;
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, nrec, 0x00020000);
+}
+// the same for an extent known to fit 31 bits (everything per block does): no 64-bit clamp
+__device__ __forceinline__ rsrc_t make_rsrc32(const void* base, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
 }
 __device__ __forceinline__ double buf_f64(rsrc_t r, int voff, int soff = 0) {
   return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
@@ -124,7 +125,7 @@ template <int NF>
 __device__ __forceinline__ void issue_stream(const RbView& A, const BlkInfo& d, int lane, uint32_t (&ix)[EPL], double (&vv)[EPL]) {
   typedef Rounds<NF> R;
   const int n = d.nb < BLK_NNZ ? d.nb : BLK_NNZ;
-  const rsrc_t ri = make_rsrc(A.idx + d.p0, (int64_t)n * 4), rv = make_rsrc(A.val + d.p0, (int64_t)n * 8);
+  const rsrc_t ri = make_rsrc32(A.idx + d.p0, n * 4), rv = make_rsrc32(A.val + d.p0, n * 8);
 #pragma unroll
   for (int u = 0; u < EPL; u++) { ix[u] = 0; if (R::has(u)) ix[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(ri, lane * 4, u * WAVE * 4, 0); }
 #pragma unroll
@@ -147,6 +148,21 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// sum of lds[j + 1] for j = a, a + step, ... < e, in that order; every lane of the wave takes part (a == e: no entry)
+__device__ __forceinline__ double row_sum(const double* __restrict__ lds, int a, int e, int step) {
+  double s = 0.0;
+  int j = a;
+  while (__any(j < e)) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const double v = lds[j + 1];           // at most 3 * step slots past the block's last entry: inside LDS_SLOTS
+      s += (j < e) ? v : 0.0;
+      j += step;
+    }
+  }
+  return s;
+}
+
 template <int NF, bool DIST, class Epi>
 __device__ __forceinline__ void rb_body(const RbView& A, const BlkInfo& d, const XVec<DIST> x, double* __restrict__ lds, const Epi& epi, int lane) {
   const int nb = d.nb, nr = d.nr;
@@ -158,7 +174,7 @@ __device__ __forceinline__ void rb_body(const RbView& A, const BlkInfo& d, const
   typename Epi::Early early[2];
   int ra[2], re[2];
   typename Epi::Pre pre[2];
-  const rsrc_t rr = make_rsrc(A.roff + d.r0, (int64_t)nr * 2);
+  const rsrc_t rr = make_rsrc32(A.roff + d.r0, nr * 2);
   const bool two = nr > WAVE;          // blocks of <= 64 rows (most of them) issue nothing for a second row per lane
   early[0] = epi.early(d.r0, nr, lane);
   early[1] = early[0];
@@ -198,13 +214,13 @@ __device__ __forceinline__ void rb_body(const RbView& A, const BlkInfo& d, const
     }
     wave_lds_sync();
     if (nr > 32) {
-      // phase 2: one lane per row, column order
+      // phase 2: one lane per row, column order.  Four entries per trip and a wave-uniform trip count (entries past
+      // the row's end are read - the staging area has the room - and replaced by zero): a per-lane loop cost six
+      // scalar instructions per entry of the longest row
 #pragma unroll
       for (int q = 0; q < 2; q++) {
         if (q == 1 && !two) break;
-        double s = 0.0;
-        for (int j = ra[q]; j < re[q]; j++) s += lds[j + 1];
-        epi.store(d.r0, nr, lane + q * WAVE, s, pre[q]);
+        epi.store(d.r0, nr, lane + q * WAVE, row_sum(lds, ra[q], re[q], 1), pre[q]);
       }
     } else {
       // phase 2 for few (longer) rows: T = 64 / 2^ceil(log2 nr) lanes share a row
@@ -213,8 +229,7 @@ __device__ __forceinline__ void rb_body(const RbView& A, const BlkInfo& d, const
       const int T = 1 << sh;
       const int g = lane >> sh, t = lane & (T - 1);
       const int a = __shfl(ra[0], g, WAVE), e = __shfl(re[0], g, WAVE);
-      double s = 0.0;
-      for (int j = a + t; j < e; j += T) s += lds[j + 1];
+      double s = row_sum(lds, a + t, e, T);
       for (int off = T >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
       const double srow = __shfl(s, (lane << sh) & (WAVE - 1), WAVE);   // row `lane` lives in lanes lane*T ..
       epi.store(d.r0, nr, lane, srow, pre[0]);
@@ -251,7 +266,7 @@ __device__ __forceinline__ void rb_body(const RbView& A, const BlkInfo& d, const
 template <bool DIST, class Epi>
 __device__ __forceinline__ void rb_block(const RbView& A, const XVec<DIST> x, double* __restrict__ lds, const Epi& epi) {
   const int lane = threadIdx.x & (WAVE - 1);
-  const int64_t bi = my_block(A.blk_list ? A.nlist : A.nblocks);
+  const int bi = my_block(A);
   if (bi < 0) return;
   const BlkInfo d = load_blk(A, bi);
   switch ((d.nb < BLK_NNZ ? d.nb : BLK_NNZ) >> 6) {     // full rounds: one straight-line variant each (every long row: 8)
@@ -279,11 +294,11 @@ struct EpiAxpby {
   __device__ __forceinline__ Early early(int32_t, int, int) const { return Early{}; }
   __device__ __forceinline__ Pre load(int32_t r0, int nr, int lr, Early) const {
     Pre p; p.z = 0.0; p.w = 0.0; p.d = 1.0; p.y2 = 0.0; p.w2 = 0.0;
-    const int64_t ext = (int64_t)nr * 8;
-    if constexpr ((F & EPI_Z) != 0) p.z = buf_f64(make_rsrc(e.z + r0, ext), lr * 8);
-    if constexpr ((F & EPI_W) != 0) p.w = buf_f64(make_rsrc(e.w + r0, ext), lr * 8);
-    if constexpr ((F & EPI_D) != 0) p.d = buf_f64(make_rsrc(e.dscale + r0, ext), lr * 8);
-    if constexpr ((F & EPI_Y) != 0) { p.y2 = buf_f64(make_rsrc(e.y2 + r0, ext), lr * 8); if (!e.aux_out) p.w2 = buf_f64(make_rsrc(e.w2 + r0, ext), lr * 8); }
+    const int ext = nr * 8;
+    if constexpr ((F & EPI_Z) != 0) p.z = buf_f64(make_rsrc32(e.z + r0, ext), lr * 8);
+    if constexpr ((F & EPI_W) != 0) p.w = buf_f64(make_rsrc32(e.w + r0, ext), lr * 8);
+    if constexpr ((F & EPI_D) != 0) p.d = buf_f64(make_rsrc32(e.dscale + r0, ext), lr * 8);
+    if constexpr ((F & EPI_Y) != 0) { p.y2 = buf_f64(make_rsrc32(e.y2 + r0, ext), lr * 8); if (!e.aux_out) p.w2 = buf_f64(make_rsrc32(e.w2 + r0, ext), lr * 8); }
     return p;
   }
   __device__ __forceinline__ void store(int32_t r0, int nr, int lr, double acc, const Pre& p) const {
@@ -291,9 +306,9 @@ struct EpiAxpby {
     double o = e.alpha * acc;
     if constexpr ((F & EPI_Z) != 0) o += e.beta * p.z;
     if constexpr ((F & EPI_W) != 0) o += e.gamma * p.w;
-    const int64_t ext = (int64_t)nr * 8;
-    buf_store_f64(make_rsrc(e.out + r0, ext), lr * 8, o);
-    if constexpr ((F & EPI_Y) != 0) buf_store_f64(make_rsrc(e.y2 + r0, ext), lr * 8, p.y2 + e.delta * (e.aux_out ? o : p.w2));
+    const int ext = nr * 8;
+    buf_store_f64(make_rsrc32(e.out + r0, ext), lr * 8, o);
+    if constexpr ((F & EPI_Y) != 0) buf_store_f64(make_rsrc32(e.y2 + r0, ext), lr * 8, p.y2 + e.delta * (e.aux_out ? o : p.w2));
   }
 };
 
@@ -321,29 +336,29 @@ struct EpiFcFirst {
   struct Pre { double b, x0, ad, mi; };
   __device__ __forceinline__ Early early(int32_t r0, int nr, int lr) const {
     // rows past the block's end read 0 = a valid column
-    return Early{(int32_t)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(wcol + r0, (int64_t)nr * 4), lr * 4, 0, 0)};
+    return Early{(int32_t)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc32(wcol + r0, nr * 4), lr * 4, 0, 0)};
   }
   __device__ __forceinline__ Pre load(int32_t r0, int nr, int lr, Early ea) const {
     Pre p;
-    const int64_t ext = (int64_t)nr * 8;
-    p.b = buf_f64(make_rsrc(b_f + r0, ext), lr * 8);
+    const int ext = nr * 8;
+    p.b = buf_f64(make_rsrc32(b_f + r0, ext), lr * 8);
     p.x0 = x_c.at_byte_offset((uint32_t)(ea.wc >= 0 ? ea.wc : 0) << 3);
     if (ea.wc < 0) p.x0 = 0.0;
     p.ad = 0.0; p.mi = 0.0;
-    if constexpr (DIAG) { p.ad = buf_f64(make_rsrc(aff_d + r0, ext), lr * 8); p.mi = buf_f64(make_rsrc(minv + r0, ext), lr * 8); }
+    if constexpr (DIAG) { p.ad = buf_f64(make_rsrc32(aff_d + r0, ext), lr * 8); p.mi = buf_f64(make_rsrc32(minv + r0, ext), lr * 8); }
     return p;
   }
   __device__ __forceinline__ void store(int32_t r0, int nr, int lr, double acc, const Pre& p) const {
     const double t4 = p.b + (-1.0) * acc;
-    const int64_t ext = (int64_t)nr * 8;
+    const int ext = nr * 8;
     if constexpr (DIAG) {
       // one F smooth with diagonal A_ff and diagonal inverse (src/FC_Smooth.F90:541-559)
       double t3 = p.ad * p.x0;
       t3 = t4 + (-1.0) * t3;
-      buf_store_f64(make_rsrc(x_f + r0, ext), lr * 8, p.x0 + p.mi * t3);
+      buf_store_f64(make_rsrc32(x_f + r0, ext), lr * 8, p.x0 + p.mi * t3);
     } else {
-      buf_store_f64(make_rsrc(t4_out + r0, ext), lr * 8, t4);
-      buf_store_f64(make_rsrc(x_f + r0, ext), lr * 8, p.x0);
+      buf_store_f64(make_rsrc32(t4_out + r0, ext), lr * 8, t4);
+      buf_store_f64(make_rsrc32(x_f + r0, ext), lr * 8, p.x0);
     }
   }
 };
@@ -388,12 +403,10 @@ static void launch_spmv_d(const RbView& v, const XVec<DIST>& xv, const SpmvEpi& 
 }
 
 void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t s, const double* x_ghost,
-                 const int32_t* blk_list, int64_t nlist) {
-  if (A.m == 0 || (blk_list && nlist == 0)) return;
-  RbView v = view_of(A);
-  if (!blk_list && A.list_ord) { blk_list = A.list_ord; nlist = A.nblocks; }
-  v.blk_list = blk_list; v.nlist = nlist;
-  const int64_t nb = blk_list ? nlist : A.nblocks;
+                 const BlkDesc* blks, int64_t nblks) {
+  if (A.m == 0 || (blks && nblks == 0)) return;
+  const RbView v = view_of(A, blks, nblks);
+  const int64_t nb = v.nblocks;
   if (A.n == 0) x = A.val;     // no columns: blocks of empty rows still read element 0 of "x"
   if (A.n_ghost > 0) {
     // distributed operand: ghost columns start at A.n - A.n_ghost
@@ -417,13 +430,11 @@ static void launch_fc_first_d(const RbView& v, const XVec<DIST>& xv, const int32
 
 void launch_fc_first(const DevMat& A_fc, const int32_t* wcol, const double* b_f, const double* x_c,
                      const double* aff_d, const double* minv, double* t4_out, double* x_f, hipStream_t s,
-                     const double* x_ghost, const int32_t* blk_list, int64_t nlist) {
-  if (A_fc.m == 0 || (blk_list && nlist == 0)) return;
+                     const double* x_ghost, const BlkDesc* blks, int64_t nblks) {
+  if (A_fc.m == 0 || (blks && nblks == 0)) return;
   if (A_fc.n == 0) x_c = A_fc.val;
-  RbView v = view_of(A_fc);
-  if (!blk_list && A_fc.list_ord) { blk_list = A_fc.list_ord; nlist = A_fc.nblocks; }
-  v.blk_list = blk_list; v.nlist = nlist;
-  const int64_t nb = blk_list ? nlist : A_fc.nblocks;
+  const RbView v = view_of(A_fc, blks, nblks);
+  const int64_t nb = v.nblocks;
   if (A_fc.n_ghost > 0) {
     if (!x_ghost) throw std::runtime_error("launch_fc_first: distributed operand without ghost values");
     const int32_t nl = (int32_t)(A_fc.n - A_fc.n_ghost);
@@ -540,7 +551,7 @@ __global__ __launch_bounds__(BLOCK) void k_chunk_blocks(int64_t m, const int64_t
       const int64_t pn = nrp[r + 1];
       const int64_t len = pn - pr;
       if (rows > 0 && (pn - p_start > BLK_NNZ || rows == BLK_ROWS)) { nblk++; rows = 0; p_start = pr; }
-      if (rows == 0 && FILL) { blk[b + nblk].p0 = pr; blk[b + nblk].row = (int32_t)r; blk[b + nblk].cbase = -1; }
+      if (rows == 0 && FILL) { BlkDesc& q = blk[b + nblk]; q.p0 = pr; q.row = (int32_t)r; q.cbase = -1; q.nb = 0; q.nr = 0; q.pad[0] = 0; q.pad[1] = 0; }
       if (FILL) roff[r] = (uint16_t)(len > BLK_NNZ ? 0 : (pr - p_start));
       rows++;
       if (len > BLK_NNZ) { nblk++; rows = 0; p_start = pn; }   // a long row closes its own block
@@ -562,7 +573,7 @@ __device__ __forceinline__ int val_slot(int s, int n) {
 // One wave per block: blocks of <= BLK_NNZ entries whose columns span less than 2^COL_BITS are sorted by
 // column (bitonic sort of (column << 16 | position) keys in LDS) and get packed index words; the others
 // keep row-major order and absolute columns (cbase stays -1).
-__global__ __launch_bounds__(BLOCK) void k_block_pack(int64_t nblocks, BlkDesc* __restrict__ blk, const int32_t* __restrict__ col,
+__global__ __launch_bounds__(BLOCK) void k_block_pack(int64_t nblocks, int64_t nnz, int64_t m, BlkDesc* __restrict__ blk, const int32_t* __restrict__ col,
                                                      const double* __restrict__ val, uint32_t* __restrict__ oidx, double* __restrict__ oval) {
   __shared__ unsigned long long keys_all[WAVES_PER_BLOCK][BLK_NNZ];
   unsigned long long* keys = keys_all[threadIdx.x >> 6];
@@ -570,8 +581,9 @@ __global__ __launch_bounds__(BLOCK) void k_block_pack(int64_t nblocks, BlkDesc* 
   const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * BLOCK) >> 6;
   for (int64_t b = wave; b < nblocks; b += nwaves) {
-    const int64_t p0 = blk[b].p0, p1 = blk[b + 1].p0;
+    const int64_t p0 = blk[b].p0, p1 = b + 1 < nblocks ? blk[b + 1].p0 : nnz;
     const int64_t nbl = p1 - p0;
+    if (lane == 0) { blk[b].nb = (int32_t)nbl; blk[b].nr = (int32_t)((b + 1 < nblocks ? (int64_t)blk[b + 1].row : m) - blk[b].row); }
     int32_t cmin = 0x7fffffff, cmax = -1;
     if (nbl <= BLK_NNZ)
       for (int i = lane; i < (int)nbl; i += WAVE) { const int32_t c = col[p0 + i]; cmin = min(cmin, c); cmax = max(cmax, c); }
@@ -625,7 +637,7 @@ __global__ __launch_bounds__(BLOCK) void k_boundary_flags(int64_t nblocks, const
   for (int64_t b = wave; b < nblocks; b += nwaves) {
     const int32_t cbase = blk[b].cbase;
     bool any = false;
-    for (int64_t k = blk[b].p0 + lane; k < blk[b + 1].p0; k += WAVE) {
+    for (int64_t k = blk[b].p0 + lane; k < blk[b].p0 + blk[b].nb; k += WAVE) {
       const int32_t c = cbase >= 0 ? cbase + (int32_t)(idx[k] >> (POS_BITS + 3)) : (int32_t)idx[k];
       any |= c >= n_local;
     }
@@ -643,6 +655,23 @@ void devmat_boundary_flags(const DevMat& A, std::vector<uint8_t>& flags, hipStre
   HIP_CHECK(hipMemcpyAsync(flags.data(), d, (size_t)A.nblocks, hipMemcpyDeviceToHost, s));
   HIP_CHECK(hipStreamSynchronize(s));
   dev_free(d);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_desc_gather(int64_t n, const BlkDesc* __restrict__ blk, const int32_t* __restrict__ order, BlkDesc* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) out[i] = blk[order[i]];
+}
+
+BlkDesc* devmat_desc_list(const DevMat& A, const int32_t* order_host, int64_t n, hipStream_t s) {
+  BlkDesc* out = (BlkDesc*)dev_alloc_exact(sizeof(BlkDesc) * (size_t)std::max<int64_t>(n, 1));
+  if (n == 0) return out;
+  int32_t* d_ord = (int32_t*)dev_alloc(sizeof(int32_t) * (size_t)n);
+  HIP_CHECK(hipMemcpyAsync(d_ord, order_host, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, s));
+  const int g = (int)std::min<int64_t>((n + BLOCK - 1) / BLOCK, MAX_BLOCKS);
+  hipLaunchKernelGGL(k_desc_gather, dim3(g), dim3(BLOCK), 0, s, n, A.blk, d_ord, out);
+  HIP_CHECK(hipStreamSynchronize(s));
+  dev_free(d_ord);
+  return out;
 }
 
 static int grid1d(int64_t n) {
@@ -676,17 +705,18 @@ void devmat_from_csr_device(int64_t m, int64_t n, const int64_t* d_rp, const int
   int64_t* d_first = (int64_t*)dev_alloc(sizeof(int64_t) * (size_t)nchunks);
   hipLaunchKernelGGL((k_chunk_blocks<false>), dim3(grid1d(nchunks)), dim3(BLOCK), 0, s, m, d_nrp, d_cnt, nullptr, nullptr, nullptr);
   out.nblocks = device_exclusive_scan(nchunks, d_cnt, d_first, s);
+  if (out.nblocks >= (1ll << 31) - 8) throw std::runtime_error("matrix has too many row blocks");
   out.blk = (BlkDesc*)dev_alloc_exact(sizeof(BlkDesc) * (size_t)(out.nblocks + 1));
   out.roff = (uint16_t*)dev_alloc_exact(sizeof(uint16_t) * (size_t)m);
   hipLaunchKernelGGL((k_chunk_blocks<true>), dim3(grid1d(nchunks)), dim3(BLOCK), 0, s, m, d_nrp, d_cnt, d_first, out.blk, out.roff);
-  const BlkDesc end{out.nnz, (int32_t)m, 0};
+  const BlkDesc end{out.nnz, (int32_t)m, 0, 0, 0, {0, 0}};       // readable padding entry (empty block)
   HIP_CHECK(hipMemcpyAsync(out.blk + out.nblocks, &end, sizeof(BlkDesc), hipMemcpyHostToDevice, s));
   out.idx = (uint32_t*)dev_alloc_exact(sizeof(uint32_t) * (size_t)(out.nnz + 1));
   out.val = (double*)dev_alloc_exact(sizeof(double) * (size_t)(out.nnz + 1));
   HIP_CHECK(hipMemsetAsync(out.idx + out.nnz, 0, sizeof(uint32_t), s));
   HIP_CHECK(hipMemsetAsync(out.val + out.nnz, 0, sizeof(double), s));
   const int g = (int)std::min<int64_t>((out.nblocks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 4096);
-  hipLaunchKernelGGL(k_block_pack, dim3(g < 1 ? 1 : g), dim3(BLOCK), 0, s, out.nblocks, out.blk, tcol, tval, out.idx, out.val);
+  hipLaunchKernelGGL(k_block_pack, dim3(g < 1 ? 1 : g), dim3(BLOCK), 0, s, out.nblocks, out.nnz, m, out.blk, tcol, tval, out.idx, out.val);
   HIP_CHECK(hipStreamSynchronize(s));
   check_launch("row-block conversion");
   dev_free(d_nrp); dev_free(d_cnt); dev_free(d_first); dev_free(tcol); dev_free(tval);
@@ -697,9 +727,9 @@ void devmat_free(DevMat& A) {
   if (A.roff) (void)hipFree(A.roff);
   if (A.idx) (void)hipFree(A.idx);
   if (A.val) (void)hipFree(A.val);
-  if (A.list_int) (void)hipFree(A.list_int);
-  if (A.list_bnd) (void)hipFree(A.list_bnd);
-  if (A.list_ord) (void)hipFree(A.list_ord);
+  if (A.desc_int) (void)hipFree(A.desc_int);
+  if (A.desc_bnd) (void)hipFree(A.desc_bnd);
+  if (A.desc_ord) (void)hipFree(A.desc_ord);
   A = DevMat();
 }
 

@@ -47,7 +47,7 @@ def _worker(rank, world, port, case, out):
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=proc_util.pg_timeout())
     try:
         torch.cuda.set_device(0)
-        # spatial processing order of the row blocks (DevMat::list_ord; from 4096 blocks on by default) for every operand,
+        # spatial processing order of the row blocks (DevMat::desc_ord; from 4096 blocks on by default) for every operand,
         # with the interior / boundary lists of the overlap case reordered along
         assert P.lib().airhip_set_tuning(b"block_order_min_blocks", 1) == 0
         gen, opts, kind = CASES[case]

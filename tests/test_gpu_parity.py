@@ -214,7 +214,7 @@ def test_ordering_hint_changes_layout_not_results(torch_mod, case):
 def test_spatial_block_order_is_bitwise_neutral(torch_mod, case, hint):
     """Operators whose rows run through several sections of a hierarchical vector (R = [Z I], the outer operator,
     A_cf / A_cc, the level operator of full smoothing) are swept in the spatial order of their row blocks
-    (DevMat::list_ord; only from 4096 blocks on by default - forced here).  The order of the blocks must not change a
+    (DevMat::desc_ord; only from 4096 blocks on by default - forced here).  The order of the blocks must not change a
     bit of PCApply, with and without a layout hint, and the V-cycle must still match the oracle."""
     torch = torch_mod
     import pflare_amd as P
