@@ -26,6 +26,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
+# defaults of the airhip_set_tuning keys (include/airhip.h): what --variants restores after each variant
+TUNING_DEFAULTS = {"spgemm_pool_entries": 0, "spgemm_pool_chunk": -1, "block_order_min_blocks": 4096, "fc_fuse": 1}
+
 RECIPES = {
     # reference GPU recipe: lumping + auto truncation + Newton matrix-free coarse solver
     "trunc": dict(a_lump=True, auto_truncate_start_level=1, auto_truncate_tol=1e-1,
@@ -333,9 +336,12 @@ def main():
             print(f"[variant {v or 'default'}] {args.steps / w:8.2f} it/s  vcycle kernels {tot / cyc:8.3f} ms  "
                   f"{cx['cycle_alg_bytes'] / (tot / cyc * 1e-3) / 1e9:7.1f} GB/s  k_rb_spmv {sp_by / (sp_ms * 1e-3) / 1e9:7.1f} GB/s",
                   file=sys.stderr, flush=True)
-            # back to the defaults before the next variant
+            for s_ in sorted(stv, key=lambda q: -q["total_ms"]):
+                a_ = s_["total_ms"] / s_["calls"]
+                log(f" v {s_['name']:28s} L{s_['level']+1:<2d} calls={s_['calls']:4d} avg={a_:8.3f} ms  {s_['alg_bytes'] / (a_ * 1e-3) / 1e9:8.1f} GB/s")
+            # back to the defaults (include/airhip.h, airhip_set_tuning) before the next variant
             for k_ in kv:
-                P.lib().airhip_set_tuning(k_.encode(), 0)
+                P.lib().airhip_set_tuning(k_.encode(), TUNING_DEFAULTS.get(k_, 0))
     run_iterations(args.warmup)
     if args.profile_kernels:
         pc.profile(True)

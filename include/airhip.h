@@ -102,7 +102,8 @@ int airhip_set_num_threads(int n, int* prev);
  * airhip_set_tuning: process-wide knobs for experiments and tests.  Keys: "spgemm_pool_entries" (caps the output pool
  *   of the device SpGEMM at that many entries, 0 = sized from the operands; a small cap forces the multi-round path),
  *   "spgemm_pool_chunk" (entries a wave takes from that pool at a time, -1 = automatic), "block_order_min_blocks"
- *   (operators with at least this many row blocks are swept in the spatial order of their rows, default 4096).
+ *   (operators with at least this many row blocks are swept in the spatial order of their rows, default 4096), "fc_fuse"
+ *   (default 1; 0 runs the one-point prolongation and the A_fc product of an F relaxation as two launches - diagnostic).
  * airhip_pcair_setup_host_only / airhip_pcinv_setup_host_only: build the hierarchy without touching a device (CPU-side
  *   tests of the setup, hierarchy export); apply / solve then fail with AIRHIP_ERR_STATE.
  * airhip_spgemm_filtered: C = filter(A*B) with the host (on_device = 0) or the device SpGEMM of the setup, drop / lump /

@@ -18,7 +18,8 @@ static thread_local std::string g_err;
 const char* airhip_last_error(void) { return g_err.c_str(); }
 int airhip_version(void) { return 100; }
 
-#define API_BEGIN try {
+struct TeamGuard { int prev; TeamGuard(); ~TeamGuard(); };      // host threads of one API call (defined below)
+#define API_BEGIN try { TeamGuard team_guard_;
 #define API_END                                                                      \
   }                                                                                  \
   catch (const std::bad_alloc&) { g_err = "out of host memory"; return AIRHIP_ERR_INTERNAL; } \
@@ -50,6 +51,7 @@ int airhip_set_tuning(const char* key, int value) {
   if (std::string(key) == "spgemm_pool_entries") airhip::spgemm_set_pool_limit(value);
   else if (std::string(key) == "spgemm_pool_chunk") airhip::spgemm_set_pool_chunk(value);
   else if (std::string(key) == "block_order_min_blocks") airhip::set_block_order_min(value);
+  else if (std::string(key) == "fc_fuse") airhip::set_fc_fuse(value != 0);
   else if (airhip::spmv_set_tuning(key, value) != 0) { g_err = std::string("unknown tuning key ") + key; return AIRHIP_ERR_ARG; }
   API_END
 }
@@ -80,12 +82,20 @@ static int cpu_share() {
     n = std::min<long long>(n, std::max<long long>(1, (q + per - 1) / per));
   return std::max(1, n);
 }
-static int g_team = 0;        // the team size for large operators
-__attribute__((constructor)) static void init_host_threads() {
-  const char* e = std::getenv("OMP_NUM_THREADS");
-  g_team = (e && *e) ? omp_get_max_threads() : std::min(cpu_share(), 32);
-  omp_set_num_threads(g_team);
+// The library never changes the process-wide OpenMP setting behind the application's back (it may share the OpenMP
+// runtime with PETSc and the user's own parallel regions): the team is chosen when an API call is entered and the
+// caller's setting is restored when the call returns (TeamGuard in API_BEGIN).
+static int g_team_override = 0;      // airhip_set_num_threads
+static int library_team() {
+  if (g_team_override > 0) return g_team_override;
+  static const int team = [] {
+    const char* e = std::getenv("OMP_NUM_THREADS");
+    return (e && *e) ? omp_get_max_threads() : std::min(cpu_share(), 32);
+  }();
+  return team;
 }
+TeamGuard::TeamGuard() : prev(omp_get_max_threads()) { omp_set_num_threads(library_team()); }
+TeamGuard::~TeamGuard() { omp_set_num_threads(prev); }
 // fewer threads for small operators: one thread per ~32k non-zeros
 struct ThreadScope {
   int prev;
@@ -97,10 +107,9 @@ struct ThreadScope {
 };
 
 int airhip_set_num_threads(int n, int* prev) {
-  API_BEGIN
-  if (prev) *prev = omp_get_max_threads();
-  if (n > 0) { omp_set_num_threads(n); g_team = n; }
-  API_END
+  if (prev) *prev = library_team();
+  if (n > 0) g_team_override = n;
+  return AIRHIP_OK;
 }
 
 // ------------------------------------------------------------------------ host matrices
@@ -464,6 +473,7 @@ static void finish_device(airhip_pcair pc) {
 
 int airhip_pcair_setup(airhip_pcair pc, const airhip_csr* A) {
   API_BEGIN
+  DevScope dev_scope(true);      // setup temporaries go back to the device also when the setup throws
   REQUIRE(pc && A && A->rowptr && A->m == A->n && A->m > 0, AIRHIP_ERR_ARG, "PCAIR needs a square CSR operator");
   REQUIRE_CSR(A, true);
   int ndev = 0;
@@ -1020,6 +1030,7 @@ int airhip_comm_destroy(airhip_comm* c) {
 // This rank's piece -> device.  The archive's arrays are only read during the call.
 int airhip_pcair_load_distributed(airhip_pcair pc, airhip_archive piece, airhip_comm comm) {
   API_BEGIN
+  DevScope dev_scope(true);
   REQUIRE(pc && piece && comm, AIRHIP_ERR_ARG, "null argument");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
@@ -1093,6 +1104,7 @@ static void pcinv_build_host(airhip_pcinv pc, const Csr& A, bool device_assist =
 
 int airhip_pcinv_setup(airhip_pcinv pc, const airhip_csr* A) {
   API_BEGIN
+  DevScope dev_scope(true);
   REQUIRE(pc && A && A->m == A->n && A->m > 0, AIRHIP_ERR_ARG, "PCPFLAREINV needs a square CSR operator");
   REQUIRE_CSR(A, true);
   int ndev = 0;
@@ -1153,6 +1165,7 @@ struct airhip_mat_s { DevMat A; hipStream_t stream = nullptr; int64_t n = 0; std
 
 int airhip_mat_create(const airhip_csr* A, airhip_mat* out) {
   API_BEGIN
+  DevScope dev_scope(true);
   REQUIRE(A && out, AIRHIP_ERR_ARG, "null argument");
   REQUIRE_CSR(A, false);
   int ndev = 0;

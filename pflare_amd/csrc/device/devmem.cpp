@@ -3,7 +3,9 @@
 #include <cstdlib>
 #include <mutex>
 #include <stdexcept>
+#include <exception>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 namespace airhip {
@@ -24,7 +26,27 @@ struct DevCache {
 };
 DevCache& cache() { static DevCache* c = new DevCache; return *c; }
 
+// journals of the DevScopes alive on this thread, innermost last
+thread_local std::vector<std::unordered_set<void*>> t_scopes;
+void note_alloc(void* p) { if (!t_scopes.empty()) t_scopes.back().insert(p); }
+void note_free(void* p) {
+  for (size_t k = t_scopes.size(); k-- > 0;) if (t_scopes[k].erase(p)) return;
+}
+
 }  // namespace
+
+DevScope::DevScope(bool trim) : trim_(trim), exceptions_(std::uncaught_exceptions()) { t_scopes.emplace_back(); }
+DevScope::~DevScope() {
+  std::unordered_set<void*> mine;
+  mine.swap(t_scopes.back());
+  t_scopes.pop_back();
+  if (std::uncaught_exceptions() > exceptions_) {
+    for (void* p : mine) dev_free(p);                    // left by an exception: nobody holds these any more
+  } else if (!t_scopes.empty()) {
+    t_scopes.back().insert(mine.begin(), mine.end());    // results: the enclosing scope answers for them now
+  }
+  if (trim_) dev_cache_trim();
+}
 
 void* dev_alloc(size_t bytes) {
   if (bytes == 0) bytes = 1;
@@ -39,6 +61,7 @@ void* dev_alloc(size_t bytes) {
       c.idle.erase(c.idle.begin() + best);
       c.idle_bytes -= blk.second;
       c.live[blk.first] = blk.second;
+      note_alloc(blk.first);
       return blk.first;
     }
   }
@@ -54,6 +77,7 @@ void* dev_alloc(size_t bytes) {
     throw std::runtime_error(std::string("hipMalloc of ") + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
   }
   if (bytes >= CACHE_MIN) { std::lock_guard<std::mutex> lock(c.mu); c.live[p] = bytes; }
+  note_alloc(p);
   return p;
 }
 
@@ -70,6 +94,7 @@ void* dev_alloc_exact(size_t bytes) {
 
 void dev_free(void* p) {
   if (!p) return;
+  note_free(p);
   DevCache& c = cache();
   {
     std::lock_guard<std::mutex> lock(c.mu);

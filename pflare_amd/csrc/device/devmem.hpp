@@ -15,4 +15,20 @@ void dev_free(void* p);                  // any pointer dev_alloc returned (null
 void* dev_alloc_exact(size_t bytes);
 void dev_cache_trim();
 size_t dev_cache_idle_bytes();
+
+// Exception safety of the setup code, which holds raw dev_alloc pointers: while a DevScope is alive on a thread every
+// block that thread takes with dev_alloc is noted (dev_free strikes it again).  When the scope is left by an exception the
+// blocks still noted go back with dev_free - nothing stays in the cache's live table for ever; when it is left normally
+// they pass to the enclosing scope (results that outlive the function).  trim = true also empties the cache on the way
+// out, normal or not (the end of a setup call: later hipMalloc calls of the application must find the memory).
+class DevScope {
+ public:
+  explicit DevScope(bool trim = false);
+  ~DevScope();
+  DevScope(const DevScope&) = delete;
+  DevScope& operator=(const DevScope&) = delete;
+ private:
+  bool trim_;
+  int exceptions_;
+};
 }  // namespace airhip

@@ -32,6 +32,8 @@ void upload_mat(const Csr& A, const int32_t* d_rowsrc, const int32_t* d_colmap, 
 // dev_row_to_host[r] = host row stored as device row r, key[host row]).  See DevMat::desc_ord.
 static int64_t g_block_order_min = 4096;      // smaller operators sit in the caches anyway
 void set_block_order_min(int64_t nblocks) { g_block_order_min = nblocks > 0 ? nblocks : 1; }
+static bool g_fc_fuse = true;
+void set_fc_fuse(bool on) { g_fc_fuse = on; }
 
 static void order_blocks_by_key(DevMat& M, const int32_t* dev_row_to_host, const int64_t* key, hipStream_t s) {
   if (M.nblocks < g_block_order_min || M.desc_ord) return;
@@ -643,7 +645,12 @@ void DevPCAIR::f_smooths(DevLevel& L, int li, bool first, int its) {
   double* x_f = xvec(li); double* x_c = x_f + L.n_f;
   const double* b_f = bvec(li);
   const bool diag_inv = L.aff_diag && L.inv_ff.kind == InvOp::DIAG;
-  if (first && L.one_point) {
+  if (first && L.one_point && !g_fc_fuse && !L.A_fc.halo && !(diag_inv && its == 1)) {
+    // diagnostic: the two steps apart
+    launch_gather(L.n_f, L.wcol.p, x_c, x_f, stream_);
+    SpmvEpi e; e.out = L.t4.p; e.alpha = -1.0; e.z = b_f; e.beta = 1.0;
+    spmv(L.A_fc, x_c, e, "t4=b_f-A_fc*x_c", li);
+  } else if (first && L.one_point) {
     // prolongation x_f = W x_c fused with t4 = b_f - A_fc x_c (and the whole smooth when A_ff
     // and its inverse are diagonal and a single F smooth is requested)
     const bool full = diag_inv && its == 1;

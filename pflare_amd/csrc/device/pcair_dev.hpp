@@ -28,6 +28,9 @@ struct DBuf {
 
 // test hook: operators with at least this many row blocks get a spatial processing order (DevMat::desc_ord); default 4096
 void set_block_order_min(int64_t nblocks);
+// diagnostic (airhip_set_tuning "fc_fuse"): 0 runs the first stage of an F relaxation as a gather (one-point prolongation)
+// followed by a plain A_fc product instead of the fused k_rb_fc_first; same results, one more pass over the F vectors
+void set_fc_fuse(bool on);
 
 // Upload a host CSR and convert it to SELL-64 on the device (rows/cols optionally permuted).
 void upload_mat(const Csr& A, const int32_t* d_rowsrc, const int32_t* d_colmap, DevMat& out, hipStream_t s, int64_t n_ghost = 0);

@@ -777,6 +777,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather_rows(int64_t nrows, const int3
 DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, bool lump, bool negate, hipStream_t s,
                 SpgemmStats* stats) {
   if (A.n != B.m) throw std::runtime_error("dev_spgemm: shape mismatch");
+  DevScope scope;      // every block below is a raw dev_alloc pointer: an exception on the way returns them all
   static const bool trace = std::getenv("AIRHIP_SPGEMM_TRACE") != nullptr;
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t_begin = now();

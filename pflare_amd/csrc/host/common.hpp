@@ -20,8 +20,8 @@ namespace airhip {
 
 // Memory of the host arrays (host/hostmem.cpp): blocks of 4 MiB and more are 2 MiB-aligned and advised as transparent
 // huge pages, blocks of 64 MiB and more wait in a bounded cache when they are released (returning tens of GB to the
-// kernel costs seconds).  free_host_array takes any pointer alloc_host_array returned; plain std::free is also valid
-// for such a pointer (the block then simply leaves the bookkeeping).
+// kernel costs seconds).  Release with free_host_array only (a block released with std::free would stay in the cache's
+// table of live blocks under its old size).
 constexpr size_t HUGE_ALIGN = 2u << 20;
 void* alloc_host_array(size_t bytes);
 void free_host_array(void* p);

@@ -68,7 +68,8 @@ void* alloc_host_array(size_t bytes) {
 void free_host_array(void* p) {
   if (!p) return;
   HostCache& c = cache();
-  {
+  // tracked blocks are 2-MiB aligned: the many small arrays (thread-local scratch inside parallel regions) skip the lock
+  if (((uintptr_t)p & (HUGE_ALIGN - 1)) == 0) {
     std::lock_guard<std::mutex> lock(c.mu);
     auto it = c.live.find(p);
     if (it != c.live.end()) {
