@@ -93,6 +93,7 @@ Rccl& rccl() {
 
 struct RcclComm final : Comm {
   void* comm = nullptr;
+  bool device_side() const override { return true; }
   ~RcclComm() override { if (comm) (void)rccl().CommDestroy(comm); }
   void exchange(const HaloPlan& p, hipStream_t s) override {
     n_exchanges++;

@@ -27,6 +27,9 @@ struct HaloPlan {
 struct Comm {
   int rank = 0, size = 1;
   virtual ~Comm() = default;
+  // true: exchange() only enqueues device work (no host synchronisation, no host callback) - it can run on a second
+  // stream beside the interior row blocks and be captured in a hipGraph.  RCCL: yes; the host-staged transport: no.
+  virtual bool device_side() const { return false; }
   // sendbuf -> peers, peers -> recvbuf; ordered after prior work on s, complete for later work on s
   virtual void exchange(const HaloPlan& p, hipStream_t s) = 0;
   // sum over ranks of n doubles at d_vals (in place); the result is also returned in h_vals and the

@@ -73,7 +73,7 @@ DevPCAIR::DevPCAIR() {
   HIP_CHECK(hipStreamCreateWithFlags(&comm_stream_, hipStreamNonBlocking));
   HIP_CHECK(hipEventCreateWithFlags(&ev_pack_, hipEventDisableTiming));
   HIP_CHECK(hipEventCreateWithFlags(&ev_recv_, hipEventDisableTiming));
-  if (const char* e = std::getenv("AIRHIP_OVERLAP")) overlap_ = std::atoi(e) != 0;
+  if (const char* e = std::getenv("AIRHIP_OVERLAP")) overlap_mode_ = std::atoi(e) != 0 ? 1 : 0;
   if (const char* e = std::getenv("AIRHIP_OVERLAP_MIN_BLOCKS")) overlap_min_blocks_ = std::atoll(e);
 }
 
@@ -242,6 +242,7 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
   g_t_h2d = g_t_convert = 0.0;
   comm_ = dist ? comm : nullptr;
   if (dist && !comm) throw std::runtime_error("a distributed hierarchy needs a communicator");
+  overlap_ = comm_ && (overlap_mode_ < 0 ? comm_->device_side() : overlap_mode_ != 0);
   plans_.clear();
   auto ng = [&](const HaloHost* h) -> int64_t { return (dist && h) ? h->n_ghost : 0; };
   n_ = A_top.m;
@@ -771,8 +772,13 @@ void DevPCAIR::vcycle() {
   }
 }
 
+// hipGraph capture of the cycle: single device, or a communicator whose exchange only enqueues device work (RCCL send /
+// receive groups are capturable; the exchange stream joins the capture through the pack / receive events).  The
+// host-staged transport synchronises the host inside the cycle and cannot be captured.
+bool DevPCAIR::graph_ok() const { return want_graph_ && !profile_ && (!comm_ || comm_->device_side()); }
+
 void DevPCAIR::run_cycle() {
-  if (want_graph_ && !profile_ && !comm_) {
+  if (graph_ok()) {
     if (!graph_exec_) {
       hipGraph_t g;
       HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
@@ -786,7 +792,7 @@ void DevPCAIR::run_cycle() {
 }
 
 void DevPCAIR::apply_permuted(const double* r, double* z) {
-  if (r != z && !(want_graph_ && !profile_ && !comm_)) {
+  if (r != z && !graph_ok()) {
     b0_ = r; xbase_ = z;          // r is preserved, z receives the cycle's output directly
     run_cycle();
     return;

@@ -124,6 +124,7 @@ class DevPCAIR {
   bool full_ = false;
   std::vector<DBuf<double>> xfull_;                     // full smoothing: solutions of levels >= 1
   void run_cycle();                                     // vcycle, through a HIP graph when enabled
+  bool graph_ok() const;
   void f_smooths(DevLevel& L, int li, bool first, int its);
   void c_smooths(DevLevel& L, int li, bool first, int its);
   void apply_inv(DevInv& I, const double* r, double* x, bool add, int stat_level, const char* tag);
@@ -138,9 +139,13 @@ class DevPCAIR {
   const double* halo_update(const DevMat& A, const double* x);
   Comm* comm_ = nullptr;
   std::vector<std::unique_ptr<HaloPlan>> plans_;
-  // exchange / compute overlap (opt-in, AIRHIP_OVERLAP=1: validated for correctness with the staged transport,
-  // not yet measured under RCCL): the exchange runs on its own stream while the interior row blocks (no ghost
-  // column) are processed; the boundary blocks follow once the ghosts have arrived
+  // exchange / compute overlap: the exchange runs on its own stream while the interior row blocks (no ghost column)
+  // are processed; the boundary blocks follow once the ghosts have arrived.  Default (overlap_mode_ = -1): ON for a
+  // transport whose exchange is pure device work (RCCL: the send / receive group then costs its latency only where an
+  // operand has too few interior blocks to cover it), OFF for the host-staged transport, whose exchange synchronises the
+  // host anyway (measured slower there).  AIRHIP_OVERLAP=0|1 forces it; correctness is covered with the staged transport
+  // by the 2- and 4-rank GPU tests.
+  int overlap_mode_ = -1;
   bool overlap_ = false;
   int64_t overlap_min_blocks_ = 8192;   // interior row blocks (x 512 non-zeros) below which the plain path is used
   hipStream_t comm_stream_ = nullptr;

@@ -150,9 +150,15 @@ def _rccl_worker(rank, world, port, out):
         pcs = P.PCAIR(a_lump=True); pcs.setup(A)
         xs = torch.ones_like(b)
         r2 = ksp.solve(b, xs, pc=pcs)
+        # the distributed cycle through a captured hipGraph (the RCCL transport's exchange is pure device work, so the
+        # capture is allowed with a communicator attached; DevPCAIR::graph_ok) must give the same iterates
+        pc.use_graph(True)
+        xg = torch.ones_like(b)
+        r3 = ksp.solve(b, xg, pc=pc)
         st = comm.stats()
         with open(out, "w") as f:
-            f.write(repr(dict(its=r1["its"], its_single=r2["its"], diff=float((x - xs).abs().max()), stats=st)))
+            f.write(repr(dict(its=r1["its"], its_single=r2["its"], its_graph=r3["its"], diff=float((x - xs).abs().max()),
+                              diff_graph=float((xg - x).abs().max()), stats=st)))
         comm.close()
     finally:
         dist.destroy_process_group()
@@ -166,6 +172,7 @@ def test_rccl_transport_loads_and_reduces(gpu, tmp_path):
     proc_util.spawn(_rccl_worker, (1, _free_port(), out), 1)
     r = eval(open(out).read())
     assert r["its"] == r["its_single"] and r["diff"] <= 1e-12, r
+    assert r["its_graph"] == r["its"] and r["diff_graph"] == 0.0, r
     assert r["stats"]["allreduces"] > 0
 
 

@@ -239,3 +239,37 @@ def test_ex6f_with_the_products_host_setup(label, opts, bound, regen):
         H = bridge.hierarchy_from_product(P.PCAIR(**popts).setup_host_only(M), M)
         return lambda r: R.vcycle(H, r)
     assert ex6f(opts, bound, regen, setup=setup) <= bound
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# python/run_parse_tests.py:41-84,124-141 of the reference: the two `adv_diff_fd` runs it parses (8 x 8, `-pc_air_smooth_type fc`
+# and `-pc_air_cf_splitting_type diag_dom -pc_air_strong_threshold 0.9`) must converge within -ksp_max_it 3, report a grid
+# complexity below 3.0 and a reuse-storage complexity of 0.  Oracle and product (host setup) both.
+PARSE_TESTS = [
+    ("fc", dict(smooth_type="fc"), dict(smooth_type="fc")),
+    ("diag_dom_0.9", dict(cf_splitting_type="diag_dom", strong_threshold=0.9), dict(cf_splitting_type="diag_dom", strong_threshold=0.9)),
+]
+
+
+@pytest.mark.parametrize("label,oopts,popts", PARSE_TESTS, ids=[t[0] for t in PARSE_TESTS])
+def test_run_parse_tests_grid_complexity_and_iterations(label, oopts, popts):
+    import pflare_amd as P
+    from oracle import bridge
+    A = R.gen_adv_diff_fd(dim=2, M=8, N=8)
+    n = A.shape[0]
+    b = np.zeros(n); x0 = np.ones(n)
+    # oracle
+    H = R.setup_air(A, R.AirOptions(**oopts))
+    sizes = [L.n for L in H.levels] + [H.coarse_A.shape[0]]
+    grid_oracle = sum(sizes) / n
+    assert grid_oracle < 3.0, (label, grid_oracle)
+    _, its, reason, _ = R.ksp_gmres(A, lambda r: R.vcycle(H, r), b, x0, rtol=1e-5, max_it=3, pc_side="left")
+    assert reason > 0 and its <= 3, (label, its, reason)
+    # product (host setup; the statistics are what -pc_air_print_stats_timings prints)
+    pc = P.PCAIR(**popts).setup_host_only(A)
+    cx = pc.complexities()
+    assert cx["grid"] < 3.0, (label, cx)
+    Hp = bridge.hierarchy_from_product(pc, A)
+    _, its_p, reason_p, _ = R.ksp_gmres(A, lambda r: R.vcycle(Hp, r), b, x0, rtol=1e-5, max_it=3, pc_side="left")
+    assert reason_p > 0 and its_p <= 3, (label, its_p, reason_p)
+    # "reuse_storage complexity == 0.0": no reuse is built, the printed value is the constant 0 (tests/test_capi.py checks the line)
