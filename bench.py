@@ -41,6 +41,26 @@ RECIPES = {
 }
 
 
+def cpu_share():
+    """CPUs this process may use: the affinity mask cut by the cgroup CPU quota (cpu.max / cfs_quota)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(per))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, -(-q // per)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -50,7 +70,8 @@ def main():
     ap.add_argument("--recipe", default="trunc", choices=sorted(RECIPES))
     ap.add_argument("--max-levels", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=8, help="Krylov iterations of the CPU baseline sample (about 2 s each at 464^3 on 32 threads)")
+    ap.add_argument("--cpu-iters", type=int, default=8, help="Krylov iterations of one CPU baseline sample (about 2 s each at 464^3 on 32 threads)")
+    ap.add_argument("--cpu-samples", type=int, default=3, help="CPU baseline samples (each --cpu-iters iterations from x0 = 1); the median is reported")
     ap.add_argument("--graph", type=int, default=0)
     ap.add_argument("--profile-kernels", type=int, default=1)
     ap.add_argument("--variants", default="", help="diagnostic: ';'-separated tunings to time on the same hierarchy, each a "
@@ -262,16 +283,25 @@ def main():
     if not args.no_cpu_baseline:
         import numpy as np
         from oracle import c_oracle
-        cores = c_oracle.set_threads(threads)
+        share = cpu_share()
+        cpu_threads = int(os.environ.get("AIRHIP_NUM_THREADS", 0)) or (args.threads if args.threads > 0 else max(1, min(share, 32)))
+        cores = c_oracle.set_threads(cpu_threads)
         ch = c_oracle.CHierarchy(pc, copy=False)
         b0 = np.zeros(n); x1 = np.ones(n)
-        tc = time.time()
-        _, its_c, _, _, hist_c = ch.ksp(hm, b0, x1, "gmres", "right", rtol=1e-300, atol=1e-300, max_it=args.cpu_iters)
-        dt = time.time() - tc
-        cpu = {"value": its_c / dt, "unit": "KSP iterations/s", "cores": cores, "kind": "port",
-               "sample": f"{its_c} right-preconditioned GMRES iterations (SpMV + AIR V-cycle + CGS) of the same "
-                         f"{M}^3 system on the same hierarchy, C/OpenMP restatement of the reference algorithm "
-                         f"(oracle/air_oracle.c), {dt:.1f}s"}
+        rates, hist_c, its_c, dts = [], [], 0, []
+        for _ in range(max(1, args.cpu_samples) if args.cpu_iters > 0 else 1):
+            tc = time.time()
+            _, its_c, _, _, hist_c = ch.ksp(hm, b0, x1, "gmres", "right", rtol=1e-300, atol=1e-300, max_it=args.cpu_iters)
+            dt = time.time() - tc
+            dts.append(dt); rates.append(its_c / dt if dt > 0 else 0.0)
+        med = sorted(rates)[len(rates) // 2]
+        cpu = {"value": med, "unit": "KSP iterations/s", "cores": cores, "kind": "port",
+               "host_logical_cpus": os.cpu_count(), "cpu_share": share, "threads": cores,
+               "samples": [round(r_, 4) for r_ in rates],
+               "sample": f"median of {len(rates)} samples of {its_c} right-preconditioned GMRES iterations (SpMV + AIR V-cycle + CGS) "
+                         f"of the same {M}^3 system on the same hierarchy, C/OpenMP restatement of the reference algorithm "
+                         f"(oracle/air_oracle.c) on {cores} threads (host: {os.cpu_count()} logical CPUs, this process may use "
+                         f"{share}), {sum(dts):.1f}s in all"}
         del ch
         log(f"[bench] cpu baseline: {cpu}")
     if not dist_mode:
