@@ -436,6 +436,22 @@ def main():
                     "heaviest_call_site": {"site": f"{site['name']} (level {site['level'] + 1})", "avg_launch_ms": site_avg,
                                            "alg_bytes": site["alg_bytes"],
                                            "achieved": site["alg_bytes"] / (site_avg * 1e-3) / 1e9}}
+        # the other profiled kernel functions of the cycle, the same way (k_rb_fc_first is a quarter of the cycle)
+        others = {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pmc_all = json.load(f)
+        except Exception:
+            pmc_all = {}
+        for kn, kk in kern.items():
+            if kn == kname or kk["bytes"] <= 0:
+                continue
+            ach = kk["bytes"] / (kk["total_ms"] * 1e-3) / 1e9
+            ent = pmc_all.get(f"{kn}@{M}") if world == 1 else None
+            others[kn] = {"achieved": ach, "frac": ach / HBM_PEAK_GBS, "avg_launch_ms": kk["total_ms"] / kk["calls"], "calls": kk["calls"],
+                          "alg_bytes_per_launch": kk["bytes"] / kk["calls"], "traffic": ent["bytes_per_launch"] if ent else None,
+                          "share_of_profiled_kernel_time": kk["total_ms"] / tot_ms}
+        roofline["other_kernels"] = others
         # whole V-cycle: algorithmic bytes of one cycle / measured kernel time of one cycle
         cycles = max(1, next((s["calls"] for s in live if s["name"].startswith("restrict") and s["level"] == 0), 1))
         vc_ms = sum(s["total_ms"] for s in live if s["level"] >= 0)     # level -1 = outer Krylov operator product
