@@ -298,7 +298,22 @@ def _refdata_worker(rank, world, port, out, case):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", sorted(PAR_LOAD_CASES))
+# The default run keeps the cases that reach a distinct path of the DISTRIBUTED device cycle (Horner / Newton matrix-free
+# applies with a halo, the zero-level PCPFLAREINV, C smoothing with its three extra operands, diagonal inverses, Neumann
+# scaling, coarse Richardson iterations, auto truncation, a general W, right preconditioning).  The others differ only in
+# what the HOST setup builds (CF splitting types, SAI / ISAI / lAIR, improvement iterations) - covered on one rank by
+# tests/test_host_setup.py and tests/test_oracle_reference_bounds.py; AIRHIP_ALL_PARALLEL_CASES=1 runs them here too
+# (each is a 2-process spawn of about 2.3 s: together they were 40 % of the GPU suite's wall-clock).
+_HOST_VARIETY_ONLY = {"258 assembled newton order 2", "260 assembled newton order 3", "755 adv 10x10 diag_dom 0.9",
+                      "758 adv 10x10 compatible relaxation 0.1", "836 diffusion power a_drop", "839 diffusion arnoldi",
+                      "842 diffusion lAIR", "851 diffusion neumann", "858 diffusion SAI", "862 diffusion ISAI",
+                      "866 diffusion weighted jacobi", "1037-1040 adv 100x100 diag_dom 0.50001",
+                      "1056-1059 adv 100x100 compatible relaxation", "1089-1090 adv 50x50 improve Z"}
+assert _HOST_VARIETY_ONLY <= set(PAR_LOAD_CASES)
+_RUN_ALL = bool(os.environ.get("AIRHIP_ALL_PARALLEL_CASES"))
+
+
+@pytest.mark.parametrize("case", [c for c in sorted(PAR_LOAD_CASES) if _RUN_ALL or c not in _HOST_VARIETY_ONLY])
 def test_reference_parallel_load_test_two_ranks(gpu, tmp_path, case):
     """tests/Makefile:212-279 (`$(MPIEXEC) -n 2 ./ex6 ...` / `./ex12f ...` on the reference's data files): the distributed
     product must converge within the reference's bound on two ranks (row-block ownership instead of the reference's graph
