@@ -105,6 +105,7 @@ void devmat_from_csr_device(int64_t m, int64_t n, const int64_t* d_rp, const int
                           const int32_t* d_rowsrc, const int32_t* d_colmap, DevMat& out, hipStream_t s,
                           int64_t n_ghost = 0);   // the last n_ghost columns are not remapped
 void devmat_free(DevMat& A);
+void devmat_reallocate(DevMat& A, hipStream_t s);      // see spmv.hip
 
 // performance knobs (not part of the stable ABI; airhip_set_tuning): see spmv.hip
 int spmv_set_tuning(const char* key, int value);

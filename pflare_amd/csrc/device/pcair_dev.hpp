@@ -31,6 +31,7 @@ void set_block_order_min(int64_t nblocks);
 // diagnostic (airhip_set_tuning "fc_fuse"): 0 runs the first stage of an F relaxation as a gather (one-point prolongation)
 // followed by a plain A_fc product instead of the fused k_rb_fc_first; same results, one more pass over the F vectors
 void set_fc_fuse(bool on);
+void set_exp_copy_x(int v);      // experiment, see pcair_dev.cpp
 
 // Upload a host CSR and convert it to SELL-64 on the device (rows/cols optionally permuted).
 void upload_mat(const Csr& A, const int32_t* d_rowsrc, const int32_t* d_colmap, DevMat& out, hipStream_t s, int64_t n_ghost = 0);
@@ -61,6 +62,7 @@ struct DevLevel {
   DevInv inv_ff, inv_cc;
   int smooth_order[10] = {0};
   DBuf<double> t4, r, t4c, rc;
+  DBuf<double> xcopy;            // experiment (exp_copy_x)
   int64_t nnz_A = 0;
   // full up / down smoothing: the level operator in the level's hierarchical ordering (inv_ff is then n x n) and the
   // residual of the level, whose C part is the next level's right-hand side

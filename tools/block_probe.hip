@@ -293,7 +293,9 @@ int main(int argc, char** argv) {
     const double ms = time_ms([&] { hipLaunchKernelGGL(kern, dim3(256 * wg_per_cu), dim3(waves * 64), 0, 0, a); });
     std::printf("%-64s %8.3f ms  %7.1f GB/s (stream + y)\n", name, ms, (stream_bytes + nblocks * 16 * 8.0) / ms * 1e-6);
   };
+  const bool only_placement = std::getenv("PROBE_PLACEMENT_ONLY") != nullptr;
   for (int window : {-256, -2048}) {
+    if (only_placement) break;
     fill_idx(window, 16);
     std::printf("-- gather + LDS row sums, stencil inside %d columns, 16 rows per block: blocks per wave / persistent waves\n", -window);
     run("reference: one block per wave, val 4 x dwordx4, idx 8 x dword", k_block<4, 1, 0, 1, 1, 1, 4>, 4, 16);
@@ -313,6 +315,41 @@ int main(int argc, char** argv) {
     }
     run_loop("k_loop persistent, 5 wg/CU, idx x4", k_loop<4, 4, 1>, 4, 5);
     run_loop("k_loop persistent, 6 wg/CU, 6 waves/SIMD forced", k_loop<1, 4, 6>, 4, 6);
+  }
+  // ---- does the relative placement of the index and the value array matter?  (per-operator rates of the benchmark move by
+  // +-8 % from run to run with the same kernel: the arrays land at other physical addresses each time)
+  {
+    fill_idx(-256, 16);
+    char* big; const size_t slack = (size_t)64 << 20;
+    CHECK(hipMalloc(&big, (size_t)nnz * 12 + 2 * slack));
+    CHECK(hipMemcpy(big, val, (size_t)nnz * 8, hipMemcpyDeviceToDevice));
+    std::printf("-- index array placed d bytes behind the end of the value array (one allocation), gather + LDS row sums\n");
+    for (size_t d : {(size_t)0, (size_t)256, (size_t)1024, (size_t)4096, (size_t)16384, (size_t)65536, (size_t)262144, (size_t)1 << 20, ((size_t)2 << 20) + 4096, ((size_t)32 << 20) + 8192}) {
+      uint32_t* ip = (uint32_t*)(big + (size_t)nnz * 8 + d);
+      CHECK(hipMemcpy(ip, idx, (size_t)nnz * 4, hipMemcpyDeviceToDevice));
+      Args a{ip, (const double*)big, blob, desc, x, y, nblocks, 16};
+      const int64_t per_class = (nblocks + 7) / 8;
+      const unsigned grid = (unsigned)(8 * ((per_class + 3) / 4));
+      const double ms = time_ms([&] { hipLaunchKernelGGL((k_block<4, 1, 0, 1, 1, 1, 4>), dim3(grid), dim3(256), 0, 0, a); });
+      std::printf("   d = %10zu   %8.3f ms  %7.1f GB/s\n", d, ms, (stream_bytes + nblocks * 16 * 8.0) / ms * 1e-6);
+    }
+    std::printf("-- the same arrays as separate allocations (new addresses each time): which = 0 both move, 1 only idx, 2 only val\n");
+    for (int which = 0; which < 3; which++)
+      for (int rep = 0; rep < 16; rep++) {
+        uint32_t* i2 = idx; double* v2 = val; void* pad;
+        CHECK(hipMalloc(&pad, ((size_t)(rep * 5 + 1) << 20) + (size_t)rep * 4096 * 37));
+        if (which != 2) { CHECK(hipMalloc(&i2, (size_t)nnz * 4)); CHECK(hipMemcpy(i2, idx, (size_t)nnz * 4, hipMemcpyDeviceToDevice)); }
+        if (which != 1) { CHECK(hipMalloc(&v2, (size_t)nnz * 8)); CHECK(hipMemcpy(v2, val, (size_t)nnz * 8, hipMemcpyDeviceToDevice)); }
+        Args a{i2, v2, blob, desc, x, y, nblocks, 16};
+        const int64_t per_class = (nblocks + 7) / 8;
+        const unsigned grid = (unsigned)(8 * ((per_class + 3) / 4));
+        const double ms = time_ms([&] { hipLaunchKernelGGL((k_block<4, 1, 0, 1, 1, 1, 4>), dim3(grid), dim3(256), 0, 0, a); });
+        std::printf("   which %d rep %2d  idx %p val %p   %8.3f ms  %7.1f GB/s\n", which, rep, (void*)i2, (void*)v2, ms, (stream_bytes + nblocks * 16 * 8.0) / ms * 1e-6);
+        if (which != 2) CHECK(hipFree(i2));
+        if (which != 1) CHECK(hipFree(v2));
+        CHECK(hipFree(pad));
+      }
+    CHECK(hipFree(big));
   }
   return 0;
 }
