@@ -85,3 +85,25 @@ def test_mpi_path_is_wired():
     assert "airhip_mpi_pcair_setup" in SRC and "MatMPIAIJGetSeqAIJ" in SRC
     assert "PETSC_VERSION_GE(3, 23, 0)" in SRC          # PetscOptionItems by value only from 3.23 on
     assert "hipDeviceSynchronize" in SRC                 # no stream handle: synchronise instead of assuming the NULL stream
+
+
+import pytest
+import shutil
+
+
+@pytest.mark.parametrize("defs", [["-DAIRHIP_WITH_MPI"], [], ["-DAIRHIP_WITH_MPI", "-DPETSC_VERSION_MINOR=22"], ["-DPETSC_VERSION_MINOR=19"],
+                                  ["-DAIRHIP_PETSC_NO_STREAM_HANDLE"]],
+                         ids=["mpi", "one-rank", "petsc-3.22-options-by-pointer", "petsc-3.19-no-stream-handle", "no-stream-handle"])
+def test_glue_passes_the_c_compiler_against_a_mock_of_the_petsc_api(defs):
+    """No PETSc in this image: the glue is compiled (-fsyntax-only -Wall -Wextra -Werror) against tests/petsc_mock, a minimal
+    mock of the PETSc API subset it uses (declarations only, written from the manual pages).  This checks the C of the file -
+    syntax, types, macro expansions, argument counts against include/airhip.h and include/airhip_mpi.h - in the
+    configurations its version macros select; it proves nothing about a real PETSc."""
+    if not shutil.which("gcc") or not os.path.exists("/opt/conda/include/mpi.h"):
+        pytest.skip("needs gcc and an mpi.h")
+    mock = os.path.join(ROOT, "tests", "petsc_mock")
+    cmd = ["gcc", "-fsyntax-only", "-std=c11", "-Wall", "-Wextra", "-Werror", "-Wno-unused-parameter", "-D__HIP_PLATFORM_AMD__"] + defs + \
+          ["-I" + mock, "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include", "-idirafter", "/opt/conda/include",
+           os.path.join(ROOT, "pflare_amd", "csrc", "petsc_glue.c")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
