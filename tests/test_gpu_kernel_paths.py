@@ -1,9 +1,11 @@
 """Every path of the row-block SpMV kernel (csrc/device/spmv.hip), hit on purpose and checked against scipy
 (airhip_mat_mult through the C ABI, <= 1e-13 relative: PFLARE_TOL_MATFREE_13, src/Pflare_Parameters.F90:209):
 
-* packed blocks (column-sorted, block-relative 23-bit columns) and raw blocks (column span >= 2^23: row-major,
-  absolute columns) - the round-1 kernel switched formats on the operator width (2^22 columns) and the wide mode,
-  the one the 464^3 benchmark runs, had no test;
+* packed blocks (column-sorted, block-relative 19-bit columns: rb.hpp COL_BITS) and raw blocks (column span >= 2^19:
+  row-major, absolute columns) - the round-1 kernel switched formats on the operator width (2^22 columns) and the wide
+  mode, the one the 464^3 benchmark runs, had no test;
+* every straight-line variant of the block code (0 ... 8 full rounds of 64 entries, with and without a partial round; values
+  of paired full rounds interleaved for 16-byte loads), on packed and on raw blocks;
 * a row longer than a block (wave-per-row reduction), rows of exactly 512 / 513 entries;
 * blocks of <= 32 rows (T lanes share a row) for every T, blocks of 128 rows (two rows per lane), empty rows;
 * matrices of 1, 2, 3 ... blocks (waves without a block, partly filled workgroups) and of many thousands;
@@ -74,7 +76,7 @@ def env(gpu):
 
 def test_packed_and_raw_blocks_on_a_wide_operator(env):
     """20 M columns: rows with local columns give packed blocks, rows with columns spread over the whole width
-    give raw blocks (span >= 2^23), both kinds interleaved in one matrix"""
+    give raw blocks (span >= 2^19), both kinds interleaved in one matrix"""
     torch, P = env
     rng = np.random.default_rng(1)
     n = 20_000_000
@@ -93,6 +95,33 @@ def test_packed_and_raw_blocks_on_a_wide_operator(env):
         cols[indptr[i]:indptr[i + 1]] = c
     vals = rng.standard_normal(indptr[-1])
     A = sp.csr_matrix((vals, cols, indptr), shape=(m, n))
+    _check(A, torch, P)
+
+
+@pytest.mark.parametrize("wide", [False, True], ids=["packed", "raw"])
+def test_every_round_count_variant(env, wide):
+    """one row per block (rows of 257 ... 512 entries cannot share a block; shorter ones are separated by an empty-free
+    filler of 512): every number of full rounds 0 ... 8, with remainders 0, 1, 63"""
+    torch, P = env
+    rng = np.random.default_rng(7 + int(wide))
+    n = 3_000_000 if wide else 40_000
+    lengths = []
+    for nf in range(0, 9):
+        for rem in (0, 1, 31, 63):
+            L = 64 * nf + rem
+            if 0 < L <= 512:
+                lengths += [L, 512]          # the 512-entry row after it closes the block
+    lengths += [64, 64, 64, 64, 64, 64, 64, 64, 1, 448, 64, 449, 63]     # several rows per block as well
+    indptr = np.concatenate([[0], np.cumsum(lengths)])
+    cols = np.empty(indptr[-1], dtype=np.int64)
+    for i, L in enumerate(lengths):
+        if wide:
+            c = rng.choice(n, size=L, replace=False)                      # span >= 2^19 almost surely
+        else:
+            lo = (i * 97) % (n - 4000)
+            c = lo + rng.choice(4000, size=L, replace=False)
+        cols[indptr[i]:indptr[i + 1]] = np.sort(c)
+    A = sp.csr_matrix((rng.standard_normal(indptr[-1]), cols, indptr), shape=(len(lengths), n))
     _check(A, torch, P)
 
 
