@@ -47,6 +47,9 @@ struct DevMat {
   // that gather the same neighbourhood of x run close together in time (DevPCAIR::upload): the descriptors again,
   // in that order
   BlkDesc* desc_ord = nullptr;
+  // transient operator (the setup's truncation test): its four arrays come from the block cache of device/devmem.hpp and go
+  // back to it - a hipMalloc that follows the release of multi-GB blocks stalls for seconds every so often
+  bool cached = false;
   bool valid() const { return blk != nullptr; }
   // algorithmic bytes of one SpMV with this operator: S(X) of SURVEY 8(d)
   double s_bytes() const { return 12.0 * nnz + 4.0 * (m + 1) + 8.0 * m + 8.0 * n; }
@@ -103,7 +106,8 @@ int mdot_scratch_doubles(int nv);
 // row rowsrc[r]; colmap (may be null): column c becomes colmap[c].
 void devmat_from_csr_device(int64_t m, int64_t n, const int64_t* d_rp, const int32_t* d_ci, const double* d_v,
                           const int32_t* d_rowsrc, const int32_t* d_colmap, DevMat& out, hipStream_t s,
-                          int64_t n_ghost = 0);   // the last n_ghost columns are not remapped
+                          int64_t n_ghost = 0,    // the last n_ghost columns are not remapped
+                          bool cached = false);   // see DevMat::cached
 void devmat_free(DevMat& A);
 void devmat_reallocate(DevMat& A, hipStream_t s);      // see spmv.hip
 

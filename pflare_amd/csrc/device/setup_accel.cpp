@@ -128,7 +128,7 @@ struct DevSetupAccel final : SetupAccel {
       const bool have = is_resident(A);
       if (!have && !A.on_host()) return false;
       DCsr dA = have ? resident : up(A);
-      devmat_from_csr_device(dA.m, dA.n, dA.rp, dA.ci, dA.v, nullptr, nullptr, B.M, stream);
+      devmat_from_csr_device(dA.m, dA.n, dA.rp, dA.ci, dA.v, nullptr, nullptr, B.M, stream, 0, true);   // arrays from / to the block cache
       HIP_CHECK(hipStreamSynchronize(stream));
       if (!have) dcsr_free(dA);
     }

@@ -682,9 +682,10 @@ static int grid1d(int64_t n) {
 }
 
 void devmat_from_csr_device(int64_t m, int64_t n, const int64_t* d_rp, const int32_t* d_ci, const double* d_v,
-                            const int32_t* d_rowsrc, const int32_t* d_colmap, DevMat& out, hipStream_t s, int64_t n_ghost) {
+                            const int32_t* d_rowsrc, const int32_t* d_colmap, DevMat& out, hipStream_t s, int64_t n_ghost, bool cached) {
   devmat_free(out);
-  out.m = m; out.n = n; out.n_ghost = n_ghost;
+  out.m = m; out.n = n; out.n_ghost = n_ghost; out.cached = cached;
+  auto alloc_out = [&](size_t bytes) { return cached ? dev_alloc(bytes) : dev_alloc_exact(bytes); };
   if (m == 0) return;
   if (m >= (1ll << 29) || n >= (1ll << 29)) throw std::runtime_error("matrix dimension exceeds the 2^29 rows / columns of the 32-bit byte offsets");
   // temporaries come from the block cache (device/devmem.hpp), the arrays of the matrix itself are exact allocations
@@ -706,13 +707,13 @@ void devmat_from_csr_device(int64_t m, int64_t n, const int64_t* d_rp, const int
   hipLaunchKernelGGL((k_chunk_blocks<false>), dim3(grid1d(nchunks)), dim3(BLOCK), 0, s, m, d_nrp, d_cnt, nullptr, nullptr, nullptr);
   out.nblocks = device_exclusive_scan(nchunks, d_cnt, d_first, s);
   if (out.nblocks >= (1ll << 31) - 8) throw std::runtime_error("matrix has too many row blocks");
-  out.blk = (BlkDesc*)dev_alloc_exact(sizeof(BlkDesc) * (size_t)(out.nblocks + 1));
-  out.roff = (uint16_t*)dev_alloc_exact(sizeof(uint16_t) * (size_t)m);
+  out.blk = (BlkDesc*)alloc_out(sizeof(BlkDesc) * (size_t)(out.nblocks + 1));
+  out.roff = (uint16_t*)alloc_out(sizeof(uint16_t) * (size_t)m);
   hipLaunchKernelGGL((k_chunk_blocks<true>), dim3(grid1d(nchunks)), dim3(BLOCK), 0, s, m, d_nrp, d_cnt, d_first, out.blk, out.roff);
   const BlkDesc end{out.nnz, (int32_t)m, 0, 0, 0, {0, 0}};       // readable padding entry (empty block)
   HIP_CHECK(hipMemcpyAsync(out.blk + out.nblocks, &end, sizeof(BlkDesc), hipMemcpyHostToDevice, s));
-  out.idx = (uint32_t*)dev_alloc_exact(sizeof(uint32_t) * (size_t)(out.nnz + 1));
-  out.val = (double*)dev_alloc_exact(sizeof(double) * (size_t)(out.nnz + 1));
+  out.idx = (uint32_t*)alloc_out(sizeof(uint32_t) * (size_t)(out.nnz + 1));
+  out.val = (double*)alloc_out(sizeof(double) * (size_t)(out.nnz + 1));
   HIP_CHECK(hipMemsetAsync(out.idx + out.nnz, 0, sizeof(uint32_t), s));
   HIP_CHECK(hipMemsetAsync(out.val + out.nnz, 0, sizeof(double), s));
   const int g = (int)std::min<int64_t>((out.nblocks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 4096);
@@ -737,7 +738,7 @@ static void move_array(void** p, size_t bytes, hipStream_t s) {
   *p = q;
 }
 void devmat_reallocate(DevMat& A, hipStream_t s) {
-  if (!A.valid()) return;
+  if (!A.valid() || A.cached) return;
   move_array((void**)&A.val, sizeof(double) * (size_t)(A.nnz + 1), s);
   move_array((void**)&A.idx, sizeof(uint32_t) * (size_t)(A.nnz + 1), s);
   move_array((void**)&A.blk, sizeof(BlkDesc) * (size_t)(A.nblocks + 1), s);
@@ -748,6 +749,7 @@ void devmat_reallocate(DevMat& A, hipStream_t s) {
 }
 
 void devmat_free(DevMat& A) {
+  if (A.cached) { dev_free(A.blk); dev_free(A.roff); dev_free(A.idx); dev_free(A.val); A.blk = nullptr; A.roff = nullptr; A.idx = nullptr; A.val = nullptr; }
   if (A.blk) (void)hipFree(A.blk);
   if (A.roff) (void)hipFree(A.roff);
   if (A.idx) (void)hipFree(A.idx);
