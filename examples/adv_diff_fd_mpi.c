@@ -8,7 +8,8 @@
  *   make -C pflare_amd/csrc mpi && make -C examples adv_diff_fd_mpi
  *   mpiexec -n 2 examples/adv_diff_fd_mpi -dim 3 -da_grid_x 24 -pc_air_a_lump 1 -ksp_max_it 6
  * Options: -dim 2|3, -da_grid_x/-da_grid_y/-da_grid_z, -u -v -w -alpha, -ksp_max_it, -ksp_rtol, -transport staged|rccl,
- * -same_device 0|1, -host_only 1 (stop after every rank has received its piece: no GPU needed), any -pc_air_<name> <value>.
+ * -same_device 0|1, -layout_hint 0|1 (brick keys for the device layout, default 1), -host_only 1 (stop after every rank has
+ * received its piece: no GPU needed), any -pc_air_<name> <value>.
  */
 #include <mpi.h>
 #include <stdio.h>
@@ -25,7 +26,7 @@ int main(int argc, char** argv) {
   int rank, size;
   MPI_Comm_rank(MPI_COMM_WORLD, &rank);
   MPI_Comm_size(MPI_COMM_WORLD, &size);
-  int dim = 3, max_it = 10, host_only = 0, same_device = 0, transport = AIRHIP_MPI_TRANSPORT_STAGED;
+  int dim = 3, max_it = 10, host_only = 0, same_device = 0, transport = AIRHIP_MPI_TRANSPORT_STAGED, use_hint = 1;
   long gx = 16, gy = -1, gz = -1;
   double u = 1.0, v = 1.0, w = 1.0, alpha = 0.0, rtol = 1e-10;
   const char* names[64]; const char* values[64]; int nopts = 0;
@@ -43,6 +44,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(k, "-ksp_rtol")) rtol = atof(val);
     else if (!strcmp(k, "-host_only")) host_only = atoi(val);
     else if (!strcmp(k, "-same_device")) same_device = atoi(val);
+    else if (!strcmp(k, "-layout_hint")) use_hint = atoi(val);
     else if (!strcmp(k, "-transport")) transport = !strcmp(val, "rccl") ? AIRHIP_MPI_TRANSPORT_RCCL : AIRHIP_MPI_TRANSPORT_STAGED;
     else if (!strncmp(k, "-pc_air_", 8) && nopts < 64) { names[nopts] = k + 8; values[nopts] = val; nopts++; }
     else DIE("unknown option %s", k);
@@ -62,9 +64,18 @@ int main(int argc, char** argv) {
   airhip_csr L;
   L.m = r1 - r0; L.n = n; L.rowptr = G.rowptr + r0; L.col = G.col; L.val = G.val;   /* rowptr stays absolute: the layer uses differences */
   /* col / val are addressed through rowptr[0]: hand over pointers that rowptr indexes correctly */
+  /* what a DM would tell the preconditioner: the 8^3 brick of each of this rank's grid points (device layout only) */
+  int64_t* hint = (int64_t*)malloc(sizeof(int64_t) * (size_t)(L.m ? L.m : 1));
+  {
+    const int64_t B = 8, nbx = (gx + B - 1) / B, nby = (gy + B - 1) / B;
+    for (int64_t r = r0; r < r1; r++) {
+      const int64_t i = r % gx, j = (r / gx) % gy, k = r / (gx * gy);
+      hint[r - r0] = (((k / B) * nby + (j / B)) * nbx + (i / B)) * (B * B * B) + ((k % B) * B + (j % B)) * B + (i % B);
+    }
+  }
   airhip_mpi_pcair pc = NULL;
   double st[5];
-  if (airhip_mpi_pcair_setup(MPI_COMM_WORLD, &L, nopts, names, values, NULL, transport, host_only, &pc, st) != AIRHIP_OK)
+  if (airhip_mpi_pcair_setup(MPI_COMM_WORLD, &L, nopts, names, values, use_hint ? hint : NULL, transport, host_only, &pc, st) != AIRHIP_OK)
     DIE("rank %d: setup failed: %s", rank, airhip_mpi_last_error());
   if (host_only) {
     double piece = st[2], total = 0.0;
@@ -72,6 +83,7 @@ int main(int argc, char** argv) {
     if (rank == 0) printf("adv_diff_fd_mpi ranks=%d n=%lld levels=%d pieces=%.0f bytes (host only)\n", size, (long long)n, (int)st[0], total);
     airhip_mpi_pcair_destroy(&pc);
     airhip_hostmat_destroy(&A);
+    free(hint);
     MPI_Finalize();
     return 0;
   }
@@ -94,7 +106,7 @@ int main(int argc, char** argv) {
   if (rank == 0)
     printf("adv_diff_fd_mpi ranks=%d n=%lld levels=%d iterations=%d reason=%d rnorm=%.6e max|x|=%.3e exchanges=%lld messages=%lld allreduces=%lld\n",
            size, (long long)n, (int)st[0], res.its, res.reason, res.rnorm, gmx, (long long)ex, (long long)msgs, (long long)ars);
-  hipFree(b); hipFree(x); free(hx);
+  hipFree(b); hipFree(x); free(hx); free(hint);
   airhip_mpi_pcair_destroy(&pc);
   airhip_hostmat_destroy(&A);
   MPI_Finalize();

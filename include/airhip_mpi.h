@@ -29,7 +29,8 @@ const char* airhip_mpi_last_error(void);
 
 /* Collective over comm.
  *   local   this rank's rows of the operator: m = owned rows, n = GLOBAL number of columns, GLOBAL column indices
- *           ascending within a row; rank r owns the rows that follow rank r-1's (MPIAIJ ownership)
+ *           ascending within a row; rank r owns the rows that follow rank r-1's (MPIAIJ ownership).  rowptr[0] need not
+ *           be 0: row i holds col / val [rowptr[i], rowptr[i+1]) (a window into a larger CSR is fine)
  *   names / values   nopts options as for airhip_pcair_set_option ("-pc_air_" prefix removed); rank 0's are used
  *   hint    optional locality key per owned row for the device layout (airhip_pcair_set_ordering_hint), or NULL
  *   host_only != 0: stop after every rank has received its piece of the hierarchy (no device needed; CPU tests) -
