@@ -6,6 +6,7 @@
 #include "rb.hpp"
 #include "devmem.hpp"
 #include <stdexcept>
+#include <algorithm>
 
 namespace airhip {
 
@@ -63,7 +64,73 @@ __global__ __launch_bounds__(BLOCK) void k_split_fill(Src A, const uint32_t* __r
 
 template <class T> T* dalloc(int64_t n) { return (T*)dev_alloc(sizeof(T) * (size_t)(n > 0 ? n : 1)); }
 
+// one wave per row of Z: its entries move over with their columns renumbered, the identity entry goes where its column
+// C[j] belongs (F[.] ascends, so the entries below C[j] are a prefix of the row)
+__global__ __launch_bounds__(BLOCK) void k_build_R(int64_t nc, const int64_t* __restrict__ zrp, const int32_t* __restrict__ zci,
+                                                  const double* __restrict__ zv, const int32_t* __restrict__ F, const int32_t* __restrict__ C,
+                                                  int64_t* __restrict__ rrp, int32_t* __restrict__ rci, double* __restrict__ rv) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * BLOCK) >> 6;
+  for (int64_t j = wave; j < nc; j += nw) {
+    const int64_t a0 = zrp[j], a1 = zrp[j + 1], base = a0 + j;
+    const int32_t cj = C[j];
+    int below = 0;
+    for (int64_t k0 = a0; k0 < a1; k0 += WAVE) {
+      const int64_t k = k0 + lane;
+      const bool valid = k < a1;
+      const int32_t col = valid ? F[zci[k]] : 0;
+      const bool lt = valid && col < cj;
+      if (valid) { const int64_t o = base + (k - a0) + (lt ? 0 : 1); rci[o] = col; rv[o] = zv[k]; }
+      below += __popcll(__ballot(lt));
+    }
+    if (lane == 0) { rrp[j] = base; rci[base + below] = cj; rv[base + below] = 1.0; if (j == nc - 1) rrp[nc] = a1 + nc; }
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_p_count(int64_t n, const uint32_t* __restrict__ code, const int32_t* __restrict__ wcol, int64_t* __restrict__ cnt) {
+  const int64_t stride = (int64_t)gridDim.x * BLOCK;
+  for (int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x; r < n; r += stride) {
+    const uint32_t c = code[r];
+    cnt[r] = (c & FBIT) ? (wcol[c & ~FBIT] >= 0 ? 1 : 0) : 1;
+  }
+}
+__global__ __launch_bounds__(BLOCK) void k_p_fill(int64_t n, const uint32_t* __restrict__ code, const int32_t* __restrict__ wcol,
+                                                 const int64_t* __restrict__ rp, int32_t* __restrict__ ci, double* __restrict__ v) {
+  const int64_t stride = (int64_t)gridDim.x * BLOCK;
+  for (int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x; r < n; r += stride) {
+    const uint32_t c = code[r];
+    const int32_t col = (c & FBIT) ? wcol[c & ~FBIT] : (int32_t)c;
+    if (col >= 0) { ci[rp[r]] = col; v[rp[r]] = 1.0; }
+  }
+}
+
 }  // namespace
+
+DCsr dev_build_R(const DCsr& Z, const int32_t* d_F, const int32_t* d_C, int64_t n, hipStream_t s) {
+  DCsr R; R.m = Z.m; R.n = n; R.nnz = Z.nnz + Z.m;
+  R.rp = dalloc<int64_t>(R.m + 1); R.ci = dalloc<int32_t>(R.nnz); R.v = dalloc<double>(R.nnz);
+  if (R.m == 0) { const int64_t z = 0; HIP_CHECK(hipMemcpy(R.rp, &z, sizeof z, hipMemcpyHostToDevice)); return R; }
+  hipLaunchKernelGGL(k_build_R, dim3(MAX_BLOCKS), dim3(BLOCK), 0, s, Z.m, Z.rp, Z.ci, Z.v, d_F, d_C, R.rp, R.ci, R.v);
+  HIP_CHECK(hipStreamSynchronize(s));
+  return R;
+}
+
+DCsr dev_build_P_one_point(int64_t n, int64_t n_c, const uint32_t* d_code, const int32_t* d_wcol, hipStream_t s) {
+  DCsr P; P.m = n; P.n = n_c;
+  int64_t* cnt = dalloc<int64_t>(n);
+  P.rp = dalloc<int64_t>(n + 1);
+  const int g = (int)std::min<int64_t>((n + BLOCK - 1) / BLOCK, MAX_BLOCKS);
+  hipLaunchKernelGGL(k_p_count, dim3(g < 1 ? 1 : g), dim3(BLOCK), 0, s, n, d_code, d_wcol, cnt);
+  P.nnz = device_exclusive_scan(n, cnt, P.rp, s);
+  HIP_CHECK(hipMemcpyAsync(P.rp + n, &P.nnz, sizeof(int64_t), hipMemcpyHostToDevice, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  dev_free(cnt);
+  P.ci = dalloc<int32_t>(P.nnz); P.v = dalloc<double>(P.nnz);
+  hipLaunchKernelGGL(k_p_fill, dim3(g < 1 ? 1 : g), dim3(BLOCK), 0, s, n, d_code, d_wcol, P.rp, P.ci, P.v);
+  HIP_CHECK(hipStreamSynchronize(s));
+  return P;
+}
 
 void dev_split_fc(const DCsr& A, const uint32_t* d_code, int64_t n_f, int64_t n_c, DCsr& A_ff, DCsr& A_fc, DCsr& A_cf, DCsr* A_cc,
                   hipStream_t s) {

@@ -12,4 +12,13 @@ namespace airhip {
 void dev_split_fc(const DCsr& A, const uint32_t* d_code, int64_t n_f, int64_t n_c, DCsr& A_ff, DCsr& A_fc, DCsr& A_cf, DCsr* A_cc,
                   hipStream_t s);
 
+// R = [Z I] in level ordering where Z already is (host twin: air_setup.cpp build_R; reference src/Grid_Transfer.F90:588-815):
+// row j of R holds Z's row j with the columns F[.] and a one at column C[j], columns ascending.  d_F / d_C: the level's F and
+// C index lists on the device.
+DCsr dev_build_R(const DCsr& Z, const int32_t* d_F, const int32_t* d_C, int64_t n, hipStream_t s);
+// P = [W; I] for the one-point classical prolongator (host twin: build_P; src/Grid_Transfer.F90:329-461): row r of P is a
+// single one at column j for the level's j-th C point, at column wcol[i] for its i-th F point (no entry when wcol[i] < 0).
+// d_code as in dev_split_fc.
+DCsr dev_build_P_one_point(int64_t n, int64_t n_c, const uint32_t* d_code, const int32_t* d_wcol, hipStream_t s);
+
 }  // namespace airhip

@@ -30,6 +30,8 @@ struct DevSetupAccel final : SetupAccel {
   DCsr res_ff, res_cf;           // blocks of the last extraction: the A of the polynomial assembly, the A of Z = -A_cf M
   uint64_t ff_tag = 0, cf_tag = 0;
   uint64_t next_tag = 0;
+  DCsr res_z;                    // the last Z = -A_cf * M (spgemm_z): R = [Z I] is assembled from it for the R*A*P that follows
+  uint64_t z_tag = 0;
   DCsr inverse;                  // last assembled polynomial inverse (the B of the Z = -A_cf * M product that follows)
   const void* inverse_key = nullptr;
   int64_t min_nnz = 200000;      // smaller products stay on the host: launch + sync overheads dominate
@@ -103,7 +105,7 @@ struct DevSetupAccel final : SetupAccel {
     for (auto& p : pending) finish_one(*p, false);
     pending.clear();
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
-    dcsr_free(resident); dcsr_free(inverse); dcsr_free(res_ff); dcsr_free(res_cf);
+    dcsr_free(resident); dcsr_free(inverse); dcsr_free(res_ff); dcsr_free(res_cf); dcsr_free(res_z);
   }
 
   bool is_resident(const Csr& A) const {
@@ -128,7 +130,11 @@ struct DevSetupAccel final : SetupAccel {
     return C;
   }
 
-  Csr spgemm(const Csr& A, const Csr& B, const SpgemmDrop& drop) override {
+  Csr spgemm(const Csr& A, const Csr& B, const SpgemmDrop& drop) override { return product(A, B, drop, false); }
+  Csr spgemm_z(const Csr& A, const Csr& B, const SpgemmDrop& drop) override { return product(A, B, drop, true); }
+
+  Csr product(const Csr& A, const Csr& B, const SpgemmDrop& drop, bool keep) {
+    dcsr_free(res_z); z_tag = 0;
     if (A.nnz() + B.nnz() < min_nnz) { sync_host(nullptr); return airhip::spgemm(A, B, drop); }
     DCsr dA, dB;
     if (A.device_tag && A.device_tag == cf_tag && res_cf.rp && res_cf.nnz == A.nnz()) { dA = res_cf; res_cf = DCsr(); cf_tag = 0; }
@@ -142,7 +148,8 @@ struct DevSetupAccel final : SetupAccel {
     sync_host(nullptr);          // a download of dA (the C-F block) may still be reading it
     dcsr_free(dA); dcsr_free(dB);
     Csr C = down(dC);
-    dcsr_free(dC);
+    if (keep) { res_z = dC; z_tag = C.device_tag = ++next_tag; }
+    else dcsr_free(dC);
     return C;
   }
 
@@ -325,6 +332,46 @@ struct DevSetupAccel final : SetupAccel {
     resident_tag = C.device_tag = ++next_tag;
     resident_key = C.on_host() ? (const void*)C.rp.data() : nullptr;   // Arr moves keep the pointer
     return C;
+  }
+
+  // R = [Z I] and the one-point P = [W; I] assembled on the device from the Z that spgemm_z left here, then the two
+  // products of rap() - the host neither builds R and P nor uploads them (R alone is as large as Z)
+  bool rap_from_z(const Csr& Z, const Arr<int32_t>& F, const Arr<int32_t>& C, const Arr<int32_t>& wcol, const Csr& A,
+                  const SpgemmDrop& drop, Csr& coarse) override {
+    static const bool enabled = [] { const char* e = std::getenv("AIRHIP_DEVICE_RP"); return !(e && e[0] == '0'); }();
+    const bool have_z = enabled && res_z.rp && Z.device_tag && Z.device_tag == z_tag && res_z.m == Z.m && res_z.nnz == Z.nnz();
+    if (!have_z || A.nnz() < min_nnz || !is_resident(A)) { dcsr_free(res_z); z_tag = 0; return false; }
+    const int64_t n = A.m, n_f = F.size(), n_c = C.size();
+    // the index lists and the prolongator's columns: 8 bytes per row of the level
+    double t0 = now_s();
+    Arr<uint32_t> code(n);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n_f; i++) code[F[i]] = (uint32_t)i | 0x80000000u;
+#pragma omp parallel for schedule(static)
+    for (int64_t j = 0; j < n_c; j++) code[C[j]] = (uint32_t)j;
+    struct Tmp { void* p; explicit Tmp(size_t b) : p(dev_alloc(b ? b : 1)) {} ~Tmp() { dev_free(p); } };
+    Tmp d_code(sizeof(uint32_t) * (size_t)n), d_F(sizeof(int32_t) * (size_t)n_f), d_C(sizeof(int32_t) * (size_t)n_c), d_w(sizeof(int32_t) * (size_t)n_f);
+    staged_h2d(d_code.p, code.data(), sizeof(uint32_t) * (size_t)n);
+    if (n_f) { staged_h2d(d_F.p, F.data(), sizeof(int32_t) * (size_t)n_f); staged_h2d(d_w.p, wcol.data(), sizeof(int32_t) * (size_t)n_f); }
+    if (n_c) staged_h2d(d_C.p, C.data(), sizeof(int32_t) * (size_t)n_c);
+    t_transfer += now_s() - t0;
+    t0 = now_s();
+    DCsr dP = dev_build_P_one_point(n, n_c, (const uint32_t*)d_code.p, (const int32_t*)d_w.p, stream);
+    DCsr dA = resident; resident = DCsr(); resident_key = nullptr; resident_tag = 0;
+    DCsr dAP = dev_spgemm(dA, dP, false, 0.0, false, false, stream);
+    dcsr_free(dA); dcsr_free(dP);
+    DCsr dR = dev_build_R(res_z, (const int32_t*)d_F.p, (const int32_t*)d_C.p, n, stream);
+    dcsr_free(res_z); z_tag = 0;
+    DCsr dC = dev_spgemm(dR, dAP, drop.enabled, drop.tol, drop.lump, drop.negate, stream);
+    t_compute += now_s() - t0;
+    dcsr_free(dR); dcsr_free(dAP);
+    coarse = Csr();
+    if (dC.nnz >= min_nnz) { coarse.m = dC.m; coarse.n = dC.n; coarse.stub_nnz = dC.nnz; }
+    else coarse = down(dC);
+    resident = dC;
+    resident_tag = coarse.device_tag = ++next_tag;
+    resident_key = coarse.on_host() ? (const void*)coarse.rp.data() : nullptr;
+    return true;
   }
 
   void materialize(Csr& A) override {

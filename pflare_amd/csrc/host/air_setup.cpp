@@ -364,7 +364,7 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o, SetupAc
     if (accel && !(product_z && o.improve_z_its == 0 && !r_dropped)) accel->sync_host(nullptr);
     if (product_z) {
       SpgemmDrop d; d.enabled = true; d.tol = o.r_drop; d.negate = true;
-      if (o.improve_z_its == 0) L.Z = accel ? accel->spgemm(Acf_z, *Mz, d) : spgemm(Acf_z, *Mz, d);
+      if (o.improve_z_its == 0) L.Z = accel ? accel->spgemm_z(Acf_z, *Mz, d) : spgemm(Acf_z, *Mz, d);
       else { d.enabled = false; Zfull = spgemm(Acf_z, *Mz, d); }
     } else {
       // lAIR / SAI (AIR_Operators_Setup.F90:698-778): the F neighbourhood of every C point out to
@@ -401,10 +401,15 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o, SetupAc
     // ---- coarse operator R (A P) with drop / lump (AIR_Operators_Setup.F90:960-1085)
     t0 = now_s();
     Csr coarse;
-    {
+    SpgemmDrop d_rap; d_rap.enabled = true; d_rap.tol = o.a_drop; d_rap.lump = o.a_lump;
+    // with the plain Z product and the one-point prolongator the accelerator assembles R = [Z I] and P = [W; I] itself,
+    // where Z and the level operator already are (reference device twin: src/Grid_Transfer.kokkos.cxx)
+    if (accel && L.one_point && !o.symmetric && accel->rap_from_z(L.Z, L.F, L.C, L.wcol, *cur, d_rap, coarse)) {
+      H->timers[5] += now_s() - t0;
+    } else {
       Csr P = build_P(L);
       Csr R = build_R(L.Z, L.F, L.C, n);
-      SpgemmDrop d; d.enabled = true; d.tol = o.a_drop; d.lump = o.a_lump;
+      SpgemmDrop d = d_rap;
       if (accel) coarse = accel->rap(R, *cur, P, d, true);
       else {
         Csr AP = spgemm(*cur, P);

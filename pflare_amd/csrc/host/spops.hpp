@@ -52,6 +52,15 @@ struct SetupAccel {
   // it comes back as the A of the next level.  device_only: the caller can work with a result whose arrays stay on
   // the accelerator (Csr::stub_nnz >= 0) and will call materialize() before any host routine reads it.
   virtual Csr rap(const Csr& R, const Csr& A, const Csr& P, const SpgemmDrop& drop, bool device_only = false) = 0;
+  // Z = filter(A * B) like spgemm(); the implementation may keep its copy of the result for rap_from_z
+  virtual Csr spgemm_z(const Csr& A, const Csr& B, const SpgemmDrop& drop) { return spgemm(A, B, drop); }
+  // filter(R * (A * P)) with R = [Z I] and the one-point P = [W; I] assembled where Z and the level operator already are
+  // (no host copy of R / P, no upload of them); false when it declines (Z or A not resident) - the caller then builds R and P
+  // and calls rap().  F / C: the level's index lists, wcol: the one-point prolongator's column per F point.
+  virtual bool rap_from_z(const Csr& Z, const Arr<int32_t>& F, const Arr<int32_t>& C, const Arr<int32_t>& wcol, const Csr& A,
+                          const SpgemmDrop& drop, Csr& coarse) {
+    (void)Z; (void)F; (void)C; (void)wcol; (void)A; (void)drop; (void)coarse; return false;
+  }
   // brings the arrays of a device-only operator to the host (no-op for an operator that is there already)
   virtual void materialize(Csr& A) { if (!A.on_host()) throw std::logic_error("this accelerator holds no device-only operators"); }
   // the four F / C blocks of the level operator (host/spops.cpp: split_fc) extracted where the operator is; A_cc only
