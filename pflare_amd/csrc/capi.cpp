@@ -485,6 +485,7 @@ int airhip_pcair_setup(airhip_pcair pc, const airhip_csr* A) {
   view_csr(A, pc->A_top);
   ThreadScope threads(A->rowptr[A->m]);
   double t0 = now_s();
+  DevArena dev_arena(pc->setup_on_device ? dev_arena_bytes_for((double)A->rowptr[A->m]) : 0);      // one block for the setup's temporaries
   {
     std::unique_ptr<SetupAccel> accel;
     if (pc->setup_on_device) accel = make_device_setup_accel(nullptr, pc->setup_device_min_nnz);

@@ -85,7 +85,7 @@ void launch_fc_first(const DevMat& A_fc, const int32_t* wcol, const double* b_f,
                      const double* x_ghost = nullptr, const BlkDesc* blks = nullptr, int64_t nblks = 0);
 // host flags (one per row block): does the block reference a ghost column?
 void devmat_boundary_flags(const DevMat& A, std::vector<uint8_t>& flags, hipStream_t s);
-// a descriptor array holding the blocks order[0 .. n) of A (device memory, released with hipFree)
+// a descriptor array holding the blocks order[0 .. n) of A (device memory, released with dev_free_exact)
 BlkDesc* devmat_desc_list(const DevMat& A, const int32_t* order_host, int64_t n, hipStream_t s);
 
 // vector kernels (n elements)

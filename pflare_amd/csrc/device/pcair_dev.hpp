@@ -21,7 +21,7 @@ struct DBuf {
   DBuf(DBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
   DBuf& operator=(DBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
   ~DBuf() { release(); }
-  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+  void release() { dev_free_exact(p); p = nullptr; n = 0; }
   void alloc(int64_t n_) { release(); n = n_; p = (T*)dev_alloc_exact(sizeof(T) * (size_t)(n_ > 0 ? n_ : 1)); }
   void upload(const T* h, int64_t n_) { alloc(n_); if (n_ > 0) staged_h2d(p, h, sizeof(T) * (size_t)n_); }
 };

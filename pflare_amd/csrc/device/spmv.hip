@@ -734,7 +734,7 @@ static void move_array(void** p, size_t bytes, hipStream_t s) {
   void* q = dev_alloc_exact(bytes);
   HIP_CHECK(hipMemcpyAsync(q, *p, bytes, hipMemcpyDeviceToDevice, s));
   HIP_CHECK(hipStreamSynchronize(s));
-  (void)hipFree(*p);
+  dev_free_exact(*p);
   *p = q;
 }
 void devmat_reallocate(DevMat& A, hipStream_t s) {
@@ -750,13 +750,13 @@ void devmat_reallocate(DevMat& A, hipStream_t s) {
 
 void devmat_free(DevMat& A) {
   if (A.cached) { dev_free(A.blk); dev_free(A.roff); dev_free(A.idx); dev_free(A.val); A.blk = nullptr; A.roff = nullptr; A.idx = nullptr; A.val = nullptr; }
-  if (A.blk) (void)hipFree(A.blk);
-  if (A.roff) (void)hipFree(A.roff);
-  if (A.idx) (void)hipFree(A.idx);
-  if (A.val) (void)hipFree(A.val);
-  if (A.desc_int) (void)hipFree(A.desc_int);
-  if (A.desc_bnd) (void)hipFree(A.desc_bnd);
-  if (A.desc_ord) (void)hipFree(A.desc_ord);
+  dev_free_exact(A.blk);
+  dev_free_exact(A.roff);
+  dev_free_exact(A.idx);
+  dev_free_exact(A.val);
+  dev_free_exact(A.desc_int);
+  dev_free_exact(A.desc_bnd);
+  dev_free_exact(A.desc_ord);
   A = DevMat();
 }
 
