@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <mutex>
+#include <thread>
 #include <stdexcept>
 #include <chrono>
 #include <cstdio>
@@ -37,6 +38,7 @@ struct Arena {
   std::map<size_t, size_t> free_by_off;             // offset -> length, neighbours merged
   std::unordered_map<void*, size_t> live;           // block -> length
   bool closing = false;                             // scope ended: release once the last block is back
+  bool pending = false;                             // the helper thread is still asking the driver for the block
   size_t peak = 0, used = 0, misses = 0;
 };
 Arena& arena() { static Arena* a = new Arena; return *a; }
@@ -203,27 +205,43 @@ size_t dev_arena_bytes_for(double nnz) {
   return std::min(want, (size_t)(0.45 * (double)free_b)) / GRANULE * GRANULE;
 }
 
+struct DevArena::Impl { std::thread worker; };
+
 DevArena::DevArena(size_t bytes) {
   if (bytes == 0) return;
   DevCache& c = cache();
-  std::lock_guard<std::mutex> lock(c.mu);
-  Arena& a = arena();
-  if (a.base) return;                                  // an enclosing call's arena is in use
-  void* p = nullptr;
-  static const bool trace = std::getenv("AIRHIP_ALLOC_TRACE") != nullptr;
-  const auto t0 = std::chrono::steady_clock::now();
-  if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return; }       // no arena: the cache path serves everything
-  if (trace) std::fprintf(stderr, "[devmem] arena of %.1f GB allocated in %.3f s\n", bytes * 1e-9, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
-  a.base = (char*)p; a.size = bytes; a.free_by_off[0] = bytes;
-  mine_ = true;
+  {
+    std::lock_guard<std::mutex> lock(c.mu);
+    Arena& a = arena();
+    if (a.base || a.pending) return;                   // an enclosing call's arena is in use (or on its way)
+    a.pending = true;
+  }
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  impl_ = new Impl;
+  impl_->worker = std::thread([bytes, dev] {
+    static const bool trace = std::getenv("AIRHIP_ALLOC_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    void* p = nullptr;
+    const bool ok = hipSetDevice(dev) == hipSuccess && hipMalloc(&p, bytes) == hipSuccess;
+    if (!ok) (void)hipGetLastError();                  // no arena: the cache path serves everything
+    if (trace) std::fprintf(stderr, "[devmem] arena of %.1f GB %s in %.3f s (helper thread)\n", bytes * 1e-9, ok ? "allocated" : "REFUSED",
+                            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    DevCache& cc = cache();
+    std::lock_guard<std::mutex> lock(cc.mu);
+    Arena& a = arena();
+    a.pending = false;
+    if (ok) { a.base = (char*)p; a.size = bytes; a.free_by_off.clear(); a.free_by_off[0] = bytes; a.closing = false; }
+  });
 }
 DevArena::~DevArena() {
-  if (!mine_) return;
+  if (!impl_) return;
+  if (impl_->worker.joinable()) impl_->worker.join();
+  delete impl_;
   DevCache& c = cache();
   std::lock_guard<std::mutex> lock(c.mu);
   Arena& a = arena();
-  a.closing = true;
-  arena_release_if_done(a);
+  if (a.base) { a.closing = true; arena_release_if_done(a); }
 }
 
 size_t dev_cache_idle_bytes() {

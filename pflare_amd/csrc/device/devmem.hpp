@@ -28,12 +28,15 @@ size_t dev_cache_idle_bytes();
 // been freed.  bytes = 0 disables it (AIRHIP_DEVICE_ARENA_GB overrides the caller's size; 0 = off).
 class DevArena {
  public:
+  // The block is requested on a helper thread (a fresh 119-GB block takes the driver about 3 s, which the first level of
+  // the setup covers); until it is there dev_alloc serves requests the old way.
   explicit DevArena(size_t bytes);
   ~DevArena();
   DevArena(const DevArena&) = delete;
   DevArena& operator=(const DevArena&) = delete;
  private:
-  bool mine_ = false;
+  struct Impl;
+  Impl* impl_ = nullptr;
 };
 // what a setup of an operator with nnz non-zeros asks for: ~300 bytes per non-zero, at most 45 % of the free device memory
 size_t dev_arena_bytes_for(double nnz);
