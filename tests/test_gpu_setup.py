@@ -333,3 +333,34 @@ def test_device_polynomial_assembly_on_denser_operators(gpu):
     pd = P.PCPFLAREINV(type="power", poly_order=3, setup_device_min_nnz=0).setup(A)
     ph = P.PCPFLAREINV(type="power", poly_order=3).setup_host_only(A)
     _same(pd.get_inverse(n)["mat"], ph.get_inverse(n)["mat"], "dense rows")
+
+
+@pytest.mark.parametrize("arena_gb", ["0", "0.3", "4"], ids=["no-arena", "arena-too-small", "arena-roomy"])
+def test_setup_arena_sizes_give_the_same_hierarchy_and_solve(gpu, arena_gb, monkeypatch):
+    """device/devmem.hpp DevArena: the setup's temporaries and the hierarchy's arrays are carved from one device block.  With no
+    arena, with one that is far too small (most requests fall back to the block cache / hipMalloc, the rest fragment it) and
+    with a roomy one the hierarchy must be the host code's, bit for bit, and the solve must not change."""
+    import torch
+    import pflare_amd as P
+    monkeypatch.setenv("AIRHIP_DEVICE_ARENA_GB", arena_gb)
+    A = P.HostMat.adv_diff_fd(dim=3, M=44, N=44, P=44)
+    opts = dict(a_lump=True)
+    pd = P.PCAIR(**opts); pd.set_option("setup_device_min_nnz", 0); pd.setup(A)
+    ph = P.PCAIR(**opts); ph.setup_host_only(A)
+    assert pd.num_levels == ph.num_levels
+    for lv in range(pd.num_levels - 1):
+        d, h = pd.export_level(lv), ph.export_level(lv)
+        assert np.array_equal(d["F"], h["F"])
+        for k in ("Z", "A_fc", "A_ff"):
+            if k in h:
+                _same(d[k], h[k], f"level {lv} {k}")
+    n = A.shape[0]
+    b = torch.zeros(n, dtype=torch.float64, device="cuda"); x = torch.ones_like(b)
+    r = P.KSP("gmres", pc_side="right", rtol=1e-10, atol=1e-50, max_it=30).solve(b, x, pc=pd)
+    assert r["reason"] > 0 and r["its"] <= 9, r
+    # a second object set up while the first one still holds arena blocks: its setup takes the old path, same result
+    p2 = P.PCAIR(**opts); p2.set_option("setup_device_min_nnz", 0); p2.setup(A)
+    x2 = torch.ones_like(b)
+    r2 = P.KSP("gmres", pc_side="right", rtol=1e-10, atol=1e-50, max_it=30).solve(b, x2, pc=p2)
+    assert r2["its"] == r["its"] and float((x2 - x).abs().max()) == 0.0
+    del pd, p2
