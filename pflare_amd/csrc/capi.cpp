@@ -1044,6 +1044,7 @@ int airhip_pcair_load_distributed(airhip_pcair pc, airhip_archive piece, airhip_
   REQUIRE(loc->nranks == comm->c->size && loc->rank == comm->c->rank, AIRHIP_ERR_ARG, "piece does not belong to this rank");
   double t0 = now_s();
   DevArena dev_arena(dev_arena_bytes_for((double)loc->A_top.nnz()));      // this rank's hierarchy in one contiguous block
+  dev_arena.wait();
   pc->dev = std::make_unique<DevPCAIR>();
   if (loc->hint.size() > 0) pc->dev->set_ordering_hint(loc->hint.data(), loc->hint.size());
   pc->dev->upload(loc->H, loc->A_top, loc.get(), comm->c.get());

@@ -234,6 +234,8 @@ DevArena::DevArena(size_t bytes) {
     if (ok) { a.base = (char*)p; a.size = bytes; a.free_by_off.clear(); a.free_by_off[0] = bytes; a.closing = false; }
   });
 }
+void DevArena::wait() { if (impl_ && impl_->worker.joinable()) impl_->worker.join(); }
+
 DevArena::~DevArena() {
   if (!impl_) return;
   if (impl_->worker.joinable()) impl_->worker.join();

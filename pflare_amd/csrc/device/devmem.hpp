@@ -32,6 +32,7 @@ class DevArena {
   // the setup covers); until it is there dev_alloc serves requests the old way.
   explicit DevArena(size_t bytes);
   ~DevArena();
+  void wait();      // until the helper thread has the block (a caller with nothing to do in the meantime)
   DevArena(const DevArena&) = delete;
   DevArena& operator=(const DevArena&) = delete;
  private:
