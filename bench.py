@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--hint-brick", type=int, default=16,
                     help="locality hint for the device layout: grid points grouped in BxBxB bricks (0: none, -1: Morton "
                          "order of the bricks of size 4); the operator keeps the reference numbering")
+    ap.add_argument("--hint-sub", type=int, default=0, help="diagnostic: with --hint-brick B, order the points of a brick in SxSxS sub-bricks")
     ap.add_argument("--hint-morton", type=int, default=0, help="diagnostic: with --hint-brick B > 0, number the bricks along a Morton curve instead of lexicographically")
     ap.add_argument("--brick", type=int, default=0, help="diagnostic: renumber the grid in BxBxB bricks before the setup (locality experiment; not the reference numbering)")
     ap.add_argument("--threads", type=int, default=0, help="host threads for setup + CPU baseline (0: cores / ranks, capped at 32 - measured best on the GPU box)")
@@ -97,6 +98,7 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd))
+    os.environ.setdefault("AIRHIP_FAULT_STAGE", "1")     # a GPU memory fault names the library step it happened in
     if "AIRHIP_DEVICE_TRUNC" not in os.environ:
         os.environ["AIRHIP_DEVICE_TRUNC"] = str(1 if args.device_trunc else 0)
 
@@ -204,7 +206,15 @@ def main():
                 bkey = (sb[:, None, None] << 2) | (sb[None, :, None] << 1) | sb[None, None, :]
             else:
                 bkey = (bi[:, None, None] * nbk + bi[None, :, None]) * nbk + bi[None, None, :]
-            key = bkey * B ** 3 + (li[:, None, None] * B + li[None, :, None]) * B + li[None, None, :]      # [k, j, i]
+            if args.hint_sub > 1 and B % args.hint_sub == 0:
+                # diagnostic: S^3 sub-bricks inside every brick (two-level locality)
+                S_ = args.hint_sub; q_ = B // S_
+                sb, sl = li // S_, li % S_
+                inner = ((sb[:, None, None] * q_ + sb[None, :, None]) * q_ + sb[None, None, :]) * S_ ** 3 + \
+                        (sl[:, None, None] * S_ + sl[None, :, None]) * S_ + sl[None, None, :]
+                key = bkey * B ** 3 + inner
+            else:
+                key = bkey * B ** 3 + (li[:, None, None] * B + li[None, :, None]) * B + li[None, None, :]      # [k, j, i]
             pc.set_ordering_hint(key.reshape(-1))
             del key
         if dist_mode:

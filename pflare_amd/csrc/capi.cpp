@@ -456,14 +456,19 @@ int airhip_pcair_set_option(airhip_pcair pc, const char* name, const char* value
   API_END
 }
 
-static void finish_device(airhip_pcair pc) {
+// AIRHIP_KEEP_DEVICE_COPIES=0: the upload copies every operator from the host again (the first version's behaviour)
+static bool keep_device_copies() { static const bool on = [] { const char* e = std::getenv("AIRHIP_KEEP_DEVICE_COPIES"); return !(e && e[0] == '0'); }(); return on; }
+
+static void finish_device(airhip_pcair pc, SetupAccel* accel = nullptr) {
   double t0 = now_s();
   pc->dev = std::make_unique<DevPCAIR>();
+  pc->dev->set_device_source(accel);
   if (!pc->hint.empty()) {
     if ((int64_t)pc->hint.size() != pc->A_top.m) throw std::runtime_error("ordering hint: one key per row of the operator is required");
     pc->dev->set_ordering_hint(pc->hint.data(), (int64_t)pc->hint.size());
   }
   pc->dev->upload(*pc->H, pc->A_top);
+  pc->dev->set_device_source(nullptr);
   pc->dev->set_use_graph(pc->use_graph);
   pc->dev->set_profile(pc->profile);
   pc->ksp.reset();
@@ -485,10 +490,11 @@ int airhip_pcair_setup(airhip_pcair pc, const airhip_csr* A) {
   view_csr(A, pc->A_top);
   ThreadScope threads(A->rowptr[A->m]);
   double t0 = now_s();
-  DevArena dev_arena(pc->setup_on_device ? dev_arena_bytes_for((double)A->rowptr[A->m]) : 0);      // one block for the setup's temporaries
+  DevArena dev_arena(pc->setup_on_device ? dev_arena_bytes_for((double)A->rowptr[A->m]) : 0, dev_arena_front_for((double)A->rowptr[A->m]));   // the setup's temporaries, then the hierarchy
+  std::unique_ptr<SetupAccel> accel;
   {
-    std::unique_ptr<SetupAccel> accel;
     if (pc->setup_on_device) accel = make_device_setup_accel(nullptr, pc->setup_device_min_nnz);
+    if (accel) accel->keep_copies(pc->device_upload && keep_device_copies());     // for finish_device below
     pc->H = setup_air(pc->A_top, pc->opt, accel.get());
     if (accel) {
       pc->accel_transfer_s = accel->t_transfer; pc->accel_compute_s = accel->t_compute;
@@ -502,7 +508,8 @@ int airhip_pcair_setup(airhip_pcair pc, const airhip_csr* A) {
   pc->host_setup_s = now_s() - t0;
   pc->byo = false;
   pc->op_nnz_top = (double)pc->A_top.nnz();
-  if (pc->device_upload) finish_device(pc);
+  if (pc->device_upload) finish_device(pc, accel.get());
+  accel.reset();
   dev_cache_trim();
   if (pc->opt.print_stats_timings) { std::printf(" %s\n", host_array_cache_report().c_str()); std::fflush(stdout); }
   trim_host_array_cache(true);   // blocks released during the setup waited for reuse; after the upload, so that the unmapping does not get in its way
@@ -1043,8 +1050,7 @@ int airhip_pcair_load_distributed(airhip_pcair pc, airhip_archive piece, airhip_
   load_local(piece->ar, *loc);
   REQUIRE(loc->nranks == comm->c->size && loc->rank == comm->c->rank, AIRHIP_ERR_ARG, "piece does not belong to this rank");
   double t0 = now_s();
-  DevArena dev_arena(dev_arena_bytes_for((double)loc->A_top.nnz()));      // this rank's hierarchy in one contiguous block
-  dev_arena.wait();
+  DevArena dev_arena(dev_arena_bytes_for((double)loc->A_top.nnz()), dev_arena_front_for((double)loc->A_top.nnz()));      // this rank's hierarchy in one contiguous range
   pc->dev = std::make_unique<DevPCAIR>();
   if (loc->hint.size() > 0) pc->dev->set_ordering_hint(loc->hint.data(), loc->hint.size());
   pc->dev->upload(loc->H, loc->A_top, loc.get(), comm->c.get());

@@ -9,11 +9,44 @@
 #include <cstdio>
 #include <exception>
 #include <map>
+#include <memory>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
+#include <functional>
+#include <atomic>
+#include <csignal>
+#include <cstring>
+#include <unistd.h>
 
 namespace airhip {
+
+namespace {
+std::atomic<const char*> g_stage{"(none)"};
+double trace_clock() {
+  static const auto t0 = std::chrono::steady_clock::now();
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+extern "C" void airhip_abort_note(int) {
+  const char* s = g_stage.load(std::memory_order_relaxed);
+  const char head[] = "[airhip] abort while in stage: ";
+  (void)!write(2, head, sizeof head - 1);
+  (void)!write(2, s, std::strlen(s));
+  (void)!write(2, "\n", 1);
+  std::signal(SIGABRT, SIG_DFL);
+  std::raise(SIGABRT);
+}
+}  // namespace
+
+void dev_stage(const char* what) {
+  static const bool on = [] {
+    const char* e = std::getenv("AIRHIP_FAULT_STAGE");
+    if (!(e && e[0] == '1')) return false;
+    std::signal(SIGABRT, airhip_abort_note);
+    return true;
+  }();
+  if (on) g_stage.store(what, std::memory_order_relaxed);
+}
 
 namespace {
 
@@ -31,36 +64,146 @@ struct DevCache {
 };
 DevCache& cache() { static DevCache* c = new DevCache; return *c; }
 
-// ---- the setup arena (guarded by DevCache::mu)
-constexpr size_t GRANULE = 2u << 20;
+// ---- the setup arena: device memory straight from the virtual-memory interface (all of it guarded by DevCache::mu).
+// tools/vmm_probe.hip on the GPU box: backing a reserved range with hipMemCreate + hipMemMap + hipMemSetAccess costs
+// 0.6 - 2.5 ms per GB in 256-MB pieces (64 GB: 0.04 - 0.17 s) where a plain hipMalloc of 64 GB took 0.5 .. 3.9 s from one
+// call to the next (and holds the driver's lock meanwhile), a read+write stream runs as fast on memory mapped like this
+// (5.19 vs 5.02 TB/s), and giving it back takes milliseconds.
+// THE RULE (tools/vmm_stress.hip, profiles/r03_vmm_stress.txt): an address that has been unmapped must never be mapped
+// again, and a reserved range must never be handed back with hipMemAddressFree.  Blocks that were filled by a copy and
+// checked by a kernel right away came back wrong on this driver when their addresses had been backed before (one
+// reservation whose pieces are unmapped and mapped again: 9 of 177 blocks; reservations that come and go: 19 of 177),
+// never when every address was backed at most once - stale translations, by the look of it.  So every arena takes a
+// fresh range, backs each piece at most once, and abandons the range (address space only) when it is done.
+constexpr size_t GRANULE = 2u << 20;             // blocks of the arena
+// physical memory is created and mapped in pieces of this size (AIRHIP_ARENA_PIECE_MB: experiments)
+const size_t PIECE = [] { const char* e = std::getenv("AIRHIP_ARENA_PIECE_MB"); return (size_t)(e && std::atoi(e) >= 2 ? std::atoi(e) / 2 * 2 : 256) << 20; }();
+constexpr size_t VA_BUDGET = (size_t)32 << 40;   // address space the process may use up this way (then: no more arenas)
+size_t g_va_used = 0;
+
+bool vm_supported() {
+  static const bool ok = [] {
+    const char* e = std::getenv("AIRHIP_DEVICE_VMM");
+    if (e && e[0] == '0') return false;
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeVirtualMemoryManagementSupported, dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return v != 0;
+  }();
+  return ok;
+}
+
+// one reserved range; every piece is backed at most once (state: 0 never, 1 backed, 2 given back for good)
+struct VmRange {
+  char* base = nullptr; size_t reserved = 0; int dev = 0;
+  std::vector<hipMemGenericAllocationHandle_t> handle;
+  std::vector<char> state;
+  size_t committed = 0;
+  bool reserve(size_t bytes) {
+    bytes = (bytes + PIECE - 1) / PIECE * PIECE;
+    if (g_va_used + bytes > VA_BUDGET) return false;
+    void* p = nullptr;
+    if (hipGetDevice(&dev) != hipSuccess || hipMemAddressReserve(&p, bytes, 0, nullptr, 0) != hipSuccess || !p) { (void)hipGetLastError(); return false; }
+    g_va_used += bytes;
+    base = (char*)p; reserved = bytes;
+    handle.assign(bytes / PIECE, hipMemGenericAllocationHandle_t{}); state.assign(bytes / PIECE, 0);
+    return true;
+  }
+  bool map_piece(size_t k) {
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
+    if (hipMemCreate(&handle[k], PIECE, &prop, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+    hipMemAccessDesc acc = {};
+    acc.location.type = hipMemLocationTypeDevice; acc.location.id = dev; acc.flags = hipMemAccessFlagsProtReadWrite;
+    if (hipMemMap(base + k * PIECE, PIECE, 0, handle[k], 0) != hipSuccess) { (void)hipGetLastError(); (void)hipMemRelease(handle[k]); return false; }
+    if (hipMemSetAccess(base + k * PIECE, PIECE, &acc, 1) != hipSuccess) {
+      (void)hipGetLastError(); (void)hipMemUnmap(base + k * PIECE, PIECE); (void)hipMemRelease(handle[k]);
+      state[k] = 2;                                  // the address has been mapped: not again
+      return false;
+    }
+    state[k] = 1; committed += PIECE;
+    return true;
+  }
+  void unmap_piece(size_t k) {
+    (void)hipMemUnmap(base + k * PIECE, PIECE); (void)hipMemRelease(handle[k]);
+    state[k] = 2; committed -= PIECE;
+  }
+  // every piece that [off, off + len) touches is backed afterwards; false: one of them cannot be (no memory, the limit, or
+  // given back earlier) - pieces backed on the way stay backed (they are free space of the arena like any other)
+  bool commit(size_t off, size_t len, size_t limit) {
+    const size_t k0 = off / PIECE, k1 = (off + len + PIECE - 1) / PIECE;
+    for (size_t k = k0; k < k1; k++) if (state[k] == 2) return false;
+    for (size_t k = k0; k < k1; k++) {
+      if (state[k] == 1) continue;
+      if (committed + PIECE > limit || !map_piece(k)) return false;
+    }
+    return true;
+  }
+  // gives back, for good, the backed pieces that lie entirely inside [off, off + len).  No kernel may still be using
+  // them: unlike hipFree, unmapping does not wait for the device
+  void decommit(size_t off, size_t len) {
+    const size_t k0 = (off + PIECE - 1) / PIECE, k1 = (off + len) / PIECE;
+    bool synced = false;
+    for (size_t k = k0; k < k1; k++) {
+      if (state[k] != 1) continue;
+      if (!synced) { (void)hipDeviceSynchronize(); synced = true; }
+      unmap_piece(k);
+    }
+  }
+  // the memory goes back, the address range is abandoned (see THE RULE)
+  void release() {
+    if (!base) return;
+    decommit(0, reserved);
+    *this = VmRange();
+  }
+};
+
+hipError_t raw_alloc(void** p, size_t bytes) { return hipMalloc(p, bytes); }
+void raw_free(void* p) { (void)hipFree(p); }
+
+// ---- one reserved range per setup, backed as far as the blocks in use reach (first fit: the blocks gather at the low
+// end); when the scope has ended the pieces under free space are handed back, the others as their blocks are freed
 struct Arena {
-  char* base = nullptr; size_t size = 0;
+  VmRange vm;
+  char* base = nullptr; size_t size = 0;            // = vm.base / vm.reserved while the arena exists
+  size_t limit = 0;                                 // most bytes that may be backed at one time
   std::map<size_t, size_t> free_by_off;             // offset -> length, neighbours merged
   std::unordered_map<void*, size_t> live;           // block -> length
   bool closing = false;                             // scope ended: release once the last block is back
-  bool pending = false;                             // the helper thread is still asking the driver for the block
-  size_t peak = 0, used = 0, misses = 0;
+  size_t peak = 0, used = 0, misses = 0, peak_committed = 0;
 };
-Arena& arena() { static Arena* a = new Arena; return *a; }
+// the arena that serves requests (at most one: the innermost setup in progress) and those of finished setups whose
+// hierarchies still hold blocks
+std::vector<std::unique_ptr<Arena>>& arenas() { static auto* v = new std::vector<std::unique_ptr<Arena>>; return *v; }
+Arena* active_arena() { auto& v = arenas(); return (!v.empty() && !v.back()->closing) ? v.back().get() : nullptr; }
 
-void* arena_alloc(Arena& a, size_t bytes) {
-  if (!a.base || a.closing) return nullptr;
+void* arena_alloc(Arena* ap, size_t bytes) {
+  if (!ap) return nullptr;
+  Arena& a = *ap;
+  static const bool trace = std::getenv("AIRHIP_ALLOC_TRACE") != nullptr;
   const size_t need = (bytes + GRANULE - 1) / GRANULE * GRANULE;
   for (auto it = a.free_by_off.begin(); it != a.free_by_off.end(); ++it) {
     if (it->second < need) continue;
     const size_t off = it->first, len = it->second;
+    if (!a.vm.commit(off, need, a.limit)) break;      // the device (or the limit) has no room for the pieces
     a.free_by_off.erase(it);
     if (len > need) a.free_by_off[off + need] = len - need;
     a.live[a.base + off] = need;
     a.used += need; if (a.used > a.peak) a.peak = a.used;
+    if (a.vm.committed > a.peak_committed) a.peak_committed = a.vm.committed;
     return a.base + off;
   }
+  if (trace) std::fprintf(stderr, "[devmem %.3f] arena: %.2f GB did not fit (in use %.1f GB, backed %.1f GB of at most %.1f GB)\n", trace_clock(), need * 1e-9,
+                          a.used * 1e-9, a.vm.committed * 1e-9, a.limit * 1e-9);
   a.misses++;
   return nullptr;
 }
-bool arena_free(Arena& a, void* p) {          // true: the block was the arena's
+// the arena a block belongs to (any of them), or null
+Arena* arena_of(void* p) {
+  for (auto& a : arenas()) if (a->live.count(p)) return a.get();
+  return nullptr;
+}
+void arena_free(Arena& a, void* p) {
   auto it = a.live.find(p);
-  if (it == a.live.end()) return false;
   size_t off = (size_t)((char*)p - a.base), len = it->second;
   a.live.erase(it);
   a.used -= len;
@@ -71,15 +214,24 @@ bool arena_free(Arena& a, void* p) {          // true: the block was the arena's
     if (prv->first + prv->second == off) { off = prv->first; len += prv->second; a.free_by_off.erase(prv); }
   }
   a.free_by_off[off] = len;
-  return true;
+  if (a.closing) a.vm.decommit(off, len);     // nothing new will be carved out of it: the memory goes back at once
 }
 void arena_release_if_done(Arena& a) {
-  if (a.base && a.closing && a.live.empty()) {
-    static const bool trace = std::getenv("AIRHIP_ALLOC_TRACE") != nullptr;
-    if (trace) std::fprintf(stderr, "[devmem] arena of %.1f GB released: peak use %.1f GB, %zu requests did not fit\n", a.size * 1e-9, a.peak * 1e-9, a.misses);
-    (void)hipFree(a.base);
-    a = Arena();
-  }
+  if (!(a.closing && a.live.empty())) return;
+  static const bool trace = std::getenv("AIRHIP_ALLOC_TRACE") != nullptr;
+  if (trace) std::fprintf(stderr, "[devmem %.3f] arena released: peak use %.1f GB, peak backing %.1f GB, %zu requests did not fit\n", trace_clock(), a.peak * 1e-9,
+                          a.peak_committed * 1e-9, a.misses);
+  a.vm.release();
+  auto& v = arenas();
+  for (size_t k = 0; k < v.size(); k++) if (v[k].get() == &a) { v.erase(v.begin() + (long)k); break; }
+}
+// dev_free / dev_free_exact: true when the block was an arena's
+bool arena_take_back(void* p) {
+  Arena* a = arena_of(p);
+  if (!a) return false;
+  arena_free(*a, p);
+  arena_release_if_done(*a);
+  return true;
 }
 
 // journals of the DevScopes alive on this thread, innermost last
@@ -104,12 +256,46 @@ DevScope::~DevScope() {
   if (trim_) dev_cache_trim();
 }
 
+namespace {
+std::mutex g_pressure_mu;
+std::vector<std::pair<int, std::function<size_t()>>> g_pressure;
+int g_pressure_next = 0;
+// asks the registered owners of optional device memory to let go of it; the bytes they freed
+size_t relieve_pressure() {
+  std::vector<std::function<size_t()>> fs;
+  { std::lock_guard<std::mutex> lock(g_pressure_mu); for (auto& f : g_pressure) fs.push_back(f.second); }
+  size_t got = 0;
+  for (auto& f : fs) got += f();
+  static const bool trace = std::getenv("AIRHIP_ALLOC_TRACE") != nullptr;
+  if (trace && !fs.empty()) std::fprintf(stderr, "[devmem %.3f] out of device memory: %.1f GB of optional copies dropped\n", trace_clock(), got * 1e-9);
+  return got;
+}
+}  // namespace
+int dev_add_pressure_handler(std::function<size_t()> f) {
+  std::lock_guard<std::mutex> lock(g_pressure_mu);
+  g_pressure.emplace_back(++g_pressure_next, std::move(f));
+  return g_pressure_next;
+}
+void dev_remove_pressure_handler(int id) {
+  std::lock_guard<std::mutex> lock(g_pressure_mu);
+  for (size_t k = 0; k < g_pressure.size(); k++) if (g_pressure[k].first == id) { g_pressure.erase(g_pressure.begin() + (long)k); return; }
+}
+
+static void* dev_alloc_once(size_t bytes, bool& failed);
 void* dev_alloc(size_t bytes) {
+  bool failed = false;
+  void* p = dev_alloc_once(bytes, failed);
+  if (failed && relieve_pressure() > 0) p = dev_alloc_once(bytes, failed);
+  if (failed) throw std::runtime_error(std::string("hipMalloc of ") + std::to_string(bytes) + " bytes failed: out of memory");
+  return p;
+}
+static void* dev_alloc_once(size_t bytes, bool& failed) {
+  failed = false;
   if (bytes == 0) bytes = 1;
   DevCache& c = cache();
   if (bytes >= CACHE_MIN) {
     std::lock_guard<std::mutex> lock(c.mu);
-    if (void* q = arena_alloc(arena(), bytes)) { note_alloc(q); return q; }
+    if (void* q = arena_alloc(active_arena(), bytes)) { note_alloc(q); return q; }
     int best = -1;          // smallest idle block that holds the request and is at most twice its size
     for (int k = 0; k < (int)c.idle.size(); k++)
       if (c.idle[k].second >= bytes && c.idle[k].second / 2 <= bytes && (best < 0 || c.idle[k].second < c.idle[best].second)) best = k;
@@ -125,20 +311,17 @@ void* dev_alloc(size_t bytes) {
   void* p = nullptr;
   static const bool trace = std::getenv("AIRHIP_ALLOC_TRACE") != nullptr;
   const auto t_begin = std::chrono::steady_clock::now();
-  hipError_t e = hipMalloc(&p, bytes);
+  hipError_t e = raw_alloc(&p, bytes);
   if (trace) {
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
-    if (dt > 0.05 || bytes >= ((size_t)1 << 30)) std::fprintf(stderr, "[devmem] hipMalloc %.2f GB took %.3f s (idle cache %.1f GB in %zu blocks)\n", bytes * 1e-9, dt, c.idle_bytes * 1e-9, c.idle.size());
+    if (dt > 0.05 || bytes >= ((size_t)1 << 30)) std::fprintf(stderr, "[devmem %.3f] hipMalloc %.2f GB took %.3f s (idle cache %.1f GB in %zu blocks)\n", trace_clock(), bytes * 1e-9, dt, c.idle_bytes * 1e-9, c.idle.size());
   }
   if (e != hipSuccess) {                 // make room and try once more
     (void)hipGetLastError();
     dev_cache_trim();
-    e = hipMalloc(&p, bytes);
+    e = raw_alloc(&p, bytes);
   }
-  if (e != hipSuccess) {
-    (void)hipGetLastError();
-    throw std::runtime_error(std::string("hipMalloc of ") + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
-  }
+  if (e != hipSuccess) { (void)hipGetLastError(); failed = true; return nullptr; }
   if (bytes >= CACHE_MIN) { std::lock_guard<std::mutex> lock(c.mu); c.live[p] = bytes; }
   note_alloc(p);
   return p;
@@ -149,21 +332,29 @@ void dev_free_exact(void* p) {
   {
     DevCache& c = cache();
     std::lock_guard<std::mutex> lock(c.mu);
-    Arena& a = arena();
-    if (a.base && arena_free(a, p)) { arena_release_if_done(a); return; }
+    if (arena_take_back(p)) return;
   }
-  (void)hipFree(p);
+  raw_free(p);
 }
 
 void* dev_alloc_exact(size_t bytes) {
   if (bytes >= CACHE_MIN) {
     DevCache& c = cache();
     std::lock_guard<std::mutex> lock(c.mu);
-    if (void* q = arena_alloc(arena(), bytes)) return q;
+    if (void* q = arena_alloc(active_arena(), bytes)) return q;
   }
   void* p = nullptr;
-  hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
-  if (e != hipSuccess) { (void)hipGetLastError(); dev_cache_trim(); e = hipMalloc(&p, bytes ? bytes : 1); }
+  hipError_t e = raw_alloc(&p, bytes ? bytes : 1);
+  if (e != hipSuccess) { (void)hipGetLastError(); dev_cache_trim(); e = raw_alloc(&p, bytes ? bytes : 1); }
+  if (e != hipSuccess && relieve_pressure() > 0) {
+    (void)hipGetLastError();
+    if (bytes >= CACHE_MIN) {
+      DevCache& c = cache();
+      std::lock_guard<std::mutex> lock(c.mu);
+      if (void* q = arena_alloc(active_arena(), bytes)) return q;
+    }
+    e = raw_alloc(&p, bytes ? bytes : 1);
+  }
   if (e != hipSuccess) {
     (void)hipGetLastError();
     throw std::runtime_error(std::string("hipMalloc of ") + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
@@ -177,8 +368,7 @@ void dev_free(void* p) {
   DevCache& c = cache();
   {
     std::lock_guard<std::mutex> lock(c.mu);
-    Arena& a = arena();
-    if (a.base && arena_free(a, p)) { arena_release_if_done(a); return; }
+    if (arena_take_back(p)) return;
     auto it = c.live.find(p);
     if (it != c.live.end()) {
       const size_t bytes = it->second;
@@ -186,64 +376,99 @@ void dev_free(void* p) {
       if (c.idle_bytes + bytes <= c.limit) { c.idle.emplace_back(p, bytes); c.idle_bytes += bytes; return; }
     }
   }
-  (void)hipFree(p);
+  raw_free(p);
 }
 
 void dev_cache_trim() {
   DevCache& c = cache();
   std::vector<std::pair<void*, size_t>> blocks;
   { std::lock_guard<std::mutex> lock(c.mu); blocks.swap(c.idle); c.idle_bytes = 0; }
-  for (const auto& b : blocks) (void)hipFree(b.first);
+  for (const auto& b : blocks) raw_free(b.first);
 }
 
 size_t dev_arena_bytes_for(double nnz) {
-  size_t want = (size_t)(300.0 * std::max(nnz, 0.0));
-  if (const char* e = std::getenv("AIRHIP_DEVICE_ARENA_GB")) want = (size_t)(std::atof(e) * 1e9);
-  if (want < ((size_t)256 << 20)) return 0;            // small problems: the cache is all they need
+  const char* e = std::getenv("AIRHIP_DEVICE_ARENA_GB");      // the limit, whatever the size of the problem (0 = no arena)
+  const size_t want = (size_t)(300.0 * std::max(nnz, 0.0));
+  if (!e && want < ((size_t)256 << 20)) return 0;              // small problems: the cache is all they need
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return 0; }
-  return std::min(want, (size_t)(0.45 * (double)free_b)) / GRANULE * GRANULE;
+  // the arena grows with the demand; the limit keeps it off the last GBs, and is the address space the arena uses up: a
+  // small problem does not take a device's worth of it (about 1 kB per non-zero is three times what the 464^3 setup needs)
+  size_t limit = std::min((size_t)(0.92 * (double)free_b), std::max((size_t)4 << 30, (size_t)(1000.0 * std::max(nnz, 0.0))));
+  if (e) limit = std::min((size_t)(0.92 * (double)free_b), (size_t)(std::atof(e) * 1e9));
+  return limit / GRANULE * GRANULE;
 }
 
-struct DevArena::Impl { std::thread worker; };
-
-DevArena::DevArena(size_t bytes) {
-  if (bytes == 0) return;
-  DevCache& c = cache();
-  {
-    std::lock_guard<std::mutex> lock(c.mu);
-    Arena& a = arena();
-    if (a.base || a.pending) return;                   // an enclosing call's arena is in use (or on its way)
-    a.pending = true;
-  }
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  impl_ = new Impl;
-  impl_->worker = std::thread([bytes, dev] {
-    static const bool trace = std::getenv("AIRHIP_ALLOC_TRACE") != nullptr;
-    const auto t0 = std::chrono::steady_clock::now();
-    void* p = nullptr;
-    const bool ok = hipSetDevice(dev) == hipSuccess && hipMalloc(&p, bytes) == hipSuccess;
-    if (!ok) (void)hipGetLastError();                  // no arena: the cache path serves everything
-    if (trace) std::fprintf(stderr, "[devmem] arena of %.1f GB %s in %.3f s (helper thread)\n", bytes * 1e-9, ok ? "allocated" : "REFUSED",
-                            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
-    DevCache& cc = cache();
-    std::lock_guard<std::mutex> lock(cc.mu);
-    Arena& a = arena();
-    a.pending = false;
-    if (ok) { a.base = (char*)p; a.size = bytes; a.free_by_off.clear(); a.free_by_off[0] = bytes; a.closing = false; }
-  });
-}
-void DevArena::wait() { if (impl_ && impl_->worker.joinable()) impl_->worker.join(); }
-
-DevArena::~DevArena() {
-  if (!impl_) return;
-  if (impl_->worker.joinable()) impl_->worker.join();
-  delete impl_;
+DevArena::DevArena(size_t bytes, size_t front_bytes) {
+  if (bytes == 0 || !vm_supported()) return;             // (a limit below one piece: an arena that can back nothing)
   DevCache& c = cache();
   std::lock_guard<std::mutex> lock(c.mu);
-  Arena& a = arena();
-  if (a.base) { a.closing = true; arena_release_if_done(a); }
+  if (active_arena()) return;                            // an enclosing call's arena is in use
+  auto a = std::make_unique<Arena>();
+  if (!a->vm.reserve(std::max(bytes, PIECE))) return;    // address space only; backed as the blocks come
+  a->base = a->vm.base; a->size = a->vm.reserved; a->limit = bytes;
+  a->free_by_off[0] = a->size;
+  static const bool trace = std::getenv("AIRHIP_ALLOC_TRACE") != nullptr;
+  if (trace) std::fprintf(stderr, "[devmem %.3f] arena: %.1f GB of address space reserved (%.1f TB used so far), at most %.1f GB backed\n", trace_clock(), a->size * 1e-9,
+                          g_va_used * 1e-12, a->limit * 1e-9);
+  mine_ = a.get();
+  arenas().push_back(std::move(a));
+  // The low end of the range - where the hierarchy's arrays will be put once the temporaries are gone - is backed piece
+  // after piece by a helper thread right away instead of whenever a block first reaches a piece: the products of the
+  // cycle ran 1.5 % slower on memory backed on demand (and one operator in twenty runs six times slower; 464^3,
+  // profiles/r03_arena_backing.txt), as fast as on one hipMalloc block on memory backed in one go.  The memory would be
+  // backed during the setup anyway; the setup takes a piece the helper has not reached yet by backing it itself.
+  size_t ahead = std::min(bytes, front_bytes) / PIECE * PIECE;
+  if (const char* e = std::getenv("AIRHIP_ARENA_FRONT_GB")) ahead = std::min(bytes, (size_t)(std::atof(e) * 1e9)) / PIECE * PIECE;
+  if (ahead) {
+    Arena* ap = arenas().back().get();
+    int dev = 0; (void)hipGetDevice(&dev);
+    std::atomic<bool>* stop = new std::atomic<bool>(false);
+    stop_ = stop;
+    helper_ = new std::thread([ap, ahead, dev, stop] {
+      if (hipSetDevice(dev) != hipSuccess) { (void)hipGetLastError(); return; }
+      const double t0 = trace_clock();
+      size_t done = 0;
+      for (size_t k = 0; k < ahead / PIECE && !stop->load(); k++) {
+        std::lock_guard<std::mutex> lk(cache().mu);
+        if (ap->closing || ap->vm.state[k] != 0) continue;
+        if (ap->vm.committed + PIECE > ap->limit || !ap->vm.map_piece(k)) break;
+        done += PIECE;
+        if (ap->vm.committed > ap->peak_committed) ap->peak_committed = ap->vm.committed;
+      }
+      static const bool tr = std::getenv("AIRHIP_ALLOC_TRACE") != nullptr;
+      if (tr) std::fprintf(stderr, "[devmem %.3f] arena: helper backed %.1f GB of the first %.1f GB in %.3f s\n", trace_clock(), done * 1e-9, ahead * 1e-9, trace_clock() - t0);
+    });
+  }
+}
+void DevArena::wait() { if (helper_) { static_cast<std::thread*>(helper_)->join(); delete static_cast<std::thread*>(helper_); helper_ = nullptr; } }
+
+DevArena::~DevArena() {
+  if (stop_) static_cast<std::atomic<bool>*>(stop_)->store(true);
+  wait();
+  delete static_cast<std::atomic<bool>*>(stop_);
+  if (!mine_) return;
+  DevCache& c = cache();
+  std::lock_guard<std::mutex> lock(c.mu);
+  for (auto& up : arenas()) {
+    if (up.get() != mine_) continue;
+    Arena& a = *up;
+    a.closing = true;
+    // what is free now goes back to the device at once; the blocks that stay (a hierarchy) keep their pieces
+    for (const auto& f : a.free_by_off) a.vm.decommit(f.first, f.second);
+    arena_release_if_done(a);
+    break;
+  }
+}
+
+size_t dev_available_bytes() {
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  DevCache& c = cache();
+  std::lock_guard<std::mutex> lock(c.mu);
+  size_t v = free_b + c.idle_bytes;
+  if (const Arena* a = active_arena()) v += a->vm.committed - a->used;      // backed, but no block on it
+  return v;
 }
 
 size_t dev_cache_idle_bytes() {

@@ -7,6 +7,7 @@
 // (the end of the setup, before the hierarchy is uploaded).
 #pragma once
 #include <cstddef>
+#include <functional>
 
 namespace airhip {
 void* dev_alloc(size_t bytes);           // throws std::runtime_error when the device is out of memory even after a trim
@@ -17,29 +18,45 @@ void dev_free(void* p);                  // any pointer dev_alloc returned (null
 void* dev_alloc_exact(size_t bytes);
 void dev_free_exact(void* p);
 void dev_cache_trim();
+// Owners of device memory that is only an optimisation (the setup's kept copies of finished operators) register a function
+// that frees it and returns the bytes; dev_alloc / dev_alloc_exact call them when the device is full and try once more.
+int dev_add_pressure_handler(std::function<size_t()> f);
+void dev_remove_pressure_handler(int id);
+// free device memory as an allocation through dev_alloc sees it: what the driver reports plus the cache's idle blocks plus
+// the backed pieces of the arena that no block uses
+size_t dev_available_bytes();
 size_t dev_cache_idle_bytes();
 
-// One arena for the temporaries of a setup call.  Measured at 464^3 (AIRHIP_ALLOC_TRACE=1): a hipMalloc of fresh device
-// memory costs 28 ms per GB (0.85 s for the 30-GB pool of a product) and now and then a second or two more, and because the
-// operators grow from level to level the block cache above rarely holds a block large enough - 24 such calls added up to
-// 9.6 s of a 29-s setup.  A DevArena takes ONE block when the setup starts; while it is alive dev_alloc carves blocks of
-// 1 MiB and more out of it (first fit, 2-MiB granules, neighbours merged again on dev_free) and only falls back to the
-// cache / hipMalloc when the arena has no room.  The arena goes back to the driver when the scope ends and its last block has
-// been freed.  bytes = 0 disables it (AIRHIP_DEVICE_ARENA_GB overrides the caller's size; 0 = off).
+// One arena for a setup call.  Measured at 464^3 (AIRHIP_ALLOC_TRACE=1): a hipMalloc of fresh device memory costs 7 - 57 ms
+// per GB from one call to the next and now and then seconds more, and because the operators grow from level to level the
+// block cache above rarely holds a block large enough - 24 such calls added up to 9.6 s of a 29-s setup.  A DevArena
+// reserves address space (hipMemAddressReserve; no memory yet); while it is alive dev_alloc and dev_alloc_exact carve
+// blocks of 1 MiB and more out of that range (first fit, 2-MiB granules, neighbours merged again on dev_free) and the
+// range is backed with physical memory as far as the blocks reach (hipMemCreate + hipMemMap in 256-MB pieces: 0.6 - 2.5 ms
+// per GB, tools/vmm_probe.hip).  When the scope ends the pieces under free space go back to the device at once, the
+// others as the blocks on them are freed (a hierarchy lives in its setup's arena).  Every address is backed at most once
+// and the range is never returned: on this driver an address that is mapped a second time reads stale data
+// (tools/vmm_stress.hip) - a setup therefore uses up address space (its limit, at most what the device holds; the
+// process stops making arenas after 32 TB and works through the cache / hipMalloc as it does without the virtual-memory
+// interface, AIRHIP_DEVICE_VMM=0).
+// bytes = the most that may be backed at one time, 0 disables the arena (AIRHIP_DEVICE_ARENA_GB sets the limit).
 class DevArena {
  public:
-  // The block is requested on a helper thread (a fresh 119-GB block takes the driver about 3 s, which the first level of
-  // the setup covers); until it is there dev_alloc serves requests the old way.
-  explicit DevArena(size_t bytes);
+  // front_bytes: how much of the low end a helper thread backs right away (devmem.cpp: DevArena::DevArena)
+  explicit DevArena(size_t bytes, size_t front_bytes = 0);
   ~DevArena();
-  void wait();      // until the helper thread has the block (a caller with nothing to do in the meantime)
+  void wait();      // until the helper thread is done
   DevArena(const DevArena&) = delete;
   DevArena& operator=(const DevArena&) = delete;
  private:
-  struct Impl;
-  Impl* impl_ = nullptr;
+  void* mine_ = nullptr;
+  void* helper_ = nullptr;      // std::thread
+  void* stop_ = nullptr;        // std::atomic<bool>
 };
-// what a setup of an operator with nnz non-zeros asks for: ~300 bytes per non-zero, at most 45 % of the free device memory
+// the front a setup of an operator with nnz non-zeros asks for: about the size of its hierarchy (350 bytes per non-zero)
+inline size_t dev_arena_front_for(double nnz) { return (size_t)(350.0 * (nnz > 0 ? nnz : 0)); }
+// the limit a setup of an operator with nnz non-zeros passes: about 1 kB per non-zero (at least 4 GB, at most 92 % of the
+// free device memory); 0 = no arena, for setups that move less than 256 MB (~300 bytes per non-zero)
 size_t dev_arena_bytes_for(double nnz);
 
 // Exception safety of the setup code, which holds raw dev_alloc pointers: while a DevScope is alive on a thread every
@@ -57,4 +74,9 @@ class DevScope {
   bool trim_;
   int exceptions_;
 };
+
+// Where the library is, for the post-mortem of a GPU memory fault (the runtime aborts the process from its own thread; no
+// exception, no error code): the long device steps of setup and upload note their name here, and with AIRHIP_FAULT_STAGE=1
+// a SIGABRT handler prints the last one noted.  `what` must be a string literal (the pointer is kept).
+void dev_stage(const char* what);
 }  // namespace airhip

@@ -6,6 +6,7 @@
 // src/FC_Smooth.F90:421-640; petsc_horner src/Gmres_Poly.F90:1418-1484; petsc_newton
 // src/Gmres_Poly_Newton.F90:763-875; Neumann shell src/Neumann_Poly.F90:19-55.
 #include "pcair_dev.hpp"
+#include "devmem.hpp"
 #include <parallel/algorithm>
 #include <cstdio>
 
@@ -14,7 +15,24 @@ namespace airhip {
 // where the upload of a hierarchy spends its time (printed with -pc_air_print_stats_timings)
 static double g_t_h2d = 0.0, g_t_convert = 0.0;
 
+// the setup accelerator that built the hierarchy being uploaded (DevPCAIR::set_device_source), or null
+static thread_local SetupAccel* t_source = nullptr;
+static int64_t g_n_from_device = 0;
+
 void upload_mat(const Csr& A, const int32_t* d_rowsrc, const int32_t* d_colmap, DevMat& out, hipStream_t s, int64_t n_ghost) {
+  // an operator the setup left on this device is converted where it is
+  if (t_source && A.device_tag) {
+    const int64_t* rp = nullptr; const int32_t* ci = nullptr; const double* v = nullptr;
+    if (t_source->device_copy(A.device_tag, A.m, A.nnz(), &rp, &ci, &v)) {
+      const double t0 = now_s();
+      devmat_from_csr_device(A.m, A.n, rp, ci, v, d_rowsrc, d_colmap, out, s, n_ghost);
+      t_source->drop_device_copy(A.device_tag);
+      g_t_convert += now_s() - t0;
+      g_n_from_device++;
+      return;
+    }
+  }
+  if (!A.on_host()) throw std::logic_error("upload of an operator that is neither on the host nor kept on the device");
   // the CSR arrays are only staged on the device: blocks from the cache, back to it afterwards
   struct Staged { void* p; explicit Staged(size_t bytes) : p(dev_alloc(bytes)) {} ~Staged() { dev_free(p); } };
   const int64_t nnz = A.nnz();
@@ -239,9 +257,11 @@ void DevPCAIR::upload_inv(const InvOp& h, DevInv& d, const DevMat* Aop, const do
 }
 
 void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy* dist, Comm* comm) {
+  dev_stage("upload of the hierarchy");
   const int L = H.no_levels();
   const double t_upload0 = now_s();
-  g_t_h2d = g_t_convert = 0.0;
+  g_t_h2d = g_t_convert = 0.0; g_n_from_device = 0;
+  struct SourceScope { SetupAccel* prev; explicit SourceScope(SetupAccel* a) : prev(t_source) { t_source = a; } ~SourceScope() { t_source = prev; } } source_scope(dist ? nullptr : source_);
   comm_ = dist ? comm : nullptr;
   if (dist && !comm) throw std::runtime_error("a distributed hierarchy needs a communicator");
   overlap_ = comm_ && (overlap_mode_ < 0 ? comm_->device_side() : overlap_mode_ != 0);
@@ -557,8 +577,8 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
     }
   }
   if (H.opt.print_stats_timings) {
-    std::printf(" hierarchy to the device: %.2f s (orderings %.2f s, host -> device copies of the operators %.2f s, conversion to row blocks %.2f s, compaction %.2f s)\n",
-                now_s() - t_upload0, t_order, g_t_h2d, g_t_convert, t_compact);
+    std::printf(" hierarchy to the device: %.2f s (orderings %.2f s, host -> device copies of the operators %.2f s, conversion to row blocks %.2f s, compaction %.2f s; %lld operators were on the device already)\n",
+                now_s() - t_upload0, t_order, g_t_h2d, g_t_convert, t_compact, (long long)g_n_from_device);
     std::fflush(stdout);
   }
 }
@@ -775,6 +795,7 @@ void DevPCAIR::vcycle_full() {
 }
 
 void DevPCAIR::vcycle() {
+  dev_stage("solve: V-cycle");
   if (full_) { vcycle_full(); return; }
   const int L = no_levels();
   // DOWN: b_{l+1} = b_c + Z b_f (identity block of R=[Z I] is the in-place b_c)

@@ -88,6 +88,9 @@ class DevPCAIR {
   // Locality keys of the fine rows (e.g. a brick / Morton index of the grid point): rows with close
   // keys are stored close together on every level.  Affects the device layout only; call before upload.
   void set_ordering_hint(const int64_t* key, int64_t n) { hint_.assign(key, key + n); }
+  // the accelerator that ran the setup on this device: upload() converts the operators it kept (SetupAccel::device_copy)
+  // where they are instead of copying them from the host again.  Only read during upload().
+  void set_device_source(SetupAccel* a) { source_ = a; }
   int64_t n() const { return n_; }
   int no_levels() const { return (int)levels_.size() + 1; }
 
@@ -135,6 +138,7 @@ class DevPCAIR {
   void end_kernel();
   void upload_inv(const InvOp& h, DevInv& d, const DevMat* Aop, const double* host_diag_of_op, const HaloHost* halo = nullptr,
                   const int32_t* d_rowsrc = nullptr, const int32_t* d_colmap = nullptr, const int32_t* pos_host = nullptr);
+  SetupAccel* source_ = nullptr;
   std::vector<int64_t> hint_;    // optional locality keys of the fine rows (see set_ordering_hint)
   // distributed operands: halo plan creation and the exchange in front of a product
   void attach_halo(DevMat& M, const HaloHost* h, const int32_t* host_colmap);

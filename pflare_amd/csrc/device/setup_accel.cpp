@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <vector>
+#include <unordered_map>
 
 namespace airhip {
 
@@ -34,7 +35,51 @@ struct DevSetupAccel final : SetupAccel {
   uint64_t z_tag = 0;
   DCsr inverse;                  // last assembled polynomial inverse (the B of the Z = -A_cf * M product that follows)
   const void* inverse_key = nullptr;
+  uint64_t inverse_tag = 0;      // Csr::device_tag of that inverse
   int64_t min_nnz = 200000;      // smaller products stay on the host: launch + sync overheads dominate
+  uint64_t fc_tag = 0;           // tag of the F-C block of the last extraction (its device copy goes straight to `kept`)
+
+  // ---- copies kept for the upload of the hierarchy (SetupAccel::keep_copies): an operator the setup is done with is
+  // retired, not freed, while the copies stay below 40 % of the device's memory
+  bool keeping = false;
+  std::unordered_map<uint64_t, DCsr> kept;
+  size_t kept_bytes = 0, kept_limit = 0;
+  static size_t bytes_of(const DCsr& d) { return sizeof(int64_t) * (size_t)(d.m + 1) + 12 * (size_t)d.nnz; }
+  void keep_copies(bool on) override {
+    keeping = on;
+    if (on && !pressure_id) pressure_id = dev_add_pressure_handler([this] { return drop_all_kept(); });
+    if (on && !kept_limit) {
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) kept_limit = (size_t)(0.40 * (double)total_b); else (void)hipGetLastError();
+    }
+  }
+  int pressure_id = 0;
+  size_t drop_all_kept() {          // the device is full: the copies are only a short cut
+    const size_t b = kept_bytes;
+    for (auto& k : kept) dcsr_free(k.second);
+    kept.clear(); kept_bytes = 0; keeping = false;
+    return b;
+  }
+  void retire(DCsr& d, uint64_t tag) {
+    if (keeping && tag && d.rp && kept_bytes + bytes_of(d) <= kept_limit && !kept.count(tag)) { kept[tag] = d; kept_bytes += bytes_of(d); d = DCsr(); }
+    else dcsr_free(d);
+  }
+  std::unordered_map<uint64_t, DCsr> lent;      // copies handed out by device_copy: not dropped under memory pressure
+  bool device_copy(uint64_t tag, int64_t m, int64_t nnz, const int64_t** rp, const int32_t** ci, const double** v) override {
+    auto it = kept.find(tag);
+    if (it == kept.end() || it->second.m != m || it->second.nnz != nnz) return false;
+    *rp = it->second.rp; *ci = it->second.ci; *v = it->second.v;
+    kept_bytes -= bytes_of(it->second);
+    lent[tag] = it->second;
+    kept.erase(it);
+    return true;
+  }
+  void drop_device_copy(uint64_t tag) override {
+    auto it = lent.find(tag);
+    if (it == lent.end()) return;
+    dcsr_free(it->second);
+    lent.erase(it);
+  }
 
   // ---- downloads that run beside the next steps (split_fc: the F-C and C-F blocks).  The host arrays belong to the
   // pending record until the copy has landed and are moved into the target Csr then (a Level that dies early - an
@@ -102,10 +147,13 @@ struct DevSetupAccel final : SetupAccel {
 
   // (the block cache is not trimmed here: the upload of the hierarchy that usually follows stages through it)
   ~DevSetupAccel() override {
+    if (pressure_id) dev_remove_pressure_handler(pressure_id);
     for (auto& p : pending) finish_one(*p, false);
     pending.clear();
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
     dcsr_free(resident); dcsr_free(inverse); dcsr_free(res_ff); dcsr_free(res_cf); dcsr_free(res_z);
+    for (auto& k : kept) dcsr_free(k.second);
+    for (auto& k : lent) dcsr_free(k.second);
   }
 
   bool is_resident(const Csr& A) const {
@@ -134,19 +182,22 @@ struct DevSetupAccel final : SetupAccel {
   Csr spgemm_z(const Csr& A, const Csr& B, const SpgemmDrop& drop) override { return product(A, B, drop, true); }
 
   Csr product(const Csr& A, const Csr& B, const SpgemmDrop& drop, bool keep) {
-    dcsr_free(res_z); z_tag = 0;
+    retire(res_z, z_tag); z_tag = 0;
     if (A.nnz() + B.nnz() < min_nnz) { sync_host(nullptr); return airhip::spgemm(A, B, drop); }
     DCsr dA, dB;
+    uint64_t b_tag = 0;
     if (A.device_tag && A.device_tag == cf_tag && res_cf.rp && res_cf.nnz == A.nnz()) { dA = res_cf; res_cf = DCsr(); cf_tag = 0; }
     else { sync_host(nullptr); dA = up(A); }
-    if (inverse_key && inverse_key == (const void*)B.rp.data() && inverse.m == B.m && inverse.nnz == B.nnz()) { dB = inverse; inverse = DCsr(); }
+    if (inverse_key && inverse_key == (const void*)B.rp.data() && inverse.m == B.m && inverse.nnz == B.nnz()) { dB = inverse; inverse = DCsr(); b_tag = inverse_tag; }
     else dB = up(B);
-    dcsr_free(inverse); inverse_key = nullptr;
+    dcsr_free(inverse); inverse_key = nullptr; inverse_tag = 0;
     const double t0 = now_s();
+    dev_stage("setup: product (Z = -A_cf * M or A * B)");
     DCsr dC = dev_spgemm(dA, dB, drop.enabled, drop.tol, drop.lump, drop.negate, stream);
+    dev_stage("setup: product, download of the result");
     t_compute += now_s() - t0;
     sync_host(nullptr);          // a download of dA (the C-F block) may still be reading it
-    dcsr_free(dA); dcsr_free(dB);
+    dcsr_free(dA); retire(dB, b_tag);      // the inverse is an operator of the hierarchy
     Csr C = down(dC);
     if (keep) { res_z = dC; z_tag = C.device_tag = ++next_tag; }
     else dcsr_free(dC);
@@ -161,6 +212,7 @@ struct DevSetupAccel final : SetupAccel {
     if (!is_resident(A)) { drop_resident(); resident = up(A); resident_key = (const void*)A.rp.data(); }
     const double t0 = now_s();
     markers.alloc(A.m);
+    dev_stage("setup: CF splitting (PMISR + DDC)");
     dev_cf_splitting_pmisr_ddc(resident, o.strong_threshold, !o.symmetric, o.max_luby_steps, rng_key(o.seed), o.ddc_its,
                                o.ddc_fraction, markers.data(), stream);
     t_cfsplit += now_s() - t0;
@@ -172,15 +224,17 @@ struct DevSetupAccel final : SetupAccel {
     if (!enabled || A.nnz() < min_nnz || c.size() < 3) return false;
     DCsr dA, dM;
     if (A.device_tag && A.device_tag == ff_tag && res_ff.rp && res_ff.nnz == A.nnz()) { dA = res_ff; res_ff = DCsr(); ff_tag = 0; }
-    else dA = up(A);
+    else dA = up(A);                       // (a fresh copy of the same host arrays: as good for the upload later)
     const double t0 = now_s();
+    dev_stage("setup: polynomial assembly");
     const bool ok = dev_poly_assemble(dA, c.data(), (int)c.size(), dM, stream);
+    dev_stage("setup: polynomial assembly, download");
     t_poly += now_s() - t0;
-    dcsr_free(dA);
+    retire(dA, A.device_tag);              // A_ff itself is an operator of the hierarchy
     if (!ok) return false;
     M = down(dM);
-    dcsr_free(inverse); inverse_key = nullptr;
-    if (final_values) { inverse = dM; inverse_key = (const void*)M.rp.data(); }   // Arr moves keep the pointer
+    dcsr_free(inverse); inverse_key = nullptr; inverse_tag = 0;
+    if (final_values) { inverse = dM; inverse_key = (const void*)M.rp.data(); inverse_tag = M.device_tag = ++next_tag; }   // Arr moves keep the pointer
     else dcsr_free(dM);
     return true;
   }
@@ -205,11 +259,13 @@ struct DevSetupAccel final : SetupAccel {
       const bool have = is_resident(A);
       if (!have && !A.on_host()) return false;
       DCsr dA = have ? resident : up(A);
+      dev_stage("setup: truncation test, row-block conversion");
       devmat_from_csr_device(dA.m, dA.n, dA.rp, dA.ci, dA.v, nullptr, nullptr, B.M, stream, 0, true);   // arrays from / to the block cache
       HIP_CHECK(hipStreamSynchronize(stream));
       if (!have) dcsr_free(dA);
     }
     const double t0 = now_s();
+    dev_stage("setup: truncation test, Arnoldi");
     double* V = B.alloc((size_t)(p + 2) * (size_t)n);
     double* w = B.alloc((size_t)n);
     double* scratch = B.alloc((size_t)mdot_scratch_doubles(p + 2));
@@ -260,6 +316,7 @@ struct DevSetupAccel final : SetupAccel {
       HIP_CHECK(hipMemcpyAsync(x, hv.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, stream));
       HIP_CHECK(hipStreamSynchronize(stream));
     }
+    dev_stage("setup: truncation test, Newton apply");
     launch_fill(n, 0.0, y, stream);
     const double* t = x;
     auto other = [&](const double* cur) { return cur == ta ? tb : ta; };
@@ -316,12 +373,15 @@ struct DevSetupAccel final : SetupAccel {
     resident_key = nullptr; resident_tag = 0;
     DCsr dP = up(P);
     double t0 = now_s();
+    dev_stage("setup: rap, A * P");
     DCsr dAP = dev_spgemm(dA, dP, false, 0.0, false, false, stream);
     t_compute += now_s() - t0;
     dcsr_free(dA); dcsr_free(dP);
     DCsr dR = up(R);
     t0 = now_s();
+    dev_stage("setup: rap, R * (A P)");
     DCsr dC = dev_spgemm(dR, dAP, drop.enabled, drop.tol, drop.lump, drop.negate, stream);
+    dev_stage("setup: rap, after the products");
     t_compute += now_s() - t0;
     dcsr_free(dR); dcsr_free(dAP);
     Csr C;
@@ -340,7 +400,7 @@ struct DevSetupAccel final : SetupAccel {
                   const SpgemmDrop& drop, Csr& coarse) override {
     static const bool enabled = [] { const char* e = std::getenv("AIRHIP_DEVICE_RP"); return !(e && e[0] == '0'); }();
     const bool have_z = enabled && res_z.rp && Z.device_tag && Z.device_tag == z_tag && res_z.m == Z.m && res_z.nnz == Z.nnz();
-    if (!have_z || A.nnz() < min_nnz || !is_resident(A)) { dcsr_free(res_z); z_tag = 0; return false; }
+    if (!have_z || A.nnz() < min_nnz || !is_resident(A)) { retire(res_z, z_tag); z_tag = 0; return false; }
     const int64_t n = A.m, n_f = F.size(), n_c = C.size();
     // the index lists and the prolongator's columns: 8 bytes per row of the level
     double t0 = now_s();
@@ -356,13 +416,18 @@ struct DevSetupAccel final : SetupAccel {
     if (n_c) staged_h2d(d_C.p, C.data(), sizeof(int32_t) * (size_t)n_c);
     t_transfer += now_s() - t0;
     t0 = now_s();
+    dev_stage("setup: rap_from_z, one-point P on the device");
     DCsr dP = dev_build_P_one_point(n, n_c, (const uint32_t*)d_code.p, (const int32_t*)d_w.p, stream);
     DCsr dA = resident; resident = DCsr(); resident_key = nullptr; resident_tag = 0;
+    dev_stage("setup: rap_from_z, A * P");
     DCsr dAP = dev_spgemm(dA, dP, false, 0.0, false, false, stream);
     dcsr_free(dA); dcsr_free(dP);
+    dev_stage("setup: rap_from_z, R = [Z I] on the device");
     DCsr dR = dev_build_R(res_z, (const int32_t*)d_F.p, (const int32_t*)d_C.p, n, stream);
-    dcsr_free(res_z); z_tag = 0;
+    retire(res_z, z_tag); z_tag = 0;
+    dev_stage("setup: rap_from_z, R * (A P)");
     DCsr dC = dev_spgemm(dR, dAP, drop.enabled, drop.tol, drop.lump, drop.negate, stream);
+    dev_stage("setup: rap_from_z, after the products");
     t_compute += now_s() - t0;
     dcsr_free(dR); dcsr_free(dAP);
     coarse = Csr();
@@ -397,8 +462,10 @@ struct DevSetupAccel final : SetupAccel {
     t_transfer += now_s() - t0;
     t0 = now_s();
     DCsr dff, dfc, dcf, dcc;
+    dev_stage("setup: F / C block extraction");
     dev_split_fc(resident, d_code, n_f, n_c, dff, dfc, dcf, A_cc ? &dcc : nullptr, stream);
     dev_free(d_code);
+    dev_stage("setup: F / C blocks, downloads");
     t_extract += now_s() - t0;
     sync_host(nullptr);
     // A_ff is read by the host at once (diagonal test, polynomial coefficients); the F-C and C-F blocks are not needed
@@ -407,7 +474,7 @@ struct DevSetupAccel final : SetupAccel {
     A_ff = down(dff);
     const bool async = async_enabled() && !A_cc;
     if (async) { begin_down(dfc, A_fc, true); begin_down(dcf, A_cf, false); }
-    else { A_fc = down(dfc); A_cf = down(dcf); dcsr_free(dfc); }
+    else { A_fc = down(dfc); A_cf = down(dcf); A_fc.device_tag = ++next_tag; retire(dfc, A_fc.device_tag); }
     if (A_cc) { *A_cc = down(dcc); dcsr_free(dcc); }
     // A_ff feeds the polynomial assembly, A_cf the Z product: they stay
     dcsr_free(res_ff); dcsr_free(res_cf);

@@ -912,9 +912,7 @@ DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, boo
   for (bool first = true;; first = false) {
     // pool: twice the inputs (more when nothing will be dropped), never more than the sum of the bounds, never more than
     // a third of the free memory
-    size_t mem_free = 0, mem_total = 0;
-    HIP_CHECK(hipMemGetInfo(&mem_free, &mem_total));
-    mem_free += dev_cache_idle_bytes();      // released blocks are handed back when a request does not fit
+    const size_t mem_free = dev_available_bytes();      // free memory + what the cache and the setup arena hold unused
     int64_t capacity = std::max<int64_t>(2 * (A.nnz + B.nnz) + (1 << 20), 2 * longest);
     // nothing is dropped: the rows keep all their distinct columns, which the sample has an estimate of
     if ((!drop_enabled || tol == 0.0) && plan.ratio < 1.0f) capacity = std::max<int64_t>(capacity, (int64_t)(1.1 * (double)plan.ratio * (double)ub_total));

@@ -90,6 +90,15 @@ struct SetupAccel {
   // (host/poly.cpp::mat_mult_powers_share_sparsity).  Returns false when it declines.  final_values: the caller will not
   // change M afterwards (the accelerator may then keep its copy for the product that follows).
   virtual bool poly_assemble(const Csr& A, const std::vector<double>& c, Csr& M, bool final_values) { (void)A; (void)c; (void)M; (void)final_values; return false; }
+  // Copies the accelerator kept of operators it produced or extracted (named by Csr::device_tag), for the upload of the
+  // hierarchy that follows the setup on the same device: keep_copies(true) asks for them (within the accelerator's own
+  // memory budget), device_copy hands out the arrays of one (CSR, the host Csr's row order; false = none kept, the caller
+  // copies the host arrays), drop_device_copy gives its memory back.
+  virtual void keep_copies(bool on) { (void)on; }
+  virtual bool device_copy(uint64_t tag, int64_t m, int64_t nnz, const int64_t** rp, const int32_t** ci, const double** v) {
+    (void)tag; (void)m; (void)nnz; (void)rp; (void)ci; (void)v; return false;
+  }
+  virtual void drop_device_copy(uint64_t tag) { (void)tag; }
   double t_transfer = 0.0, t_compute = 0.0, t_cfsplit = 0.0, t_poly = 0.0, t_extract = 0.0;
 };
 // the accelerator the polynomial assembly may use (set by setup_air for its duration; null = host only)

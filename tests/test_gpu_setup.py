@@ -335,11 +335,12 @@ def test_device_polynomial_assembly_on_denser_operators(gpu):
     _same(pd.get_inverse(n)["mat"], ph.get_inverse(n)["mat"], "dense rows")
 
 
-@pytest.mark.parametrize("arena_gb", ["0", "0.3", "4"], ids=["no-arena", "arena-too-small", "arena-roomy"])
+@pytest.mark.parametrize("arena_gb", ["0", "0.1", "0.3", "4"], ids=["no-arena", "arena-backs-nothing", "arena-one-piece", "arena-roomy"])
 def test_setup_arena_sizes_give_the_same_hierarchy_and_solve(gpu, arena_gb, monkeypatch):
-    """device/devmem.hpp DevArena: the setup's temporaries and the hierarchy's arrays are carved from one device block.  With no
-    arena, with one that is far too small (most requests fall back to the block cache / hipMalloc, the rest fragment it) and
-    with a roomy one the hierarchy must be the host code's, bit for bit, and the solve must not change."""
+    """device/devmem.hpp DevArena: the setup's temporaries and the hierarchy's arrays are carved from one reserved address range
+    that is backed with memory piece by piece (256 MB each).  With no arena, with a limit below one piece (every request falls
+    back to the block cache / hipMalloc), with room for a single piece and with a roomy limit the hierarchy must be the host
+    code's, bit for bit, and the solve must not change."""
     import torch
     import pflare_amd as P
     monkeypatch.setenv("AIRHIP_DEVICE_ARENA_GB", arena_gb)
