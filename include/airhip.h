@@ -216,6 +216,13 @@ int airhip_pcair_complexities(airhip_pcair pc, double* grid, double* op, double*
 int airhip_pcair_cycle_alg_bytes(airhip_pcair pc, double* bytes);
 int airhip_pcair_setup_times(airhip_pcair pc, double* host_setup_s, double* upload_s);
 /* free the host copy of the hierarchy (export functions then fail with AIRHIP_ERR_STATE) */
+/* A hierarchy set up on the device keeps the operators no host routine reads (A_cf, the assembled A_ff inverses, Z) there
+ * during the setup; a thread of the library copies them into the host hierarchy after airhip_pcair_setup has returned (the
+ * solve does not need them).  Every call that reads the host hierarchy (level_get, level_inv, coarse_get, partition_create,
+ * release_host, a new setup, destroy) waits for that thread by itself; this call only waits, and reports how long the
+ * thread ran.  AIRHIP_DEFER_DOWNLOADS=0 in the environment: everything is copied during the setup, as in the reference's
+ * host build (src/AIR_MG_Setup.F90 keeps all operators as host Mats). */
+int airhip_pcair_host_mirror_wait(airhip_pcair pc, double* seconds);
 int airhip_pcair_release_host(airhip_pcair pc);
 /* run the V-cycle through a captured HIP graph (default off) */
 int airhip_pcair_use_graph(airhip_pcair pc, int on);

@@ -42,7 +42,7 @@ DECLARED_SYMBOLS = [
     "airhip_pcair_sync", "airhip_pcair_destroy", "airhip_pcair_num_levels", "airhip_pcair_level_sizes",
     "airhip_pcair_level_get", "airhip_pcair_level_inv", "airhip_pcair_level_smooth_order",
     "airhip_pcair_coarse_get", "airhip_pcair_complexities", "airhip_pcair_cycle_alg_bytes", "airhip_pcair_setup_times",
-    "airhip_pcair_release_host", "airhip_pcair_use_graph", "airhip_pcair_profile",
+    "airhip_pcair_release_host", "airhip_pcair_host_mirror_wait", "airhip_pcair_use_graph", "airhip_pcair_profile",
     "airhip_pcair_profile_reset", "airhip_pcair_profile_count", "airhip_pcair_profile_get", "airhip_pcair_profile_kernel",
     "airhip_pcinv_create", "airhip_pcinv_set_option", "airhip_pcinv_setup", "airhip_pcinv_apply",
     "airhip_pcinv_sync", "airhip_pcinv_get_inv", "airhip_pcinv_destroy",
@@ -114,6 +114,7 @@ def lib():
         "airhip_pcair_cycle_alg_bytes": [vp, pd],
         "airhip_pcair_setup_times": [vp, pd, pd],
         "airhip_pcair_release_host": [vp],
+        "airhip_pcair_host_mirror_wait": [vp, pd],
         "airhip_pcair_use_graph": [vp, C.c_int],
         "airhip_pcair_profile": [vp, C.c_int],
         "airhip_pcair_profile_reset": [vp],

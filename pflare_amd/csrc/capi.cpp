@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
+#include <exception>
 
 using namespace airhip;
 
@@ -363,6 +365,15 @@ struct airhip_pcair_s {
   bool device_upload = true;      // false: keep the hierarchy on the host only (it will be partitioned)
   std::vector<int64_t> hint;      // optional locality keys of the fine rows (device layout only)
   double accel_transfer_s = 0, accel_compute_s = 0;
+  // ---- the host mirror of a hierarchy set up on the device: the operators whose download the setup deferred are fetched
+  // by this thread after the upload (mirror_join() before anything reads pc->H's matrices)
+  std::unique_ptr<SetupAccel> mirror_accel;
+  std::thread mirror_thread;
+  std::exception_ptr mirror_error;
+  double mirror_s = 0;
+  double cplx[5] = {0, 0, 0, 0, 0};     // complexities, taken before the mirror starts
+  bool cplx_valid = false;
+  ~airhip_pcair_s() { if (mirror_thread.joinable()) mirror_thread.join(); }
   StreamLink link;                // orders the library stream against the caller's
 };
 
@@ -456,6 +467,31 @@ int airhip_pcair_set_option(airhip_pcair pc, const char* name, const char* value
   API_END
 }
 
+// Waits for the host mirror (see airhip_pcair_s::mirror_thread); an error of the thread surfaces here
+static void mirror_join(airhip_pcair pc) {
+  if (!pc) return;
+  if (pc->mirror_thread.joinable()) pc->mirror_thread.join();
+  pc->mirror_accel.reset();
+  if (pc->mirror_error) { std::exception_ptr e = pc->mirror_error; pc->mirror_error = nullptr; std::rethrow_exception(e); }
+}
+// every operator of the hierarchy whose arrays are still on the device only
+static void mirror_fetch(Hierarchy& H, SetupAccel& accel) {
+  for (auto& lp : H.levels) {
+    Level& l = *lp;
+    for (Csr* c : {&l.A_ff, &l.A_fc, &l.A_cf, &l.A_cc, &l.Z, &l.W, &l.inv_ff.mat, &l.inv_cc.mat, &l.A_full})
+      if (!c->on_host()) { const uint64_t tag = c->device_tag; accel.materialize(*c); accel.drop_device_copy(tag); }
+  }
+  if (!H.coarse_A.on_host()) accel.materialize(H.coarse_A);
+  if (!H.coarse_inv.mat.on_host()) accel.materialize(H.coarse_inv.mat);
+}
+static bool hierarchy_has_stubs(const Hierarchy& H) {
+  for (auto& lp : H.levels) {
+    const Level& l = *lp;
+    for (const Csr* c : {&l.A_ff, &l.A_fc, &l.A_cf, &l.A_cc, &l.Z, &l.W, &l.inv_ff.mat, &l.inv_cc.mat, &l.A_full}) if (!c->on_host()) return true;
+  }
+  return !H.coarse_A.on_host() || !H.coarse_inv.mat.on_host();
+}
+
 // AIRHIP_KEEP_DEVICE_COPIES=0: the upload copies every operator from the host again (the first version's behaviour)
 static bool keep_device_copies() { static const bool on = [] { const char* e = std::getenv("AIRHIP_KEEP_DEVICE_COPIES"); return !(e && e[0] == '0'); }(); return on; }
 
@@ -486,7 +522,8 @@ int airhip_pcair_setup(airhip_pcair pc, const airhip_csr* A) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
     g_err = "no HIP device: the PCAIR solve phase has no CPU fallback"; return AIRHIP_ERR_HIP;
   }
-  pc->dev.reset(); pc->H.reset();
+  mirror_join(pc);
+  pc->dev.reset(); pc->H.reset(); pc->cplx_valid = false; pc->mirror_s = 0.0;
   view_csr(A, pc->A_top);
   ThreadScope threads(A->rowptr[A->m]);
   double t0 = now_s();
@@ -495,6 +532,7 @@ int airhip_pcair_setup(airhip_pcair pc, const airhip_csr* A) {
   {
     if (pc->setup_on_device) accel = make_device_setup_accel(nullptr, pc->setup_device_min_nnz);
     if (accel) accel->keep_copies(pc->device_upload && keep_device_copies());     // for finish_device below
+    if (accel) accel->defer_downloads(pc->device_upload && keep_device_copies());  // fetched by the mirror thread afterwards
     pc->H = setup_air(pc->A_top, pc->opt, accel.get());
     if (accel) {
       pc->accel_transfer_s = accel->t_transfer; pc->accel_compute_s = accel->t_compute;
@@ -509,6 +547,25 @@ int airhip_pcair_setup(airhip_pcair pc, const airhip_csr* A) {
   pc->byo = false;
   pc->op_nnz_top = (double)pc->A_top.nnz();
   if (pc->device_upload) finish_device(pc, accel.get());
+  // the numbers print_stats and airhip_pcair_complexities report, while nothing else touches the hierarchy
+  pc->cplx_valid = false;
+  if (airhip_pcair_complexities(pc, &pc->cplx[0], &pc->cplx[1], &pc->cplx[2], &pc->cplx[3], &pc->cplx[4]) == 0) pc->cplx_valid = true;
+  if (accel && hierarchy_has_stubs(*pc->H)) {
+    // The operators whose download was deferred come to the host beside whatever the caller does next (the solve does
+    // not need them); everything that reads the host hierarchy waits for this thread first (mirror_join).
+    accel->release_copies();
+    int dev = 0; (void)hipGetDevice(&dev);
+    pc->mirror_accel = std::move(accel);
+    pc->mirror_error = nullptr;
+    pc->mirror_thread = std::thread([pc, dev] {
+      const double t0 = now_s();
+      try {
+        if (hipSetDevice(dev) != hipSuccess) throw std::runtime_error("host mirror: hipSetDevice failed");
+        mirror_fetch(*pc->H, *pc->mirror_accel);
+      } catch (...) { pc->mirror_error = std::current_exception(); }
+      pc->mirror_s = now_s() - t0;
+    });
+  }
   accel.reset();
   dev_cache_trim();
   if (pc->opt.print_stats_timings) { std::printf(" %s\n", host_array_cache_report().c_str()); std::fflush(stdout); }
@@ -531,6 +588,7 @@ int airhip_pcair_setup(airhip_pcair pc, const airhip_csr* A) {
 // the setup and by hierarchy export); apply / solve calls then fail with AIRHIP_ERR_STATE.
 int airhip_pcair_setup_host_only(airhip_pcair pc, const airhip_csr* A) {
   API_BEGIN
+  mirror_join(pc);
   REQUIRE(pc && A && A->rowptr && A->m == A->n && A->m > 0, AIRHIP_ERR_ARG, "PCAIR needs a square CSR operator");
   REQUIRE_CSR(A, true);
   pc->dev.reset(); pc->H.reset();
@@ -572,6 +630,7 @@ static void fill_inv(const airhip_invop* in, InvOp& out, int64_t n) {
 
 int airhip_pcair_begin_levels(airhip_pcair pc, int no_levels, const airhip_csr* A_top) {
   API_BEGIN
+  mirror_join(pc);
   REQUIRE(pc && no_levels >= 1 && A_top, AIRHIP_ERR_ARG, "bad argument");
   REQUIRE_CSR(A_top, true);
   pc->dev.reset();
@@ -690,7 +749,10 @@ int airhip_pcair_sync(airhip_pcair pc) {
 }
 int airhip_pcair_destroy(airhip_pcair* pc) {
   API_BEGIN
-  if (pc && *pc) { delete *pc; *pc = nullptr; }
+  if (pc && *pc) {
+    try { mirror_join(*pc); } catch (...) {}      // an error of the host mirror dies with the object
+    delete *pc; *pc = nullptr;
+  }
   API_END
 }
 
@@ -706,6 +768,7 @@ int airhip_pcair_num_levels(airhip_pcair pc, int* no_levels) {
 int airhip_pcair_level_sizes(airhip_pcair pc, int level, int64_t* n, int64_t* n_f, int64_t* n_c, int* aff_diag,
                              int* one_point, int64_t* nnz_A) {
   API_BEGIN
+  mirror_join(pc);
   REQUIRE(pc && pc->H, AIRHIP_ERR_STATE, "host hierarchy not available");
   const int L = pc->H->no_levels();
   REQUIRE(level >= 0 && level < L, AIRHIP_ERR_ARG, "level out of range");
@@ -740,6 +803,7 @@ static void expose_inv(const InvOp& in, airhip_invop* out) {
 int airhip_pcair_level_get(airhip_pcair pc, int level, const char* which, airhip_csr* csr, const int32_t** idx,
                            const double** vec, int64_t* len) {
   API_BEGIN
+  mirror_join(pc);
   REQUIRE(pc && pc->H && which, AIRHIP_ERR_STATE, "host hierarchy not available");
   REQUIRE(level >= 0 && level < pc->H->no_levels() - 1, AIRHIP_ERR_ARG, "level out of range");
   const Level& lv = *pc->H->levels[level];
@@ -770,6 +834,7 @@ int airhip_pcair_level_get(airhip_pcair pc, int level, const char* which, airhip
 
 int airhip_pcair_level_inv(airhip_pcair pc, int level, int which_c, airhip_invop* inv) {
   API_BEGIN
+  mirror_join(pc);
   REQUIRE(pc && pc->H && inv, AIRHIP_ERR_STATE, "host hierarchy not available");
   const int L = pc->H->no_levels();
   REQUIRE(level >= 0 && level < L, AIRHIP_ERR_ARG, "level out of range");
@@ -788,6 +853,7 @@ int airhip_pcair_level_smooth_order(airhip_pcair pc, int level, int* so) {
 
 int airhip_pcair_coarse_get(airhip_pcair pc, airhip_csr* A) {
   API_BEGIN
+  mirror_join(pc);
   REQUIRE(pc && pc->H && A, AIRHIP_ERR_STATE, "host hierarchy not available");
   expose_csr(pc->H->coarse_A, A);
   API_END
@@ -796,6 +862,14 @@ int airhip_pcair_coarse_get(airhip_pcair pc, airhip_csr* A) {
 int airhip_pcair_complexities(airhip_pcair pc, double* grid, double* op, double* cycle, double* storage, double* cyc_bytes) {
   API_BEGIN
   REQUIRE(pc && pc->H, AIRHIP_ERR_STATE, "host hierarchy not available");
+  if (pc->cplx_valid) {      // taken at the end of the setup (the host mirror may still be filling the operators in)
+    if (grid) *grid = pc->cplx[0];
+    if (op) *op = pc->cplx[1];
+    if (cycle) *cycle = pc->cplx[2];
+    if (storage) *storage = pc->cplx[3];
+    if (cyc_bytes) *cyc_bytes = pc->dev ? pc->dev->cycle_alg_bytes() : 0.0;
+    return AIRHIP_OK;
+  }
   const Hierarchy& H = *pc->H;
   // src/AIR_MG_Stats.F90:79-382
   double rows = 0, opn = 0, stor = 0, cyc = 0;
@@ -868,8 +942,16 @@ int airhip_pcair_setup_times(airhip_pcair pc, double* host_setup_s, double* uplo
   if (upload_s) *upload_s = pc->upload_s;
   API_END
 }
+int airhip_pcair_host_mirror_wait(airhip_pcair pc, double* seconds) {
+  API_BEGIN
+  REQUIRE(pc, AIRHIP_ERR_ARG, "null argument");
+  mirror_join(pc);
+  if (seconds) *seconds = pc->mirror_s;
+  API_END
+}
 int airhip_pcair_release_host(airhip_pcair pc) {
   API_BEGIN
+  mirror_join(pc);
   REQUIRE(pc, AIRHIP_ERR_ARG, "null argument");
   pc->H.reset(); pc->A_top = Csr();
   API_END
@@ -930,6 +1012,7 @@ struct airhip_comm_s { std::unique_ptr<Comm> c; };
 
 int airhip_partition_create(airhip_pcair pc, const airhip_csr* A_top, int nranks, const int32_t* owner, airhip_partition* out) {
   API_BEGIN
+  mirror_join(pc);
   REQUIRE(pc && pc->H && A_top && owner && out && nranks >= 1, AIRHIP_ERR_ARG, "partitioning needs a PCAIR with its host hierarchy");
   REQUIRE_CSR(A_top, true);
   auto* h = new airhip_partition_s;
@@ -1039,6 +1122,7 @@ int airhip_comm_destroy(airhip_comm* c) {
 // This rank's piece -> device.  The archive's arrays are only read during the call.
 int airhip_pcair_load_distributed(airhip_pcair pc, airhip_archive piece, airhip_comm comm) {
   API_BEGIN
+  mirror_join(pc);
   DevScope dev_scope(true);
   REQUIRE(pc && piece && comm, AIRHIP_ERR_ARG, "null argument");
   int ndev = 0;

@@ -430,11 +430,16 @@ DevArena::DevArena(size_t bytes, size_t front_bytes) {
       const double t0 = trace_clock();
       size_t done = 0;
       for (size_t k = 0; k < ahead / PIECE && !stop->load(); k++) {
-        std::lock_guard<std::mutex> lk(cache().mu);
-        if (ap->closing || ap->vm.state[k] != 0) continue;
-        if (ap->vm.committed + PIECE > ap->limit || !ap->vm.map_piece(k)) break;
-        done += PIECE;
-        if (ap->vm.committed > ap->peak_committed) ap->peak_committed = ap->vm.committed;
+        {
+          std::lock_guard<std::mutex> lk(cache().mu);
+          if (ap->closing || ap->vm.state[k] != 0) continue;
+          if (ap->vm.committed + PIECE > ap->limit || !ap->vm.map_piece(k)) break;
+          done += PIECE;
+          if (ap->vm.committed > ap->peak_committed) ap->peak_committed = ap->vm.committed;
+        }
+        // the mutex is not fair: without a pause the setup's own requests wait until this loop is through (on a box whose
+        // memory has not been used before a piece takes 8 ms - 4.2 s for the whole front, all of it in the first level)
+        std::this_thread::sleep_for(std::chrono::microseconds(150));
       }
       static const bool tr = std::getenv("AIRHIP_ALLOC_TRACE") != nullptr;
       if (tr) std::fprintf(stderr, "[devmem %.3f] arena: helper backed %.1f GB of the first %.1f GB in %.3f s\n", trace_clock(), done * 1e-9, ahead * 1e-9, trace_clock() - t0);

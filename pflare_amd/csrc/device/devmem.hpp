@@ -53,8 +53,10 @@ class DevArena {
   void* helper_ = nullptr;      // std::thread
   void* stop_ = nullptr;        // std::atomic<bool>
 };
-// the front a setup of an operator with nnz non-zeros asks for: about the size of its hierarchy (350 bytes per non-zero)
-inline size_t dev_arena_front_for(double nnz) { return (size_t)(350.0 * (nnz > 0 ? nnz : 0)); }
+// the front a setup of an operator with nnz non-zeros asks for: about what the setup has backed at its peak (500 bytes per
+// non-zero; the hierarchy itself ends up in the lower two thirds).  On a box whose memory has not been used before, backing
+// costs 30 ms per GB and the setup would otherwise pay it in its products (464^3: R*A*P 7.3 -> 9.5 s)
+inline size_t dev_arena_front_for(double nnz) { return (size_t)(500.0 * (nnz > 0 ? nnz : 0)); }
 // the limit a setup of an operator with nnz non-zeros passes: about 1 kB per non-zero (at least 4 GB, at most 92 % of the
 // free device memory); 0 = no arena, for setups that move less than 256 MB (~300 bytes per non-zero)
 size_t dev_arena_bytes_for(double nnz);

@@ -17,6 +17,8 @@
 #include <cstdlib>
 #include <vector>
 #include <unordered_map>
+#include <unordered_set>
+#include <mutex>
 
 namespace airhip {
 
@@ -40,10 +42,17 @@ struct DevSetupAccel final : SetupAccel {
   uint64_t fc_tag = 0;           // tag of the F-C block of the last extraction (its device copy goes straight to `kept`)
 
   // ---- copies kept for the upload of the hierarchy (SetupAccel::keep_copies): an operator the setup is done with is
-  // retired, not freed, while the copies stay below 40 % of the device's memory
-  bool keeping = false;
+  // retired, not freed, while the copies stay below 40 % of the device's memory.  With defer_downloads() on top, the
+  // operators no host routine of the plain recipe reads (A_cf, the assembled inverse, Z) are not downloaded at all
+  // during the setup: the caller gets stubs (Csr::stub_nnz >= 0) and fetches them with materialize() when it likes
+  // (capi.cpp: a thread, after the upload) - until then the copy here is the only one (`host_missing`) and stays.
+  bool keeping = false, defer_ok = false, plain = false;
+  std::mutex mu_kept;            // kept / lent / host_missing: the mirror thread and the pressure handler
   std::unordered_map<uint64_t, DCsr> kept;
+  std::unordered_map<uint64_t, DCsr> lent;      // copies handed out by device_copy: not dropped under memory pressure
+  std::unordered_set<uint64_t> host_missing;
   size_t kept_bytes = 0, kept_limit = 0;
+  int pressure_id = 0;
   static size_t bytes_of(const DCsr& d) { return sizeof(int64_t) * (size_t)(d.m + 1) + 12 * (size_t)d.nnz; }
   void keep_copies(bool on) override {
     keeping = on;
@@ -53,19 +62,46 @@ struct DevSetupAccel final : SetupAccel {
       if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) kept_limit = (size_t)(0.40 * (double)total_b); else (void)hipGetLastError();
     }
   }
-  int pressure_id = 0;
-  size_t drop_all_kept() {          // the device is full: the copies are only a short cut
-    const size_t b = kept_bytes;
-    for (auto& k : kept) dcsr_free(k.second);
-    kept.clear(); kept_bytes = 0; keeping = false;
+  void defer_downloads(bool on) override { defer_ok = on; }
+  void plain_recipe(bool on) override { plain = on; }
+  // may an operator of this size stay on the device alone?
+  bool can_defer(const DCsr& d) {
+    const char* e = std::getenv("AIRHIP_DEFER_DOWNLOADS");      // (read every time: the tests switch it)
+    const bool enabled = !(e && e[0] == '0');
+    std::lock_guard<std::mutex> lk(mu_kept);
+    return enabled && keeping && defer_ok && plain && kept_bytes + bytes_of(d) <= kept_limit;
+  }
+  static Csr stub_of(const DCsr& d, uint64_t tag) { Csr C; C.m = d.m; C.n = d.n; C.stub_nnz = d.nnz; C.device_tag = tag; return C; }
+  size_t drop_all_kept() {          // the device is full: the copies are only a short cut - except the only ones
+    std::unique_lock<std::mutex> lk(mu_kept, std::try_to_lock);
+    if (!lk.owns_lock()) return 0;
+    size_t b = 0;
+    for (auto it = kept.begin(); it != kept.end();) {
+      if (host_missing.count(it->first)) { ++it; continue; }
+      b += bytes_of(it->second); dcsr_free(it->second); it = kept.erase(it);
+    }
+    kept_bytes -= b; keeping = false;
     return b;
   }
   void retire(DCsr& d, uint64_t tag) {
-    if (keeping && tag && d.rp && kept_bytes + bytes_of(d) <= kept_limit && !kept.count(tag)) { kept[tag] = d; kept_bytes += bytes_of(d); d = DCsr(); }
+    if (!d.rp) return;
+    std::lock_guard<std::mutex> lk(mu_kept);
+    const bool only_copy = tag && host_missing.count(tag);
+    if (tag && !kept.count(tag) && (only_copy || (keeping && kept_bytes + bytes_of(d) <= kept_limit))) { kept[tag] = d; kept_bytes += bytes_of(d); d = DCsr(); }
+    else if (only_copy) throw std::logic_error("setup accelerator: two device copies of an operator that is not on the host");
     else dcsr_free(d);
   }
-  std::unordered_map<uint64_t, DCsr> lent;      // copies handed out by device_copy: not dropped under memory pressure
+  // what still sits in the slots of the level loop (the last inverse - the coarse solver's has no product after it -, the
+  // last Z, a C-F block no product came for) joins the kept copies
+  void settle() {
+    retire(inverse, inverse_tag); inverse_key = nullptr; inverse_tag = 0;
+    retire(res_z, z_tag); z_tag = 0;
+    bool only; { std::lock_guard<std::mutex> lk(mu_kept); only = cf_tag && host_missing.count(cf_tag); }
+    if (only) { retire(res_cf, cf_tag); cf_tag = 0; }
+  }
   bool device_copy(uint64_t tag, int64_t m, int64_t nnz, const int64_t** rp, const int32_t** ci, const double** v) override {
+    settle();
+    std::lock_guard<std::mutex> lk(mu_kept);
     auto it = kept.find(tag);
     if (it == kept.end() || it->second.m != m || it->second.nnz != nnz) return false;
     *rp = it->second.rp; *ci = it->second.ci; *v = it->second.v;
@@ -75,10 +111,19 @@ struct DevSetupAccel final : SetupAccel {
     return true;
   }
   void drop_device_copy(uint64_t tag) override {
-    auto it = lent.find(tag);
-    if (it == lent.end()) return;
-    dcsr_free(it->second);
-    lent.erase(it);
+    std::lock_guard<std::mutex> lk(mu_kept);
+    for (auto* m : {&lent, &kept}) {
+      auto it = m->find(tag);
+      if (it == m->end()) continue;
+      if (host_missing.count(tag)) {           // still the only copy: back to (or stays in) `kept`
+        if (m == &lent) { kept[tag] = it->second; kept_bytes += bytes_of(it->second); lent.erase(it); }
+        return;
+      }
+      if (m == &kept) kept_bytes -= bytes_of(it->second);
+      dcsr_free(it->second);
+      m->erase(it);
+      return;
+    }
   }
 
   // ---- downloads that run beside the next steps (split_fc: the F-C and C-F blocks).  The host arrays belong to the
@@ -183,23 +228,40 @@ struct DevSetupAccel final : SetupAccel {
 
   Csr product(const Csr& A, const Csr& B, const SpgemmDrop& drop, bool keep) {
     retire(res_z, z_tag); z_tag = 0;
-    if (A.nnz() + B.nnz() < min_nnz) { sync_host(nullptr); return airhip::spgemm(A, B, drop); }
+    if (A.on_host() && B.on_host() && A.nnz() + B.nnz() < min_nnz) { sync_host(nullptr); return airhip::spgemm(A, B, drop); }
     DCsr dA, dB;
-    uint64_t b_tag = 0;
-    if (A.device_tag && A.device_tag == cf_tag && res_cf.rp && res_cf.nnz == A.nnz()) { dA = res_cf; res_cf = DCsr(); cf_tag = 0; }
-    else { sync_host(nullptr); dA = up(A); }
-    if (inverse_key && inverse_key == (const void*)B.rp.data() && inverse.m == B.m && inverse.nnz == B.nnz()) { dB = inverse; inverse = DCsr(); b_tag = inverse_tag; }
-    else dB = up(B);
-    dcsr_free(inverse); inverse_key = nullptr; inverse_tag = 0;
+    uint64_t a_tag = 0, b_tag = 0;
+    if (A.device_tag && A.device_tag == cf_tag && res_cf.rp && res_cf.nnz == A.nnz()) { dA = res_cf; res_cf = DCsr(); a_tag = cf_tag; cf_tag = 0; }
+    else {
+      if (!A.on_host()) throw std::logic_error("setup accelerator: the device copy of a product's left operand is gone");
+      sync_host(nullptr); dA = up(A);
+    }
+    const bool b_here = inverse.rp && inverse.m == B.m && inverse.nnz == B.nnz() &&
+                        ((B.device_tag && B.device_tag == inverse_tag) || (B.on_host() && inverse_key && inverse_key == (const void*)B.rp.data()));
+    if (b_here) { dB = inverse; inverse = DCsr(); b_tag = inverse_tag; }
+    else {
+      if (!B.on_host()) throw std::logic_error("setup accelerator: the device copy of a product's right operand is gone");
+      dB = up(B);
+    }
+    retire(inverse, inverse_tag); inverse_key = nullptr; inverse_tag = 0;
     const double t0 = now_s();
     dev_stage("setup: product (Z = -A_cf * M or A * B)");
     DCsr dC = dev_spgemm(dA, dB, drop.enabled, drop.tol, drop.lump, drop.negate, stream);
-    dev_stage("setup: product, download of the result");
     t_compute += now_s() - t0;
     sync_host(nullptr);          // a download of dA (the C-F block) may still be reading it
-    dcsr_free(dA); retire(dB, b_tag);      // the inverse is an operator of the hierarchy
-    Csr C = down(dC);
-    if (keep) { res_z = dC; z_tag = C.device_tag = ++next_tag; }
+    // the C-F block is only kept when the host has not got it yet; the inverse is an operator of the hierarchy
+    { bool only; { std::lock_guard<std::mutex> lk(mu_kept); only = a_tag && host_missing.count(a_tag); } if (only) retire(dA, a_tag); else dcsr_free(dA); }
+    retire(dB, b_tag);
+    Csr C;
+    if (keep && can_defer(dC)) {
+      C = stub_of(dC, ++next_tag);
+      std::lock_guard<std::mutex> lk(mu_kept); host_missing.insert(C.device_tag);
+    } else {
+      dev_stage("setup: product, download of the result");
+      C = down(dC);
+      if (keep) C.device_tag = ++next_tag;
+    }
+    if (keep) { res_z = dC; z_tag = C.device_tag; }
     else dcsr_free(dC);
     return C;
   }
@@ -228,12 +290,17 @@ struct DevSetupAccel final : SetupAccel {
     const double t0 = now_s();
     dev_stage("setup: polynomial assembly");
     const bool ok = dev_poly_assemble(dA, c.data(), (int)c.size(), dM, stream);
-    dev_stage("setup: polynomial assembly, download");
     t_poly += now_s() - t0;
     retire(dA, A.device_tag);              // A_ff itself is an operator of the hierarchy
     if (!ok) return false;
+    retire(inverse, inverse_tag); inverse_key = nullptr; inverse_tag = 0;
+    if (final_values && can_defer(dM)) {
+      M = stub_of(dM, ++next_tag);
+      { std::lock_guard<std::mutex> lk(mu_kept); host_missing.insert(M.device_tag); }
+      inverse = dM; inverse_tag = M.device_tag;
+      return true;
+    }
     M = down(dM);
-    dcsr_free(inverse); inverse_key = nullptr; inverse_tag = 0;
     if (final_values) { inverse = dM; inverse_key = (const void*)M.rp.data(); inverse_tag = M.device_tag = ++next_tag; }   // Arr moves keep the pointer
     else dcsr_free(dM);
     return true;
@@ -441,11 +508,38 @@ struct DevSetupAccel final : SetupAccel {
 
   void materialize(Csr& A) override {
     if (A.on_host()) return;
-    if (!is_resident(A)) throw std::logic_error("materialize: the device copy of the operator is gone");
     const uint64_t tag = A.device_tag;
-    A = down(resident);
+    if (is_resident(A)) {
+      A = down(resident);
+      A.device_tag = tag;
+      resident_key = (const void*)A.rp.data();
+      return;
+    }
+    // an operator whose download was deferred: wherever its copy is at the moment (it stays there: the upload may
+    // still want it; release_copies / drop_device_copy give it back)
+    DCsr d;
+    {
+      std::lock_guard<std::mutex> lk(mu_kept);
+      auto it = kept.find(tag);
+      if (it != kept.end()) d = it->second;
+      else if ((it = lent.find(tag)) != lent.end()) d = it->second;
+    }
+    if (!d.rp && tag && tag == z_tag) d = res_z;
+    if (!d.rp && tag && tag == cf_tag) d = res_cf;
+    if (!d.rp && tag && tag == inverse_tag) d = inverse;
+    if (!d.rp || d.m != A.m || d.nnz != A.nnz()) throw std::logic_error("materialize: the device copy of the operator is gone");
+    A = down(d);
     A.device_tag = tag;
-    resident_key = (const void*)A.rp.data();
+    std::lock_guard<std::mutex> lk(mu_kept);
+    host_missing.erase(tag);
+  }
+  void release_copies() override {
+    settle();
+    std::lock_guard<std::mutex> lk(mu_kept);
+    for (auto it = kept.begin(); it != kept.end();) {
+      if (host_missing.count(it->first)) { ++it; continue; }
+      kept_bytes -= bytes_of(it->second); dcsr_free(it->second); it = kept.erase(it);
+    }
   }
 
   // the F / C blocks of the resident level operator
@@ -473,13 +567,21 @@ struct DevSetupAccel final : SetupAccel {
     // Z product (only with AIRHIP_ASYNC_DOWNLOAD=1, see async_enabled)
     A_ff = down(dff);
     const bool async = async_enabled() && !A_cc;
+    const bool defer_cf = !async && !A_cc && can_defer(dcf);       // only the Z product reads the C-F block
     if (async) { begin_down(dfc, A_fc, true); begin_down(dcf, A_cf, false); }
-    else { A_fc = down(dfc); A_cf = down(dcf); A_fc.device_tag = ++next_tag; retire(dfc, A_fc.device_tag); }
+    else {
+      A_fc = down(dfc);
+      if (!defer_cf) A_cf = down(dcf);
+      A_fc.device_tag = ++next_tag; retire(dfc, A_fc.device_tag);
+    }
     if (A_cc) { *A_cc = down(dcc); dcsr_free(dcc); }
     // A_ff feeds the polynomial assembly, A_cf the Z product: they stay
-    dcsr_free(res_ff); dcsr_free(res_cf);
+    dcsr_free(res_ff);
+    { bool only; { std::lock_guard<std::mutex> lk(mu_kept); only = cf_tag && host_missing.count(cf_tag); } if (only) retire(res_cf, cf_tag); else dcsr_free(res_cf); }   // a C-F block no product came for
     res_ff = dff; ff_tag = A_ff.device_tag = ++next_tag;
-    res_cf = dcf; cf_tag = A_cf.device_tag = ++next_tag;
+    if (defer_cf) { A_cf = stub_of(dcf, ++next_tag); std::lock_guard<std::mutex> lk(mu_kept); host_missing.insert(A_cf.device_tag); }
+    else A_cf.device_tag = ++next_tag;
+    res_cf = dcf; cf_tag = A_cf.device_tag;
     return true;
   }
 };

@@ -188,6 +188,10 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o, SetupAc
   // with an accelerator the level operators below the top stay on it until a host routine asks for one
   auto on_host = [&]() -> const Csr& { if (!cur->on_host()) accel->materialize(owned); return *cur; };
   const bool any_c = o.any_c_smooths();
+  // the recipe in which no host routine reads A_cf, the assembled A_ff inverse or Z: the accelerator may leave them on
+  // the device (SetupAccel::defer_downloads); every other combination of options gets all blocks on the host as before
+  if (accel) accel->plain_recipe(o.z_type == 0 && o.improve_z_its == 0 && o.improve_w_its == 0 && o.strong_r_threshold == 0.0 && !o.symmetric &&
+                                 o.one_point_classical_prolong && !any_c && !o.full_smoothing && !o.diag_scale_polys && !o.matrix_free_polys);
   bool auto_truncated = false;
   const double t_setup = now_s();
   if (o.print_stats_timings) std::printf(" Timers are cumulative\n");     // src/AIR_MG_Setup.F90:130
@@ -407,6 +411,7 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o, SetupAc
     if (accel && L.one_point && !o.symmetric && accel->rap_from_z(L.Z, L.F, L.C, L.wcol, *cur, d_rap, coarse)) {
       H->timers[5] += now_s() - t0;
     } else {
+      if (accel) accel->materialize(L.Z);        // (a stub when its download was deferred)
       Csr P = build_P(L);
       Csr R = build_R(L.Z, L.F, L.C, n);
       SpgemmDrop d = d_rap;

@@ -99,6 +99,13 @@ struct SetupAccel {
     (void)tag; (void)m; (void)nnz; (void)rp; (void)ci; (void)v; return false;
   }
   virtual void drop_device_copy(uint64_t tag) { (void)tag; }
+  // defer_downloads(true): the caller can live with stubs (Csr::stub_nnz >= 0) for the operators no host routine of the
+  // plain recipe reads and will fetch them with materialize() after the setup (the device copy is the only one until
+  // then and is kept whatever happens); plain_recipe: set_air tells whether the options are that recipe.
+  // release_copies: every kept copy whose operator is on the host goes back to the device memory pool.
+  virtual void defer_downloads(bool on) { (void)on; }
+  virtual void plain_recipe(bool on) { (void)on; }
+  virtual void release_copies() {}
   double t_transfer = 0.0, t_compute = 0.0, t_cfsplit = 0.0, t_poly = 0.0, t_extract = 0.0;
 };
 // the accelerator the polynomial assembly may use (set by setup_air for its duration; null = host only)

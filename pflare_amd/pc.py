@@ -400,6 +400,13 @@ class PCAIR:
         check(lib().airhip_pcair_setup_times(self._h, C.byref(a), C.byref(b)))
         return dict(host_setup_s=a.value, upload_s=b.value)
 
+    def host_mirror_wait(self):
+        """Waits for the thread that completes the host copy of a hierarchy set up on the device (include/airhip.h:
+        airhip_pcair_host_mirror_wait); returns the seconds that thread ran (0.0 if there was none)."""
+        t = C.c_double(0.0)
+        check(lib().airhip_pcair_host_mirror_wait(self._h, C.byref(t)))
+        return t.value
+
     def release_host(self):
         check(lib().airhip_pcair_release_host(self._h))
 

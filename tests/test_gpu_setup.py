@@ -365,3 +365,39 @@ def test_setup_arena_sizes_give_the_same_hierarchy_and_solve(gpu, arena_gb, monk
     r2 = P.KSP("gmres", pc_side="right", rtol=1e-10, atol=1e-50, max_it=30).solve(b, x2, pc=p2)
     assert r2["its"] == r["its"] and float((x2 - x).abs().max()) == 0.0
     del pd, p2
+
+
+@pytest.mark.parametrize("defer", ["1", "0"], ids=["deferred-downloads", "eager-downloads"])
+def test_host_mirror_of_a_device_setup_is_the_host_codes_hierarchy(gpu, defer, monkeypatch):
+    """capi.cpp mirror thread / device/setup_accel.cpp defer_downloads: in the plain recipe A_cf, the assembled A_ff inverse and Z
+    stay on the device during the setup and a thread of the library copies them to the host afterwards; whoever reads the host
+    hierarchy waits for it.  Every operator must be the host code's, bit for bit, with the downloads deferred and with
+    AIRHIP_DEFER_DOWNLOADS=0 (everything copied during the setup); the solve on the device hierarchy - converted from the copies the
+    setup kept on the device - must be the same in both."""
+    import torch
+    import pflare_amd as P
+    monkeypatch.setenv("AIRHIP_DEFER_DOWNLOADS", defer)
+    A = P.HostMat.adv_diff_fd(dim=3, M=40, N=40, P=40)
+    opts = dict(a_lump=True)
+    pd = P.PCAIR(**opts); pd.set_option("setup_device_min_nnz", 0); pd.setup(A)
+    n = A.shape[0]
+    b = torch.zeros(n, dtype=torch.float64, device="cuda"); x = torch.ones_like(b)
+    r = P.KSP("gmres", pc_side="right", rtol=1e-10, atol=1e-50, max_it=30).solve(b, x, pc=pd)     # beside the mirror thread
+    t = pd.host_mirror_wait()
+    assert t >= 0.0 and (defer == "1") == (t > 0.0), t
+    ph = P.PCAIR(**opts); ph.setup_host_only(A)
+    assert pd.num_levels == ph.num_levels and pd.complexities()["storage"] == pytest.approx(ph.complexities()["storage"], rel=1e-14)
+    for lv in range(pd.num_levels - 1):
+        d, h = pd.export_level(lv), ph.export_level(lv)
+        assert np.array_equal(d["F"], h["F"])
+        for k in ("Z", "A_fc", "A_ff", "A_cf"):
+            if k in h:
+                _same(d[k], h[k], f"level {lv} {k}")
+        if h["inv_ff"].get("mat") is not None:
+            _same(d["inv_ff"]["mat"], h["inv_ff"]["mat"], f"level {lv} M_ff")
+    assert r["reason"] > 0 and r["its"] <= 9, r
+    # a second setup on the same object while the first hierarchy's mirror may still be running
+    pd.setup(A)
+    x2 = torch.ones_like(b)
+    r2 = P.KSP("gmres", pc_side="right", rtol=1e-10, atol=1e-50, max_it=30).solve(b, x2, pc=pd)
+    assert r2["its"] == r["its"] and float((x2 - x).abs().max()) == 0.0
