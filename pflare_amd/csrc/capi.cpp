@@ -12,6 +12,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <mutex>
 #include <exception>
 
 using namespace airhip;
@@ -369,11 +370,17 @@ struct airhip_pcair_s {
   // by this thread after the upload (mirror_join() before anything reads pc->H's matrices)
   std::unique_ptr<SetupAccel> mirror_accel;
   std::thread mirror_thread;
+  std::mutex mirror_mu;          // joining: the owner's calls and the device allocator's pressure handler
+  int mirror_pressure_id = 0;
   std::exception_ptr mirror_error;
   double mirror_s = 0;
   double cplx[5] = {0, 0, 0, 0, 0};     // complexities, taken before the mirror starts
   bool cplx_valid = false;
-  ~airhip_pcair_s() { if (mirror_thread.joinable()) mirror_thread.join(); }
+  ~airhip_pcair_s() {
+    if (mirror_pressure_id) dev_remove_pressure_handler(mirror_pressure_id);
+    std::lock_guard<std::mutex> lock(mirror_mu);
+    if (mirror_thread.joinable()) mirror_thread.join();
+  }
   StreamLink link;                // orders the library stream against the caller's
 };
 
@@ -470,7 +477,8 @@ int airhip_pcair_set_option(airhip_pcair pc, const char* name, const char* value
 // Waits for the host mirror (see airhip_pcair_s::mirror_thread); an error of the thread surfaces here
 static void mirror_join(airhip_pcair pc) {
   if (!pc) return;
-  if (pc->mirror_thread.joinable()) pc->mirror_thread.join();
+  if (pc->mirror_pressure_id) { dev_remove_pressure_handler(pc->mirror_pressure_id); pc->mirror_pressure_id = 0; }
+  { std::lock_guard<std::mutex> lock(pc->mirror_mu); if (pc->mirror_thread.joinable()) pc->mirror_thread.join(); }
   pc->mirror_accel.reset();
   if (pc->mirror_error) { std::exception_ptr e = pc->mirror_error; pc->mirror_error = nullptr; std::rethrow_exception(e); }
 }
@@ -531,7 +539,7 @@ int airhip_pcair_setup(airhip_pcair pc, const airhip_csr* A) {
   std::unique_ptr<SetupAccel> accel;
   {
     if (pc->setup_on_device) accel = make_device_setup_accel(nullptr, pc->setup_device_min_nnz);
-    if (accel) accel->keep_copies(pc->device_upload && keep_device_copies());     // for finish_device below
+    if (accel) accel->keep_copies(pc->device_upload && keep_device_copies(), (double)A->rowptr[A->m]);     // for finish_device below
     if (accel) accel->defer_downloads(pc->device_upload && keep_device_copies());  // fetched by the mirror thread afterwards
     pc->H = setup_air(pc->A_top, pc->opt, accel.get());
     if (accel) {
@@ -546,6 +554,9 @@ int airhip_pcair_setup(airhip_pcair pc, const airhip_csr* A) {
   pc->host_setup_s = now_s() - t0;
   pc->byo = false;
   pc->op_nnz_top = (double)pc->A_top.nnz();
+  // the temporaries of the setup are gone: their range of device memory goes back before the hierarchy takes its own
+  if (accel) accel->release_temporaries();
+  dev_arena.recycle_temporaries();
   if (pc->device_upload) finish_device(pc, accel.get());
   // the numbers print_stats and airhip_pcair_complexities report, while nothing else touches the hierarchy
   pc->cplx_valid = false;
@@ -564,6 +575,14 @@ int airhip_pcair_setup(airhip_pcair pc, const airhip_csr* A) {
         mirror_fetch(*pc->H, *pc->mirror_accel);
       } catch (...) { pc->mirror_error = std::current_exception(); }
       pc->mirror_s = now_s() - t0;
+    });
+    // until the thread is through, its device copies (up to 40 % of the device) are still there: an allocation of the
+    // library that finds the device full waits for it instead of failing
+    pc->mirror_pressure_id = dev_add_pressure_handler([pc]() -> size_t {
+      std::lock_guard<std::mutex> lock(pc->mirror_mu);
+      if (!pc->mirror_thread.joinable() || std::this_thread::get_id() == pc->mirror_thread.get_id()) return 0;
+      pc->mirror_thread.join();
+      return 1;
     });
   }
   accel.reset();
@@ -1134,7 +1153,7 @@ int airhip_pcair_load_distributed(airhip_pcair pc, airhip_archive piece, airhip_
   load_local(piece->ar, *loc);
   REQUIRE(loc->nranks == comm->c->size && loc->rank == comm->c->rank, AIRHIP_ERR_ARG, "piece does not belong to this rank");
   double t0 = now_s();
-  DevArena dev_arena(dev_arena_bytes_for((double)loc->A_top.nnz()), dev_arena_front_for((double)loc->A_top.nnz()));      // this rank's hierarchy in one contiguous range
+  DevArena dev_arena(dev_arena_bytes_for((double)loc->A_top.nnz()), dev_arena_front_for(0.7 * (double)loc->A_top.nnz()));      // this rank's hierarchy in one contiguous range
   pc->dev = std::make_unique<DevPCAIR>();
   if (loc->hint.size() > 0) pc->dev->set_ordering_hint(loc->hint.data(), loc->hint.size());
   pc->dev->upload(loc->H, loc->A_top, loc.get(), comm->c.get());

@@ -18,6 +18,8 @@
 #include <csignal>
 #include <cstring>
 #include <unistd.h>
+#include <execinfo.h>
+#include <sys/mman.h>
 
 namespace airhip {
 
@@ -27,14 +29,17 @@ double trace_clock() {
   static const auto t0 = std::chrono::steady_clock::now();
   return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
-extern "C" void airhip_abort_note(int) {
+extern "C" void airhip_abort_note(int sig) {
   const char* s = g_stage.load(std::memory_order_relaxed);
-  const char head[] = "[airhip] abort while in stage: ";
+  const char head[] = "[airhip] fatal signal while in stage: ";
   (void)!write(2, head, sizeof head - 1);
   (void)!write(2, s, std::strlen(s));
   (void)!write(2, "\n", 1);
-  std::signal(SIGABRT, SIG_DFL);
-  std::raise(SIGABRT);
+  void* frames[48];
+  const int n = backtrace(frames, 48);
+  backtrace_symbols_fd(frames, n, 2);
+  std::signal(sig, SIG_DFL);
+  std::raise(sig);
 }
 }  // namespace
 
@@ -43,6 +48,7 @@ void dev_stage(const char* what) {
     const char* e = std::getenv("AIRHIP_FAULT_STAGE");
     if (!(e && e[0] == '1')) return false;
     std::signal(SIGABRT, airhip_abort_note);
+    if (e[1] == '1') std::signal(SIGSEGV, airhip_abort_note);      // AIRHIP_FAULT_STAGE=11: segmentation faults too (native backtrace)
     return true;
   }();
   if (on) g_stage.store(what, std::memory_order_relaxed);
@@ -64,21 +70,25 @@ struct DevCache {
 };
 DevCache& cache() { static DevCache* c = new DevCache; return *c; }
 
-// ---- the setup arena: device memory straight from the virtual-memory interface (all of it guarded by DevCache::mu).
+// ---- the setup arenas: device memory straight from the virtual-memory interface (all of it guarded by DevCache::mu).
 // tools/vmm_probe.hip on the GPU box: backing a reserved range with hipMemCreate + hipMemMap + hipMemSetAccess costs
-// 0.6 - 2.5 ms per GB in 256-MB pieces (64 GB: 0.04 - 0.17 s) where a plain hipMalloc of 64 GB took 0.5 .. 3.9 s from one
-// call to the next (and holds the driver's lock meanwhile), a read+write stream runs as fast on memory mapped like this
-// (5.19 vs 5.02 TB/s), and giving it back takes milliseconds.
-// THE RULE (tools/vmm_stress.hip, profiles/r03_vmm_stress.txt): an address that has been unmapped must never be mapped
-// again, and a reserved range must never be handed back with hipMemAddressFree.  Blocks that were filled by a copy and
-// checked by a kernel right away came back wrong on this driver when their addresses had been backed before (one
-// reservation whose pieces are unmapped and mapped again: 9 of 177 blocks; reservations that come and go: 19 of 177),
-// never when every address was backed at most once - stale translations, by the look of it.  So every arena takes a
-// fresh range, backs each piece at most once, and abandons the range (address space only) when it is done.
+// 0.6 - 2.5 ms per GB in 256-MB pieces (64 GB: 0.04 - 0.17 s; 30 ms per GB on memory nobody has used since the box came
+// up) where a plain hipMalloc of 64 GB took 0.5 .. 3.9 s from one call to the next (and holds the driver's lock meanwhile),
+// and a read+write stream runs as fast on memory mapped like this (5.19 vs 5.02 TB/s).
+// Two facts of this driver shape the design (tools/vmm_probe.hip, tools/vmm_stress.hip, profiles/r03_vmm_*.txt):
+//  * the memory under a range only goes back to the device when the whole range is freed (hipMemAddressFree) - unmapping
+//    and releasing pieces does not return it;
+//  * an address that is mapped a second time reads stale data: blocks filled by a copy and checked by a kernel right away
+//    came back wrong when their addresses had been backed before (one reservation whose pieces are unmapped and mapped
+//    again: 9 of 177 blocks; reservations that come and go: 19 of 177), never when every address was backed at most once.
+//    The device's addresses are the process's own (a reservation is an inaccessible CPU mapping), so a freed range is
+//    covered at once with an inaccessible mapping of our own and nobody is ever given those addresses again (0 of 177).
+// Hence: one range per class of blocks with a common lifetime, every piece backed at most once, the range freed as a whole
+// when its last block is gone.
 constexpr size_t GRANULE = 2u << 20;             // blocks of the arena
 // physical memory is created and mapped in pieces of this size (AIRHIP_ARENA_PIECE_MB: experiments)
 const size_t PIECE = [] { const char* e = std::getenv("AIRHIP_ARENA_PIECE_MB"); return (size_t)(e && std::atoi(e) >= 2 ? std::atoi(e) / 2 * 2 : 256) << 20; }();
-constexpr size_t VA_BUDGET = (size_t)32 << 40;   // address space the process may use up this way (then: no more arenas)
+constexpr size_t VA_BUDGET = (size_t)64 << 40;   // address space the process may use up this way (then: no more arenas)
 size_t g_va_used = 0;
 
 bool vm_supported() {
@@ -92,23 +102,28 @@ bool vm_supported() {
   return ok;
 }
 
-// one reserved range; every piece is backed at most once (state: 0 never, 1 backed, 2 given back for good)
+// what the arenas of one DevArena scope may back together
+struct Group { size_t committed = 0, limit = 0, peak = 0; };
+
+// one reserved range; every piece is backed at most once
 struct VmRange {
   char* base = nullptr; size_t reserved = 0; int dev = 0;
   std::vector<hipMemGenericAllocationHandle_t> handle;
-  std::vector<char> state;
+  std::vector<char> state;                           // 0 never backed, 1 backed, 2 unusable
   size_t committed = 0;
-  bool reserve(size_t bytes) {
+  std::shared_ptr<Group> group;
+  bool reserve(size_t bytes, std::shared_ptr<Group> g) {
     bytes = (bytes + PIECE - 1) / PIECE * PIECE;
     if (g_va_used + bytes > VA_BUDGET) return false;
     void* p = nullptr;
     if (hipGetDevice(&dev) != hipSuccess || hipMemAddressReserve(&p, bytes, 0, nullptr, 0) != hipSuccess || !p) { (void)hipGetLastError(); return false; }
     g_va_used += bytes;
-    base = (char*)p; reserved = bytes;
+    base = (char*)p; reserved = bytes; group = std::move(g);
     handle.assign(bytes / PIECE, hipMemGenericAllocationHandle_t{}); state.assign(bytes / PIECE, 0);
     return true;
   }
   bool map_piece(size_t k) {
+    if (group->committed + PIECE > group->limit) return false;
     hipMemAllocationProp prop = {};
     prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
     if (hipMemCreate(&handle[k], PIECE, &prop, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
@@ -117,42 +132,43 @@ struct VmRange {
     if (hipMemMap(base + k * PIECE, PIECE, 0, handle[k], 0) != hipSuccess) { (void)hipGetLastError(); (void)hipMemRelease(handle[k]); return false; }
     if (hipMemSetAccess(base + k * PIECE, PIECE, &acc, 1) != hipSuccess) {
       (void)hipGetLastError(); (void)hipMemUnmap(base + k * PIECE, PIECE); (void)hipMemRelease(handle[k]);
-      state[k] = 2;                                  // the address has been mapped: not again
+      state[k] = 2;                                  // its addresses have been mapped once: never again
       return false;
     }
-    state[k] = 1; committed += PIECE;
+    state[k] = 1; committed += PIECE; group->committed += PIECE;
+    if (group->committed > group->peak) group->peak = group->committed;
     return true;
   }
-  void unmap_piece(size_t k) {
-    (void)hipMemUnmap(base + k * PIECE, PIECE); (void)hipMemRelease(handle[k]);
-    state[k] = 2; committed -= PIECE;
-  }
-  // every piece that [off, off + len) touches is backed afterwards; false: one of them cannot be (no memory, the limit, or
-  // given back earlier) - pieces backed on the way stay backed (they are free space of the arena like any other)
-  bool commit(size_t off, size_t len, size_t limit) {
+  // every piece that [off, off + len) touches is backed afterwards, plus `ahead` more bytes beyond it while that is possible
+  // (pieces backed in one go); false: one of the pieces asked for cannot be (no memory, the limit) - pieces backed on the way
+  // stay backed (free space of the arena like any other)
+  bool commit(size_t off, size_t len, size_t ahead = 0) {
     const size_t k0 = off / PIECE, k1 = (off + len + PIECE - 1) / PIECE;
+    bool fresh = false;
     for (size_t k = k0; k < k1; k++) if (state[k] == 2) return false;
     for (size_t k = k0; k < k1; k++) {
       if (state[k] == 1) continue;
-      if (committed + PIECE > limit || !map_piece(k)) return false;
+      if (!map_piece(k)) return false;
+      fresh = true;
     }
+    if (fresh) for (size_t k = k1; k < state.size() && k < k1 + ahead / PIECE; k++) if (state[k] == 0 && !map_piece(k)) break;
     return true;
   }
-  // gives back, for good, the backed pieces that lie entirely inside [off, off + len).  No kernel may still be using
-  // them: unlike hipFree, unmapping does not wait for the device
-  void decommit(size_t off, size_t len) {
-    const size_t k0 = (off + PIECE - 1) / PIECE, k1 = (off + len) / PIECE;
-    bool synced = false;
-    for (size_t k = k0; k < k1; k++) {
-      if (state[k] != 1) continue;
-      if (!synced) { (void)hipDeviceSynchronize(); synced = true; }
-      unmap_piece(k);
-    }
-  }
-  // the memory goes back, the address range is abandoned (see THE RULE)
+  // Everything goes back: memory and addresses - and the addresses are taken out of circulation for good.  No kernel may
+  // still be using the range: unlike hipFree, unmapping does not wait for the device
   void release() {
     if (!base) return;
-    decommit(0, reserved);
+    (void)hipDeviceSynchronize();
+    for (size_t k = 0; k < state.size(); k++)
+      if (state[k] == 1) { (void)hipMemUnmap(base + k * PIECE, PIECE); (void)hipMemRelease(handle[k]); committed -= PIECE; group->committed -= PIECE; }
+    (void)hipMemAddressFree(base, reserved);
+    void* t = mmap(base, reserved, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE | MAP_FIXED_NOREPLACE, -1, 0);
+    if (t != (void*)base) {
+      // somebody was quicker (or the kernel is too old for MAP_FIXED_NOREPLACE): these addresses may come back - no more
+      // arenas in this process, the cache / hipMalloc path serves everything from here on
+      if (t != MAP_FAILED) (void)munmap(t, reserved);
+      g_va_used = VA_BUDGET;
+    }
     *this = VmRange();
   }
 };
@@ -160,21 +176,26 @@ struct VmRange {
 hipError_t raw_alloc(void** p, size_t bytes) { return hipMalloc(p, bytes); }
 void raw_free(void* p) { (void)hipFree(p); }
 
-// ---- one reserved range per setup, backed as far as the blocks in use reach (first fit: the blocks gather at the low
-// end); when the scope has ended the pieces under free space are handed back, the others as their blocks are freed
+// ---- one range per class of blocks (DevClass), backed as far as the blocks in use reach (first fit: the blocks gather at
+// the low end), freed as a whole when it has been closed and its last block is gone
 struct Arena {
   VmRange vm;
   char* base = nullptr; size_t size = 0;            // = vm.base / vm.reserved while the arena exists
-  size_t limit = 0;                                 // most bytes that may be backed at one time
+  int cls = 0;
+  const void* owner = nullptr;                      // the DevArena scope it belongs to
+  size_t ahead = 0;                                 // back this much beyond a request that needs fresh pieces
   std::map<size_t, size_t> free_by_off;             // offset -> length, neighbours merged
   std::unordered_map<void*, size_t> live;           // block -> length
-  bool closing = false;                             // scope ended: release once the last block is back
+  bool closing = false;                             // no new blocks: release once the last block is back
   size_t peak = 0, used = 0, misses = 0, peak_committed = 0;
 };
-// the arena that serves requests (at most one: the innermost setup in progress) and those of finished setups whose
-// hierarchies still hold blocks
 std::vector<std::unique_ptr<Arena>>& arenas() { static auto* v = new std::vector<std::unique_ptr<Arena>>; return *v; }
-Arena* active_arena() { auto& v = arenas(); return (!v.empty() && !v.back()->closing) ? v.back().get() : nullptr; }
+// the arena of class c that serves requests: that of the innermost scope in progress
+Arena* active_arena(int c) {
+  auto& v = arenas();
+  for (size_t k = v.size(); k-- > 0;) if (v[k]->cls == c && !v[k]->closing) return v[k].get();
+  return nullptr;
+}
 
 void* arena_alloc(Arena* ap, size_t bytes) {
   if (!ap) return nullptr;
@@ -184,7 +205,7 @@ void* arena_alloc(Arena* ap, size_t bytes) {
   for (auto it = a.free_by_off.begin(); it != a.free_by_off.end(); ++it) {
     if (it->second < need) continue;
     const size_t off = it->first, len = it->second;
-    if (!a.vm.commit(off, need, a.limit)) break;      // the device (or the limit) has no room for the pieces
+    if (!a.vm.commit(off, need, a.ahead)) break;      // the device (or the limit) has no room for the pieces
     a.free_by_off.erase(it);
     if (len > need) a.free_by_off[off + need] = len - need;
     a.live[a.base + off] = need;
@@ -192,8 +213,8 @@ void* arena_alloc(Arena* ap, size_t bytes) {
     if (a.vm.committed > a.peak_committed) a.peak_committed = a.vm.committed;
     return a.base + off;
   }
-  if (trace) std::fprintf(stderr, "[devmem %.3f] arena: %.2f GB did not fit (in use %.1f GB, backed %.1f GB of at most %.1f GB)\n", trace_clock(), need * 1e-9,
-                          a.used * 1e-9, a.vm.committed * 1e-9, a.limit * 1e-9);
+  if (trace) std::fprintf(stderr, "[devmem %.3f] arena %d: %.2f GB did not fit (in use %.1f GB, backed %.1f GB; the scope's arenas together %.1f of at most %.1f GB)\n",
+                          trace_clock(), a.cls, need * 1e-9, a.used * 1e-9, a.vm.committed * 1e-9, a.vm.group->committed * 1e-9, a.vm.group->limit * 1e-9);
   a.misses++;
   return nullptr;
 }
@@ -214,12 +235,11 @@ void arena_free(Arena& a, void* p) {
     if (prv->first + prv->second == off) { off = prv->first; len += prv->second; a.free_by_off.erase(prv); }
   }
   a.free_by_off[off] = len;
-  if (a.closing) a.vm.decommit(off, len);     // nothing new will be carved out of it: the memory goes back at once
 }
 void arena_release_if_done(Arena& a) {
   if (!(a.closing && a.live.empty())) return;
   static const bool trace = std::getenv("AIRHIP_ALLOC_TRACE") != nullptr;
-  if (trace) std::fprintf(stderr, "[devmem %.3f] arena released: peak use %.1f GB, peak backing %.1f GB, %zu requests did not fit\n", trace_clock(), a.peak * 1e-9,
+  if (trace) std::fprintf(stderr, "[devmem %.3f] arena %d released: peak use %.1f GB, peak backing %.1f GB, %zu requests did not fit\n", trace_clock(), a.cls, a.peak * 1e-9,
                           a.peak_committed * 1e-9, a.misses);
   a.vm.release();
   auto& v = arenas();
@@ -233,6 +253,8 @@ bool arena_take_back(void* p) {
   arena_release_if_done(*a);
   return true;
 }
+
+thread_local int t_class = DEV_TEMP;
 
 // journals of the DevScopes alive on this thread, innermost last
 thread_local std::vector<std::unordered_set<void*>> t_scopes;
@@ -281,12 +303,24 @@ void dev_remove_pressure_handler(int id) {
   for (size_t k = 0; k < g_pressure.size(); k++) if (g_pressure[k].first == id) { g_pressure.erase(g_pressure.begin() + (long)k); return; }
 }
 
+static std::string memory_state() {
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) (void)hipGetLastError();
+  DevCache& c = cache();
+  std::lock_guard<std::mutex> lock(c.mu);
+  std::string st = "driver reports " + std::to_string(free_b >> 20) + " MiB free of " + std::to_string(total_b >> 20) + ", block cache holds " +
+                   std::to_string(c.idle_bytes >> 20) + " MiB idle";
+  { size_t lb = 0; for (auto& kv : c.live) lb += kv.second; st += " and " + std::to_string(lb >> 20) + " MiB in use outside the arenas"; }
+  for (auto& a : arenas()) st += ", arena (" + std::string(a->closing ? "of a finished setup" : "active") + ") " + std::to_string(a->used >> 20) + " MiB in blocks / " +
+                                 std::to_string(a->vm.committed >> 20) + " MiB backed";
+  return st;
+}
 static void* dev_alloc_once(size_t bytes, bool& failed);
 void* dev_alloc(size_t bytes) {
   bool failed = false;
   void* p = dev_alloc_once(bytes, failed);
   if (failed && relieve_pressure() > 0) p = dev_alloc_once(bytes, failed);
-  if (failed) throw std::runtime_error(std::string("hipMalloc of ") + std::to_string(bytes) + " bytes failed: out of memory");
+  if (failed) throw std::runtime_error(std::string("hipMalloc of ") + std::to_string(bytes) + " bytes failed: out of memory (" + memory_state() + ")");
   return p;
 }
 static void* dev_alloc_once(size_t bytes, bool& failed) {
@@ -295,7 +329,7 @@ static void* dev_alloc_once(size_t bytes, bool& failed) {
   DevCache& c = cache();
   if (bytes >= CACHE_MIN) {
     std::lock_guard<std::mutex> lock(c.mu);
-    if (void* q = arena_alloc(active_arena(), bytes)) { note_alloc(q); return q; }
+    if (void* q = arena_alloc(active_arena(t_class), bytes)) { note_alloc(q); return q; }
     int best = -1;          // smallest idle block that holds the request and is at most twice its size
     for (int k = 0; k < (int)c.idle.size(); k++)
       if (c.idle[k].second >= bytes && c.idle[k].second / 2 <= bytes && (best < 0 || c.idle[k].second < c.idle[best].second)) best = k;
@@ -341,7 +375,7 @@ void* dev_alloc_exact(size_t bytes) {
   if (bytes >= CACHE_MIN) {
     DevCache& c = cache();
     std::lock_guard<std::mutex> lock(c.mu);
-    if (void* q = arena_alloc(active_arena(), bytes)) return q;
+    if (void* q = arena_alloc(active_arena(DEV_HIER), bytes)) return q;
   }
   void* p = nullptr;
   hipError_t e = raw_alloc(&p, bytes ? bytes : 1);
@@ -351,13 +385,13 @@ void* dev_alloc_exact(size_t bytes) {
     if (bytes >= CACHE_MIN) {
       DevCache& c = cache();
       std::lock_guard<std::mutex> lock(c.mu);
-      if (void* q = arena_alloc(active_arena(), bytes)) return q;
+      if (void* q = arena_alloc(active_arena(DEV_HIER), bytes)) return q;
     }
     e = raw_alloc(&p, bytes ? bytes : 1);
   }
   if (e != hipSuccess) {
     (void)hipGetLastError();
-    throw std::runtime_error(std::string("hipMalloc of ") + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
+    throw std::runtime_error(std::string("hipMalloc of ") + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e) + " (" + memory_state() + ")");
   }
   return p;
 }
@@ -399,71 +433,131 @@ size_t dev_arena_bytes_for(double nnz) {
   return limit / GRANULE * GRANULE;
 }
 
-DevArena::DevArena(size_t bytes, size_t front_bytes) {
-  if (bytes == 0 || !vm_supported()) return;             // (a limit below one piece: an arena that can back nothing)
-  DevCache& c = cache();
-  std::lock_guard<std::mutex> lock(c.mu);
-  if (active_arena()) return;                            // an enclosing call's arena is in use
+DevClassScope::DevClassScope(int cls) : prev_(t_class) { t_class = cls; }
+DevClassScope::~DevClassScope() { t_class = prev_; }
+
+namespace {
+// a fresh arena of class c for the scope `owner`; null when there is no address space to be had
+Arena* open_arena(int c, const void* owner, std::shared_ptr<Group> g, size_t va_bytes, size_t ahead) {
   auto a = std::make_unique<Arena>();
-  if (!a->vm.reserve(std::max(bytes, PIECE))) return;    // address space only; backed as the blocks come
-  a->base = a->vm.base; a->size = a->vm.reserved; a->limit = bytes;
+  if (!a->vm.reserve(std::max(va_bytes, PIECE), std::move(g))) return nullptr;
+  a->base = a->vm.base; a->size = a->vm.reserved; a->cls = c; a->owner = owner; a->ahead = ahead;
   a->free_by_off[0] = a->size;
   static const bool trace = std::getenv("AIRHIP_ALLOC_TRACE") != nullptr;
-  if (trace) std::fprintf(stderr, "[devmem %.3f] arena: %.1f GB of address space reserved (%.1f TB used so far), at most %.1f GB backed\n", trace_clock(), a->size * 1e-9,
-                          g_va_used * 1e-12, a->limit * 1e-9);
-  mine_ = a.get();
+  if (trace) std::fprintf(stderr, "[devmem %.3f] arena %d: %.1f GB of address space reserved (%.2f TB used so far)\n", trace_clock(), c, a->size * 1e-9, g_va_used * 1e-12);
   arenas().push_back(std::move(a));
-  // The low end of the range - where the hierarchy's arrays will be put once the temporaries are gone - is backed piece
-  // after piece by a helper thread right away instead of whenever a block first reaches a piece: the products of the
-  // cycle ran 1.5 % slower on memory backed on demand (and one operator in twenty runs six times slower; 464^3,
-  // profiles/r03_arena_backing.txt), as fast as on one hipMalloc block on memory backed in one go.  The memory would be
-  // backed during the setup anyway; the setup takes a piece the helper has not reached yet by backing it itself.
-  size_t ahead = std::min(bytes, front_bytes) / PIECE * PIECE;
-  if (const char* e = std::getenv("AIRHIP_ARENA_FRONT_GB")) ahead = std::min(bytes, (size_t)(std::atof(e) * 1e9)) / PIECE * PIECE;
-  if (ahead) {
-    Arena* ap = arenas().back().get();
-    int dev = 0; (void)hipGetDevice(&dev);
-    std::atomic<bool>* stop = new std::atomic<bool>(false);
-    stop_ = stop;
-    helper_ = new std::thread([ap, ahead, dev, stop] {
-      if (hipSetDevice(dev) != hipSuccess) { (void)hipGetLastError(); return; }
-      const double t0 = trace_clock();
-      size_t done = 0;
-      for (size_t k = 0; k < ahead / PIECE && !stop->load(); k++) {
-        {
-          std::lock_guard<std::mutex> lk(cache().mu);
-          if (ap->closing || ap->vm.state[k] != 0) continue;
-          if (ap->vm.committed + PIECE > ap->limit || !ap->vm.map_piece(k)) break;
-          done += PIECE;
-          if (ap->vm.committed > ap->peak_committed) ap->peak_committed = ap->vm.committed;
-        }
-        // the mutex is not fair: without a pause the setup's own requests wait until this loop is through (on a box whose
-        // memory has not been used before a piece takes 8 ms - 4.2 s for the whole front, all of it in the first level)
-        std::this_thread::sleep_for(std::chrono::microseconds(150));
-      }
-      static const bool tr = std::getenv("AIRHIP_ALLOC_TRACE") != nullptr;
-      if (tr) std::fprintf(stderr, "[devmem %.3f] arena: helper backed %.1f GB of the first %.1f GB in %.3f s\n", trace_clock(), done * 1e-9, ahead * 1e-9, trace_clock() - t0);
-    });
+  return arenas().back().get();
+}
+void close_arenas(const void* owner, int c) {      // c < 0: all classes
+  auto& v = arenas();
+  for (size_t k = v.size(); k-- > 0;) {
+    Arena& a = *v[k];
+    if (a.owner != owner || a.closing || (c >= 0 && a.cls != c)) continue;
+    a.closing = true;
+    arena_release_if_done(a);                       // (erases v[k]: the loop runs downwards)
   }
 }
-void DevArena::wait() { if (helper_) { static_cast<std::thread*>(helper_)->join(); delete static_cast<std::thread*>(helper_); helper_ = nullptr; } }
+}  // namespace
 
-DevArena::~DevArena() {
-  if (stop_) static_cast<std::atomic<bool>*>(stop_)->store(true);
-  wait();
-  delete static_cast<std::atomic<bool>*>(stop_);
-  if (!mine_) return;
+struct DevArena::Impl {
+  std::shared_ptr<Group> group;
+  size_t bytes = 0;
+  std::thread helper;
+  std::atomic<bool> stop{false};
+};
+
+DevArena::DevArena(size_t bytes, size_t front_bytes) {
+  if (bytes == 0 || !vm_supported()) return;             // (a limit below one piece: arenas that can back nothing)
   DevCache& c = cache();
   std::lock_guard<std::mutex> lock(c.mu);
-  for (auto& up : arenas()) {
-    if (up.get() != mine_) continue;
-    Arena& a = *up;
-    a.closing = true;
-    // what is free now goes back to the device at once; the blocks that stay (a hierarchy) keep their pieces
-    for (const auto& f : a.free_by_off) a.vm.decommit(f.first, f.second);
-    arena_release_if_done(a);
-    break;
+  if (active_arena(DEV_TEMP) || active_arena(DEV_HIER) || active_arena(DEV_KEPT)) return;      // an enclosing call's arenas are in use
+  impl_ = new Impl;
+  impl_->bytes = bytes;
+  impl_->group = std::make_shared<Group>();
+  impl_->group->limit = bytes;
+  // three ranges (address space only), one per class of blocks; together they may back `bytes`.  The long-lived arrays get
+  // their pieces 8 GB at a time (pieces backed in one go are where the cycle's kernels run fastest: the products ran 1.5 %
+  // slower, and one operator in twenty runs six times slower, on pieces backed one by one between other work -
+  // profiles/r03_arena_backing.txt)
+  Arena* tmp = open_arena(DEV_TEMP, this, impl_->group, bytes, 0);
+  open_arena(DEV_KEPT, this, impl_->group, bytes, 0);
+  open_arena(DEV_HIER, this, impl_->group, bytes, (size_t)8 << 30);
+  if (!tmp) { close_arenas(this, -1); delete impl_; impl_ = nullptr; return; }
+  // The low end of the temporaries' range is backed piece after piece by a helper thread right away instead of whenever a
+  // block first reaches a piece: on a box whose memory has not been used before a piece costs 8 ms, and the setup would
+  // pay that in its products (464^3: R*A*P 7.3 -> 9.5 s).  The memory would be backed during the setup anyway; the setup
+  // takes a piece the helper has not reached yet by backing it itself.
+  size_t ahead = std::min(bytes, front_bytes) / PIECE * PIECE;
+  if (const char* e = std::getenv("AIRHIP_ARENA_FRONT_GB")) ahead = std::min(bytes, (size_t)(std::atof(e) * 1e9)) / PIECE * PIECE;
+  start_helper(DEV_TEMP, ahead);
+}
+
+// backs the first `ahead` bytes of the scope's arena of class cls piece after piece (the caller holds no lock of the cache)
+void DevArena::start_helper(int cls, size_t ahead) {
+  if (!impl_ || ahead < PIECE) return;
+  int dev = 0; (void)hipGetDevice(&dev);
+  Impl* im = impl_;
+  const void* owner = this;
+  im->stop.store(false);
+  impl_->helper = std::thread([im, owner, ahead, dev, cls] {
+    if (hipSetDevice(dev) != hipSuccess) { (void)hipGetLastError(); return; }
+    const double t0 = trace_clock();
+    size_t done = 0;
+    for (size_t k = 0; k < ahead / PIECE && !im->stop.load(); k++) {
+      {
+        std::lock_guard<std::mutex> lk(cache().mu);
+        Arena* ap = nullptr;
+        for (auto& a : arenas()) if (a->owner == owner && a->cls == cls && !a->closing) ap = a.get();
+        if (!ap || k >= ap->vm.state.size()) break;         // the arena is gone (recycled, scope over)
+        if (ap->vm.state[k] != 0) continue;
+        if (!ap->vm.map_piece(k)) break;
+        done += PIECE;
+        if (ap->vm.committed > ap->peak_committed) ap->peak_committed = ap->vm.committed;
+      }
+      // the mutex is not fair: without a pause the caller's own requests wait until this loop is through
+      std::this_thread::sleep_for(std::chrono::microseconds(150));
+    }
+    static const bool tr = std::getenv("AIRHIP_ALLOC_TRACE") != nullptr;
+    if (tr) std::fprintf(stderr, "[devmem %.3f] arena %d: helper backed %.1f GB of the first %.1f GB in %.3f s\n", trace_clock(), cls, done * 1e-9, ahead * 1e-9, trace_clock() - t0);
+  });
+}
+void DevArena::wait() { if (impl_ && impl_->helper.joinable()) impl_->helper.join(); }
+
+void DevArena::recycle_temporaries(size_t hier_front) {
+  if (!impl_) return;
+  impl_->stop.store(true);
+  wait();
+  {
+    DevCache& c = cache();
+    std::lock_guard<std::mutex> lock(c.mu);
+    close_arenas(this, DEV_TEMP);                            // empty by now in the normal course: freed here and now
+    open_arena(DEV_TEMP, this, impl_->group, impl_->bytes, 0);
   }
+  // (hier_front: measured at 464^3, a helper that backs the hierarchy's 131 GB at once out of the memory that has just come
+  // back takes 4.1 s - 31 ms per GB, the driver is still clearing what was freed - and holds up the upload's own requests
+  // meanwhile (upload 4.4 -> 5.8 s); backed 8 GB at a time as the arrays come, the same memory costs 0.85 s.  Off by default.)
+  if (hier_front) start_helper(DEV_HIER, std::min(impl_->bytes, hier_front) / PIECE * PIECE);
+}
+
+DevArena::~DevArena() {
+  if (!impl_) return;
+  impl_->stop.store(true);
+  wait();
+  {
+    DevCache& c = cache();
+    std::lock_guard<std::mutex> lock(c.mu);
+    static const bool trace = std::getenv("AIRHIP_ALLOC_TRACE") != nullptr;
+    if (trace) std::fprintf(stderr, "[devmem %.3f] setup scope over: its arenas backed %.1f GB at the peak\n", trace_clock(), impl_->group->peak * 1e-9);
+    close_arenas(this, -1);
+  }
+  delete impl_;
+}
+
+int dev_class_of(void* p) {
+  DevCache& c = cache();
+  std::lock_guard<std::mutex> lock(c.mu);
+  const Arena* a = arena_of(p);
+  return a ? a->cls : -1;
 }
 
 size_t dev_available_bytes() {
@@ -472,7 +566,7 @@ size_t dev_available_bytes() {
   DevCache& c = cache();
   std::lock_guard<std::mutex> lock(c.mu);
   size_t v = free_b + c.idle_bytes;
-  if (const Arena* a = active_arena()) v += a->vm.committed - a->used;      // backed, but no block on it
+  for (auto& a : arenas()) if (!a->closing) v += a->vm.committed - a->used;      // backed, but no block on it
   return v;
 }
 

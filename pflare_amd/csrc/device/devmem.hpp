@@ -27,39 +27,58 @@ void dev_remove_pressure_handler(int id);
 size_t dev_available_bytes();
 size_t dev_cache_idle_bytes();
 
-// One arena for a setup call.  Measured at 464^3 (AIRHIP_ALLOC_TRACE=1): a hipMalloc of fresh device memory costs 7 - 57 ms
+// Arenas for a setup call.  Measured at 464^3 (AIRHIP_ALLOC_TRACE=1): a hipMalloc of fresh device memory costs 7 - 57 ms
 // per GB from one call to the next and now and then seconds more, and because the operators grow from level to level the
 // block cache above rarely holds a block large enough - 24 such calls added up to 9.6 s of a 29-s setup.  A DevArena
-// reserves address space (hipMemAddressReserve; no memory yet); while it is alive dev_alloc and dev_alloc_exact carve
-// blocks of 1 MiB and more out of that range (first fit, 2-MiB granules, neighbours merged again on dev_free) and the
-// range is backed with physical memory as far as the blocks reach (hipMemCreate + hipMemMap in 256-MB pieces: 0.6 - 2.5 ms
-// per GB, tools/vmm_probe.hip).  When the scope ends the pieces under free space go back to the device at once, the
-// others as the blocks on them are freed (a hierarchy lives in its setup's arena).  Every address is backed at most once
-// and the range is never returned: on this driver an address that is mapped a second time reads stale data
-// (tools/vmm_stress.hip) - a setup therefore uses up address space (its limit, at most what the device holds; the
-// process stops making arenas after 32 TB and works through the cache / hipMalloc as it does without the virtual-memory
-// interface, AIRHIP_DEVICE_VMM=0).
-// bytes = the most that may be backed at one time, 0 disables the arena (AIRHIP_DEVICE_ARENA_GB sets the limit).
+// reserves address space (hipMemAddressReserve; no memory yet), one range per class of blocks:
+//   DEV_TEMP  what dev_alloc hands out by default: the temporaries of the setup (and, after recycle_temporaries(), of the
+//             upload) - the range goes back as soon as they are gone;
+//   DEV_KEPT  dev_alloc under a DevClassScope(DEV_KEPT): operators the setup keeps on the device until the upload has
+//             converted them and the host mirror has fetched them;
+//   DEV_HIER  dev_alloc_exact: the arrays that stay (the hierarchy).
+// While the scope is alive blocks of 1 MiB and more are carved out of the class's range (first fit, 2-MiB granules,
+// neighbours merged again on dev_free) and the range is backed with physical memory as far as the blocks reach
+// (hipMemCreate + hipMemMap in 256-MB pieces: 0.6 - 2.5 ms per GB, tools/vmm_probe.hip).  A range is freed - memory and
+// addresses - when it has been closed (end of the scope; recycle_temporaries) and its last block is gone; its addresses
+// are then taken out of circulation (devmem.cpp: on this driver an address that is mapped a second time reads stale
+// data), so a setup uses up address space: three times its limit, at most what the device holds each; the process stops
+// making arenas after 64 TB and works through the cache / hipMalloc as it does without the virtual-memory interface
+// (AIRHIP_DEVICE_VMM=0).
+// bytes = the most the three may back together, 0 disables the arenas (AIRHIP_DEVICE_ARENA_GB sets the limit).
+enum { DEV_TEMP = 0, DEV_KEPT = 1, DEV_HIER = 2 };
+class DevClassScope {      // the class dev_alloc serves on this thread (DEV_TEMP outside any scope)
+ public:
+  explicit DevClassScope(int cls);
+  ~DevClassScope();
+  DevClassScope(const DevClassScope&) = delete;
+  DevClassScope& operator=(const DevClassScope&) = delete;
+ private:
+  int prev_;
+};
+int dev_class_of(void* p);      // the class of the arena a block came from, -1 for a block from the cache / hipMalloc
 class DevArena {
  public:
-  // front_bytes: how much of the low end a helper thread backs right away (devmem.cpp: DevArena::DevArena)
+  // front_bytes: how much of the temporaries' range a helper thread backs right away (devmem.cpp: DevArena::DevArena)
   explicit DevArena(size_t bytes, size_t front_bytes = 0);
   ~DevArena();
   void wait();      // until the helper thread is done
+  // the temporaries are gone (the setup proper is over): their range goes back to the device and a fresh one serves the
+  // temporaries of what follows (the upload of the hierarchy)
+  // hier_front: how much of the range of the arrays that stay a helper thread backs right away
+  void recycle_temporaries(size_t hier_front = 0);
   DevArena(const DevArena&) = delete;
   DevArena& operator=(const DevArena&) = delete;
  private:
-  void* mine_ = nullptr;
-  void* helper_ = nullptr;      // std::thread
-  void* stop_ = nullptr;        // std::atomic<bool>
+  struct Impl;
+  Impl* impl_ = nullptr;
+  void start_helper(int cls, size_t ahead);
 };
-// the front a setup of an operator with nnz non-zeros asks for: about what the setup has backed at its peak (500 bytes per
-// non-zero; the hierarchy itself ends up in the lower two thirds).  On a box whose memory has not been used before, backing
-// costs 30 ms per GB and the setup would otherwise pay it in its products (464^3: R*A*P 7.3 -> 9.5 s)
-inline size_t dev_arena_front_for(double nnz) { return (size_t)(500.0 * (nnz > 0 ? nnz : 0)); }
 // the limit a setup of an operator with nnz non-zeros passes: about 1 kB per non-zero (at least 4 GB, at most 92 % of the
 // free device memory); 0 = no arena, for setups that move less than 256 MB (~300 bytes per non-zero)
 size_t dev_arena_bytes_for(double nnz);
+// the front a setup of an operator with nnz non-zeros asks for: about what its temporaries need at their peak (350 bytes
+// per non-zero)
+inline size_t dev_arena_front_for(double nnz) { return (size_t)(350.0 * (nnz > 0 ? nnz : 0)); }
 
 // Exception safety of the setup code, which holds raw dev_alloc pointers: while a DevScope is alive on a thread every
 // block that thread takes with dev_alloc is noted (dev_free strikes it again).  When the scope is left by an exception the

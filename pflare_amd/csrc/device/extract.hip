@@ -105,7 +105,32 @@ __global__ __launch_bounds__(BLOCK) void k_p_fill(int64_t n, const uint32_t* __r
   }
 }
 
+// column of the largest |entry| of every row, the first one on ties, -1 for an empty row (host: one_point_W); one wave per row
+__global__ __launch_bounds__(BLOCK) void k_one_point_w(int64_t m, const int64_t* __restrict__ rp, const int32_t* __restrict__ ci,
+                                                      const double* __restrict__ v, int32_t* __restrict__ wcol) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * BLOCK) >> 6;
+  for (int64_t i = wave; i < m; i += nw) {
+    const int64_t a0 = rp[i], a1 = rp[i + 1];
+    double best = -1.0; int64_t at = -1;               // this lane's entries in ascending position: the first maximum stays
+    for (int64_t k = a0 + lane; k < a1; k += 64) { const double a = fabs(v[k]); if (a > best) { best = a; at = k; } }
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ob = __shfl_xor(best, off, 64);
+      const int64_t oa = __shfl_xor(at, off, 64);
+      if (oa >= 0 && (at < 0 || ob > best || (ob == best && oa < at))) { best = ob; at = oa; }
+    }
+    if (lane == 0) wcol[i] = at >= 0 ? ci[at] : -1;
+  }
+}
+
 }  // namespace
+
+void dev_one_point_w(const DCsr& A_fc, int32_t* d_wcol, hipStream_t s) {
+  if (A_fc.m == 0) return;
+  const int g = (int)std::max<int64_t>(1, std::min<int64_t>((A_fc.m + 3) / 4, MAX_BLOCKS));
+  hipLaunchKernelGGL(k_one_point_w, dim3(g), dim3(BLOCK), 0, s, A_fc.m, A_fc.rp, A_fc.ci, A_fc.v, d_wcol);
+  HIP_CHECK(hipStreamSynchronize(s));
+}
 
 DCsr dev_build_R(const DCsr& Z, const int32_t* d_F, const int32_t* d_C, int64_t n, hipStream_t s) {
   DCsr R; R.m = Z.m; R.n = n; R.nnz = Z.nnz + Z.m;

@@ -20,5 +20,8 @@ DCsr dev_build_R(const DCsr& Z, const int32_t* d_F, const int32_t* d_C, int64_t 
 // single one at column j for the level's j-th C point, at column wcol[i] for its i-th F point (no entry when wcol[i] < 0).
 // d_code as in dev_split_fc.
 DCsr dev_build_P_one_point(int64_t n, int64_t n_c, const uint32_t* d_code, const int32_t* d_wcol, hipStream_t s);
+// the one-point classical prolongator's column per F point (host twin: air_setup.cpp one_point_W; src/Grid_Transfer.F90:
+// 329-461): the column of the largest |entry| of the row of A_fc, the first one on ties, -1 for an empty row
+void dev_one_point_w(const DCsr& A_fc, int32_t* d_wcol, hipStream_t s);
 
 }  // namespace airhip

@@ -39,7 +39,8 @@ struct DevSetupAccel final : SetupAccel {
   const void* inverse_key = nullptr;
   uint64_t inverse_tag = 0;      // Csr::device_tag of that inverse
   int64_t min_nnz = 200000;      // smaller products stay on the host: launch + sync overheads dominate
-  uint64_t fc_tag = 0;           // tag of the F-C block of the last extraction (its device copy goes straight to `kept`)
+  DCsr res_fc;                   // the F-C block of the last extraction, until the one-point prolongator has been read off it
+  uint64_t fc_tag = 0;
 
   // ---- copies kept for the upload of the hierarchy (SetupAccel::keep_copies): an operator the setup is done with is
   // retired, not freed, while the copies stay below 40 % of the device's memory.  With defer_downloads() on top, the
@@ -54,12 +55,18 @@ struct DevSetupAccel final : SetupAccel {
   size_t kept_bytes = 0, kept_limit = 0;
   int pressure_id = 0;
   static size_t bytes_of(const DCsr& d) { return sizeof(int64_t) * (size_t)(d.m + 1) + 12 * (size_t)d.nnz; }
-  void keep_copies(bool on) override {
+  void keep_copies(bool on, double top_nnz) override {
     keeping = on;
     if (on && !pressure_id) pressure_id = dev_add_pressure_handler([this] { return drop_all_kept(); });
     if (on && !kept_limit) {
+      // 36 % of the device (with the hierarchy's own arrays beside them during the upload that is nearly all of it), and never into what the setup itself will need: its temporaries peak at ~350 bytes per
+      // non-zero of the top operator (464^3: 137 GB), 450 with a margin.  (The copies whose operators are not on the
+      // host cannot be dropped when memory runs out, so the budget has to be safe beforehand.)
       size_t free_b = 0, total_b = 0;
-      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) kept_limit = (size_t)(0.40 * (double)total_b); else (void)hipGetLastError();
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        const double room = (double)dev_available_bytes() - 450.0 * std::max(top_nnz, 0.0);     // (the arena's helper is backing memory already)
+        kept_limit = (size_t)std::max(0.0, std::min(0.36 * (double)total_b, room));
+      } else (void)hipGetLastError();
     }
   }
   void defer_downloads(bool on) override { defer_ok = on; }
@@ -87,7 +94,9 @@ struct DevSetupAccel final : SetupAccel {
     if (!d.rp) return;
     std::lock_guard<std::mutex> lk(mu_kept);
     const bool only_copy = tag && host_missing.count(tag);
-    if (tag && !kept.count(tag) && (only_copy || (keeping && kept_bytes + bytes_of(d) <= kept_limit))) { kept[tag] = d; kept_bytes += bytes_of(d); d = DCsr(); }
+    // (a copy in the temporaries' range - an operand uploaded from the host - would hold that whole range back: not kept)
+    const bool pins_temporaries = dev_class_of(d.v ? (void*)d.v : (void*)d.rp) == DEV_TEMP;
+    if (tag && !kept.count(tag) && (only_copy || (keeping && !pins_temporaries && kept_bytes + bytes_of(d) <= kept_limit))) { kept[tag] = d; kept_bytes += bytes_of(d); d = DCsr(); }
     else if (only_copy) throw std::logic_error("setup accelerator: two device copies of an operator that is not on the host");
     else dcsr_free(d);
   }
@@ -96,6 +105,7 @@ struct DevSetupAccel final : SetupAccel {
   void settle() {
     retire(inverse, inverse_tag); inverse_key = nullptr; inverse_tag = 0;
     retire(res_z, z_tag); z_tag = 0;
+    retire(res_fc, fc_tag); fc_tag = 0;
     bool only; { std::lock_guard<std::mutex> lk(mu_kept); only = cf_tag && host_missing.count(cf_tag); }
     if (only) { retire(res_cf, cf_tag); cf_tag = 0; }
   }
@@ -196,7 +206,7 @@ struct DevSetupAccel final : SetupAccel {
     for (auto& p : pending) finish_one(*p, false);
     pending.clear();
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
-    dcsr_free(resident); dcsr_free(inverse); dcsr_free(res_ff); dcsr_free(res_cf); dcsr_free(res_z);
+    dcsr_free(resident); dcsr_free(inverse); dcsr_free(res_ff); dcsr_free(res_cf); dcsr_free(res_z); dcsr_free(res_fc);
     for (auto& k : kept) dcsr_free(k.second);
     for (auto& k : lent) dcsr_free(k.second);
   }
@@ -246,7 +256,7 @@ struct DevSetupAccel final : SetupAccel {
     retire(inverse, inverse_tag); inverse_key = nullptr; inverse_tag = 0;
     const double t0 = now_s();
     dev_stage("setup: product (Z = -A_cf * M or A * B)");
-    DCsr dC = dev_spgemm(dA, dB, drop.enabled, drop.tol, drop.lump, drop.negate, stream);
+    DCsr dC = dev_spgemm(dA, dB, drop.enabled, drop.tol, drop.lump, drop.negate, stream, nullptr, keep && keeping ? DEV_KEPT : DEV_TEMP);
     t_compute += now_s() - t0;
     sync_host(nullptr);          // a download of dA (the C-F block) may still be reading it
     // the C-F block is only kept when the host has not got it yet; the inverse is an operator of the hierarchy
@@ -281,6 +291,22 @@ struct DevSetupAccel final : SetupAccel {
     return true;
   }
 
+  bool one_point_w(const Csr& A_fc, Arr<int32_t>& wcol) override {
+    if (!(A_fc.device_tag && A_fc.device_tag == fc_tag && res_fc.rp && res_fc.m == A_fc.m && res_fc.nnz == A_fc.nnz())) return false;
+    const double t0 = now_s();
+    dev_stage("setup: one-point prolongator");
+    wcol.alloc(A_fc.m);
+    if (A_fc.m > 0) {
+      int32_t* d_w = (int32_t*)dev_alloc(sizeof(int32_t) * (size_t)A_fc.m);
+      dev_one_point_w(res_fc, d_w, stream);
+      staged_d2h(wcol.data(), d_w, sizeof(int32_t) * (size_t)A_fc.m);
+      dev_free(d_w);
+    }
+    retire(res_fc, fc_tag); fc_tag = 0;
+    t_extract += now_s() - t0;
+    return true;
+  }
+
   bool poly_assemble(const Csr& A, const std::vector<double>& c, Csr& M, bool final_values) override {
     static const bool enabled = [] { const char* e = std::getenv("AIRHIP_DEVICE_POLY"); return !(e && e[0] == '0'); }();
     if (!enabled || A.nnz() < min_nnz || c.size() < 3) return false;
@@ -289,7 +315,8 @@ struct DevSetupAccel final : SetupAccel {
     else dA = up(A);                       // (a fresh copy of the same host arrays: as good for the upload later)
     const double t0 = now_s();
     dev_stage("setup: polynomial assembly");
-    const bool ok = dev_poly_assemble(dA, c.data(), (int)c.size(), dM, stream);
+    bool ok;
+    { DevClassScope cls(final_values && keeping ? DEV_KEPT : DEV_TEMP); ok = dev_poly_assemble(dA, c.data(), (int)c.size(), dM, stream); }
     t_poly += now_s() - t0;
     retire(dA, A.device_tag);              // A_ff itself is an operator of the hierarchy
     if (!ok) return false;
@@ -527,11 +554,18 @@ struct DevSetupAccel final : SetupAccel {
     if (!d.rp && tag && tag == z_tag) d = res_z;
     if (!d.rp && tag && tag == cf_tag) d = res_cf;
     if (!d.rp && tag && tag == inverse_tag) d = inverse;
+    if (!d.rp && tag && tag == fc_tag) d = res_fc;
     if (!d.rp || d.m != A.m || d.nnz != A.nnz()) throw std::logic_error("materialize: the device copy of the operator is gone");
     A = down(d);
     A.device_tag = tag;
     std::lock_guard<std::mutex> lk(mu_kept);
     host_missing.erase(tag);
+  }
+  void release_temporaries() override {
+    settle();
+    drop_resident(); dcsr_free(res_ff); ff_tag = 0;
+    bool only; { std::lock_guard<std::mutex> lk(mu_kept); only = cf_tag && host_missing.count(cf_tag); }
+    if (!only) { dcsr_free(res_cf); cf_tag = 0; }
   }
   void release_copies() override {
     settle();
@@ -557,7 +591,7 @@ struct DevSetupAccel final : SetupAccel {
     t0 = now_s();
     DCsr dff, dfc, dcf, dcc;
     dev_stage("setup: F / C block extraction");
-    dev_split_fc(resident, d_code, n_f, n_c, dff, dfc, dcf, A_cc ? &dcc : nullptr, stream);
+    { DevClassScope cls(keeping ? DEV_KEPT : DEV_TEMP); dev_split_fc(resident, d_code, n_f, n_c, dff, dfc, dcf, A_cc ? &dcc : nullptr, stream); }
     dev_free(d_code);
     dev_stage("setup: F / C blocks, downloads");
     t_extract += now_s() - t0;
@@ -570,9 +604,12 @@ struct DevSetupAccel final : SetupAccel {
     const bool defer_cf = !async && !A_cc && can_defer(dcf);       // only the Z product reads the C-F block
     if (async) { begin_down(dfc, A_fc, true); begin_down(dcf, A_cf, false); }
     else {
-      A_fc = down(dfc);
+      // the F-C block: only the one-point prolongator reads it (one_point_w below does that here)
+      retire(res_fc, fc_tag);
+      if (!A_cc && can_defer(dfc)) { A_fc = stub_of(dfc, ++next_tag); std::lock_guard<std::mutex> lk(mu_kept); host_missing.insert(A_fc.device_tag); }
+      else { A_fc = down(dfc); A_fc.device_tag = ++next_tag; }
+      res_fc = dfc; fc_tag = A_fc.device_tag;
       if (!defer_cf) A_cf = down(dcf);
-      A_fc.device_tag = ++next_tag; retire(dfc, A_fc.device_tag);
     }
     if (A_cc) { *A_cc = down(dcc); dcsr_free(dcc); }
     // A_ff feeds the polynomial assembly, A_cf the Z product: they stay

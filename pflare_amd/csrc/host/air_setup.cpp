@@ -347,7 +347,10 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o, SetupAc
       L.one_point = false;
     } else if (o.one_point_classical_prolong) {
       L.one_point = true;
-      one_point_W(L.A_fc, L.wcol);
+      if (!(accel && accel->one_point_w(L.A_fc, L.wcol))) {
+        if (accel) accel->materialize(L.A_fc);     // (a stub when its download was deferred)
+        one_point_W(L.A_fc, L.wcol);
+      }
     } else {
       if (!product_z) throw std::runtime_error("lAIR / SAI restrictors need the one-point classical prolongator");
       L.one_point = false;

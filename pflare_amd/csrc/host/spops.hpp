@@ -61,6 +61,9 @@ struct SetupAccel {
                           const SpgemmDrop& drop, Csr& coarse) {
     (void)Z; (void)F; (void)C; (void)wcol; (void)A; (void)drop; (void)coarse; return false;
   }
+  // wcol[i] = column of the largest |entry| of row i of A_fc (air_setup.cpp one_point_W) where the accelerator holds the
+  // block; false when it declines (the caller then needs A_fc on the host)
+  virtual bool one_point_w(const Csr& A_fc, Arr<int32_t>& wcol) { (void)A_fc; (void)wcol; return false; }
   // brings the arrays of a device-only operator to the host (no-op for an operator that is there already)
   virtual void materialize(Csr& A) { if (!A.on_host()) throw std::logic_error("this accelerator holds no device-only operators"); }
   // the four F / C blocks of the level operator (host/spops.cpp: split_fc) extracted where the operator is; A_cc only
@@ -91,10 +94,10 @@ struct SetupAccel {
   // change M afterwards (the accelerator may then keep its copy for the product that follows).
   virtual bool poly_assemble(const Csr& A, const std::vector<double>& c, Csr& M, bool final_values) { (void)A; (void)c; (void)M; (void)final_values; return false; }
   // Copies the accelerator kept of operators it produced or extracted (named by Csr::device_tag), for the upload of the
-  // hierarchy that follows the setup on the same device: keep_copies(true) asks for them (within the accelerator's own
-  // memory budget), device_copy hands out the arrays of one (CSR, the host Csr's row order; false = none kept, the caller
+  // hierarchy that follows the setup on the same device: keep_copies(true, nnz of the top operator) asks for them (within
+  // the accelerator's own memory budget), device_copy hands out the arrays of one (CSR, the host Csr's row order; false = none kept, the caller
   // copies the host arrays), drop_device_copy gives its memory back.
-  virtual void keep_copies(bool on) { (void)on; }
+  virtual void keep_copies(bool on, double top_nnz = 0.0) { (void)on; (void)top_nnz; }
   virtual bool device_copy(uint64_t tag, int64_t m, int64_t nnz, const int64_t** rp, const int32_t** ci, const double** v) {
     (void)tag; (void)m; (void)nnz; (void)rp; (void)ci; (void)v; return false;
   }
@@ -106,6 +109,8 @@ struct SetupAccel {
   virtual void defer_downloads(bool on) { (void)on; }
   virtual void plain_recipe(bool on) { (void)on; }
   virtual void release_copies() {}
+  // the setup proper is over: everything the accelerator still holds that is not a kept copy goes back to its memory pool
+  virtual void release_temporaries() {}
   double t_transfer = 0.0, t_compute = 0.0, t_cfsplit = 0.0, t_poly = 0.0, t_extract = 0.0;
 };
 // the accelerator the polynomial assembly may use (set by setup_air for its duration; null = host only)

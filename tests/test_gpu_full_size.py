@@ -70,6 +70,8 @@ def test_config3_464_vcycle_against_the_c_oracle_linearity_and_true_residual(gpu
     # identical iteration count and convergence reason, final residual norms agreeing to 2 digits (SURVEY 8d parity gate)
     assert res["its"] == its_cpu and res["reason"] == reason_cpu, (res, its_cpu, reason_cpu)
     assert abs(res["rnorm"] - rn_cpu) <= 0.05 * rn_cpu, (res["rnorm"], rn_cpu)
+    print("torch allocator:", torch.cuda.memory_allocated() >> 20, "MiB allocated,", torch.cuda.memory_reserved() >> 20, "MiB reserved; device free",
+          torch.cuda.mem_get_info()[0] >> 20, "MiB")
     dA = P.DeviceMat(A)
     r = torch.empty_like(b); r0 = torch.empty_like(b)
     dA.mult(sol, r)

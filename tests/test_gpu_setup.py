@@ -395,6 +395,8 @@ def test_host_mirror_of_a_device_setup_is_the_host_codes_hierarchy(gpu, defer, m
                 _same(d[k], h[k], f"level {lv} {k}")
         if h["inv_ff"].get("mat") is not None:
             _same(d["inv_ff"]["mat"], h["inv_ff"]["mat"], f"level {lv} M_ff")
+        if h.get("wcol") is not None:          # the one-point prolongator, read off A_fc on the device
+            assert np.array_equal(d["wcol"], h["wcol"]), f"level {lv} wcol"
     assert r["reason"] > 0 and r["its"] <= 9, r
     # a second setup on the same object while the first hierarchy's mirror may still be running
     pd.setup(A)

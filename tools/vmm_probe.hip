@@ -107,9 +107,10 @@ int main(int argc, char** argv) {
     }
     CK(hipMemGetInfo(&f1, &t));
     for (size_t k = 0; k < nchunks; k++) { CK(hipMemUnmap((char*)base + k * chunk, chunk)); CK(hipMemRelease(handles[k])); }
+    size_t f15 = 0; CK(hipMemGetInfo(&f15, &t));
     CK(hipMemAddressFree(base, nchunks * chunk));
     CK(hipMemGetInfo(&f2, &t));
-    std::printf("round %d: free %.1f GB -> mapped %.1f GB -> released %.1f GB\n", round, f0 * 1e-9, f1 * 1e-9, f2 * 1e-9);
+    std::printf("round %d: free %.1f GB -> mapped %.1f GB -> unmapped + released %.1f GB -> address range freed %.1f GB\n", round, f0 * 1e-9, f1 * 1e-9, f15 * 1e-9, f2 * 1e-9);
   }
   return 0;
 }

@@ -6,11 +6,14 @@
 // MODE 0: every block is its own reservation, freed with hipMemUnmap + hipMemRelease + hipMemAddressFree (address ranges come
 //         and go);  MODE 1: one reservation for the whole run, blocks are sub-ranges whose pieces are mapped on allocation and
 //         unmapped on release (addresses are backed, given back and backed again);  MODE 2: one reservation, pieces are mapped
-//         on first use and never unmapped;  MODE 3: plain hipMalloc / hipFree (control).
+//         on first use and never unmapped;  MODE 3: plain hipMalloc / hipFree (control);  MODE 4: as MODE 0, but every freed
+//         range is covered at once with an inaccessible CPU mapping (mmap PROT_NONE, MAP_FIXED_NOREPLACE) so that the address
+//         range is never handed out again.
 // A random sequence of allocations and releases; every block is filled by a host -> device copy of a pattern that depends on
 // the block's serial number (hipMemcpy from pinned-in-place host memory, as the library's staged_h2d does), checked at once by a
 // kernel, and checked again by a kernel and by a device -> host copy right before it is released.  Prints the first mismatches.
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -53,7 +56,7 @@ int main(int argc, char** argv) {
   unsigned long long* d_bad = nullptr; CK(hipMalloc((void**)&d_bad, 8));
   std::mt19937_64 rng(12345);
   std::vector<Block> live;
-  size_t live_bytes = 0; uint64_t serial = 0; long long mism = 0, allocs = 0;
+  size_t live_bytes = 0; uint64_t serial = 0; long long mism = 0, allocs = 0, tomb_fail = 0;
   // host staging buffer: pageable, registered for each copy like the library does
   const size_t host_max = 6ull << 30;
   uint64_t* host = (uint64_t*)std::malloc(host_max);
@@ -72,7 +75,7 @@ int main(int argc, char** argv) {
       if (bytes > host_max) bytes = host_max;
       Block b; b.bytes = bytes; b.serial = ++serial; b.off = 0;
       const size_t rounded = (bytes + PIECE - 1) / PIECE * PIECE;
-      if (mode == 0) {
+      if (mode == 0 || mode == 4) {
         void* q = nullptr; CK(hipMemAddressReserve(&q, rounded, 0, nullptr, 0)); b.p = (char*)q;
         for (size_t k = 0; k < rounded / PIECE; k++) {
           hipMemGenericAllocationHandle_t h; CK(hipMemCreate(&h, PIECE, &prop, 0));
@@ -115,10 +118,14 @@ int main(int argc, char** argv) {
       size_t bad = 0; for (size_t i = 0; i < b.bytes / 8; i++) bad += host[i] != pat(b.serial, i);
       if (bad) { mism++; if (mism < 20) std::printf("  MISMATCH (before the release, copy): block %llu of %.3f GB: %zu words differ\n", (unsigned long long)b.serial, b.bytes * 1e-9, bad); }
       CK(hipDeviceSynchronize());
-      if (mode == 0) {
+      if (mode == 0 || mode == 4) {
         const size_t rounded = (b.bytes + PIECE - 1) / PIECE * PIECE;
         for (size_t q = 0; q < b.h.size(); q++) { CK(hipMemUnmap(b.p + q * PIECE, PIECE)); CK(hipMemRelease(b.h[q])); }
         CK(hipMemAddressFree(b.p, rounded));
+        if (mode == 4) {
+          void* t = mmap(b.p, rounded, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE | MAP_FIXED_NOREPLACE, -1, 0);
+          if (t != (void*)b.p) { tomb_fail++; if (t != MAP_FAILED) munmap(t, rounded); }
+        }
       } else if (mode == 1 || mode == 2) {
         const size_t need = (b.bytes + (2u << 20) - 1) / (2u << 20) * (2u << 20);
         for (size_t q = b.off / PIECE; q <= (b.off + need - 1) / PIECE; q++) {
@@ -132,6 +139,8 @@ int main(int argc, char** argv) {
       } else CK(hipFree(b.p));
     }
   }
-  std::printf("mode %d: %d steps, %lld allocations, %.1f GB live at the end, %lld blocks with mismatches\n", mode, rounds, allocs, live_bytes * 1e-9, mism);
+  std::printf("mode %d: %d steps, %lld allocations, %.1f GB live at the end, %lld blocks with mismatches", mode, rounds, allocs, live_bytes * 1e-9, mism);
+  if (mode == 4) std::printf(", %lld freed ranges could not be covered", tomb_fail);
+  std::printf("\n");
   return mism ? 1 : 0;
 }
