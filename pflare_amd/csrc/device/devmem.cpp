@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <exception>
 #include <map>
+#include <deque>
 #include <memory>
 #include <unordered_map>
 #include <unordered_set>
@@ -103,7 +104,10 @@ bool vm_supported() {
 }
 
 // what the arenas of one DevArena scope may back together
-struct Group { size_t committed = 0, limit = 0, peak = 0; };
+// spare: physical pieces a freed range of the scope has left behind - the next piece any of its arenas backs takes one of
+// these (in the order they were created) instead of asking the driver for fresh memory, which it would first have to clear
+// (31 ms per GB right after a release, measured at 464^3: the hierarchy's 131 GB out of the temporaries' memory)
+struct Group { size_t committed = 0, limit = 0, peak = 0; std::deque<hipMemGenericAllocationHandle_t> spare; };
 
 // one reserved range; every piece is backed at most once
 struct VmRange {
@@ -123,10 +127,14 @@ struct VmRange {
     return true;
   }
   bool map_piece(size_t k) {
-    if (group->committed + PIECE > group->limit) return false;
-    hipMemAllocationProp prop = {};
-    prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
-    if (hipMemCreate(&handle[k], PIECE, &prop, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+    const bool reuse = !group->spare.empty();
+    if (!reuse && group->committed + PIECE > group->limit) return false;
+    if (reuse) { handle[k] = group->spare.front(); group->spare.pop_front(); group->committed -= PIECE; }      // (counted again below)
+    else {
+      hipMemAllocationProp prop = {};
+      prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
+      if (hipMemCreate(&handle[k], PIECE, &prop, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+    }
     hipMemAccessDesc acc = {};
     acc.location.type = hipMemLocationTypeDevice; acc.location.id = dev; acc.flags = hipMemAccessFlagsProtReadWrite;
     if (hipMemMap(base + k * PIECE, PIECE, 0, handle[k], 0) != hipSuccess) { (void)hipGetLastError(); (void)hipMemRelease(handle[k]); return false; }
@@ -156,11 +164,17 @@ struct VmRange {
   }
   // Everything goes back: memory and addresses - and the addresses are taken out of circulation for good.  No kernel may
   // still be using the range: unlike hipFree, unmapping does not wait for the device
-  void release() {
+  // keep_pieces: the physical pieces stay with the scope (Group::spare) for the ranges that are still growing
+  void release(bool keep_pieces = false) {
     if (!base) return;
     (void)hipDeviceSynchronize();
-    for (size_t k = 0; k < state.size(); k++)
-      if (state[k] == 1) { (void)hipMemUnmap(base + k * PIECE, PIECE); (void)hipMemRelease(handle[k]); committed -= PIECE; group->committed -= PIECE; }
+    for (size_t k = 0; k < state.size(); k++) {
+      if (state[k] != 1) continue;
+      (void)hipMemUnmap(base + k * PIECE, PIECE);
+      committed -= PIECE;
+      if (keep_pieces) group->spare.push_back(handle[k]);      // still counted in group->committed
+      else { (void)hipMemRelease(handle[k]); group->committed -= PIECE; }
+    }
     (void)hipMemAddressFree(base, reserved);
     void* t = mmap(base, reserved, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE | MAP_FIXED_NOREPLACE, -1, 0);
     if (t != (void*)base) {
@@ -187,6 +201,7 @@ struct Arena {
   std::map<size_t, size_t> free_by_off;             // offset -> length, neighbours merged
   std::unordered_map<void*, size_t> live;           // block -> length
   bool closing = false;                             // no new blocks: release once the last block is back
+  bool leave_pieces = false;                        // ... and leave the physical pieces to the scope's other arenas
   size_t peak = 0, used = 0, misses = 0, peak_committed = 0;
 };
 std::vector<std::unique_ptr<Arena>>& arenas() { static auto* v = new std::vector<std::unique_ptr<Arena>>; return *v; }
@@ -241,7 +256,7 @@ void arena_release_if_done(Arena& a) {
   static const bool trace = std::getenv("AIRHIP_ALLOC_TRACE") != nullptr;
   if (trace) std::fprintf(stderr, "[devmem %.3f] arena %d released: peak use %.1f GB, peak backing %.1f GB, %zu requests did not fit\n", trace_clock(), a.cls, a.peak * 1e-9,
                           a.peak_committed * 1e-9, a.misses);
-  a.vm.release();
+  a.vm.release(a.leave_pieces);
   auto& v = arenas();
   for (size_t k = 0; k < v.size(); k++) if (v[k].get() == &a) { v.erase(v.begin() + (long)k); break; }
 }
@@ -448,12 +463,12 @@ Arena* open_arena(int c, const void* owner, std::shared_ptr<Group> g, size_t va_
   arenas().push_back(std::move(a));
   return arenas().back().get();
 }
-void close_arenas(const void* owner, int c) {      // c < 0: all classes
+void close_arenas(const void* owner, int c, bool leave_pieces = false) {      // c < 0: all classes
   auto& v = arenas();
   for (size_t k = v.size(); k-- > 0;) {
     Arena& a = *v[k];
     if (a.owner != owner || a.closing || (c >= 0 && a.cls != c)) continue;
-    a.closing = true;
+    a.closing = true; a.leave_pieces = leave_pieces;
     arena_release_if_done(a);                       // (erases v[k]: the loop runs downwards)
   }
 }
@@ -530,7 +545,9 @@ void DevArena::recycle_temporaries(size_t hier_front) {
   {
     DevCache& c = cache();
     std::lock_guard<std::mutex> lock(c.mu);
-    close_arenas(this, DEV_TEMP);                            // empty by now in the normal course: freed here and now
+    // (empty by now in the normal course: freed here and now; an arena that still holds a block when the scope ends must
+    // not leave pieces to a scope that no longer exists - ~DevArena clears the flag)
+    close_arenas(this, DEV_TEMP, true);
     open_arena(DEV_TEMP, this, impl_->group, impl_->bytes, 0);
   }
   // (hier_front: measured at 464^3, a helper that backs the hierarchy's 131 GB at once out of the memory that has just come
@@ -549,6 +566,10 @@ DevArena::~DevArena() {
     static const bool trace = std::getenv("AIRHIP_ALLOC_TRACE") != nullptr;
     if (trace) std::fprintf(stderr, "[devmem %.3f] setup scope over: its arenas backed %.1f GB at the peak\n", trace_clock(), impl_->group->peak * 1e-9);
     close_arenas(this, -1);
+    for (auto& a : arenas()) if (a->owner == this) a->leave_pieces = false;
+    // the pieces nobody took
+    for (auto h : impl_->group->spare) { (void)hipMemRelease(h); impl_->group->committed -= PIECE; }
+    impl_->group->spare.clear();
   }
   delete impl_;
 }
