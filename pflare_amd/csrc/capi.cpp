@@ -1153,7 +1153,7 @@ int airhip_pcair_load_distributed(airhip_pcair pc, airhip_archive piece, airhip_
   load_local(piece->ar, *loc);
   REQUIRE(loc->nranks == comm->c->size && loc->rank == comm->c->rank, AIRHIP_ERR_ARG, "piece does not belong to this rank");
   double t0 = now_s();
-  DevArena dev_arena(dev_arena_bytes_for((double)loc->A_top.nnz()), dev_arena_front_for(0.7 * (double)loc->A_top.nnz()));      // this rank's hierarchy in one contiguous range
+  DevArena dev_arena(dev_arena_bytes_for((double)loc->A_top.nnz()), 0);      // this rank's hierarchy in one contiguous range (its staging blocks in another)
   pc->dev = std::make_unique<DevPCAIR>();
   if (loc->hint.size() > 0) pc->dev->set_ordering_hint(loc->hint.data(), loc->hint.size());
   pc->dev->upload(loc->H, loc->A_top, loc.get(), comm->c.get());
