@@ -98,7 +98,7 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd))
-    os.environ.setdefault("AIRHIP_FAULT_STAGE", "1")     # a GPU memory fault names the library step it happened in
+    os.environ.setdefault("AIRHIP_FAULT_STAGE", "11")    # a GPU memory fault names the library step it happened in; a segmentation fault prints a native backtrace
     if "AIRHIP_DEVICE_TRUNC" not in os.environ:
         os.environ["AIRHIP_DEVICE_TRUNC"] = str(1 if args.device_trunc else 0)
 

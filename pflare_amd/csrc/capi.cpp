@@ -98,7 +98,7 @@ static int library_team() {
   }();
   return team;
 }
-TeamGuard::TeamGuard() : prev(omp_get_max_threads()) { omp_set_num_threads(library_team()); }
+TeamGuard::TeamGuard() : prev(omp_get_max_threads()) { omp_set_num_threads(library_team()); dev_drain_releases(); }
 TeamGuard::~TeamGuard() { omp_set_num_threads(prev); }
 // fewer threads for small operators: one thread per ~32k non-zeros
 struct ThreadScope {
@@ -561,6 +561,7 @@ int airhip_pcair_setup(airhip_pcair pc, const airhip_csr* A) {
   // the numbers print_stats and airhip_pcair_complexities report, while nothing else touches the hierarchy
   pc->cplx_valid = false;
   if (airhip_pcair_complexities(pc, &pc->cplx[0], &pc->cplx[1], &pc->cplx[2], &pc->cplx[3], &pc->cplx[4]) == 0) pc->cplx_valid = true;
+  dev_arena.finish();      // the ranges of this call that are empty go back now: not beside the thread below
   if (accel && hierarchy_has_stubs(*pc->H)) {
     // The operators whose download was deferred come to the host beside whatever the caller does next (the solve does
     // not need them); everything that reads the host hierarchy waits for this thread first (mirror_join).

@@ -55,6 +55,9 @@ class DevClassScope {      // the class dev_alloc serves on this thread (DEV_TEM
  private:
   int prev_;
 };
+// ranges whose last block came back on a thread other than their maker's are freed by the maker's next call of this (the
+// C API calls it on entry)
+void dev_drain_releases();
 int dev_class_of(void* p);      // the class of the arena a block came from, -1 for a block from the cache / hipMalloc
 class DevArena {
  public:
@@ -66,6 +69,8 @@ class DevArena {
   // temporaries of what follows (the upload of the hierarchy)
   // hier_front: how much of the range of the arrays that stay a helper thread backs right away
   void recycle_temporaries(size_t hier_front = 0);
+  // what the destructor does, ahead of it (the caller is about to start a thread that must not run beside these frees)
+  void finish();
   DevArena(const DevArena&) = delete;
   DevArena& operator=(const DevArena&) = delete;
  private:
@@ -100,4 +105,5 @@ class DevScope {
 // exception, no error code): the long device steps of setup and upload note their name here, and with AIRHIP_FAULT_STAGE=1
 // a SIGABRT handler prints the last one noted.  `what` must be a string literal (the pointer is kept).
 void dev_stage(const char* what);
+void dev_note_host_copy(void* host, size_t bytes);      // the host array a large copy is working on (post-mortem only)
 }  // namespace airhip

@@ -1,5 +1,6 @@
 #include "staged_copy.hpp"
 #include "dev.hpp"
+#include "devmem.hpp"
 #include <cstring>
 #include <cstdlib>
 #include <algorithm>
@@ -55,6 +56,7 @@ static int copy_mode() {
 constexpr size_t PIN_MIN = 32ull << 20;
 static bool pinned_copy(void* dst, const void* src, size_t bytes, bool to_device) {
   void* host = to_device ? const_cast<void*>(src) : dst;
+  dev_note_host_copy(host, bytes);
   if (!to_device) {
     // a fresh destination: fault the pages in with all threads first (registering would do it with one)
     char* p = (char*)host;

@@ -351,5 +351,41 @@ int main(int argc, char** argv) {
       }
     CHECK(hipFree(big));
   }
+  // ---- the same through the virtual-memory interface: does the size of the physical pieces under the value / index arrays
+  // matter?  (PROBE_VMM=1; every repetition takes fresh addresses and fresh pieces)
+  if (std::getenv("PROBE_VMM")) {
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = 0;
+    hipMemAccessDesc acc = {};
+    acc.location.type = hipMemLocationTypeDevice; acc.location.id = 0; acc.flags = hipMemAccessFlagsProtReadWrite;
+    auto vm_alloc = [&](size_t bytes, size_t piece, std::vector<hipMemGenericAllocationHandle_t>& hs) -> char* {
+      const size_t total = (bytes + piece - 1) / piece * piece;
+      void* q = nullptr; CHECK(hipMemAddressReserve(&q, total, 0, nullptr, 0));
+      for (size_t o = 0; o < total; o += piece) {
+        hipMemGenericAllocationHandle_t h; CHECK(hipMemCreate(&h, piece, &prop, 0));
+        CHECK(hipMemMap((char*)q + o, piece, 0, h, 0)); CHECK(hipMemSetAccess((char*)q + o, piece, &acc, 1));
+        hs.push_back(h);
+      }
+      return (char*)q;       // (never unmapped: the probe exits)
+    };
+    std::printf("-- value and index arrays on pieces of the virtual-memory interface (fresh addresses and pieces every time)\n");
+    const bool order_only = std::getenv("PROBE_VMM")[0] == '2';      // PROBE_VMM=2: 256-MB pieces only, in the order the driver hands memory out
+    for (size_t piece : {(size_t)2 << 20, (size_t)32 << 20, (size_t)256 << 20, (size_t)1 << 30, (size_t)4 << 30})
+      for (int rep = 0; rep < (order_only ? 24 : 6); rep++) {
+        if (order_only && piece != ((size_t)256 << 20)) break;
+        std::vector<hipMemGenericAllocationHandle_t> hs;
+        void* pad; CHECK(hipMalloc(&pad, ((size_t)(rep * 5 + 1) << 20) + (size_t)rep * 4096 * 37));
+        double* v2 = (double*)vm_alloc((size_t)nnz * 8, piece, hs);
+        uint32_t* i2 = (uint32_t*)vm_alloc((size_t)nnz * 4, piece, hs);
+        CHECK(hipMemcpy(v2, val, (size_t)nnz * 8, hipMemcpyDeviceToDevice));
+        CHECK(hipMemcpy(i2, idx, (size_t)nnz * 4, hipMemcpyDeviceToDevice));
+        Args a{i2, v2, blob, desc, x, y, nblocks, 16};
+        const int64_t per_class = (nblocks + 7) / 8;
+        const unsigned grid = (unsigned)(8 * ((per_class + 3) / 4));
+        const double ms = time_ms([&] { hipLaunchKernelGGL((k_block<4, 1, 0, 1, 1, 1, 4>), dim3(grid), dim3(256), 0, 0, a); });
+        std::printf("   piece %5zu MB rep %d   %8.3f ms  %7.1f GB/s\n", piece >> 20, rep, ms, (stream_bytes + nblocks * 16 * 8.0) / ms * 1e-6);
+        CHECK(hipFree(pad));
+      }
+  }
   return 0;
 }

@@ -56,7 +56,8 @@ int main(int argc, char** argv) {
   unsigned long long* d_bad = nullptr; CK(hipMalloc((void**)&d_bad, 8));
   std::mt19937_64 rng(12345);
   std::vector<Block> live;
-  size_t live_bytes = 0; uint64_t serial = 0; long long mism = 0, allocs = 0, tomb_fail = 0;
+  size_t live_bytes = 0; uint64_t serial = 0; long long mism = 0, allocs = 0, tomb_fail = 0, tomb_gone = 0;
+  std::vector<std::pair<char*, size_t>> covers;
   // host staging buffer: pageable, registered for each copy like the library does
   const size_t host_max = 6ull << 30;
   uint64_t* host = (uint64_t*)std::malloc(host_max);
@@ -125,6 +126,13 @@ int main(int argc, char** argv) {
         if (mode == 4) {
           void* t = mmap(b.p, rounded, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE | MAP_FIXED_NOREPLACE, -1, 0);
           if (t != (void*)b.p) { tomb_fail++; if (t != MAP_FAILED) munmap(t, rounded); }
+          else covers.push_back({b.p, rounded});
+          // are the covers of the ranges freed earlier still there?  (a second cover that succeeds means the first one is gone)
+          for (auto& c : covers) {
+            void* t2 = mmap(c.first, c.second, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE | MAP_FIXED_NOREPLACE, -1, 0);
+            if (t2 == (void*)c.first) tomb_gone++;
+            else if (t2 != MAP_FAILED) munmap(t2, c.second);
+          }
         }
       } else if (mode == 1 || mode == 2) {
         const size_t need = (b.bytes + (2u << 20) - 1) / (2u << 20) * (2u << 20);
@@ -140,7 +148,7 @@ int main(int argc, char** argv) {
     }
   }
   std::printf("mode %d: %d steps, %lld allocations, %.1f GB live at the end, %lld blocks with mismatches", mode, rounds, allocs, live_bytes * 1e-9, mism);
-  if (mode == 4) std::printf(", %lld freed ranges could not be covered", tomb_fail);
+  if (mode == 4) std::printf(", %lld freed ranges could not be covered, %lld covers found removed later", tomb_fail, tomb_gone);
   std::printf("\n");
   return mism ? 1 : 0;
 }
