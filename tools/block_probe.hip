@@ -20,6 +20,7 @@ struct Args {
   const uint32_t* idx; const double* val;     // two arrays (BLOB = 0)
   const char* blob;                            // BLOB = 1: per block [val 4 KB][idx 2 KB]
   const Desc* desc; const double* x; double* y; int64_t nblocks; int rows_per_block;
+  int skew = 0;                                // class g starts g * skew blocks into its eighth (wraps around)
 };
 
 // VW: 2 = 8 x dwordx2 value loads, 4 = 4 x dwordx4 (pairs of rounds interleaved in memory)
@@ -31,8 +32,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_block(Args a) {
   const int g = blockIdx.x & 7;
   const int64_t bi = blockIdx.x >> 3;
   const int64_t lo = a.nblocks * g / 8, hi = a.nblocks * (g + 1) / 8;
-  const int64_t b = lo + bi * WAVES + wid;
+  int64_t b = lo + bi * WAVES + wid;
   if (b >= hi) return;
+  if (a.skew) b = lo + (b - lo + (int64_t)g * a.skew) % (hi - lo);
   int64_t p0 = b * NNZ;
   if (DESC) {
     const Desc __attribute__((address_space(4)))* dp = (const Desc __attribute__((address_space(4)))*)(uintptr_t)a.desc;
@@ -318,7 +320,8 @@ int main(int argc, char** argv) {
   }
   // ---- does the relative placement of the index and the value array matter?  (per-operator rates of the benchmark move by
   // +-8 % from run to run with the same kernel: the arrays land at other physical addresses each time)
-  {
+  if (std::getenv("PROBE_SKIP_MALLOC")) fill_idx(-256, 16);
+  else {
     fill_idx(-256, 16);
     char* big; const size_t slack = (size_t)64 << 20;
     CHECK(hipMalloc(&big, (size_t)nnz * 12 + 2 * slack));
@@ -371,7 +374,7 @@ int main(int argc, char** argv) {
     std::printf("-- value and index arrays on pieces of the virtual-memory interface (fresh addresses and pieces every time)\n");
     const bool order_only = std::getenv("PROBE_VMM")[0] == '2';      // PROBE_VMM=2: 256-MB pieces only, in the order the driver hands memory out
     for (size_t piece : {(size_t)2 << 20, (size_t)32 << 20, (size_t)256 << 20, (size_t)1 << 30, (size_t)4 << 30})
-      for (int rep = 0; rep < (order_only ? 24 : 6); rep++) {
+      for (int rep = 0; rep < (order_only ? (std::getenv("PROBE_REPS") ? std::atoi(std::getenv("PROBE_REPS")) : 24) : 6); rep++) {
         if (order_only && piece != ((size_t)256 << 20)) break;
         std::vector<hipMemGenericAllocationHandle_t> hs;
         void* pad; CHECK(hipMalloc(&pad, ((size_t)(rep * 5 + 1) << 20) + (size_t)rep * 4096 * 37));
@@ -383,7 +386,12 @@ int main(int argc, char** argv) {
         const int64_t per_class = (nblocks + 7) / 8;
         const unsigned grid = (unsigned)(8 * ((per_class + 3) / 4));
         const double ms = time_ms([&] { hipLaunchKernelGGL((k_block<4, 1, 0, 1, 1, 1, 4>), dim3(grid), dim3(256), 0, 0, a); });
-        std::printf("   piece %5zu MB rep %d   %8.3f ms  %7.1f GB/s\n", piece >> 20, rep, ms, (stream_bytes + nblocks * 16 * 8.0) / ms * 1e-6);
+        // the same arrays with the eight XCD streams started at different phases of their eighths
+        double ms_skew[3]; int skews[3] = {1237, 4099, 17};
+        for (int q = 0; q < 3; q++) { a.skew = skews[q]; ms_skew[q] = time_ms([&] { hipLaunchKernelGGL((k_block<4, 1, 0, 1, 1, 1, 4>), dim3(grid), dim3(256), 0, 0, a); }); }
+        const double by = stream_bytes + nblocks * 16 * 8.0;
+        std::printf("   piece %5zu MB rep %d   %8.3f ms  %7.1f GB/s   skew 1237: %7.1f  4099: %7.1f  17: %7.1f\n", piece >> 20, rep, ms, by / ms * 1e-6,
+                    by / ms_skew[0] * 1e-6, by / ms_skew[1] * 1e-6, by / ms_skew[2] * 1e-6);
         CHECK(hipFree(pad));
       }
   }
