@@ -562,6 +562,7 @@ int airhip_pcair_setup(airhip_pcair pc, const airhip_csr* A) {
   pc->cplx_valid = false;
   if (airhip_pcair_complexities(pc, &pc->cplx[0], &pc->cplx[1], &pc->cplx[2], &pc->cplx[3], &pc->cplx[4]) == 0) pc->cplx_valid = true;
   dev_arena.finish();      // the ranges of this call that are empty go back now: not beside the thread below
+  (void)dev_check_covers();
   if (accel && hierarchy_has_stubs(*pc->H)) {
     // The operators whose download was deferred come to the host beside whatever the caller does next (the solve does
     // not need them); everything that reads the host hierarchy waits for this thread first (mirror_join).
@@ -574,6 +575,7 @@ int airhip_pcair_setup(airhip_pcair pc, const airhip_csr* A) {
       try {
         if (hipSetDevice(dev) != hipSuccess) throw std::runtime_error("host mirror: hipSetDevice failed");
         mirror_fetch(*pc->H, *pc->mirror_accel);
+        (void)dev_check_covers();
       } catch (...) { pc->mirror_error = std::current_exception(); }
       pc->mirror_s = now_s() - t0;
     });

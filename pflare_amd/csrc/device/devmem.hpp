@@ -58,6 +58,7 @@ class DevClassScope {      // the class dev_alloc serves on this thread (DEV_TEM
 // ranges whose last block came back on a thread other than their maker's are freed by the maker's next call of this (the
 // C API calls it on entry)
 void dev_drain_releases();
+int dev_check_covers();      // post-condition check of the freed ranges' covers (devmem.cpp); the number that had to be put back
 int dev_class_of(void* p);      // the class of the arena a block came from, -1 for a block from the cache / hipMalloc
 class DevArena {
  public:
