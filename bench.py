@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 # defaults of the airhip_set_tuning keys (include/airhip.h): what --variants restores after each variant
-TUNING_DEFAULTS = {"spgemm_pool_entries": 0, "spgemm_pool_chunk": -1, "block_order_min_blocks": 4096, "fc_fuse": 1, "exp_copy_x": 0}
+TUNING_DEFAULTS = {"spgemm_pool_entries": 0, "spgemm_pool_chunk": -1, "block_order_min_blocks": 4096, "fc_fuse": 1}
 
 RECIPES = {
     # reference GPU recipe: lumping + auto truncation + Newton matrix-free coarse solver
@@ -98,7 +98,6 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd))
-    os.environ.setdefault("AIRHIP_FAULT_STAGE", "11")    # a GPU memory fault names the library step it happened in; a segmentation fault prints a native backtrace
     if "AIRHIP_DEVICE_TRUNC" not in os.environ:
         os.environ["AIRHIP_DEVICE_TRUNC"] = str(1 if args.device_trunc else 0)
 

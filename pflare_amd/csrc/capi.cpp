@@ -55,7 +55,6 @@ int airhip_set_tuning(const char* key, int value) {
   else if (std::string(key) == "spgemm_pool_chunk") airhip::spgemm_set_pool_chunk(value);
   else if (std::string(key) == "block_order_min_blocks") airhip::set_block_order_min(value);
   else if (std::string(key) == "fc_fuse") airhip::set_fc_fuse(value != 0);
-  else if (std::string(key) == "exp_copy_x") airhip::set_exp_copy_x(value);
   else if (airhip::spmv_set_tuning(key, value) != 0) { g_err = std::string("unknown tuning key ") + key; return AIRHIP_ERR_ARG; }
   API_END
 }
@@ -1349,13 +1348,19 @@ int airhip_ksp_solve_on_stream(const airhip_ksp_options* o, airhip_mat A, airhip
     const int64_t n = dev.n();
     if (!pc->ksp) { pc->ksp = std::make_unique<DevKSP>(n); pc->kb.alloc(n); pc->kx.alloc(n); }
     pc->link.after_caller(dev.stream(), caller);
+    dev.prof_begin("Krylov to hierarchical order", -1, 40.0 * n, "k_gather");
     dev.to_permuted(d_b, pc->kb.p);
     dev.to_permuted(d_x, pc->kx.p);
+    dev.prof_end();
     KspOperator op; op.A = &dev.A_perm(); op.stream = dev.stream(); op.comm = dev.comm();
+    op.prof_begin = [&dev](const char* name, double bytes, const char* kernel) { dev.prof_begin(name, -1, bytes, kernel); };
+    op.prof_end = [&dev]() { dev.prof_end(); };
     op.pc = [&dev](const double* in, double* out) { dev.apply_permuted(in, out); };
     op.mult = [&dev](const double* x, const SpmvEpi& e) { dev.spmv(dev.A_perm(), x, e, "outer A*x (Krylov)", -1); };
     r = pc->ksp->solve(op, ko, pc->kb.p, pc->kx.p);
+    dev.prof_begin("Krylov to natural order", -1, 20.0 * n, "k_gather");
     dev.to_natural(pc->kx.p, d_x);
+    dev.prof_end();
     HIP_CHECK(hipStreamSynchronize(dev.stream()));
   } else {
     REQUIRE(A, AIRHIP_ERR_ARG, "an operator is required without a preconditioner");

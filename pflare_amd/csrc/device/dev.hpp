@@ -98,8 +98,10 @@ void launch_scatter(int64_t n, const int32_t* idx, const double* in, double* out
 void launch_fill(int64_t n, double v, double* out, hipStream_t s);
 // dots[k] = <w, V_k>, k < nv (V_k = V + k*ld); two-stage deterministic reduction using `scratch`
 void launch_mdot(int64_t n, const double* w, const double* V, int64_t ld, int nv, double* scratch, double* dots, hipStream_t s);
-// w += sum_k coef[k] V_k  (coef on device)
-void launch_maxpy(int64_t n, double* w, const double* V, int64_t ld, int nv, const double* coef, hipStream_t s);
+// w += sum_k coef[k] V_k  (coef on device); zero_first: w = sum_k ... (w is not read); norm_scratch / norm_out (device):
+// *norm_out = sum of squares of the result, computed in the same pass (scratch: mdot_scratch_doubles(1) doubles)
+void launch_maxpy(int64_t n, double* w, const double* V, int64_t ld, int nv, const double* coef, hipStream_t s,
+                  bool zero_first = false, double* norm_scratch = nullptr, double* norm_out = nullptr);
 int mdot_scratch_doubles(int nv);
 
 // CSR (device) -> row-block CSR conversion.  rowsrc (may be null): destination row r takes source
@@ -109,7 +111,6 @@ void devmat_from_csr_device(int64_t m, int64_t n, const int64_t* d_rp, const int
                           int64_t n_ghost = 0,    // the last n_ghost columns are not remapped
                           bool cached = false);   // see DevMat::cached
 void devmat_free(DevMat& A);
-void devmat_reallocate(DevMat& A, hipStream_t s);      // see spmv.hip
 
 // performance knobs (not part of the stable ABI; airhip_set_tuning): see spmv.hip
 int spmv_set_tuning(const char* key, int value);

@@ -35,8 +35,8 @@ struct RangeNote { void* base; size_t size; int covered; };
 RangeNote g_released[16]; std::atomic<int> g_nreleased{0};
 std::atomic<void*> g_copy_host{nullptr}; std::atomic<size_t> g_copy_bytes{0};
 void hex_out(const char* label, uintptr_t v) {
-  char buf[64]; int n = 0;
-  for (const char* c = label; *c; c++) buf[n++] = *c;
+  char buf[160]; int n = 0;
+  for (const char* c = label; *c && n < 128; c++) buf[n++] = *c;
   buf[n++] = '0'; buf[n++] = 'x';
   for (int sh = 60; sh >= 0; sh -= 4) buf[n++] = "0123456789abcdef"[(v >> sh) & 15];
   buf[n++] = '\n';
@@ -117,15 +117,27 @@ DevCache& cache() { static DevCache* c = new DevCache; return *c; }
 // Hence: one range per class of blocks with a common lifetime, every piece backed at most once, the range freed as a whole
 // when its last block is gone.
 constexpr size_t GRANULE = 2u << 20;             // blocks of the arena
-// physical memory is created and mapped in pieces of this size (AIRHIP_ARENA_PIECE_MB: experiments)
-const size_t PIECE = [] { const char* e = std::getenv("AIRHIP_ARENA_PIECE_MB"); return (size_t)(e && std::atoi(e) >= 2 ? std::atoi(e) / 2 * 2 : 256) << 20; }();
+constexpr size_t PIECE = (size_t)256 << 20;    // physical memory is created and mapped in pieces of this size
 constexpr size_t VA_BUDGET = (size_t)64 << 40;   // address space the process may use up this way (then: no more arenas)
 size_t g_va_used = 0;
 
+// The arenas are OFF by default since round 4.  Records of round 3 (464^3): 3 of 24 runs died in the host-mirror thread with a
+// segmentation fault whose address lay inside a host array that glibc had mapped inside a device range this file had freed
+// AND covered (PROT_NONE, MAP_FIXED_NOREPLACE) a moment before - so the cover went away after it had been laid, and then the
+// array's pages went too: somebody unmapped that range twice after hipMemAddressFree had returned.  The faults began with the
+// commit that left the physical handles of a freed range alive (Group::spare, re-mapped into the other ranges).  Reading of
+// that timeline (NOT confirmed by an experiment - the round's instruction was to stop experimenting with the allocator): the
+// runtime's bookkeeping of a physical handle keeps the address range it was first mapped at, and finishes that range's
+// teardown (a munmap / a fresh PROT_NONE MAP_FIXED mapping over it) only when the handle is unmapped again or released -
+// long after the range was handed back and covered, whatever then lives at those addresses.  Consequences: the plain path
+// (block cache + hipMalloc, ~2 s more per 464^3 setup, nothing in the solve) is the default; with AIRHIP_DEVICE_VMM=1 the
+// arenas no longer hand physical pieces from a freed range to the others (every handle is released before its range's
+// addresses are), the thread rules and the covers stay as they were.
 bool vm_supported() {
   static const bool ok = [] {
+    // OPT-IN since round 4 (AIRHIP_DEVICE_VMM=1): see "the arenas are off by default" below
     const char* e = std::getenv("AIRHIP_DEVICE_VMM");
-    if (e && e[0] == '0') return false;
+    if (!(e && e[0] == '1')) return false;
     int dev = 0, v = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeVirtualMemoryManagementSupported, dev) != hipSuccess) { (void)hipGetLastError(); return false; }
     return v != 0;
@@ -538,18 +550,11 @@ DevArena::DevArena(size_t bytes, size_t front_bytes) {
   open_arena(DEV_KEPT, this, impl_->group, bytes, 0);
   open_arena(DEV_HIER, this, impl_->group, bytes, (size_t)8 << 30);
   if (!tmp) { close_arenas(this, -1); delete impl_; impl_ = nullptr; return; }
-  if (const char* e = std::getenv("AIRHIP_ARENA_BALLAST_GB")) {
-    // experiment (tools/block_probe.hip, PROBE_VMM=2: the same kernel runs at 5.3, 5.9 or 6.1 TB/s depending on which part of
-    // the device's memory its arrays are on, in the order the driver hands it out): hold the first N GB back
-    const size_t bal = (size_t)(std::atof(e) * 1e9) / PIECE * PIECE;
-    if (bal) if (Arena* b = open_arena(3, this, impl_->group, bal, 0)) (void)b->vm.commit(0, bal);
-  }
   // The low end of the temporaries' range is backed piece after piece by a helper thread right away instead of whenever a
   // block first reaches a piece: on a box whose memory has not been used before a piece costs 8 ms, and the setup would
   // pay that in its products (464^3: R*A*P 7.3 -> 9.5 s).  The memory would be backed during the setup anyway; the setup
   // takes a piece the helper has not reached yet by backing it itself.
   size_t ahead = std::min(bytes, front_bytes) / PIECE * PIECE;
-  if (const char* e = std::getenv("AIRHIP_ARENA_FRONT_GB")) ahead = std::min(bytes, (size_t)(std::atof(e) * 1e9)) / PIECE * PIECE;
   start_helper(DEV_TEMP, ahead);
 }
 
@@ -593,7 +598,7 @@ void DevArena::recycle_temporaries(size_t hier_front) {
     std::lock_guard<std::mutex> lock(c.mu);
     // (empty by now in the normal course: freed here and now; an arena that still holds a block when the scope ends must
     // not leave pieces to a scope that no longer exists - ~DevArena clears the flag)
-    close_arenas(this, DEV_TEMP, true);
+    close_arenas(this, DEV_TEMP, false);      // (no physical pieces are handed on any more: see vm_supported)
     open_arena(DEV_TEMP, this, impl_->group, impl_->bytes, 0);
   }
   // (hier_front: measured at 464^3, a helper that backs the hierarchy's 131 GB at once out of the memory that has just come

@@ -93,9 +93,18 @@ void launch_fill(int64_t n, double v, double* out, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Multi-dot / multi-axpy (outer Krylov: VecMDot + VecMAXPY of classical Gram-Schmidt)
+// Multi-dot / multi-axpy (outer Krylov: VecMDot + VecMAXPY of classical Gram-Schmidt; the setup's Arnoldi)
+//
+// One pass each: every vector is read exactly once per call.  Round 3 launched the basis in slices of 8 / 4 / 2 / 1
+// vectors, each slice reading w (0.8 GB at 464^3) again, took the norm of the orthogonalised vector in a pass of its own
+// and read 8 bytes per lane per load.  Here one kernel instance per number of vectors (1 ... 32, compile time, so that
+// all loads of an element pair are in flight together - guards around single vectors would serialise them) reads
+// 16 bytes per lane per load; the multi-axpy optionally leaves the partial sums of squares of its result behind, so
+// the norm that classical Gram-Schmidt needs next costs no pass.  Reductions are two-stage and deterministic (fixed
+// grid, fixed order).
 // ---------------------------------------------------------------------------------------
-constexpr int MDOT_BLOCKS = 1024;
+constexpr int MDOT_BLOCKS = 2048;          // 256 CUs x 8 workgroups
+constexpr int MDOT_MAXV = 32;              // vectors per launch
 int mdot_scratch_doubles(int nv) { return MDOT_BLOCKS * (nv > 0 ? nv : 1); }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -103,31 +112,53 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// block-level sums of K per-thread values -> partial[blockIdx * stride + k0 + k]
 template <int K>
-__global__ __launch_bounds__(BLOCK) void k_mdot_partial(int64_t n, const double* __restrict__ w, const double* __restrict__ V,
-                                                       int64_t ld, double* __restrict__ partial, int nv_total, int k0) {
-  double acc[K];
-#pragma unroll
-  for (int k = 0; k < K; k++) acc[k] = 0.0;
-  const int64_t stride = (int64_t)gridDim.x * BLOCK;
-  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
-    const double wi = w[i];
-#pragma unroll
-    for (int k = 0; k < K; k++) acc[k] = fma(wi, V[(int64_t)(k0 + k) * ld + i], acc[k]);
-  }
+__device__ __forceinline__ void block_sums(const double (&acc)[K], double* __restrict__ partial, int stride, int k0) {
   __shared__ double red[WAVES_PER_BLOCK][K];
   const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < K; k++) {
-    double v = wave_sum(acc[k]);
+    const double v = wave_sum(acc[k]);
     if (lane == 0) red[wid][k] = v;
   }
   __syncthreads();
   if (threadIdx.x < K) {
     double v = 0.0;
     for (int q = 0; q < WAVES_PER_BLOCK; q++) v += red[q][threadIdx.x];
-    partial[(int64_t)blockIdx.x * nv_total + k0 + threadIdx.x] = v;
+    partial[(int64_t)blockIdx.x * stride + k0 + threadIdx.x] = v;
   }
+}
+
+// partial[b * nv_total + k0 + k] = sum over block b's elements of w_i * V_{k0+k, i}.  VEC: two elements per lane and
+// load (n even, every vector 16-byte aligned)
+template <int K, bool VEC>
+__global__ __launch_bounds__(BLOCK) void k_mdot_partial(int64_t n, const double* __restrict__ w, const double* __restrict__ V,
+                                                       int64_t ld, double* __restrict__ partial, int nv_total, int k0) {
+  double acc[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) acc[k] = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * BLOCK;
+  const double* __restrict__ V0 = V + (int64_t)k0 * ld;
+  if constexpr (VEC) {
+    const int64_t n2 = n >> 1;
+    const double2* __restrict__ w2 = reinterpret_cast<const double2*>(w);
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n2; i += stride) {
+      const double2 wi = w2[i];
+      double2 v[K];
+#pragma unroll
+      for (int k = 0; k < K; k++) v[k] = reinterpret_cast<const double2*>(V0 + (int64_t)k * ld)[i];
+#pragma unroll
+      for (int k = 0; k < K; k++) acc[k] = fma(wi.y, v[k].y, fma(wi.x, v[k].x, acc[k]));
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+      const double wi = w[i];
+#pragma unroll
+      for (int k = 0; k < K; k++) acc[k] = fma(wi, V0[(int64_t)k * ld + i], acc[k]);
+    }
+  }
+  block_sums<K>(acc, partial, nv_total, k0);
 }
 
 // second stage: one wave per dot product, lanes stride over the block partials, fixed-order wave
@@ -142,47 +173,110 @@ __global__ __launch_bounds__(BLOCK) void k_mdot_final(int nblocks, int nv, const
   }
 }
 
+static int stream_blocks(int64_t n) {
+  int blocks = grid_for_n(n, 2);
+  return blocks > MDOT_BLOCKS ? MDOT_BLOCKS : blocks;
+}
+static bool vec2_ok(int64_t n, int64_t ld, const void* a, const void* b) {
+  return (n & 1) == 0 && (ld & 1) == 0 && (((uintptr_t)a | (uintptr_t)b) & 15) == 0;
+}
+
+template <bool VEC>
+static void mdot_dispatch(int k, int blocks, hipStream_t s, int64_t n, const double* w, const double* V, int64_t ld, double* scratch, int nv, int k0) {
+  switch (k) {
+#define C(K) case K: hipLaunchKernelGGL((k_mdot_partial<K, VEC>), dim3(blocks), dim3(BLOCK), 0, s, n, w, V, ld, scratch, nv, k0); break;
+    C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16)
+    C(17) C(18) C(19) C(20) C(21) C(22) C(23) C(24) C(25) C(26) C(27) C(28) C(29) C(30) C(31) C(32)
+#undef C
+  }
+}
+
 void launch_mdot(int64_t n, const double* w, const double* V, int64_t ld, int nv, double* scratch, double* dots, hipStream_t s) {
   if (nv <= 0) return;
-  int blocks = grid_for_n(n, 4);
-  if (blocks > MDOT_BLOCKS) blocks = MDOT_BLOCKS;
-  int k0 = 0;
-  while (k0 < nv) {
-    int rem = nv - k0;
-    if (rem >= 8) { hipLaunchKernelGGL(k_mdot_partial<8>, dim3(blocks), dim3(BLOCK), 0, s, n, w, V, ld, scratch, nv, k0); k0 += 8; }
-    else if (rem >= 4) { hipLaunchKernelGGL(k_mdot_partial<4>, dim3(blocks), dim3(BLOCK), 0, s, n, w, V, ld, scratch, nv, k0); k0 += 4; }
-    else if (rem >= 2) { hipLaunchKernelGGL(k_mdot_partial<2>, dim3(blocks), dim3(BLOCK), 0, s, n, w, V, ld, scratch, nv, k0); k0 += 2; }
-    else { hipLaunchKernelGGL(k_mdot_partial<1>, dim3(blocks), dim3(BLOCK), 0, s, n, w, V, ld, scratch, nv, k0); k0 += 1; }
+  const int blocks = stream_blocks(n);
+  const bool vec = vec2_ok(n, ld, w, V);
+  for (int k0 = 0; k0 < nv; k0 += MDOT_MAXV) {
+    const int k = nv - k0 < MDOT_MAXV ? nv - k0 : MDOT_MAXV;
+    if (vec) mdot_dispatch<true>(k, blocks, s, n, w, V, ld, scratch, nv, k0);
+    else mdot_dispatch<false>(k, blocks, s, n, w, V, ld, scratch, nv, k0);
   }
   hipLaunchKernelGGL(k_mdot_final, dim3(1), dim3(BLOCK), 0, s, blocks, nv, scratch, dots);
 }
 
-template <int K>
+// w_i <- (ZERO ? 0 : w_i) + sum_k coef[k0 + k] V_{k0+k, i} (k ascending: the order of a sequence of axpys);
+// NORM: the block's sum of squares of the result goes to partial[blockIdx]
+template <int K, bool VEC, bool ZERO, bool NORM>
 __global__ __launch_bounds__(BLOCK) void k_maxpy(int64_t n, double* __restrict__ w, const double* __restrict__ V, int64_t ld,
-                                                const double* __restrict__ coef, int k0) {
+                                                const double* __restrict__ coef, int k0, double* __restrict__ partial) {
   double c[K];
 #pragma unroll
   for (int k = 0; k < K; k++) c[k] = coef[k0 + k];
+  const double* __restrict__ V0 = V + (int64_t)k0 * ld;
   const int64_t stride = (int64_t)gridDim.x * BLOCK;
-  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
-    double acc = w[i];
+  double ss[1] = {0.0};
+  if constexpr (VEC) {
+    const int64_t n2 = n >> 1;
+    double2* __restrict__ w2 = reinterpret_cast<double2*>(w);
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n2; i += stride) {
+      double2 a = ZERO ? make_double2(0.0, 0.0) : w2[i];
+      double2 v[K];
 #pragma unroll
-    for (int k = 0; k < K; k++) acc = fma(c[k], V[(int64_t)(k0 + k) * ld + i], acc);
-    w[i] = acc;
+      for (int k = 0; k < K; k++) v[k] = reinterpret_cast<const double2*>(V0 + (int64_t)k * ld)[i];
+#pragma unroll
+      for (int k = 0; k < K; k++) { a.x = fma(c[k], v[k].x, a.x); a.y = fma(c[k], v[k].y, a.y); }
+      w2[i] = a;
+      if constexpr (NORM) ss[0] = fma(a.y, a.y, fma(a.x, a.x, ss[0]));
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+      double a = ZERO ? 0.0 : w[i];
+#pragma unroll
+      for (int k = 0; k < K; k++) a = fma(c[k], V0[(int64_t)k * ld + i], a);
+      w[i] = a;
+      if constexpr (NORM) ss[0] = fma(a, a, ss[0]);
+    }
+  }
+  if constexpr (NORM) block_sums<1>(ss, partial, 1, 0);
+}
+
+template <bool VEC, bool ZERO, bool NORM>
+static void maxpy_dispatch(int k, int blocks, hipStream_t s, int64_t n, double* w, const double* V, int64_t ld, const double* coef, int k0, double* partial) {
+  switch (k) {
+#define C(K) case K: hipLaunchKernelGGL((k_maxpy<K, VEC, ZERO, NORM>), dim3(blocks), dim3(BLOCK), 0, s, n, w, V, ld, coef, k0, partial); break;
+    C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16)
+    C(17) C(18) C(19) C(20) C(21) C(22) C(23) C(24) C(25) C(26) C(27) C(28) C(29) C(30) C(31) C(32)
+#undef C
   }
 }
 
-void launch_maxpy(int64_t n, double* w, const double* V, int64_t ld, int nv, const double* coef, hipStream_t s) {
-  if (nv <= 0 || n == 0) return;
-  const int blocks = grid_for_n(n);
-  int k0 = 0;
-  while (k0 < nv) {
-    int rem = nv - k0;
-    if (rem >= 8) { hipLaunchKernelGGL(k_maxpy<8>, dim3(blocks), dim3(BLOCK), 0, s, n, w, V, ld, coef, k0); k0 += 8; }
-    else if (rem >= 4) { hipLaunchKernelGGL(k_maxpy<4>, dim3(blocks), dim3(BLOCK), 0, s, n, w, V, ld, coef, k0); k0 += 4; }
-    else if (rem >= 2) { hipLaunchKernelGGL(k_maxpy<2>, dim3(blocks), dim3(BLOCK), 0, s, n, w, V, ld, coef, k0); k0 += 2; }
-    else { hipLaunchKernelGGL(k_maxpy<1>, dim3(blocks), dim3(BLOCK), 0, s, n, w, V, ld, coef, k0); k0 += 1; }
+// w (+)= sum_k coef[k] V_k  (coef on device).  zero_first: w = sum ... (w is not read).  norm_scratch / norm_out (device,
+// both or neither; scratch of mdot_scratch_doubles(1)): *norm_out = sum of squares of the result, at no extra pass.
+void launch_maxpy(int64_t n, double* w, const double* V, int64_t ld, int nv, const double* coef, hipStream_t s,
+                  bool zero_first, double* norm_scratch, double* norm_out) {
+  if (n == 0) return;
+  if (nv <= 0) {
+    if (zero_first) launch_fill(n, 0.0, w, s);
+    if (norm_out) launch_mdot(n, w, w, 0, 1, norm_scratch, norm_out, s);
+    return;
   }
+  const int blocks = stream_blocks(n);
+  const bool vec = vec2_ok(n, ld, w, V);
+  for (int k0 = 0; k0 < nv; k0 += MDOT_MAXV) {
+    const int k = nv - k0 < MDOT_MAXV ? nv - k0 : MDOT_MAXV;
+    const bool zero = zero_first && k0 == 0, norm = norm_out && k0 + k == nv;
+    const int variant = (vec ? 4 : 0) | (zero ? 2 : 0) | (norm ? 1 : 0);
+    switch (variant) {
+      case 0: maxpy_dispatch<false, false, false>(k, blocks, s, n, w, V, ld, coef, k0, norm_scratch); break;
+      case 1: maxpy_dispatch<false, false, true>(k, blocks, s, n, w, V, ld, coef, k0, norm_scratch); break;
+      case 2: maxpy_dispatch<false, true, false>(k, blocks, s, n, w, V, ld, coef, k0, norm_scratch); break;
+      case 3: maxpy_dispatch<false, true, true>(k, blocks, s, n, w, V, ld, coef, k0, norm_scratch); break;
+      case 4: maxpy_dispatch<true, false, false>(k, blocks, s, n, w, V, ld, coef, k0, norm_scratch); break;
+      case 5: maxpy_dispatch<true, false, true>(k, blocks, s, n, w, V, ld, coef, k0, norm_scratch); break;
+      case 6: maxpy_dispatch<true, true, false>(k, blocks, s, n, w, V, ld, coef, k0, norm_scratch); break;
+      default: maxpy_dispatch<true, true, true>(k, blocks, s, n, w, V, ld, coef, k0, norm_scratch); break;
+    }
+  }
+  if (norm_out) hipLaunchKernelGGL(k_mdot_final, dim3(1), dim3(BLOCK), 0, s, blocks, 1, norm_scratch, norm_out);
 }
 
 }  // namespace airhip

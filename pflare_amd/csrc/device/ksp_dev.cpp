@@ -28,21 +28,32 @@ int converged_default(ConvState& st, int it, double rnorm, const KspOptions& o) 
 DevKSP::DevKSP(int64_t n) : n_(n) {
   w_.alloc(n); t_.alloc(n);
   scratch_.alloc(mdot_scratch_doubles(64));
-  ddots_.alloc(64); dcoef_.alloc(64);
+  ddots_.alloc(64); dcoef_.alloc(64); dnorm_.alloc(1);
 }
 
-// dots of the local parts land in ddots_; summed over the ranks when distributed
-void DevKSP::fetch_dots(double* host, int n, hipStream_t s) {
-  if (comm_) { comm_->allreduce_sum(ddots_.p, host, n, s); return; }
-  HIP_CHECK(hipMemcpyAsync(host, ddots_.p, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+// the timed sections of the solver's own kernels (KspOperator::prof_begin / prof_end; level -1 of the owner's statistics)
+struct DevKSP::Timed {
+  const KspOperator& op;
+  Timed(const KspOperator& o, const char* name, double bytes, const char* kernel) : op(o) { if (op.prof_begin) op.prof_begin(name, bytes, kernel); }
+  ~Timed() { if (op.prof_end) op.prof_end(); }
+};
+
+// sums of the local parts (device, n doubles at d) to the host; summed over the ranks when distributed
+void DevKSP::fetch_dots(const double* d, double* host, int n, hipStream_t s) {
+  if (comm_) { comm_->allreduce_sum(const_cast<double*>(d), host, n, s); return; }
+  HIP_CHECK(hipMemcpyAsync(host, d, sizeof(double) * n, hipMemcpyDeviceToHost, s));
   HIP_CHECK(hipStreamSynchronize(s));
 }
 
-double DevKSP::norm2(const double* v, hipStream_t s) {
-  launch_mdot(n_, v, v, 0, 1, scratch_.p, ddots_.p, s);
+double DevKSP::norm2(const KspOperator& op, const double* v, hipStream_t s) {
+  { Timed t(op, "Krylov norm", 8.0 * n_, "k_mdot_partial"); launch_mdot(n_, v, v, 0, 1, scratch_.p, ddots_.p, s); }
   double h = 0.0;
-  fetch_dots(&h, 1, s);
+  fetch_dots(ddots_.p, &h, 1, s);
   return std::sqrt(h);
+}
+void DevKSP::scale(const KspOperator& op, double a, double* v, hipStream_t s) {
+  Timed t(op, "Krylov scale", 16.0 * n_, "k_axpby");
+  launch_axpby(n_, a, v, 0.0, nullptr, v, s);
 }
 
 KspResult DevKSP::solve(const KspOperator& op, const KspOptions& o, const double* d_b, double* d_x) {
@@ -76,8 +87,8 @@ KspResult DevKSP::richardson(const KspOperator& op, const KspOptions& o, const d
   const bool prec = (o.norm_type == 0);
   double* r = w_.p; double* z = t_.p;
   ConvState st;
-  double bn = norm2(b, s);
-  if (prec && bn != 0.0) { if (op.pc) op.pc(b, z); else HIP_CHECK(hipMemcpyAsync(z, b, 8 * (size_t)n_, hipMemcpyDeviceToDevice, s)); bn = norm2(z, s); }
+  double bn = norm2(op, b, s);
+  if (prec && bn != 0.0) { if (op.pc) op.pc(b, z); else HIP_CHECK(hipMemcpyAsync(z, b, 8 * (size_t)n_, hipMemcpyDeviceToDevice, s)); bn = norm2(op, z, s); }
   st.bnorm = bn;
   auto apply_pc = [&](const double* in, double* out) {
     if (op.pc) op.pc(in, out); else HIP_CHECK(hipMemcpyAsync(out, in, 8 * (size_t)n_, hipMemcpyDeviceToDevice, s));
@@ -86,17 +97,17 @@ KspResult DevKSP::richardson(const KspOperator& op, const KspOptions& o, const d
   double rnorm = 0.0;
   int reason = 0, its = 0;
   for (int i = 0; i < o.max_it; i++) {
-    if (prec) { apply_pc(r, z); rnorm = norm2(z, s); } else rnorm = norm2(r, s);
+    if (prec) { apply_pc(r, z); rnorm = norm2(op, z, s); } else rnorm = norm2(op, r, s);
     R.history.push_back(rnorm);
     reason = converged_default(st, i, rnorm, o);
     if (reason) break;
     if (!prec) apply_pc(r, z);
-    launch_axpby(n_, 1.0, z, 1.0, x, x, s);
+    { Timed t(op, "Krylov x+=z", 24.0 * n_, "k_axpby"); launch_axpby(n_, 1.0, z, 1.0, x, x, s); }
     its++;
     residual(op, b, x, r);
   }
   if (!reason) {
-    if (prec) { apply_pc(r, z); rnorm = norm2(z, s); } else rnorm = norm2(r, s);
+    if (prec) { apply_pc(r, z); rnorm = norm2(op, z, s); } else rnorm = norm2(op, r, s);
     R.history.push_back(rnorm);
     if (its >= o.max_it) { reason = converged_default(st, its, rnorm, o); if (!reason) reason = -3; }
   }
@@ -115,8 +126,8 @@ KspResult DevKSP::gmres(const KspOperator& op, const KspOptions& o, const double
     if (op.pc) op.pc(in, out); else HIP_CHECK(hipMemcpyAsync(out, in, 8 * (size_t)n_, hipMemcpyDeviceToDevice, s));
   };
   ConvState st;
-  double bn = norm2(b, s);
-  if (!right && bn != 0.0) { apply_pc(b, t_.p); bn = norm2(t_.p, s); }
+  double bn = norm2(op, b, s);
+  if (!right && bn != 0.0) { apply_pc(b, t_.p); bn = norm2(op, t_.p, s); }
   st.bnorm = bn;
 
   int its = 0, reason = 0;
@@ -129,7 +140,7 @@ KspResult DevKSP::gmres(const KspOperator& op, const KspOptions& o, const double
     // V0 = (B)(b - A x)
     if (right) residual(op, b, x, Vk(0));
     else { residual(op, b, x, w_.p); apply_pc(w_.p, Vk(0)); }
-    double res = norm2(Vk(0), s);
+    double res = norm2(op, Vk(0), s);
     rnorm = res;
     if (first) {
       R.history.push_back(res);
@@ -138,7 +149,7 @@ KspResult DevKSP::gmres(const KspOperator& op, const KspOptions& o, const double
       first = false;
       if (reason) break;
     }
-    launch_axpby(n_, 1.0 / res, Vk(0), 0.0, nullptr, Vk(0), s);
+    scale(op, 1.0 / res, Vk(0), s);
     std::fill(hh.begin(), hh.end(), 0.0);
     grs[0] = res;
     int it = 0;
@@ -147,14 +158,17 @@ KspResult DevKSP::gmres(const KspOperator& op, const KspOptions& o, const double
       double* w = Vk(it + 1);
       if (right) { apply_pc(Vk(it), t_.p); SpmvEpi e; e.out = w; op_mult(op, t_.p, e); }
       else { SpmvEpi e; e.out = t_.p; op_mult(op, Vk(it), e); apply_pc(t_.p, w); }
-      // classical Gram-Schmidt: one multi-dot, one multi-axpy
-      launch_mdot(n_, w, V_.p, n_, it + 1, scratch_.p, ddots_.p, s);
-      fetch_dots(lhh.data(), it + 1, s);
+      // classical Gram-Schmidt: one multi-dot and one multi-axpy, each a single pass over w and the basis; the norm of
+      // the orthogonalised vector rides along in the multi-axpy
+      { Timed t(op, "Krylov multi-dot", 8.0 * n_ * (it + 2), "k_mdot_partial"); launch_mdot(n_, w, V_.p, n_, it + 1, scratch_.p, ddots_.p, s); }
+      fetch_dots(ddots_.p, lhh.data(), it + 1, s);
       for (int j = 0; j <= it; j++) { H(j, it) = lhh[j]; nrs[j] = -lhh[j]; }
       HIP_CHECK(hipMemcpyAsync(dcoef_.p, nrs.data(), sizeof(double) * (it + 1), hipMemcpyHostToDevice, s));
-      launch_maxpy(n_, w, V_.p, n_, it + 1, dcoef_.p, s);
-      double tt = norm2(w, s);
-      if (tt != 0.0) launch_axpby(n_, 1.0 / tt, w, 0.0, nullptr, w, s);
+      { Timed t(op, "Krylov multi-axpy + norm", 8.0 * n_ * (it + 3), "k_maxpy"); launch_maxpy(n_, w, V_.p, n_, it + 1, dcoef_.p, s, false, scratch_.p, dnorm_.p); }
+      double tt = 0.0;
+      fetch_dots(dnorm_.p, &tt, 1, s);
+      tt = std::sqrt(tt);
+      if (tt != 0.0) scale(op, 1.0 / tt, w, s);
       H(it + 1, it) = tt;
       double hapbnd = grs[it] != 0.0 ? std::fabs(tt / grs[it]) : haptol;
       if (hapbnd > haptol) hapbnd = haptol;
@@ -195,11 +209,11 @@ KspResult DevKSP::gmres(const KspOperator& op, const KspOptions& o, const double
       }
       HIP_CHECK(hipMemcpyAsync(dcoef_.p, nrs.data(), sizeof(double) * it, hipMemcpyHostToDevice, s));
       if (right) {
-        launch_fill(n_, 0.0, w_.p, s);
-        launch_maxpy(n_, w_.p, V_.p, n_, it, dcoef_.p, s);
+        { Timed t(op, "Krylov solution multi-axpy", 8.0 * n_ * (it + 1), "k_maxpy"); launch_maxpy(n_, w_.p, V_.p, n_, it, dcoef_.p, s, true); }
         apply_pc(w_.p, t_.p);
+        Timed t(op, "Krylov x+=z", 24.0 * n_, "k_axpby");
         launch_axpby(n_, 1.0, t_.p, 1.0, x, x, s);
-      } else launch_maxpy(n_, x, V_.p, n_, it, dcoef_.p, s);
+      } else { Timed t(op, "Krylov solution multi-axpy", 8.0 * n_ * (it + 2), "k_maxpy"); launch_maxpy(n_, x, V_.p, n_, it, dcoef_.p, s); }
       HIP_CHECK(hipStreamSynchronize(s));   // nrs (host) is reused by the next cycle
     }
     if (!reason && its >= o.max_it) reason = -3;

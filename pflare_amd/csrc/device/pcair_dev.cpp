@@ -52,8 +52,6 @@ static int64_t g_block_order_min = 4096;      // smaller operators sit in the ca
 void set_block_order_min(int64_t nblocks) { g_block_order_min = nblocks > 0 ? nblocks : 1; }
 static bool g_fc_fuse = true;
 void set_fc_fuse(bool on) { g_fc_fuse = on; }
-static int g_exp_copy_x = 0;      // experiment: the A_ff product gathers from a dedicated copy of x_f (1) / from a copy inside a large buffer (2)
-void set_exp_copy_x(int v) { g_exp_copy_x = v; }
 
 static void order_blocks_by_key(DevMat& M, const int32_t* dev_row_to_host, const int64_t* key, hipStream_t s) {
   if (M.nblocks < g_block_order_min || M.desc_ord) return;
@@ -562,23 +560,9 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
   }
   HIP_CHECK(hipStreamSynchronize(stream_));
   dev_cache_trim();       // the staging blocks
-  double t_compact = 0.0;
-  {
-    // optionally the hierarchy once more, into the memory the setup has just given back (devmat_reallocate): +1.3 % on
-    // k_rb_spmv at 464^3 (0.656 -> 0.665, twice each on one box) for 3.4 s of hipMalloc / hipFree - off by default
-    static const int mode = [] { const char* e = std::getenv("AIRHIP_COMPACT"); return e ? std::atoi(e) : 0; }();
-    if (mode) {
-      const double t0 = now_s();
-      devmat_reallocate(A_perm_, stream_); devmat_reallocate(coarse_A_, stream_); devmat_reallocate(coarse_inv_.mat, stream_);
-      for (auto& l : levels_) {
-        for (DevMat* m : {&l->A_ff, &l->A_fc, &l->A_cf, &l->A_cc, &l->Z, &l->W, &l->inv_ff.mat, &l->inv_cc.mat, &l->A_full}) devmat_reallocate(*m, stream_);
-      }
-      t_compact = now_s() - t0;
-    }
-  }
   if (H.opt.print_stats_timings) {
-    std::printf(" hierarchy to the device: %.2f s (orderings %.2f s, host -> device copies of the operators %.2f s, conversion to row blocks %.2f s, compaction %.2f s; %lld operators were on the device already)\n",
-                now_s() - t_upload0, t_order, g_t_h2d, g_t_convert, t_compact, (long long)g_n_from_device);
+    std::printf(" hierarchy to the device: %.2f s (orderings %.2f s, host -> device copies of the operators %.2f s, conversion to row blocks %.2f s; %lld operators were on the device already)\n",
+                now_s() - t_upload0, t_order, g_t_h2d, g_t_convert, (long long)g_n_from_device);
     std::fflush(stdout);
   }
 }
@@ -719,13 +703,7 @@ void DevPCAIR::f_smooths(DevLevel& L, int li, bool first, int its) {
     if (L.aff_diag) launch_pointwise_mult(L.n_f, -1.0, L.aff_d.p, x_f, 1.0, L.t4.p, L.r.p, stream_);
     else {
       SpmvEpi e; e.out = L.r.p; e.alpha = -1.0; e.z = L.t4.p; e.beta = 1.0;
-      const double* xs = x_f;
-      if (g_exp_copy_x) {
-        if (L.xcopy.n < L.n_f) L.xcopy.alloc(L.n_f);
-        HIP_CHECK(hipMemcpyAsync(L.xcopy.p, x_f, sizeof(double) * (size_t)L.n_f, hipMemcpyDeviceToDevice, stream_));
-        xs = L.xcopy.p;
-      }
-      spmv(L.A_ff, xs, e, "r=t4-A_ff*x_f", li);
+      spmv(L.A_ff, x_f, e, "r=t4-A_ff*x_f", li);
     }
     apply_inv(L.inv_ff, L.r.p, x_f, true, li, "x_f+=M_ff*r");
   }

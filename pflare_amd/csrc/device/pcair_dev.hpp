@@ -31,7 +31,6 @@ void set_block_order_min(int64_t nblocks);
 // diagnostic (airhip_set_tuning "fc_fuse"): 0 runs the first stage of an F relaxation as a gather (one-point prolongation)
 // followed by a plain A_fc product instead of the fused k_rb_fc_first; same results, one more pass over the F vectors
 void set_fc_fuse(bool on);
-void set_exp_copy_x(int v);      // experiment, see pcair_dev.cpp
 
 // Upload a host CSR and convert it to SELL-64 on the device (rows/cols optionally permuted).
 void upload_mat(const Csr& A, const int32_t* d_rowsrc, const int32_t* d_colmap, DevMat& out, hipStream_t s, int64_t n_ghost = 0);
@@ -62,7 +61,6 @@ struct DevLevel {
   DevInv inv_ff, inv_cc;
   int smooth_order[10] = {0};
   DBuf<double> t4, r, t4c, rc;
-  DBuf<double> xcopy;            // experiment (exp_copy_x)
   int64_t nnz_A = 0;
   // full up / down smoothing: the level operator in the level's hierarchical ordering (inv_ff is then n x n) and the
   // residual of the level, whose C part is the next level's right-hand side
@@ -119,6 +117,15 @@ class DevPCAIR {
   int coarse_richardson_its_ = 0;
   std::vector<int64_t> off_;     // off_[l]: start of the level-l vector inside the level-1 vector
 
+  // a timed section for kernels outside the cycle (the outer Krylov method's): HIP events under (name, level) while
+  // profiling is on; `kernel` = the HIP kernel function, the row a kernel trace aggregates by
+  void prof_begin(const char* name, int level, double bytes, const char* kernel) {
+    if (!profile_) return;
+    const int id = stat_id(name, level, bytes);
+    stats_[id].kernel = kernel;
+    begin_kernel(id);
+  }
+  void prof_end() { end_kernel(); }
   // SpMV on the library stream, timed under (name, level) when profiling is on
   void spmv(const DevMat& A, const double* x, const SpmvEpi& e, const char* name, int level, double bytes_override = -1);
 
@@ -210,6 +217,9 @@ struct KspOperator {
   // mandatory for a distributed operator, whose product needs a halo exchange)
   std::function<void(const double*, const SpmvEpi&)> mult;
   Comm* comm = nullptr;         // distributed: dots and norms are summed over the ranks
+  // optional: the owner's statistics time the solver's own kernels too (name, algorithmic bytes, kernel function)
+  std::function<void(const char*, double, const char*)> prof_begin;
+  std::function<void()> prof_end;
 };
 
 class DevKSP {
@@ -218,13 +228,15 @@ class DevKSP {
   ~DevKSP() = default;
   KspResult solve(const KspOperator& op, const KspOptions& o, const double* d_b, double* d_x);
  private:
-  double norm2(const double* v, hipStream_t s);
-  void fetch_dots(double* host, int n, hipStream_t s);
+  struct Timed;
+  double norm2(const KspOperator& op, const double* v, hipStream_t s);
+  void scale(const KspOperator& op, double a, double* v, hipStream_t s);
+  void fetch_dots(const double* d, double* host, int n, hipStream_t s);
   Comm* comm_ = nullptr;
   KspResult richardson(const KspOperator& op, const KspOptions& o, const double* b, double* x);
   KspResult gmres(const KspOperator& op, const KspOptions& o, const double* b, double* x);
   int64_t n_;
-  DBuf<double> V_, w_, t_, scratch_, ddots_, dcoef_;
+  DBuf<double> V_, w_, t_, scratch_, ddots_, dcoef_, dnorm_;
   int v_alloc_ = 0;
 };
 

@@ -136,76 +136,9 @@ struct DevSetupAccel final : SetupAccel {
     }
   }
 
-  // ---- downloads that run beside the next steps (split_fc: the F-C and C-F blocks).  The host arrays belong to the
-  // pending record until the copy has landed and are moved into the target Csr then (a Level that dies early - an
-  // exception - never owns memory a DMA is still writing to); the target is a stub meanwhile.
-  struct Pending {
-    Csr* target; DCsr d; bool free_device;
-    Arr<int64_t> rp; Arr<int32_t> ci; Arr<double> v;
-    void* pinned[3]; hipEvent_t done;
-  };
-  std::vector<std::unique_ptr<Pending>> pending;
-  hipStream_t copy_stream = nullptr;
-  // Off by default: measured at 464^3 the copies did leave the critical path (transfers 5.5 -> 4.0 s) but the products that
-  // ran beside them took 3.9 s longer (11.0 -> 14.9 s: their small control read-backs queue behind the 2-GB copies on the
-  // copy engine), 25.9 -> 27.8 s of setup in all.  AIRHIP_ASYNC_DOWNLOAD=1 switches it on.
-  static bool async_enabled() { static const bool on = [] { const char* e = std::getenv("AIRHIP_ASYNC_DOWNLOAD"); return e && e[0] == '1'; }(); return on; }
-
-  void begin_down(DCsr d, Csr& target, bool free_device) {
-    const double t0 = now_s();
-    if (!copy_stream) HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
-    auto p = std::make_unique<Pending>();
-    p->target = &target; p->d = d; p->free_device = free_device;
-    p->rp.alloc(d.m + 1); p->ci.alloc(d.nnz); p->v.alloc(d.nnz);
-    target = Csr(); target.m = d.m; target.n = d.n; target.stub_nnz = d.nnz;
-    struct Part { void* host; const void* dev; size_t bytes; } parts[3] = {
-        {p->rp.data(), d.rp, sizeof(int64_t) * (size_t)(d.m + 1)}, {p->ci.data(), d.ci, sizeof(int32_t) * (size_t)d.nnz},
-        {p->v.data(), d.v, sizeof(double) * (size_t)d.nnz}};
-    HIP_CHECK(hipStreamSynchronize(stream));                     // the extraction kernels have written the source
-    for (int k = 0; k < 3; k++) {
-      p->pinned[k] = nullptr;
-      if (parts[k].bytes == 0) continue;
-      // fault the fresh pages in with all threads, pin them where they are (600 GB/s on 2-MiB pages), queue the copy
-      char* q = (char*)parts[k].host;
-      const long long pages = (long long)((parts[k].bytes + 4095) >> 12);
-#pragma omp parallel for schedule(static)
-      for (long long i = 0; i < pages; i++) { volatile char* c = q + ((size_t)i << 12); *c = *c; }
-      if (parts[k].bytes >= (32u << 20) && hipHostRegister(parts[k].host, parts[k].bytes, hipHostRegisterDefault) == hipSuccess) p->pinned[k] = parts[k].host;
-      else (void)hipGetLastError();
-      HIP_CHECK(hipMemcpyAsync(parts[k].host, parts[k].dev, parts[k].bytes, hipMemcpyDeviceToHost, copy_stream));
-    }
-    HIP_CHECK(hipEventCreateWithFlags(&p->done, hipEventDisableTiming));
-    HIP_CHECK(hipEventRecord(p->done, copy_stream));
-    pending.push_back(std::move(p));
-    t_transfer += now_s() - t0;
-  }
-  // assign = false: the targets may be gone (destructor on an exception path) - only wait and clean up
-  void finish_one(Pending& p, bool assign) {
-    const double t0 = now_s();
-    (void)hipEventSynchronize(p.done);
-    (void)hipEventDestroy(p.done);
-    for (int k = 0; k < 3; k++) if (p.pinned[k]) (void)hipHostUnregister(p.pinned[k]);
-    if (p.free_device) dcsr_free(p.d);
-    if (assign) {
-      const uint64_t tag = p.target->device_tag;
-      p.target->rp = std::move(p.rp); p.target->ci = std::move(p.ci); p.target->v = std::move(p.v);
-      p.target->stub_nnz = -1; p.target->device_tag = tag;
-    }
-    t_transfer += now_s() - t0;
-  }
-  void sync_host(const Csr* which) override {
-    for (size_t k = 0; k < pending.size();) {
-      if (!which || pending[k]->target == which) { finish_one(*pending[k], true); pending.erase(pending.begin() + (long)k); }
-      else k++;
-    }
-  }
-
   // (the block cache is not trimmed here: the upload of the hierarchy that usually follows stages through it)
   ~DevSetupAccel() override {
     if (pressure_id) dev_remove_pressure_handler(pressure_id);
-    for (auto& p : pending) finish_one(*p, false);
-    pending.clear();
-    if (copy_stream) (void)hipStreamDestroy(copy_stream);
     dcsr_free(resident); dcsr_free(inverse); dcsr_free(res_ff); dcsr_free(res_cf); dcsr_free(res_z); dcsr_free(res_fc);
     for (auto& k : kept) dcsr_free(k.second);
     for (auto& k : lent) dcsr_free(k.second);
@@ -238,13 +171,13 @@ struct DevSetupAccel final : SetupAccel {
 
   Csr product(const Csr& A, const Csr& B, const SpgemmDrop& drop, bool keep) {
     retire(res_z, z_tag); z_tag = 0;
-    if (A.on_host() && B.on_host() && A.nnz() + B.nnz() < min_nnz) { sync_host(nullptr); return airhip::spgemm(A, B, drop); }
+    if (A.on_host() && B.on_host() && A.nnz() + B.nnz() < min_nnz) return airhip::spgemm(A, B, drop);
     DCsr dA, dB;
     uint64_t a_tag = 0, b_tag = 0;
     if (A.device_tag && A.device_tag == cf_tag && res_cf.rp && res_cf.nnz == A.nnz()) { dA = res_cf; res_cf = DCsr(); a_tag = cf_tag; cf_tag = 0; }
     else {
       if (!A.on_host()) throw std::logic_error("setup accelerator: the device copy of a product's left operand is gone");
-      sync_host(nullptr); dA = up(A);
+      dA = up(A);
     }
     const bool b_here = inverse.rp && inverse.m == B.m && inverse.nnz == B.nnz() &&
                         ((B.device_tag && B.device_tag == inverse_tag) || (B.on_host() && inverse_key && inverse_key == (const void*)B.rp.data()));
@@ -258,7 +191,6 @@ struct DevSetupAccel final : SetupAccel {
     dev_stage("setup: product (Z = -A_cf * M or A * B)");
     DCsr dC = dev_spgemm(dA, dB, drop.enabled, drop.tol, drop.lump, drop.negate, stream, nullptr, keep && keeping ? DEV_KEPT : DEV_TEMP);
     t_compute += now_s() - t0;
-    sync_host(nullptr);          // a download of dA (the C-F block) may still be reading it
     // the C-F block is only kept when the host has not got it yet; the inverse is an operator of the hierarchy
     { bool only; { std::lock_guard<std::mutex> lk(mu_kept); only = a_tag && host_missing.count(a_tag); } if (only) retire(dA, a_tag); else dcsr_free(dA); }
     retire(dB, b_tag);
@@ -595,22 +527,15 @@ struct DevSetupAccel final : SetupAccel {
     dev_free(d_code);
     dev_stage("setup: F / C blocks, downloads");
     t_extract += now_s() - t0;
-    sync_host(nullptr);
-    // A_ff is read by the host at once (diagonal test, polynomial coefficients); the F-C and C-F blocks are not needed
-    // there before the prolongator / the end of the level: their copies run beside the coefficients, the assembly and the
-    // Z product (only with AIRHIP_ASYNC_DOWNLOAD=1, see async_enabled)
+    // A_ff is read by the host at once (diagonal test, polynomial coefficients)
     A_ff = down(dff);
-    const bool async = async_enabled() && !A_cc;
-    const bool defer_cf = !async && !A_cc && can_defer(dcf);       // only the Z product reads the C-F block
-    if (async) { begin_down(dfc, A_fc, true); begin_down(dcf, A_cf, false); }
-    else {
-      // the F-C block: only the one-point prolongator reads it (one_point_w below does that here)
-      retire(res_fc, fc_tag);
-      if (!A_cc && can_defer(dfc)) { A_fc = stub_of(dfc, ++next_tag); std::lock_guard<std::mutex> lk(mu_kept); host_missing.insert(A_fc.device_tag); }
-      else { A_fc = down(dfc); A_fc.device_tag = ++next_tag; }
-      res_fc = dfc; fc_tag = A_fc.device_tag;
-      if (!defer_cf) A_cf = down(dcf);
-    }
+    const bool defer_cf = !A_cc && can_defer(dcf);       // only the Z product reads the C-F block
+    // the F-C block: only the one-point prolongator reads it (one_point_w below does that here)
+    retire(res_fc, fc_tag);
+    if (!A_cc && can_defer(dfc)) { A_fc = stub_of(dfc, ++next_tag); std::lock_guard<std::mutex> lk(mu_kept); host_missing.insert(A_fc.device_tag); }
+    else { A_fc = down(dfc); A_fc.device_tag = ++next_tag; }
+    res_fc = dfc; fc_tag = A_fc.device_tag;
+    if (!defer_cf) A_cf = down(dcf);
     if (A_cc) { *A_cc = down(dcc); dcsr_free(dcc); }
     // A_ff feeds the polynomial assembly, A_cf the Z product: they stay
     dcsr_free(res_ff);

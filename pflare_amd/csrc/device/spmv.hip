@@ -723,31 +723,6 @@ void devmat_from_csr_device(int64_t m, int64_t n, const int64_t* d_rp, const int
   dev_free(d_nrp); dev_free(d_cnt); dev_free(d_first); dev_free(tcol); dev_free(tval);
 }
 
-// Moves the arrays of an operator to freshly allocated memory (same contents).  Called for the whole hierarchy once the
-// setup's temporaries and its block cache have been given back: the setup allocates and releases hundreds of GB, so the
-// arrays it leaves behind sit in whatever physical chunks were free at the time, and a kernel whose every wave opens two
-// new pages pays for the address translations of a finely fragmented mapping (tools/block_probe.hip: the same kernel on the
-// same data runs 5.2 ... 6.0 TB/s from one allocation to the next).  Allocated from an emptied pool the arrays get large
-// contiguous ranges.
-static void move_array(void** p, size_t bytes, hipStream_t s) {
-  if (!*p || bytes == 0) return;
-  void* q = dev_alloc_exact(bytes);
-  HIP_CHECK(hipMemcpyAsync(q, *p, bytes, hipMemcpyDeviceToDevice, s));
-  HIP_CHECK(hipStreamSynchronize(s));
-  dev_free_exact(*p);
-  *p = q;
-}
-void devmat_reallocate(DevMat& A, hipStream_t s) {
-  if (!A.valid() || A.cached) return;
-  move_array((void**)&A.val, sizeof(double) * (size_t)(A.nnz + 1), s);
-  move_array((void**)&A.idx, sizeof(uint32_t) * (size_t)(A.nnz + 1), s);
-  move_array((void**)&A.blk, sizeof(BlkDesc) * (size_t)(A.nblocks + 1), s);
-  move_array((void**)&A.roff, sizeof(uint16_t) * (size_t)A.m, s);
-  move_array((void**)&A.desc_ord, sizeof(BlkDesc) * (size_t)A.nblocks, s);
-  move_array((void**)&A.desc_int, sizeof(BlkDesc) * (size_t)std::max<int64_t>(A.n_int, 1), s);
-  move_array((void**)&A.desc_bnd, sizeof(BlkDesc) * (size_t)std::max<int64_t>(A.n_bnd, 1), s);
-}
-
 void devmat_free(DevMat& A) {
   if (A.cached) { dev_free(A.blk); dev_free(A.roff); dev_free(A.idx); dev_free(A.val); A.blk = nullptr; A.roff = nullptr; A.idx = nullptr; A.val = nullptr; }
   dev_free_exact(A.blk);

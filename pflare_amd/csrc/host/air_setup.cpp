@@ -335,7 +335,6 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o, SetupAc
     };
     // ---- W / P
     t0 = now_s();
-    if (accel) accel->sync_host(&L.A_fc);          // the F-C block may still be on its way from the accelerator
     Csr Mz_store;
     const Csr* Mz = nullptr;
     if (product_z) {
@@ -367,8 +366,6 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o, SetupAc
     // ---- Z / R
     t0 = now_s();
     Csr Zfull;
-    // only the plain product reads A_cf where the accelerator holds it; every other path reads the host arrays
-    if (accel && !(product_z && o.improve_z_its == 0 && !r_dropped)) accel->sync_host(nullptr);
     if (product_z) {
       SpgemmDrop d; d.enabled = true; d.tol = o.r_drop; d.negate = true;
       if (o.improve_z_its == 0) L.Z = accel ? accel->spgemm_z(Acf_z, *Mz, d) : spgemm(Acf_z, *Mz, d);
@@ -401,7 +398,6 @@ std::unique_ptr<Hierarchy> setup_air(const Csr& A0, const AirOptions& o, SetupAc
     }
     Mz_store = Csr();
     inv_asm = InvOp();
-    if (accel) accel->sync_host(nullptr);          // every block of this level is on the host from here on
     H->timers[4] += now_s() - t0;
     if (o.symmetric) L.W = transpose_csr(L.Z);
 

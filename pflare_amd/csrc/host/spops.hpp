@@ -72,11 +72,6 @@ struct SetupAccel {
                         Csr& A_ff, Csr& A_fc, Csr& A_cf, Csr* A_cc) {
     (void)A; (void)markers; (void)newidx; (void)n_f; (void)n_c; (void)A_ff; (void)A_fc; (void)A_cf; (void)A_cc; return false;
   }
-  // split_fc may hand back A_fc / A_cf as stubs (Csr::stub_nnz >= 0) whose arrays are still on their way to the host
-  // (the copies run beside the polynomial coefficients, the assembly and the Z product).  sync_host(&A) completes the
-  // copy into A, sync_host(nullptr) all of them; the caller does so before a host routine reads such a block and before
-  // the level is finished.
-  virtual void sync_host(const Csr* which) { (void)which; }
   // Auto-truncation test (src/AIR_MG_Setup.F90:158-256) evaluated by the accelerator: ||A M r - r|| / ||r|| for the
   // matrix-free Newton coarse solver M built from `seed`.  Returns false when it cannot do it (the host then does).
   // The value is only used to DECIDE (with a safety margin, see air_setup.cpp); the solver that ends up in the
