@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--profile-kernels", type=int, default=1)
     ap.add_argument("--variants", default="", help="diagnostic: ';'-separated tunings to time on the same hierarchy, each a "
                     "','-separated list of key=value for airhip_set_tuning (keys: include/airhip.h)")
+    ap.add_argument("--tuning", default="", help="diagnostic: ','-separated key=value for airhip_set_tuning BEFORE the setup "
+                    "(e.g. mb16_max_rows=128: which row blocks are converted to the 16-bit multi-base form)")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--hint-brick", type=int, default=16,
                     help="locality hint for the device layout: grid points grouped in BxBxB bricks (0: none, -1: Morton "
@@ -115,6 +117,9 @@ def main():
     torch.cuda.set_device(local_rank)
     import pflare_amd as P
     P.lib().airhip_set_device(local_rank)
+    for t_ in [t for t in args.tuning.split(",") if t.strip()]:
+        if P.lib().airhip_set_tuning(t_.split("=")[0].strip().encode(), int(t_.split("=")[1])) != 0:
+            raise SystemExit(f"unknown tuning {t_}")
     dist = meta = None
     # AIRHIP_BENCH_FORCE_DIST=1: run the distributed code path (RCCL communicator, partition, shipping,
     # collective timing) even with a single rank - a rehearsal of everything but the peer traffic
@@ -276,7 +281,8 @@ def main():
         dist.broadcast_object_list(box, src=0, group=meta)
         info = box[0]
         info["t_distribute"] = time.time() - t0
-        log(f"[bench] partition + ship + upload: {info['t_distribute']:.1f}s")
+        info["phases"] = dict(pcl.distribute_phases)        # this rank's: rank 0 cuts and ships, the others receive
+        log(f"[bench] partition + ship + upload: {info['t_distribute']:.1f}s {info['phases']}")
         if rank == 0:
             pc.release_host()
         pc = pcl
@@ -381,6 +387,27 @@ def main():
             # back to the defaults (include/airhip.h, airhip_set_tuning) before the next variant
             for k_ in kv:
                 P.lib().airhip_set_tuning(k_.encode(), TUNING_DEFAULTS.get(k_, 0))
+    def graph_rehearsal():
+        """AFTER the measurement (rank 0 has printed its line by the time it gets here): the same iterations with the
+        distributed cycle captured in a hipGraph (RCCL send / receive groups inside the capture).  Never run with N > 1
+        before the driver's scaling run, so it must not be able to cost the line; the result goes to stderr."""
+        if not (dist_mode and transport == "rccl" and not args.graph and os.environ.get("AIRHIP_BENCH_GRAPH_REHEARSAL", "1") == "1"):
+            return
+        try:
+            pc.use_graph(True)
+            r_ = P.KSP(max_it=200, **ksp_kw).solve(b, x.fill_(1.0), pc=pc)
+            barrier(); t_ = time.perf_counter()
+            run_iterations(args.steps)
+            barrier(); w_ = time.perf_counter() - t_
+            if rank == 0:
+                print(f"[bench] graph rehearsal (cycle captured in a hipGraph, RCCL exchanges inside): {args.steps / w_:.2f} iterations/s, "
+                      f"converged solve its={r_['its']} rnorm={r_['rnorm']:.3e} (measured line: {args.steps / wall:.2f} iterations/s)",
+                      file=sys.stderr, flush=True)
+        except Exception as e:      # noqa: BLE001 - a rehearsal
+            print(f"[bench] rank {rank}: graph rehearsal failed: {e!r}", file=sys.stderr, flush=True)
+        finally:
+            pc.use_graph(False)
+
     run_iterations(args.warmup)
     if args.profile_kernels:
         pc.profile(True)
@@ -403,7 +430,20 @@ def main():
         cab = torch.tensor([pc.cycle_alg_bytes()], dtype=torch.float64, device="cpu" if staged else "cuda")
         dist.all_reduce(cab)
         cx = dict(cx); cx["cycle_alg_bytes"] = float(cab.item())
+        # every rank's own account of the timed iterations, for rank 0's line: kernel time, exposed exchange time, traffic
+        live_r = [s for s in stats if s["calls"] > 0]
+        mine = {"rank": rank,
+                "vcycle_kernel_ms_per_step": sum(s["total_ms"] for s in live_r if s["level"] >= 0) / args.steps,
+                "outer_and_krylov_kernel_ms_per_step": sum(s["total_ms"] for s in live_r if s["level"] == -1) / args.steps,
+                "exposed_exchange_ms_per_step": sum(s["total_ms"] for s in live_r if s["kernel"] == "halo_exchange") / args.steps,
+                "halo_exchanges_per_step": info["comm_timed"]["exchanges"] / args.steps,
+                "halo_bytes_sent_per_step": info["comm_timed"]["bytes_sent"] / args.steps,
+                "device_ms_per_step": ms_dev / args.steps, "phases": info.get("phases")}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine, group=meta)
+        info["per_rank"] = per_rank
         if rank != 0:
+            graph_rehearsal()
             dist.barrier()
             dist.destroy_process_group()
             return
@@ -464,8 +504,21 @@ def main():
         # whole V-cycle: algorithmic bytes of one cycle / measured kernel time of one cycle
         cycles = max(1, next((s["calls"] for s in live if s["name"].startswith("restrict") and s["level"] == 0), 1))
         vc_ms = sum(s["total_ms"] for s in live if s["level"] >= 0)     # level -1 = outer Krylov operator product
+        # two denominators, both per cycle: SURVEY 8(d)'s B_cycle (counts the identity blocks of R / P and their vector
+        # terms, which the layout never executes) and the S(X) of the operands the cycle's kernels actually executed
         roofline["vcycle_alg_GBs"] = cx["cycle_alg_bytes"] / (vc_ms / cycles * 1e-3) / 1e9
+        roofline["vcycle_exec_GBs"] = sum(s["alg_bytes"] * s["calls"] for s in live if s["level"] >= 0) / (vc_ms * 1e-3) / 1e9
         roofline["vcycle_kernel_ms"] = vc_ms / cycles
+        # the rest of a step (level -1 = the Krylov method's own kernels): outer product, Gram-Schmidt, norms, scaling
+        outer_ms = sum(s["total_ms"] for s in live if s["level"] < 0 and s["name"].startswith("outer"))
+        kry = [s for s in live if s["level"] == -1 and s["name"].startswith("Krylov ") and not s["name"].startswith("Krylov to ")]
+        kry_ms = sum(s["total_ms"] for s in kry)
+        roofline["outer_product_ms_per_step"] = outer_ms / args.steps
+        roofline["krylov_kernels_ms_per_step"] = kry_ms / args.steps
+        roofline["krylov_kernels_GBs"] = (sum(s["alg_bytes"] * s["calls"] for s in kry) / (kry_ms * 1e-3) / 1e9) if kry_ms > 0 else None
+        # complete accounting: kernels timed inside the solves / device time of the solves (the rest: host round trips
+        # of the dot products, launch gaps)
+        roofline["profiled_share_of_device_ms"] = (vc_ms + outer_ms + kry_ms) / ms_dev if ms_dev > 0 else None
         if args.verbose:
             for s in sorted(live, key=lambda s: -s["total_ms"])[:60]:
                 a = s["total_ms"] / s["calls"]
@@ -498,7 +551,34 @@ def main():
                    "device_ms_of_timed_solves": ms_dev, "hip_graph": bool(args.graph)},
         "roofline": roofline, "cpu_baseline": cpu,
     }
+    # the residual history of the converged solve against the committed single-GPU history (same hierarchy for every N: the
+    # setup is bit-reproducible; differences are the summation orders of the distributed dot products and halo'ed rows)
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "bench_history_n1.json")) as f:
+            fx = json.load(f).get(str(M))
+        if fx and args.recipe == fx["recipe"]:
+            h = res0["history"]; k = min(len(h), len(fx["history"]))
+            out["config"]["history_check"] = {
+                "fixture": "tests/golden/bench_history_n1.json", "entries": k, "iterations_fixture": fx["iterations"],
+                "max_rel_diff": max(abs(h[i] - fx["history"][i]) / max(abs(fx["history"][i]), 1e-300) for i in range(k)) if k else None}
+    except (OSError, ValueError, KeyError):
+        pass
+    if args.verbose:
+        log(f"[bench] residual history of the converged solve: {json.dumps(res0['history'])}")
     if dist_mode:
+        out["config"]["phases_s"] = {"setup_rank0": t_setup, **{f"{k}_rank0": v for k, v in (info.get("phases") or {}).items()}}
+        out["config"]["per_rank"] = info.get("per_rank")
+        # the model of tools/dist_model.py on this run's own counts (constants NOT measured: 15 us per send / receive group,
+        # 50 GB/s per peer): kernels + exchanges one after the other, i.e. without overlap - an upper bound to compare with
+        try:
+            pr = info["per_rank"]
+            kmax = max(r_["vcycle_kernel_ms_per_step"] + r_["outer_and_krylov_kernel_ms_per_step"] for r_ in pr)
+            emax = max(r_["halo_exchanges_per_step"] * 0.015 + r_["halo_bytes_sent_per_step"] / 50e9 * 1e3 for r_ in pr)
+            out["config"]["model"] = {"kernels_ms_per_step": kmax, "exchanges_ms_per_step_unhidden": emax,
+                                      "predicted_ms_per_step_without_overlap": kmax + emax,
+                                      "assumptions": "15 us per exchange + bytes / 50 GB/s (tools/dist_model.py); not measured"}
+        except Exception:      # noqa: BLE001 - diagnostic only
+            pass
         out["config"]["distribute_s"] = info["t_distribute"]
         out["config"]["halo_exchanges_rank0"] = info["comm"]["exchanges"]
         out["config"]["allreduces_rank0"] = info["comm"]["allreduces"]
@@ -509,6 +589,7 @@ def main():
             out["roofline"]["note"] = "kernel timings of rank 0"
     print(json.dumps(out), flush=True)
     if dist_mode:
+        graph_rehearsal()
         dist.barrier()
         dist.destroy_process_group()
 

@@ -46,7 +46,7 @@ DECLARED_SYMBOLS = [
     "airhip_pcair_profile_reset", "airhip_pcair_profile_count", "airhip_pcair_profile_get", "airhip_pcair_profile_kernel",
     "airhip_pcinv_create", "airhip_pcinv_set_option", "airhip_pcinv_setup", "airhip_pcinv_apply",
     "airhip_pcinv_sync", "airhip_pcinv_get_inv", "airhip_pcinv_destroy",
-    "airhip_mat_create", "airhip_mat_mult", "airhip_mat_destroy",
+    "airhip_mat_create", "airhip_mat_mult", "airhip_mat_destroy", "airhip_mat_blocks",
     "airhip_ksp_default_options", "airhip_ksp_solve",
     "airhip_partition_create", "airhip_partition_extract", "airhip_partition_destroy",
     "airhip_archive_create", "airhip_archive_add", "airhip_archive_count", "airhip_archive_item",
@@ -134,6 +134,7 @@ def lib():
         "airhip_mat_mult": [vp, vp, vp],
         "airhip_mat_mult_on_stream": [vp, vp, vp, vp],
         "airhip_mat_destroy": [pvp],
+        "airhip_mat_blocks": [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), vp, vp, vp, vp],
         "airhip_ksp_default_options": [C.POINTER(airhip_ksp_options)],
         "airhip_ksp_solve": [C.POINTER(airhip_ksp_options), vp, vp, vp, vp, vp, C.POINTER(airhip_ksp_result), pd,
                              C.c_int, pint],

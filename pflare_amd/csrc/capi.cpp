@@ -1313,6 +1313,21 @@ int airhip_mat_mult_on_stream(airhip_mat A, const double* d_x, double* d_y, void
   A->link.before_caller(A->stream, caller);
   API_END
 }
+int airhip_mat_blocks(airhip_mat A, int64_t* nblocks, int64_t* idx_bytes, int64_t* nnz, void* desc, void* idx, double* val, void* roff) {
+  API_BEGIN
+  REQUIRE(A && nblocks && idx_bytes && nnz, AIRHIP_ERR_ARG, "null argument");
+  const DevMat& M = A->A;
+  *nblocks = M.nblocks; *idx_bytes = M.idx_bytes; *nnz = M.nnz;
+  if (desc) {
+    REQUIRE(idx && val && roff, AIRHIP_ERR_ARG, "null argument");
+    HIP_CHECK(hipStreamSynchronize(A->stream));
+    if (M.nblocks) HIP_CHECK(hipMemcpy(desc, M.blk, sizeof(BlkDesc) * (size_t)M.nblocks, hipMemcpyDeviceToHost));
+    if (M.idx_bytes) HIP_CHECK(hipMemcpy(idx, M.idx, (size_t)M.idx_bytes, hipMemcpyDeviceToHost));
+    if (M.nnz) HIP_CHECK(hipMemcpy(val, M.val, sizeof(double) * (size_t)M.nnz, hipMemcpyDeviceToHost));
+    if (M.m) HIP_CHECK(hipMemcpy(roff, M.roff, sizeof(uint16_t) * (size_t)M.m, hipMemcpyDeviceToHost));
+  }
+  API_END
+}
 int airhip_mat_destroy(airhip_mat* A) {
   API_BEGIN
   if (A && *A) { devmat_free((*A)->A); if ((*A)->stream) (void)hipStreamDestroy((*A)->stream); delete *A; *A = nullptr; }

@@ -17,17 +17,25 @@
 
 namespace airhip {
 
-// One row block: a self-contained 32-byte descriptor, read with ONE scalar load (s_load_dwordx8).  cbase >= 0: the
-// block's entries are stored SORTED BY COLUMN, every index word holds ((column - cbase) * 8) << 10 | (row-major
-// position + 1).  cbase < 0 ("raw" block: a column span of 2^19 or more, or a single row longer than 512): entries in
-// row-major order, index word = absolute column.  nb / nr: the block's non-zeros and rows (round 2 derived them from
-// the next descriptor, and a launch over a list of blocks read the list first: two dependent scalar loads more).
-struct alignas(32) BlkDesc { int64_t p0; int32_t row; int32_t cbase; int32_t nb; int32_t nr; int32_t pad[2]; };
+// One row block: a self-contained 32-byte descriptor, read with ONE scalar load (s_load_dwordx8).  p0: the block's first
+// value (values are 8 bytes per non-zero for every block); ip: byte offset of the block's index region in DevMat::idx
+// (a multiple of 4); nb / nr: its non-zeros and rows.  Three kinds of index region, told apart by cbase:
+//   cbase >= 0   "packed": entries SORTED BY COLUMN, one 32-bit word each, ((column - cbase) * 8) << 10 | (row-major
+//                position + 1) - blocks of many short rows whose columns span less than 2^19;
+//   cbase == -1  "raw": row-major order, one 32-bit word = the absolute column (a single row longer than 512, or a block
+//                that fits neither of the others);
+//   cbase <= -2  "multi-base": row-major order, ONE 16-BIT WORD per entry, window << ob | offset, in front of them a table
+//                of up to 64 windows (byte offset of the window's first column, 32 bits each); meta = -(cbase + 2) holds
+//                ob (bits 0-4) and the number of windows (bits 5-).  10 bytes per non-zero + the table: blocks of few long
+//                rows (the deep levels: a row's sorted columns are its row-major order anyway) and blocks whose columns
+//                run through several sections of a hierarchical vector (A_fc), which were raw before round 4.
+struct alignas(32) BlkDesc { int64_t p0; int32_t row; int32_t cbase; int32_t nb; int32_t nr; int64_t ip; };
+constexpr int MB_OB_MASK = 31, MB_WIN_SHIFT = 5, MB_MAX_WIN = 64;
 
 // Row-block CSR.  One wavefront streams a block's (index word, value) pairs with coalesced loads, gathers x,
 // stages the products a_ij * x_j in LDS at their row-major positions and then sums every row's LDS segment
-// (one lane per row, or T lanes per row when the block holds few long rows).  12 bytes per non-zero for every
-// operator width; 2 bytes per row of block-relative row offsets.
+// (one lane per row, or T lanes per row when the block holds few long rows; a block of one row is summed in
+// registers).  12 or 10 bytes per non-zero (BlkDesc); 2 bytes per row of block-relative row offsets.
 struct DevMat {
   int64_t m = 0, n = 0;          // rows, cols (n includes the ghost columns of a distributed operand)
   int64_t n_ghost = 0;           // distributed operand: columns [n - n_ghost, n) are ghost values
@@ -36,7 +44,8 @@ struct DevMat {
   int64_t nblocks = 0;
   BlkDesc* blk = nullptr;        // [nblocks] in storage order
   uint16_t* roff = nullptr;      // [m] start of row r relative to its block's first non-zero
-  uint32_t* idx = nullptr;       // [nnz+1] index words (one readable padding entry)
+  uint8_t* idx = nullptr;        // [idx_bytes + 4] the blocks' index regions back to back (BlkDesc::ip), one readable padding word
+  int64_t idx_bytes = 0;
   double* val = nullptr;         // [nnz+1]
   // distributed operand: the row blocks that touch no ghost column (interior) / at least one (boundary), as
   // descriptor arrays of their own; the interior blocks run while the neighbour exchange is in flight
@@ -54,7 +63,7 @@ struct DevMat {
   // algorithmic bytes of one SpMV with this operator: S(X) of SURVEY 8(d)
   double s_bytes() const { return 12.0 * nnz + 4.0 * (m + 1) + 8.0 * m + 8.0 * n; }
   // bytes the format actually holds
-  double stored_bytes() const { return 12.0 * (nnz + 1) + 2.0 * m + 32.0 * nblocks * (desc_ord ? 2 : 1); }
+  double stored_bytes() const { return 8.0 * (nnz + 1) + (double)idx_bytes + 4.0 + 2.0 * m + 32.0 * nblocks * (desc_ord ? 2 : 1); }
 };
 
 // out_i = alpha * s_i + beta * z_i + gamma * w_i,  s = (A x)_i [ * dscale_i ]

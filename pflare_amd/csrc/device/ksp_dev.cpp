@@ -5,6 +5,7 @@
 // (SURVEY.md 8a-a19); the reference leaves them to PETSc.
 #include "pcair_dev.hpp"
 #include <cmath>
+#include <string>
 
 namespace airhip {
 
@@ -160,11 +161,13 @@ KspResult DevKSP::gmres(const KspOperator& op, const KspOptions& o, const double
       else { SpmvEpi e; e.out = t_.p; op_mult(op, Vk(it), e); apply_pc(t_.p, w); }
       // classical Gram-Schmidt: one multi-dot and one multi-axpy, each a single pass over w and the basis; the norm of
       // the orthogonalised vector rides along in the multi-axpy
-      { Timed t(op, "Krylov multi-dot", 8.0 * n_ * (it + 2), "k_mdot_partial"); launch_mdot(n_, w, V_.p, n_, it + 1, scratch_.p, ddots_.p, s); }
+      // (statistics per basis size: the bytes of a call site are fixed)
+      const std::string tag = " (" + std::to_string(it + 1) + ")";
+      { Timed t(op, ("Krylov multi-dot" + tag).c_str(), 8.0 * n_ * (it + 2), "k_mdot_partial"); launch_mdot(n_, w, V_.p, n_, it + 1, scratch_.p, ddots_.p, s); }
       fetch_dots(ddots_.p, lhh.data(), it + 1, s);
       for (int j = 0; j <= it; j++) { H(j, it) = lhh[j]; nrs[j] = -lhh[j]; }
       HIP_CHECK(hipMemcpyAsync(dcoef_.p, nrs.data(), sizeof(double) * (it + 1), hipMemcpyHostToDevice, s));
-      { Timed t(op, "Krylov multi-axpy + norm", 8.0 * n_ * (it + 3), "k_maxpy"); launch_maxpy(n_, w, V_.p, n_, it + 1, dcoef_.p, s, false, scratch_.p, dnorm_.p); }
+      { Timed t(op, ("Krylov multi-axpy + norm" + tag).c_str(), 8.0 * n_ * (it + 3), "k_maxpy"); launch_maxpy(n_, w, V_.p, n_, it + 1, dcoef_.p, s, false, scratch_.p, dnorm_.p); }
       double tt = 0.0;
       fetch_dots(dnorm_.p, &tt, 1, s);
       tt = std::sqrt(tt);
@@ -209,11 +212,11 @@ KspResult DevKSP::gmres(const KspOperator& op, const KspOptions& o, const double
       }
       HIP_CHECK(hipMemcpyAsync(dcoef_.p, nrs.data(), sizeof(double) * it, hipMemcpyHostToDevice, s));
       if (right) {
-        { Timed t(op, "Krylov solution multi-axpy", 8.0 * n_ * (it + 1), "k_maxpy"); launch_maxpy(n_, w_.p, V_.p, n_, it, dcoef_.p, s, true); }
+        { Timed t(op, ("Krylov solution multi-axpy (" + std::to_string(it) + ")").c_str(), 8.0 * n_ * (it + 1), "k_maxpy"); launch_maxpy(n_, w_.p, V_.p, n_, it, dcoef_.p, s, true); }
         apply_pc(w_.p, t_.p);
         Timed t(op, "Krylov x+=z", 24.0 * n_, "k_axpby");
         launch_axpby(n_, 1.0, t_.p, 1.0, x, x, s);
-      } else { Timed t(op, "Krylov solution multi-axpy", 8.0 * n_ * (it + 2), "k_maxpy"); launch_maxpy(n_, x, V_.p, n_, it, dcoef_.p, s); }
+      } else { Timed t(op, ("Krylov solution multi-axpy (" + std::to_string(it) + ")").c_str(), 8.0 * n_ * (it + 2), "k_maxpy"); launch_maxpy(n_, x, V_.p, n_, it, dcoef_.p, s); }
       HIP_CHECK(hipStreamSynchronize(s));   // nrs (host) is reused by the next cycle
     }
     if (!reason && its >= o.max_it) reason = -3;

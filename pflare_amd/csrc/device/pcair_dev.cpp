@@ -138,6 +138,7 @@ void DevPCAIR::resolve_events() {
   for (auto& p : pending_) {
     float ms = 0.f;
     HIP_CHECK(hipEventElapsedTime(&ms, p.a, p.b));
+    if (ms < 0.f) ms = 0.f;      // (an exchange that ended before the interior blocks did: nothing exposed)
     stats_[p.stat].calls++; stats_[p.stat].ms += ms;
     event_pool_.push_back(p.a); event_pool_.push_back(p.b);
   }
@@ -175,9 +176,28 @@ bool DevPCAIR::begin_exchange(const DevMat& A, const double* x) {
   HIP_CHECK(hipStreamWaitEvent(comm_stream_, ev_pack_, 0));
   comm_->exchange(p, comm_stream_);
   HIP_CHECK(hipEventRecord(ev_recv_, comm_stream_));
+  if (profile_) {      // when the exchange was over, for wait_exchange's "exposed" statistic
+    hipEvent_t b;
+    if (!event_pool_.empty()) { b = event_pool_.back(); event_pool_.pop_back(); } else HIP_CHECK(hipEventCreate(&b));
+    HIP_CHECK(hipEventRecord(b, comm_stream_));
+    exch_end_ = b;
+  }
   return true;
 }
-void DevPCAIR::wait_exchange() { HIP_CHECK(hipStreamWaitEvent(stream_, ev_recv_, 0)); }
+// the boundary blocks wait for the ghosts.  Profiling: the time between the end of the interior blocks and the end of the
+// exchange (zero when the exchange was hidden) goes to the statistic "halo exchange, exposed"
+void DevPCAIR::wait_exchange() {
+  if (profile_ && exch_end_) {
+    hipEvent_t a;
+    if (!event_pool_.empty()) { a = event_pool_.back(); event_pool_.pop_back(); } else HIP_CHECK(hipEventCreate(&a));
+    HIP_CHECK(hipEventRecord(a, stream_));
+    const int id = stat_id("halo exchange, exposed", -2, 0.0);
+    stats_[id].kernel = "halo_exchange";
+    pending_.push_back({a, exch_end_, id});
+    exch_end_ = nullptr;
+  }
+  HIP_CHECK(hipStreamWaitEvent(stream_, ev_recv_, 0));
+}
 
 // ---------------------------------------------------------------------------------------
 // distributed operands
@@ -213,8 +233,12 @@ void DevPCAIR::attach_halo(DevMat& M, const HaloHost* h, const int32_t* host_col
 const double* DevPCAIR::halo_update(const DevMat& A, const double* x) {
   if (!A.halo) return nullptr;
   HaloPlan& p = *A.halo;
+  // (not overlapped: the whole exchange, pack kernel included, is exposed)
+  hipEvent_t saved_a = cur_a_; const int saved_stat = cur_stat_;
+  if (profile_) { const int id = stat_id("halo exchange, exposed", -2, 0.0); stats_[id].kernel = "halo_exchange"; begin_kernel(id); }
   if (p.n_send) launch_gather(p.n_send, p.send_idx, x, p.sendbuf, stream_);
   comm_->exchange(p, stream_);
+  if (profile_) { end_kernel(); cur_a_ = saved_a; cur_stat_ = saved_stat; }
   return p.recvbuf;
 }
 
@@ -563,6 +587,13 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
   if (H.opt.print_stats_timings) {
     std::printf(" hierarchy to the device: %.2f s (orderings %.2f s, host -> device copies of the operators %.2f s, conversion to row blocks %.2f s; %lld operators were on the device already)\n",
                 now_s() - t_upload0, t_order, g_t_h2d, g_t_convert, (long long)g_n_from_device);
+    // what the index streams hold (12 bytes per non-zero = 8 of value + 4 of index in the packed / raw forms)
+    double nz = 0, ib = 0;
+    auto acc = [&](const DevMat& m) { if (m.valid()) { nz += (double)m.nnz; ib += (double)m.idx_bytes; } };
+    acc(A_perm_); acc(coarse_A_); acc(coarse_inv_.mat);
+    for (auto& l : levels_) for (const DevMat* m : {&l->A_ff, &l->A_fc, &l->A_cf, &l->A_cc, &l->Z, &l->W, &l->inv_ff.mat, &l->inv_cc.mat, &l->A_full}) acc(*m);
+    std::printf(" row blocks on the device: %.3g non-zeros, index regions %.2f bytes per non-zero (values 8), %.1f GB in all\n",
+                nz, nz > 0 ? ib / nz : 0.0, storage_bytes() * 1e-9);
     std::fflush(stdout);
   }
 }

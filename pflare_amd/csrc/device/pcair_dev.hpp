@@ -163,6 +163,7 @@ class DevPCAIR {
   int64_t overlap_min_blocks_ = 8192;   // interior row blocks (x 512 non-zeros) below which the plain path is used
   hipStream_t comm_stream_ = nullptr;
   hipEvent_t ev_pack_ = nullptr, ev_recv_ = nullptr;
+  hipEvent_t exch_end_ = nullptr;       // profiling: end of the exchange in flight (begin_exchange -> wait_exchange)
   bool begin_exchange(const DevMat& A, const double* x);   // true: split launch (interior, wait_exchange, boundary)
   void wait_exchange();
   // level-0 rhs is only read and the solution of every level is a suffix of one buffer: PCApply in

@@ -15,14 +15,14 @@ constexpr int CHUNK_ROWS = 512;     // the block partition is greedy inside chun
 constexpr int POS_BITS = 10;
 constexpr uint32_t POS_MASK = (1u << POS_BITS) - 1u;
 constexpr int COL_BITS = 32 - POS_BITS - 3;   // 19: a packed block's columns span less than 2^19
-// products staged per wave: slot 0 is the dummy slot of padding lanes; the row sums (four entries per trip, up to 32
-// lanes per row) read up to 3 * 32 slots past a row's end and discard what they find there
-constexpr int LDS_SLOTS = BLK_NNZ + 2 + 96;
+// products staged per wave: slot 0 is the dummy slot of padding lanes, slots 1 .. 512 the row-major positions; the row
+// sums clamp their reads to slot 513
+constexpr int LDS_SLOTS = BLK_NNZ + 2;
 
 struct RbView {
   const BlkDesc* __restrict__ blk;        // the blocks this launch processes, in processing order
   const uint16_t* __restrict__ roff;
-  const uint32_t* __restrict__ idx;
+  const uint8_t* __restrict__ idx;
   const double* __restrict__ val;
   int32_t nblocks;                        // how many
   int32_t per_class;                      // ceil(nblocks / 8): the blocks of one XCD class (see my_block)

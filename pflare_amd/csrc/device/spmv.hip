@@ -66,10 +66,21 @@ __device__ __forceinline__ int my_block(const RbView& A) {
   return (k < A.per_class && b < A.nblocks) ? b : -1;
 }
 
-// ---- tuning knobs (airhip_set_tuning): none at present; the hook stays for experiments
-int spmv_set_tuning(const char*, int) { return -1; }
+// ---- tuning knobs (airhip_set_tuning): which blocks the conversion stores in the 16-bit multi-base form (dev.hpp).
+//   mb16          0: none (the round-3 format: packed or raw), 1 (default): see mb16_max_rows
+//   mb16_max_rows blocks of at most this many rows go multi-base (default 8; 128 = every block that can), blocks whose
+//                 columns span 2^19 or more (raw otherwise) always do.  Row-major order is free for a block of few long
+//                 rows; a block of many short rows gathers better in column order (the packed form).
+// They act when an operator is converted (upload of a hierarchy), not on operators that exist.
+static int g_mb16 = 1, g_mb16_max_rows = 8;
+int spmv_set_tuning(const char* key, int value) {
+  const std::string k(key);
+  if (k == "mb16") { g_mb16 = value != 0; return 0; }
+  if (k == "mb16_max_rows") { g_mb16_max_rows = value < 0 ? 0 : value; return 0; }
+  return -1;
+}
 
-struct BlkInfo { int64_t p0; int32_t r0, cbase, nb, nr; };
+struct BlkInfo { int64_t p0, ip; int32_t r0, cbase, nb, nr; };
 
 // The block descriptor is read through the constant address space: the address is wave-uniform, so the compiler
 // emits one scalar load (s_load_dwordx8, counted by lgkmcnt) instead of vector loads whose wait (vmcnt is in order)
@@ -84,14 +95,16 @@ __device__ __forceinline__ BlkInfo load_blk(const RbView& A, int b) {
   o.cbase = bp[b].cbase;
   o.nb = bp[b].nb;
   o.nr = bp[b].nr;
+  o.ip = bp[b].ip;
   return o;
 }
 
 // ---- buffer addressing.  Every per-block array (index words, values, row offsets, epilogue vectors) is read
 // through a buffer resource whose extent is the block's: lanes past the end get 0 from the hardware range check
 // (and stores past the end are dropped), so the kernel needs no clamps, no exec-mask branches and one 32-bit
-// offset register per array.  An out-of-range index word 0 decodes to position 0 = the dummy LDS slot and to the
-// block's first column, so padding lanes gather a valid address and park a zero product where nobody reads it.
+// offset register per array.  An out-of-range index word 0 decodes to the block's first column (packed: position 0 =
+// the dummy LDS slot; multi-base: window 0, offset 0), so padding lanes gather a valid address of the block's own and
+// their zero value makes a zero product.
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ rsrc_t make_rsrc(const void* base, int64_t bytes) {
   const int nrec = bytes > 0x7fffffffll ? 0x7fffffff : (int)bytes;
@@ -114,20 +127,17 @@ __device__ __forceinline__ void buf_store_f64(rsrc_t r, int voff, double v) {
 // because wave-uniform branches around the single loads cost more than they save (256^3: restriction -10 %).
 template <int NF> struct Rounds {
   static constexpr int nu = NF < EPL ? NF + 1 : EPL;      // rounds issued
-  static constexpr int npair = NF >> 1;                   // interleaved value pairs
+  static constexpr int npair = NF >> 1;                   // interleaved pairs of full rounds
   __device__ __forceinline__ static constexpr bool has(int u) { return u < nu; }
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// the block's first 512 (index, value) pairs into registers: index words round by round, values pair by pair
+// the block's first 512 values into registers, pair by pair (16-byte loads on the interleaved placement)
 template <int NF>
-__device__ __forceinline__ void issue_stream(const RbView& A, const BlkInfo& d, int lane, uint32_t (&ix)[EPL], double (&vv)[EPL]) {
+__device__ __forceinline__ void issue_values(const RbView& A, const BlkInfo& d, int n, int lane, double (&vv)[EPL]) {
   typedef Rounds<NF> R;
-  const int n = d.nb < BLK_NNZ ? d.nb : BLK_NNZ;
-  const rsrc_t ri = make_rsrc32(A.idx + d.p0, n * 4), rv = make_rsrc32(A.val + d.p0, n * 8);
-#pragma unroll
-  for (int u = 0; u < EPL; u++) { ix[u] = 0; if (R::has(u)) ix[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(ri, lane * 4, u * WAVE * 4, 0); }
+  const rsrc_t rv = make_rsrc32(A.val + d.p0, n * 8);
 #pragma unroll
   for (int i = 0; i < EPL / 2; i++) {
     if (i < R::npair) {
@@ -142,20 +152,57 @@ __device__ __forceinline__ void issue_stream(const RbView& A, const BlkInfo& d, 
   }
 }
 
+// 32-bit index words (packed and raw blocks), round by round, then the values
+template <int NF>
+__device__ __forceinline__ void issue_stream(const RbView& A, const BlkInfo& d, int lane, uint32_t (&ix)[EPL], double (&vv)[EPL]) {
+  typedef Rounds<NF> R;
+  const int n = d.nb < BLK_NNZ ? d.nb : BLK_NNZ;
+  const rsrc_t ri = make_rsrc32(A.idx + d.ip, n * 4);
+#pragma unroll
+  for (int u = 0; u < EPL; u++) { ix[u] = 0; if (R::has(u)) ix[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(ri, lane * 4, u * WAVE * 4, 0); }
+  issue_values<NF>(A, d, n, lane, vv);
+}
+
+// 16-bit index words of a multi-base block: the words of every pair of full rounds are interleaved like the values (one
+// dword per lane holds slot 64 (2i) + lane in its low half and slot 64 (2i + 1) + lane in its high half), the rest is in
+// slot order; in front of them the table of windows, one per lane.  Then the values.
+template <int NF>
+__device__ __forceinline__ void issue_stream_mb(const RbView& A, const BlkInfo& d, int nwin, int lane, uint32_t& tab, uint32_t (&iw)[EPL], double (&vv)[EPL]) {
+  typedef Rounds<NF> R;
+  const uint8_t* __restrict__ ib = A.idx + d.ip;
+  tab = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc32(ib, nwin * 4), lane * 4, 0, 0);
+  const rsrc_t ri = make_rsrc32(ib + nwin * 4, d.nb * 2);
+#pragma unroll
+  for (int i = 0; i < EPL / 2; i++) {
+    iw[2 * i] = 0; iw[2 * i + 1] = 0;
+    if (i < R::npair) {
+      const uint32_t q = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(ri, lane * 4, i * 2 * WAVE * 2, 0);
+      iw[2 * i] = q & 0xffffu; iw[2 * i + 1] = q >> 16;
+    } else {
+      if (R::has(2 * i)) iw[2 * i] = (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(ri, lane * 2, 2 * i * WAVE * 2, 0);
+      if (R::has(2 * i + 1)) iw[2 * i + 1] = (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(ri, lane * 2, (2 * i + 1) * WAVE * 2, 0);
+    }
+  }
+  issue_values<NF>(A, d, d.nb, lane, vv);
+}
+
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// sum of lds[j + 1] for j = a, a + step, ... < e, in that order; every lane of the wave takes part (a == e: no entry)
+// sum of lds[j + 1] for j = a, a + step, ... < e, in that order; every lane of the wave takes part (a == e: no entry).
+// Four entries per trip and a wave-uniform trip count: lanes whose row is shorter than the block's longest keep reading
+// (clamped to the last slot of the staging area) and add zero - a per-lane loop cost six scalar instructions per entry
+// of the longest row
 __device__ __forceinline__ double row_sum(const double* __restrict__ lds, int a, int e, int step) {
   double s = 0.0;
   int j = a;
   while (__any(j < e)) {
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const double v = lds[j + 1];           // at most 3 * step slots past the block's last entry: inside LDS_SLOTS
+      const double v = lds[(j < BLK_NNZ ? j : BLK_NNZ) + 1];
       s += (j < e) ? v : 0.0;
       j += step;
     }
@@ -163,6 +210,48 @@ __device__ __forceinline__ double row_sum(const double* __restrict__ lds, int a,
   return s;
 }
 
+// row offsets of this lane's (at most two) rows: ra / re = first / one past the last entry, relative to the block
+__device__ __forceinline__ void load_row_ranges(const RbView& A, const BlkInfo& d, int lane, bool two, int (&ra)[2], int (&re)[2]) {
+  const rsrc_t rr = make_rsrc32(A.roff + d.r0, d.nr * 2);
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    ra[q] = 0; re[q] = 0;
+    if (q == 0 || two) {
+      const int r = lane + q * WAVE;
+      ra[q] = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rr, r * 2, 0, 0);
+      const int rnext = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rr, r * 2 + 2, 0, 0);
+      re[q] = (r + 1 < d.nr) ? rnext : (r < d.nr ? d.nb : 0);       // no row: ra = re = 0, nothing to sum
+    }
+  }
+}
+
+// phase 2 of a block whose products are staged in LDS at their row-major positions: the row sums, then the epilogue
+template <class Epi>
+__device__ __forceinline__ void sum_rows(const BlkInfo& d, const double* __restrict__ lds, const Epi& epi, int lane, bool two,
+                                         const int (&ra)[2], const int (&re)[2], const typename Epi::Pre (&pre)[2]) {
+  const int nr = d.nr;
+  if (nr > 32) {
+    // one lane per row, column order
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      if (q == 1 && !two) break;
+      epi.store(d.r0, nr, lane + q * WAVE, row_sum(lds, ra[q], re[q], 1), pre[q]);
+    }
+  } else {
+    // few (longer) rows: T = 64 / 2^ceil(log2 nr) lanes share a row
+    int sh = 6;
+    while ((WAVE >> sh) < nr) { sh--; }       // 2^(6-sh) >= nr groups
+    const int T = 1 << sh;
+    const int g = lane >> sh, t = lane & (T - 1);
+    const int a = __shfl(ra[0], g, WAVE), e = __shfl(re[0], g, WAVE);
+    double s = row_sum(lds, a + t, e, T);
+    for (int off = T >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
+    const double srow = __shfl(s, (lane << sh) & (WAVE - 1), WAVE);   // row `lane` lives in lanes lane*T ..
+    epi.store(d.r0, nr, lane, srow, pre[0]);
+  }
+}
+
+// packed and raw blocks (32-bit index words)
 template <int NF, bool DIST, class Epi>
 __device__ __forceinline__ void rb_body(const RbView& A, const BlkInfo& d, const XVec<DIST> x, double* __restrict__ lds, const Epi& epi, int lane) {
   const int nb = d.nb, nr = d.nr;
@@ -174,21 +263,11 @@ __device__ __forceinline__ void rb_body(const RbView& A, const BlkInfo& d, const
   typename Epi::Early early[2];
   int ra[2], re[2];
   typename Epi::Pre pre[2];
-  const rsrc_t rr = make_rsrc32(A.roff + d.r0, nr * 2);
   const bool two = nr > WAVE;          // blocks of <= 64 rows (most of them) issue nothing for a second row per lane
   early[0] = epi.early(d.r0, nr, lane);
   early[1] = early[0];
   if (two) early[1] = epi.early(d.r0, nr, lane + WAVE);
-#pragma unroll
-  for (int q = 0; q < 2; q++) {
-    ra[q] = 0; re[q] = 0;
-    if (q == 0 || two) {
-      const int r = lane + q * WAVE;
-      ra[q] = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rr, r * 2, 0, 0);
-      const int rnext = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rr, r * 2 + 2, 0, 0);
-      re[q] = (r + 1 < nr) ? rnext : (r < nr ? nb : 0);       // no row: ra = re = 0, nothing to sum
-    }
-  }
+  load_row_ranges(A, d, lane, two, ra, re);
   // gather x for the rounds the block has
   double xx[EPL];
   if (sorted) {
@@ -213,31 +292,11 @@ __device__ __forceinline__ void rb_body(const RbView& A, const BlkInfo& d, const
       for (int u = 0; u < EPL; u++) if (R::has(u)) { const int k = lane + u * WAVE; lds[k < nb ? k + 1 : 0] = vv[u] * xx[u]; }
     }
     wave_lds_sync();
-    if (nr > 32) {
-      // phase 2: one lane per row, column order.  Four entries per trip and a wave-uniform trip count (entries past
-      // the row's end are read - the staging area has the room - and replaced by zero): a per-lane loop cost six
-      // scalar instructions per entry of the longest row
-#pragma unroll
-      for (int q = 0; q < 2; q++) {
-        if (q == 1 && !two) break;
-        epi.store(d.r0, nr, lane + q * WAVE, row_sum(lds, ra[q], re[q], 1), pre[q]);
-      }
-    } else {
-      // phase 2 for few (longer) rows: T = 64 / 2^ceil(log2 nr) lanes share a row
-      int sh = 6;
-      while ((WAVE >> sh) < nr) { sh--; }       // 2^(6-sh) >= nr groups
-      const int T = 1 << sh;
-      const int g = lane >> sh, t = lane & (T - 1);
-      const int a = __shfl(ra[0], g, WAVE), e = __shfl(re[0], g, WAVE);
-      double s = row_sum(lds, a + t, e, T);
-      for (int off = T >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
-      const double srow = __shfl(s, (lane << sh) & (WAVE - 1), WAVE);   // row `lane` lives in lanes lane*T ..
-      epi.store(d.r0, nr, lane, srow, pre[0]);
-    }
+    sum_rows(d, lds, epi, lane, two, ra, re, pre);
   } else {
     // one long row: the whole wave reduces it.  The first 512 entries are already in registers (stream and
     // gather above: all eight rounds exist); the rest is read with four independent chains per lane
-    const uint32_t* __restrict__ ip = A.idx + d.p0;
+    const uint32_t* __restrict__ ip = reinterpret_cast<const uint32_t*>(A.idx + d.ip);
     const double* __restrict__ vp = A.val + d.p0;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
@@ -259,6 +318,59 @@ __device__ __forceinline__ void rb_body(const RbView& A, const BlkInfo& d, const
   }
 }
 
+// multi-base blocks (16-bit index words, row-major order; at most 512 entries)
+template <int NF, bool DIST, class Epi>
+__device__ __forceinline__ void rb_body_mb(const RbView& A, const BlkInfo& d, const XVec<DIST> x, double* __restrict__ lds, const Epi& epi, int lane) {
+  const int nr = d.nr;
+  typedef Rounds<NF> R;
+  const int meta = -(d.cbase + 2);
+  const int ob = meta & MB_OB_MASK, nwin = meta >> MB_WIN_SHIFT;
+  uint32_t tab; uint32_t iw[EPL]; double vv[EPL];
+  issue_stream_mb<NF>(A, d, nwin, lane, tab, iw, vv);
+  typename Epi::Early early[2];
+  int ra[2], re[2];
+  typename Epi::Pre pre[2];
+  const bool two = nr > WAVE;
+  const bool one = nr == 1;            // the common case on the deep levels: no staging, no row offsets
+  early[0] = epi.early(d.r0, nr, lane);
+  early[1] = early[0];
+  if (two) early[1] = epi.early(d.r0, nr, lane + WAVE);
+  ra[0] = ra[1] = re[0] = re[1] = 0;
+  if (!one) load_row_ranges(A, d, lane, two, ra, re);
+  // column = window's first column + offset: the table lives in one register across the lanes (ds_bpermute)
+  const uint32_t omask = (1u << ob) - 1u;
+  double xx[EPL];
+#pragma unroll
+  for (int u = 0; u < EPL; u++) {
+    xx[u] = 0.0;
+    if (R::has(u)) {
+      const uint32_t base = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((iw[u] >> ob) << 2), (int)tab);
+      xx[u] = x.at_byte_offset(base + ((iw[u] & omask) << 3));
+    }
+  }
+  pre[0] = epi.load(d.r0, nr, lane, early[0]);
+  pre[1] = pre[0];
+  if (two) pre[1] = epi.load(d.r0, nr, lane + WAVE, early[1]);
+  if (one) {
+    // one row: lane l holds entries l, l + 64, ... - what it would read back from the staging area.  Same products, same
+    // order of additions as the staged path (multiply, then add: no contraction)
+    double s = 0.0;
+    {
+#pragma clang fp contract(off)
+#pragma unroll
+      for (int u = 0; u < EPL; u++) if (R::has(u)) { const double p = vv[u] * xx[u]; s = s + p; }
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
+    epi.store(d.r0, nr, lane, s, pre[0]);
+    return;
+  }
+  // phase 1: the slot is the row-major position
+#pragma unroll
+  for (int u = 0; u < EPL; u++) if (R::has(u)) lds[lane + u * WAVE + 1] = vv[u] * xx[u];
+  wave_lds_sync();
+  sum_rows(d, lds, epi, lane, two, ra, re, pre);
+}
+
 // Epi interface (r0 = first row of the block, nr = its rows, lr = this lane's local row, may be >= nr):
 //   Early early(r0, nr, lr)            loads whose result feeds another load (issued with the stream)
 //   Pre   load(r0, nr, lr, Early)      the epilogue's inputs, issued before the gather is waited for
@@ -269,7 +381,22 @@ __device__ __forceinline__ void rb_block(const RbView& A, const XVec<DIST> x, do
   const int bi = my_block(A);
   if (bi < 0) return;
   const BlkInfo d = load_blk(A, bi);
-  switch ((d.nb < BLK_NNZ ? d.nb : BLK_NNZ) >> 6) {     // full rounds: one straight-line variant each (every long row: 8)
+  const int nf = (d.nb < BLK_NNZ ? d.nb : BLK_NNZ) >> 6;     // full rounds: one straight-line variant each (every long row: 8)
+  if (d.cbase <= -2) {
+    switch (nf) {
+      case 8: rb_body_mb<8, DIST>(A, d, x, lds, epi, lane); break;
+      case 7: rb_body_mb<7, DIST>(A, d, x, lds, epi, lane); break;
+      case 6: rb_body_mb<6, DIST>(A, d, x, lds, epi, lane); break;
+      case 5: rb_body_mb<5, DIST>(A, d, x, lds, epi, lane); break;
+      case 4: rb_body_mb<4, DIST>(A, d, x, lds, epi, lane); break;
+      case 3: rb_body_mb<3, DIST>(A, d, x, lds, epi, lane); break;
+      case 2: rb_body_mb<2, DIST>(A, d, x, lds, epi, lane); break;
+      case 1: rb_body_mb<1, DIST>(A, d, x, lds, epi, lane); break;
+      default: rb_body_mb<0, DIST>(A, d, x, lds, epi, lane); break;
+    }
+    return;
+  }
+  switch (nf) {
     case 8: rb_body<8, DIST>(A, d, x, lds, epi, lane); break;
     case 7: rb_body<7, DIST>(A, d, x, lds, epi, lane); break;
     case 6: rb_body<6, DIST>(A, d, x, lds, epi, lane); break;
@@ -551,7 +678,7 @@ __global__ __launch_bounds__(BLOCK) void k_chunk_blocks(int64_t m, const int64_t
       const int64_t pn = nrp[r + 1];
       const int64_t len = pn - pr;
       if (rows > 0 && (pn - p_start > BLK_NNZ || rows == BLK_ROWS)) { nblk++; rows = 0; p_start = pr; }
-      if (rows == 0 && FILL) { BlkDesc& q = blk[b + nblk]; q.p0 = pr; q.row = (int32_t)r; q.cbase = -1; q.nb = 0; q.nr = 0; q.pad[0] = 0; q.pad[1] = 0; }
+      if (rows == 0 && FILL) { BlkDesc& q = blk[b + nblk]; q.p0 = pr; q.row = (int32_t)r; q.cbase = -1; q.nb = 0; q.nr = 0; q.ip = 0; }
       if (FILL) roff[r] = (uint16_t)(len > BLK_NNZ ? 0 : (pr - p_start));
       rows++;
       if (len > BLK_NNZ) { nblk++; rows = 0; p_start = pn; }   // a long row closes its own block
@@ -570,32 +697,39 @@ __device__ __forceinline__ int val_slot(int s, int n) {
   return (s >> 7) * (2 * WAVE) + 2 * (s & (WAVE - 1)) + ((s >> 6) & 1);
 }
 
-// One wave per block: blocks of <= BLK_NNZ entries whose columns span less than 2^COL_BITS are sorted by
-// column (bitonic sort of (column << 16 | position) keys in LDS) and get packed index words; the others
-// keep row-major order and absolute columns (cbase stays -1).
-__global__ __launch_bounds__(BLOCK) void k_block_pack(int64_t nblocks, int64_t nnz, int64_t m, BlkDesc* __restrict__ blk, const int32_t* __restrict__ col,
-                                                     const double* __restrict__ val, uint32_t* __restrict__ oidx, double* __restrict__ oval) {
+// One wave per block: decides the block's kind (dev.hpp: BlkDesc), writes its values in the interleaved placement and its
+// index region IN PLACE over the block's columns (`col`, 4 bytes per entry: every kind needs at most that; all columns
+// of a block of <= 512 entries are in LDS before the first write) and leaves the region's size in BlkDesc::ip for the
+// compaction that follows.
+//   packed: columns span < 2^COL_BITS: sorted by column (bitonic sort of (column << 16 | position) keys in LDS);
+//   multi-base (mb_on; blocks of <= mb_max_rows rows, and blocks that cannot be packed): the windows are the distinct
+//     values of column >> ob over the block's sorted columns, ob the largest of 14 ... 10 for which there are at most
+//     2^(16 - ob) (<= 64) of them; a window's base is its smallest column;
+//   raw: the rest (and rows longer than 512).
+__global__ __launch_bounds__(BLOCK) void k_block_pack(int64_t nblocks, int64_t nnz, int64_t m, BlkDesc* __restrict__ blk, int32_t* col,
+                                                     const double* __restrict__ val, double* __restrict__ oval, int mb_on, int mb_max_rows) {
   __shared__ unsigned long long keys_all[WAVES_PER_BLOCK][BLK_NNZ];
+  __shared__ uint32_t tab_all[WAVES_PER_BLOCK][MB_MAX_WIN];
+  __shared__ unsigned short word_all[WAVES_PER_BLOCK][BLK_NNZ];
   unsigned long long* keys = keys_all[threadIdx.x >> 6];
+  uint32_t* tab = tab_all[threadIdx.x >> 6];
+  unsigned short* word = word_all[threadIdx.x >> 6];
   const int lane = threadIdx.x & (WAVE - 1);
   const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * BLOCK) >> 6;
+  auto lds_sync = [] { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
   for (int64_t b = wave; b < nblocks; b += nwaves) {
     const int64_t p0 = blk[b].p0, p1 = b + 1 < nblocks ? blk[b + 1].p0 : nnz;
     const int64_t nbl = p1 - p0;
-    if (lane == 0) { blk[b].nb = (int32_t)nbl; blk[b].nr = (int32_t)((b + 1 < nblocks ? (int64_t)blk[b + 1].row : m) - blk[b].row); }
-    int32_t cmin = 0x7fffffff, cmax = -1;
-    if (nbl <= BLK_NNZ)
-      for (int i = lane; i < (int)nbl; i += WAVE) { const int32_t c = col[p0 + i]; cmin = min(cmin, c); cmax = max(cmax, c); }
-    for (int off = 32; off > 0; off >>= 1) { cmin = min(cmin, __shfl_xor(cmin, off, WAVE)); cmax = max(cmax, __shfl_xor(cmax, off, WAVE)); }
-    const bool pack = nbl > 0 && nbl <= BLK_NNZ && (int64_t)cmax - (int64_t)cmin < (int64_t)(1u << COL_BITS);
-    if (!pack) {
-      // row-major order, absolute columns; the first 512 values in the interleaved placement (a long row has more)
+    const int nrows = (int)((b + 1 < nblocks ? (int64_t)blk[b + 1].row : m) - blk[b].row);
+    if (lane == 0) { blk[b].nb = (int32_t)nbl; blk[b].nr = nrows; blk[b].ip = 4 * nbl; }
+    uint32_t* oidx = reinterpret_cast<uint32_t*>(col);
+    if (nbl == 0 || nbl > BLK_NNZ) {
+      // row-major order, absolute columns (already in place); the first 512 values in the interleaved placement
       const int n512 = (int)(nbl < BLK_NNZ ? nbl : BLK_NNZ);
       for (int64_t k = p0 + lane; k < p1; k += WAVE) {
-        oidx[k] = (uint32_t)col[k];
-        const int64_t s = k - p0;
-        oval[s < n512 ? p0 + val_slot((int)s, n512) : k] = val[k];
+        const int64_t q = k - p0;
+        oval[q < n512 ? p0 + val_slot((int)q, n512) : k] = val[k];
       }
       continue;
     }
@@ -603,8 +737,7 @@ __global__ __launch_bounds__(BLOCK) void k_block_pack(int64_t nblocks, int64_t n
     int P2 = WAVE; while (P2 < nb) P2 <<= 1;
     for (int i = lane; i < P2; i += WAVE)
       keys[i] = i < nb ? (((unsigned long long)(uint32_t)col[p0 + i]) << 16) | (unsigned long long)i : ~0ull;
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    lds_sync();
     for (int size = 2; size <= P2; size <<= 1)
       for (int stride = size >> 1; stride > 0; stride >>= 1) {
         for (int i = lane; i < P2 / 2; i += WAVE) {
@@ -614,33 +747,110 @@ __global__ __launch_bounds__(BLOCK) void k_block_pack(int64_t nblocks, int64_t n
           const unsigned long long ka = keys[a], kb = keys[bb];
           if ((ka > kb) == asc) { keys[a] = kb; keys[bb] = ka; }
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        lds_sync();
       }
-    for (int i = lane; i < nb; i += WAVE) {
-      const unsigned long long k = keys[i];
-      const int pos = (int)(k & 0xffffull);
-      oidx[p0 + i] = ((uint32_t)((int32_t)(k >> 16) - cmin) << (POS_BITS + 3)) | (uint32_t)(pos + 1);
-      oval[p0 + val_slot(i, nb)] = val[p0 + pos];
+    const int32_t cmin = (int32_t)(keys[0] >> 16), cmax = (int32_t)(keys[nb - 1] >> 16);
+    const bool can_pack = (int64_t)cmax - (int64_t)cmin < (int64_t)(1u << COL_BITS);
+    // multi-base?  count the windows for ob = 14 ... 10
+    int ob = 0, nwin = 0;
+    if (mb_on && (!can_pack || nrows <= mb_max_rows)) {
+      for (int t = 14; t >= 10 && ob == 0; t--) {
+        int cnt = 0;
+        for (int i0 = 0; i0 < nb; i0 += WAVE) {
+          const int i = i0 + lane;
+          const bool fl = i < nb && (i == 0 || (((uint32_t)(keys[i] >> 16)) >> t) != (((uint32_t)(keys[i - 1] >> 16)) >> t));
+          cnt += __popcll(__ballot(fl));
+        }
+        if (cnt <= (1 << (16 - t)) && cnt <= MB_MAX_WIN && 4 * cnt + 2 * nb <= 4 * nb) { ob = t; nwin = cnt; }
+      }
     }
-    if (lane == 0) blk[b].cbase = cmin;
-    __builtin_amdgcn_wave_barrier();
+    if (ob) {
+      // window of every sorted entry, its base; then the words at their row-major positions
+      int run = 0;
+      for (int i0 = 0; i0 < nb; i0 += WAVE) {
+        const int i = i0 + lane;
+        // (the keys of the round before carry their window in bits 48..: compare the column fields only)
+        const bool fl = i < nb && (i == 0 || (((uint32_t)(keys[i] >> 16)) >> ob) != (((uint32_t)(keys[i - 1] >> 16)) >> ob));
+        const unsigned long long bal = __ballot(fl);
+        const int id = run + __popcll(bal & ((lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull)))) - 1;
+        if (fl) tab[id] = (uint32_t)(keys[i] >> 16);
+        if (i < nb) keys[i] = (keys[i] & 0xffffffffffffull) | ((unsigned long long)id << 48);   // columns are < 2^29: bits 48.. are free
+        run += __popcll(bal);
+      }
+      lds_sync();
+      for (int i = lane; i < nb; i += WAVE) {
+        const unsigned long long k = keys[i];
+        const int id = (int)(k >> 48), pos = (int)(k & 0xffffull);
+        const uint32_t c = (uint32_t)((k >> 16) & 0xffffffffull);
+        word[val_slot(pos, nb)] = (unsigned short)((id << ob) | (int)(c - tab[id]));
+      }
+      lds_sync();
+      // region: table (byte offsets of the windows' first columns), then the words two per dword
+      uint32_t* reg = oidx + p0;
+      for (int k = lane; k < nwin; k += WAVE) reg[k] = tab[k] << 3;
+      const int nd = (nb + 1) >> 1;
+      for (int k = lane; k < nd; k += WAVE) {
+        const uint32_t lo = word[2 * k], hi = 2 * k + 1 < nb ? word[2 * k + 1] : 0u;
+        reg[nwin + k] = lo | (hi << 16);
+      }
+      for (int i = lane; i < nb; i += WAVE) oval[p0 + val_slot(i, nb)] = val[p0 + i];
+      if (lane == 0) { blk[b].cbase = -2 - (ob | (nwin << MB_WIN_SHIFT)); blk[b].ip = 4 * (int64_t)(nwin + nd); }
+    } else if (can_pack) {
+      for (int i = lane; i < nb; i += WAVE) {
+        const unsigned long long k = keys[i];
+        const int pos = (int)(k & 0xffffull);
+        oidx[p0 + i] = ((uint32_t)((int32_t)(k >> 16) - cmin) << (POS_BITS + 3)) | (uint32_t)(pos + 1);
+        oval[p0 + val_slot(i, nb)] = val[p0 + pos];
+      }
+      if (lane == 0) blk[b].cbase = cmin;
+    } else {
+      for (int i = lane; i < nb; i += WAVE) oval[p0 + val_slot(i, nb)] = val[p0 + i];
+    }
+    lds_sync();
   }
 }
 
+// the index regions back to back: ip_in[b] = size of block b's region (bytes, a multiple of 4), ip_out[b] = its offset in the
+// compact stream; the region is copied from where k_block_pack left it (byte 4 * p0 of `src`)
+__global__ __launch_bounds__(BLOCK) void k_region_sizes(int64_t nblocks, const BlkDesc* __restrict__ blk, int64_t* __restrict__ sz) {
+  const int64_t stride = (int64_t)gridDim.x * BLOCK;
+  for (int64_t b = (int64_t)blockIdx.x * BLOCK + threadIdx.x; b < nblocks; b += stride) sz[b] = blk[b].ip;
+}
+__global__ __launch_bounds__(BLOCK) void k_idx_compact(int64_t nblocks, BlkDesc* __restrict__ blk, const int64_t* __restrict__ off,
+                                                      const uint32_t* __restrict__ src, uint8_t* __restrict__ dst) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * BLOCK) >> 6;
+  for (int64_t b = wave; b < nblocks; b += nwaves) {
+    const int64_t nd = blk[b].ip >> 2, o = off[b];
+    const uint32_t* __restrict__ from = src + blk[b].p0;
+    uint32_t* __restrict__ to = reinterpret_cast<uint32_t*>(dst + o);
+    for (int64_t k = lane; k < nd; k += WAVE) to[k] = from[k];
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) blk[b].ip = o;
+  }
+}
+
+// column of the k-th stored entry of a block (any kind; storage order, which is all a scan over the entries needs)
+__device__ __forceinline__ int32_t stored_column(const BlkDesc& d, const uint8_t* __restrict__ idx, int64_t k) {
+  const uint32_t* __restrict__ w = reinterpret_cast<const uint32_t*>(idx + d.ip);
+  if (d.cbase >= 0) return d.cbase + (int32_t)(w[k] >> (POS_BITS + 3));
+  if (d.cbase == -1) return (int32_t)w[k];
+  const int meta = -(d.cbase + 2), ob = meta & MB_OB_MASK, nwin = meta >> MB_WIN_SHIFT;
+  const uint32_t q = (w[nwin + (k >> 1)] >> ((k & 1) * 16)) & 0xffffu;
+  return (int32_t)((w[q >> ob] >> 3) + (q & ((1u << ob) - 1u)));
+}
+
 // flag[b] = 1 if block b references a ghost column (column >= n_local); one wave per block
-__global__ __launch_bounds__(BLOCK) void k_boundary_flags(int64_t nblocks, const BlkDesc* __restrict__ blk, const uint32_t* __restrict__ idx,
+__global__ __launch_bounds__(BLOCK) void k_boundary_flags(int64_t nblocks, const BlkDesc* __restrict__ blk, const uint8_t* __restrict__ idx,
                                                          int32_t n_local, uint8_t* __restrict__ flag) {
   const int lane = threadIdx.x & (WAVE - 1);
   const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * BLOCK) >> 6;
   for (int64_t b = wave; b < nblocks; b += nwaves) {
-    const int32_t cbase = blk[b].cbase;
+    const BlkDesc d = blk[b];
     bool any = false;
-    for (int64_t k = blk[b].p0 + lane; k < blk[b].p0 + blk[b].nb; k += WAVE) {
-      const int32_t c = cbase >= 0 ? cbase + (int32_t)(idx[k] >> (POS_BITS + 3)) : (int32_t)idx[k];
-      any |= c >= n_local;
-    }
+    for (int64_t k = lane; k < d.nb; k += WAVE) any |= stored_column(d, idx, k) >= n_local;
     if (__any(any) && lane == 0) flag[b] = 1;
   }
 }
@@ -710,17 +920,23 @@ void devmat_from_csr_device(int64_t m, int64_t n, const int64_t* d_rp, const int
   out.blk = (BlkDesc*)alloc_out(sizeof(BlkDesc) * (size_t)(out.nblocks + 1));
   out.roff = (uint16_t*)alloc_out(sizeof(uint16_t) * (size_t)m);
   hipLaunchKernelGGL((k_chunk_blocks<true>), dim3(grid1d(nchunks)), dim3(BLOCK), 0, s, m, d_nrp, d_cnt, d_first, out.blk, out.roff);
-  const BlkDesc end{out.nnz, (int32_t)m, 0, 0, 0, {0, 0}};       // readable padding entry (empty block)
+  const BlkDesc end{out.nnz, (int32_t)m, 0, 0, 0, 0};            // readable padding entry (empty block)
   HIP_CHECK(hipMemcpyAsync(out.blk + out.nblocks, &end, sizeof(BlkDesc), hipMemcpyHostToDevice, s));
-  out.idx = (uint32_t*)alloc_out(sizeof(uint32_t) * (size_t)(out.nnz + 1));
   out.val = (double*)alloc_out(sizeof(double) * (size_t)(out.nnz + 1));
-  HIP_CHECK(hipMemsetAsync(out.idx + out.nnz, 0, sizeof(uint32_t), s));
   HIP_CHECK(hipMemsetAsync(out.val + out.nnz, 0, sizeof(double), s));
   const int g = (int)std::min<int64_t>((out.nblocks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 4096);
-  hipLaunchKernelGGL(k_block_pack, dim3(g < 1 ? 1 : g), dim3(BLOCK), 0, s, out.nblocks, out.nnz, m, out.blk, tcol, tval, out.idx, out.val);
+  // kinds, values and index regions (in place over tcol), then the regions back to back
+  hipLaunchKernelGGL(k_block_pack, dim3(g < 1 ? 1 : g), dim3(BLOCK), 0, s, out.nblocks, out.nnz, m, out.blk, tcol, tval, out.val, g_mb16, g_mb16_max_rows);
+  int64_t* d_sz = (int64_t*)dev_alloc(sizeof(int64_t) * (size_t)out.nblocks);
+  int64_t* d_off = (int64_t*)dev_alloc(sizeof(int64_t) * (size_t)out.nblocks);
+  hipLaunchKernelGGL(k_region_sizes, dim3(grid1d(out.nblocks)), dim3(BLOCK), 0, s, out.nblocks, out.blk, d_sz);
+  out.idx_bytes = device_exclusive_scan(out.nblocks, d_sz, d_off, s);
+  out.idx = (uint8_t*)alloc_out((size_t)out.idx_bytes + 4);
+  HIP_CHECK(hipMemsetAsync(out.idx + out.idx_bytes, 0, 4, s));
+  hipLaunchKernelGGL(k_idx_compact, dim3(g < 1 ? 1 : g), dim3(BLOCK), 0, s, out.nblocks, out.blk, d_off, reinterpret_cast<const uint32_t*>(tcol), out.idx);
   HIP_CHECK(hipStreamSynchronize(s));
   check_launch("row-block conversion");
-  dev_free(d_nrp); dev_free(d_cnt); dev_free(d_first); dev_free(tcol); dev_free(tval);
+  dev_free(d_nrp); dev_free(d_cnt); dev_free(d_first); dev_free(tcol); dev_free(tval); dev_free(d_sz); dev_free(d_off);
 }
 
 void devmat_free(DevMat& A) {

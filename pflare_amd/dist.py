@@ -273,28 +273,52 @@ def distribute(pc_global, A_top, owner, comm, src=0, meta_group=None, bulk_group
     """Collective.  Rank `src` passes its set-up PCAIR (host hierarchy present), the fine
     operator and owner[]; the others pass None.  Returns this rank's distributed PCAIR and the
     global indices of its rows."""
+    import time
     import torch.distributed as dist
     rank, size = dist.get_rank(), dist.get_world_size()
     mine = None
+    phases = dict(cut_plan_s=0.0, cut_extract_s=0.0, ship_s=0.0, upload_s=0.0)
     if rank == src:
+        # the cut of rank r + 1 (OpenMP inside the library, the GIL released) runs on a worker thread while the piece of
+        # rank r travels: at 464^3 the two were ~40 s one after the other (extrapolated from 6 s at 256^3)
+        from concurrent.futures import ThreadPoolExecutor
+        t0 = time.time()
         part = Partition(pc_global, A_top, size, owner)
-        for r in range(size):
-            ar = part.extract(r)
-            if log:
-                log(f"piece of rank {r}: {ar.nbytes() / 1e9:.2f} GB")
-            if r == src:
-                mine = ar
-            else:
-                _send_piece(ar, r, meta_group, bulk_group, bulk_on_gpu)
-                ar.close()
+        phases["cut_plan_s"] = time.time() - t0
+
+        def cut(r):
+            t = time.time()
+            a = part.extract(r)
+            return a, time.time() - t
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            nxt = pool.submit(cut, 0)
+            for r in range(size):
+                ar, dt = nxt.result()
+                phases["cut_extract_s"] += dt
+                if r + 1 < size:
+                    nxt = pool.submit(cut, r + 1)
+                if log:
+                    log(f"piece of rank {r}: {ar.nbytes() / 1e9:.2f} GB (cut in {dt:.1f} s)")
+                if r == src:
+                    mine = ar
+                else:
+                    t = time.time()
+                    _send_piece(ar, r, meta_group, bulk_group, bulk_on_gpu)
+                    phases["ship_s"] += time.time() - t
+                    ar.close()
         part.close()
     else:
+        t = time.time()
         mine = _recv_piece(src, meta_group, bulk_group, bulk_on_gpu)
+        phases["ship_s"] = time.time() - t      # includes the wait for the pieces of the ranks before this one
     gid = dict(mine.items())["gid"].copy()
     pc = PCAIR()
     if profile:
         pc.profile(True)
+    t = time.time()
     check(lib().airhip_pcair_load_distributed(pc._h, mine._h, comm._h))
+    phases["upload_s"] = time.time() - t
     mine.close()
     pc._comm = comm          # the communicator must outlive the PCAIR
+    pc.distribute_phases = phases
     return pc, gid

@@ -505,6 +505,17 @@ class DeviceMat:
         check(lib().airhip_mat_mult(self._h, _ptr(x), _ptr(y)))
         return y
 
+    def blocks(self):
+        """diagnostic: the row-block form as it lies on the device (airhip_mat_blocks): descriptors (structured array),
+        index regions (bytes), values, row offsets"""
+        nb, ib, nz = C.c_int64(), C.c_int64(), C.c_int64()
+        check(lib().airhip_mat_blocks(self._h, C.byref(nb), C.byref(ib), C.byref(nz), None, None, None, None))
+        desc = np.zeros(nb.value, dtype=np.dtype([("p0", "<i8"), ("row", "<i4"), ("cbase", "<i4"), ("nb", "<i4"), ("nr", "<i4"), ("ip", "<i8")]))
+        idx = np.zeros(max(ib.value, 1), dtype=np.uint8); val = np.zeros(max(nz.value, 1)); roff = np.zeros(max(self.shape[0], 1), dtype=np.uint16)
+        check(lib().airhip_mat_blocks(self._h, C.byref(nb), C.byref(ib), C.byref(nz), desc.ctypes.data, idx.ctypes.data, val.ctypes.data,
+                                      roff.ctypes.data))
+        return desc, idx[:ib.value], val[:nz.value], roff[:self.shape[0]]
+
     def mult_async(self, x, y):
         """y = A x ordered on torch's current stream, no host synchronisation"""
         check(lib().airhip_mat_mult_on_stream(self._h, _ptr(x), _ptr(y), _caller_stream(x)))

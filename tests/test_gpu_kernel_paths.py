@@ -1,9 +1,12 @@
 """Every path of the row-block SpMV kernel (csrc/device/spmv.hip), hit on purpose and checked against scipy
 (airhip_mat_mult through the C ABI, <= 1e-13 relative: PFLARE_TOL_MATFREE_13, src/Pflare_Parameters.F90:209):
 
-* packed blocks (column-sorted, block-relative 19-bit columns: rb.hpp COL_BITS) and raw blocks (column span >= 2^19:
-  row-major, absolute columns) - the round-1 kernel switched formats on the operator width (2^22 columns) and the wide
-  mode, the one the 464^3 benchmark runs, had no test;
+* packed blocks (column-sorted, block-relative 19-bit columns: rb.hpp COL_BITS), raw blocks (row-major, absolute columns)
+  and multi-base blocks (row-major, 16-bit window | offset words, dev.hpp BlkDesc) - every test of this file runs under
+  three conversion settings: the default (blocks of <= 8 rows and blocks that cannot be packed go multi-base), multi-base
+  off (the round-3 format) and multi-base wherever it fits; the three must agree BIT FOR BIT (same products, same order
+  of additions) - the round-1 kernel switched formats on the operator width (2^22 columns) and the wide mode, the one
+  the 464^3 benchmark runs, had no test;
 * every straight-line variant of the block code (0 ... 8 full rounds of 64 entries, with and without a partial round; values
   of paired full rounds interleaved for 16-byte loads), on packed and on raw blocks;
 * a row longer than a block (wave-per-row reduction), rows of exactly 512 / 513 entries;
@@ -67,11 +70,22 @@ def _rows(lengths, n, rng, local=None):
     return sp.csr_matrix((vals, cols, indptr), shape=(m, n))
 
 
-@pytest.fixture(scope="module")
-def env(gpu):
+FORMATS = {"default": (1, 8), "mb16-off": (0, 8), "mb16-everywhere": (1, 128)}
+
+
+def _set_format(P, name):
+    on, rows = FORMATS[name]
+    assert P.lib().airhip_set_tuning(b"mb16", on) == 0
+    assert P.lib().airhip_set_tuning(b"mb16_max_rows", rows) == 0
+
+
+@pytest.fixture(scope="module", params=list(FORMATS))
+def env(gpu, request):
     import torch
     import pflare_amd as P
-    return torch, P
+    _set_format(P, request.param)
+    yield torch, P
+    _set_format(P, "default")
 
 
 def test_packed_and_raw_blocks_on_a_wide_operator(env):
@@ -209,8 +223,137 @@ def test_fused_epilogues_through_matrix_free_polynomials(env, itype, order, diag
 
 
 def test_tuning_hook_refuses_unknown_keys(env):
-    """airhip_set_tuning is declared in the header; the kernels currently expose no knob, so every key is refused
-    with AIRHIP_ERR_ARG and an error text"""
+    """airhip_set_tuning is declared in the header; an unknown key is refused with AIRHIP_ERR_ARG and an error text"""
     torch, P = env
     assert P.lib().airhip_set_tuning(b"no_such_key", 1) != 0
     assert b"no_such_key" in P.lib().airhip_last_error()
+
+
+def _val_slot(s, n):
+    """memory position of the value (and of the 16-bit word) of logical slot s in a block of n <= 512 entries: every pair of
+    full rounds of 64 is interleaved lane by lane (spmv.hip: val_slot)"""
+    npair = (n >> 6) >> 1
+    s = np.asarray(s)
+    inter = (s >> 7) * 128 + 2 * (s & 63) + ((s >> 6) & 1)
+    return np.where(s >= 128 * npair, s, inter)
+
+
+def decode_blocks(dm):
+    """the CSR a DeviceMat holds, decoded from its row blocks on the host (every kind of index region, dev.hpp BlkDesc)"""
+    desc, idx, val, roff = dm.blocks()
+    m = dm.shape[0]
+    indptr = np.zeros(m + 1, dtype=np.int64)
+    cols_out, vals_out = [], []
+    kinds = {"packed": 0, "raw": 0, "multi-base": 0}
+    for d in desc:
+        p0, row, cbase, nb, nr, ip = (int(d[k]) for k in ("p0", "row", "cbase", "nb", "nr", "ip"))
+        if nb == 0:
+            continue
+        assert ip % 4 == 0
+        n512 = min(nb, 512)
+        slot = np.arange(nb)
+        vpos = np.where(slot < n512, _val_slot(np.minimum(slot, n512 - 1), n512), slot)
+        v = val[p0 + vpos]                                   # value of logical slot s
+        if cbase >= 0:
+            w = idx[ip:ip + 4 * nb].view("<u4")
+            col = cbase + (w >> 13).astype(np.int64)
+            pos = (w & 1023).astype(np.int64) - 1            # row-major position of slot s
+            assert np.array_equal(np.sort(pos), np.arange(nb)), "positions of a packed block are not a permutation"
+            assert np.all(np.diff(col) >= 0), "a packed block is not sorted by column"
+            c_rm = np.empty(nb, dtype=np.int64); v_rm = np.empty(nb)
+            c_rm[pos] = col; v_rm[pos] = v
+            kinds["packed"] += 1
+        elif cbase == -1:
+            c_rm = idx[ip:ip + 4 * nb].view("<u4").astype(np.int64); v_rm = v
+            kinds["raw"] += 1
+        else:
+            meta = -(cbase + 2); ob = meta & 31; nwin = meta >> 5
+            assert nb <= 512 and 1 <= nwin <= 64 and nwin <= (1 << (16 - ob))
+            tab = idx[ip:ip + 4 * nwin].view("<u4").astype(np.int64)
+            assert np.all(tab % 8 == 0) and np.all(np.diff(tab) > 0)
+            words = idx[ip + 4 * nwin:ip + 4 * nwin + 2 * nb].view("<u2").astype(np.int64)
+            wd = words[_val_slot(slot, nb)]                  # word of logical slot s = row-major position s
+            assert np.all((wd >> ob) < nwin)
+            c_rm = tab[wd >> ob] // 8 + (wd & ((1 << ob) - 1)); v_rm = v
+            kinds["multi-base"] += 1
+        # rows of the block
+        ro = roff[row:row + nr].astype(np.int64)
+        if nb > 512:
+            assert nr == 1
+            ro = np.zeros(1, dtype=np.int64)
+        ends = np.concatenate([ro[1:], [nb]])
+        assert ro[0] == 0 and np.all(ends >= ro)
+        indptr[row + 1:row + nr + 1] = ends - ro
+        cols_out.append((p0, c_rm)); vals_out.append(v_rm)
+    np.cumsum(indptr, out=indptr)
+    nnz = int(indptr[-1])
+    cols = np.zeros(nnz, dtype=np.int64); vals = np.zeros(nnz)
+    for (p0, c), v in zip(cols_out, vals_out):
+        cols[p0:p0 + c.size] = c; vals[p0:p0 + c.size] = v
+    return indptr, cols, vals, kinds
+
+
+def test_row_blocks_decode_to_the_matrix_that_went_in(env):
+    """index work is bit-exact: the device's row blocks - packed, raw and multi-base regions, interleaved values, row
+    offsets - decoded on the host give back the CSR entry for entry"""
+    torch, P = env
+    rng = np.random.default_rng(21)
+    mats = [_rows([per_row] * 200, 70_000, rng, local=30_000) for per_row in (1, 3, 8, 40, 64, 65, 100, 127, 128, 129, 200, 256, 300, 511, 512)]
+    mats += [_rows([per_row] * 150, 3_000_000, rng) for per_row in (2, 9, 70, 300)]
+    mats.append(_rows(rng.integers(0, 600, size=1500), 500_000, rng, local=9000))
+    mats.append(_rows([5, 513, 700, 2, 4097, 1, 512, 511, 0, 0, 3], 40_000, rng))
+    # rows that touch a few far-apart clusters (the sections of a hierarchical vector): windows of every width
+    m = 3000
+    lengths = rng.integers(1, 60, size=m)
+    indptr = np.concatenate([[0], np.cumsum(lengths)])
+    cols = np.empty(indptr[-1], dtype=np.int64)
+    for i in range(m):
+        k = int(lengths[i])
+        centres = np.array([0, 900_000, 1_400_000, 1_650_000, 1_780_000]) + (i // 4) * 37
+        c = centres[rng.integers(0, 5, size=k)] + rng.integers(0, 3000, size=k)
+        cols[indptr[i]:indptr[i + 1]] = np.sort(c)
+    A5 = sp.csr_matrix((rng.standard_normal(indptr[-1]), cols, indptr), shape=(m, 2_000_000))
+    A5.sum_duplicates(); A5.sort_indices()
+    mats.append(A5)
+    seen = {"packed": 0, "raw": 0, "multi-base": 0}
+    for A in mats:
+        A = sp.csr_matrix(A); A.sum_duplicates(); A.sort_indices()
+        dm = P.DeviceMat(A)
+        ip, ci, v, kinds = decode_blocks(dm)
+        assert np.array_equal(ip, A.indptr.astype(np.int64))
+        assert np.array_equal(ci, A.indices.astype(np.int64))
+        assert np.array_equal(v, A.data)
+        for k in kinds:
+            seen[k] += kinds[k]
+    assert seen["packed"] + seen["raw"] + seen["multi-base"] > 0
+
+
+def test_the_three_conversions_agree_bit_for_bit(gpu):
+    """the same operators converted with multi-base blocks off / by default / everywhere: identical products.  Rows of
+    every length class, local and scattered columns (windows of every width, blocks that cannot be packed), 1 ... 128 rows
+    per block, long rows"""
+    import torch
+    import pflare_amd as P
+    rng = np.random.default_rng(11)
+    mats = []
+    for per_row in (1, 3, 8, 40, 64, 100, 200, 256, 300, 511, 512):
+        mats.append(_rows([per_row] * 300, 70_000, rng, local=30_000))        # windows of 2^10 ... 2^14 entries all occur
+        mats.append(_rows([per_row] * 300, 3_000_000, rng))                   # span >= 2^19: multi-base or raw
+    mats.append(_rows(rng.integers(0, 600, size=2000), 500_000, rng, local=9000))
+    mats.append(_rows([5, 513, 700, 2, 4097, 1, 512, 511], 40_000, rng))
+    try:
+        outs = {}
+        for name in FORMATS:
+            _set_format(P, name)
+            outs[name] = []
+            for A in mats:
+                dm = P.DeviceMat(A)
+                x = torch.from_numpy(lcg_vector(A.shape[1])).cuda()
+                y = torch.empty(A.shape[0], dtype=torch.float64, device="cuda")
+                dm.mult(x, y)
+                outs[name].append(y)
+        for name in ("mb16-off", "mb16-everywhere"):
+            for k, (a, b) in enumerate(zip(outs["default"], outs[name])):
+                assert torch.equal(a, b), (name, k)
+    finally:
+        _set_format(P, "default")
