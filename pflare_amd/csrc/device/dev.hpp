@@ -31,6 +31,8 @@ namespace airhip {
 //                run through several sections of a hierarchical vector (A_fc), which were raw before round 4.
 struct alignas(32) BlkDesc { int64_t p0; int32_t row; int32_t cbase; int32_t nb; int32_t nr; int64_t ip; };
 constexpr int MB_OB_MASK = 31, MB_WIN_SHIFT = 5, MB_MAX_WIN = 64;
+// the blocks the lean kernels process (spmv.hip): multi-base blocks, and raw blocks of at most 512 entries
+__host__ __device__ inline bool lean_block(const BlkDesc& q) { return q.cbase <= -2 || (q.cbase == -1 && q.nb <= 512); }
 
 // Row-block CSR.  One wavefront streams a block's (index word, value) pairs with coalesced loads, gathers x,
 // stages the products a_ij * x_j in LDS at their row-major positions and then sums every row's LDS segment
@@ -47,15 +49,17 @@ struct DevMat {
   uint8_t* idx = nullptr;        // [idx_bytes + 4] the blocks' index regions back to back (BlkDesc::ip), one readable padding word
   int64_t idx_bytes = 0;
   double* val = nullptr;         // [nnz+1]
-  // distributed operand: the row blocks that touch no ghost column (interior) / at least one (boundary), as
-  // descriptor arrays of their own; the interior blocks run while the neighbour exchange is in flight
+  // Launch lists: copies of the descriptors in processing order, the multi-base blocks FIRST (they run in the lean kernels,
+  // the other kinds in the *_g kernels - spmv.hip): [0, n_mb*) multi-base, [n_mb*, n*) the rest, each part in order.
+  //  desc_ord  all nblocks blocks.  Storage order, or - operators whose rows run through the sections of a hierarchical
+  //            vector - the spatial order of their rows, so that the blocks of different sections that gather the same
+  //            neighbourhood of x run close together in time (DevPCAIR::upload);
+  //  desc_int / desc_bnd  distributed operand: the row blocks that touch no ghost column (interior) / at least one
+  //            (boundary); the interior blocks run while the neighbour exchange is in flight
+  BlkDesc* desc_ord = nullptr; int64_t n_mb = 0;
   BlkDesc* desc_int = nullptr; BlkDesc* desc_bnd = nullptr;
-  int64_t n_int = 0, n_bnd = 0;
-  // optional processing order of the row blocks (all nblocks of them): operators whose rows run through the sections
-  // of a hierarchical vector are swept in the spatial order of their rows, so that the blocks of different sections
-  // that gather the same neighbourhood of x run close together in time (DevPCAIR::upload): the descriptors again,
-  // in that order
-  BlkDesc* desc_ord = nullptr;
+  int64_t n_int = 0, n_bnd = 0, n_mb_int = 0, n_mb_bnd = 0;
+  int64_t nnz_mb = 0;            // non-zeros in multi-base blocks
   // transient operator (the setup's truncation test): its four arrays come from the block cache of device/devmem.hpp and go
   // back to it - a hipMalloc that follows the release of multi-GB blocks stalls for seconds every so often
   bool cached = false;
@@ -64,6 +68,8 @@ struct DevMat {
   double s_bytes() const { return 12.0 * nnz + 4.0 * (m + 1) + 8.0 * m + 8.0 * n; }
   // bytes the format actually holds
   double stored_bytes() const { return 8.0 * (nnz + 1) + (double)idx_bytes + 4.0 + 2.0 * m + 32.0 * nblocks * (desc_ord ? 2 : 1); }
+  // share of s_bytes() that the lean kernels' launches carry
+  double mb_share() const { return nnz > 0 ? (double)nnz_mb / (double)nnz : 1.0; }
 };
 
 // out_i = alpha * s_i + beta * z_i + gamma * w_i,  s = (A x)_i [ * dscale_i ]
@@ -80,10 +86,12 @@ struct SpmvEpi {
   int setup_phase = 0;
 };
 
+// which launch list (DevMat) and which of its two parts a launch covers
+enum { RB_ALL = 0, RB_INTERIOR = 1, RB_BOUNDARY = 2 };
+enum { RB_BOTH = 0, RB_MB = 1, RB_GENERAL = 2 };
 // x_ghost: the received ghost values of a distributed operand (A.n_ghost entries), else null
-// blks / nblks: restrict the launch to these row blocks (descriptor array; null = all, in A.desc_ord's order if present)
 void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t s, const double* x_ghost = nullptr,
-                 const BlkDesc* blks = nullptr, int64_t nblks = 0);
+                 int list = RB_ALL, int part = RB_BOTH);
 
 // Fused first stage of an F-point relaxation with a one-point prolongator:
 //   acc = (A_fc x_c)_i ; t4 = b_f_i - acc ; x0 = x_c[wcol_i] (0 if wcol_i < 0)
@@ -91,11 +99,14 @@ void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t
 //   split mode                     :  t4_out_i = t4 ; x_f_i = x0
 void launch_fc_first(const DevMat& A_fc, const int32_t* wcol, const double* b_f, const double* x_c,
                      const double* aff_d, const double* minv, double* t4_out, double* x_f, hipStream_t s,
-                     const double* x_ghost = nullptr, const BlkDesc* blks = nullptr, int64_t nblks = 0);
+                     const double* x_ghost = nullptr, int list = RB_ALL, int part = RB_BOTH);
 // host flags (one per row block): does the block reference a ghost column?
 void devmat_boundary_flags(const DevMat& A, std::vector<uint8_t>& flags, hipStream_t s);
-// a descriptor array holding the blocks order[0 .. n) of A (device memory, released with dev_free_exact)
-BlkDesc* devmat_desc_list(const DevMat& A, const int32_t* order_host, int64_t n, hipStream_t s);
+// a launch list holding the blocks order[0 .. n) of A, multi-base blocks first (device memory, released with
+// dev_free_exact); *n_mb = how many of them are multi-base
+BlkDesc* devmat_desc_list(const DevMat& A, const int32_t* order_host, int64_t n, hipStream_t s, int64_t* n_mb);
+// host side of the same: stable partition of descriptors, multi-base blocks first; returns their number
+int64_t partition_descs_host(std::vector<BlkDesc>& v);
 
 // vector kernels (n elements)
 void launch_axpby(int64_t n, double a, const double* x, double b, const double* y, double* out, hipStream_t s);  // out = a x + b y

@@ -52,9 +52,11 @@ static int64_t g_block_order_min = 4096;      // smaller operators sit in the ca
 void set_block_order_min(int64_t nblocks) { g_block_order_min = nblocks > 0 ? nblocks : 1; }
 static bool g_fc_fuse = true;
 void set_fc_fuse(bool on) { g_fc_fuse = on; }
+static int g_fc_spatial = 1;       // 0 off, 1 levels with at least 4096 C points, 2 every level (tests)
+void set_fc_spatial(int mode) { g_fc_spatial = mode; }
 
 static void order_blocks_by_key(DevMat& M, const int32_t* dev_row_to_host, const int64_t* key, hipStream_t s) {
-  if (M.nblocks < g_block_order_min || M.desc_ord) return;
+  if (M.nblocks < g_block_order_min || M.cached) return;
   std::vector<BlkDesc> blk((size_t)M.nblocks);
   HIP_CHECK(hipMemcpyAsync(blk.data(), M.blk, sizeof(BlkDesc) * (size_t)M.nblocks, hipMemcpyDeviceToHost, s));
   HIP_CHECK(hipStreamSynchronize(s));
@@ -62,11 +64,12 @@ static void order_blocks_by_key(DevMat& M, const int32_t* dev_row_to_host, const
 #pragma omp parallel for schedule(static)
   for (int64_t b = 0; b < M.nblocks; b++) kb[(size_t)b] = {key[dev_row_to_host ? dev_row_to_host[blk[(size_t)b].row] : blk[(size_t)b].row], (int32_t)b};
   __gnu_parallel::sort(kb.begin(), kb.end());
-  // the descriptors themselves in that order (a launch reads them front to back: no index list in between)
+  // the descriptors themselves in that order (a launch reads them front to back: no index list in between), multi-base
+  // blocks first (DevMat: launch lists); replaces the storage-order list of the conversion
   std::vector<BlkDesc> ord((size_t)M.nblocks);
 #pragma omp parallel for schedule(static)
   for (int64_t b = 0; b < M.nblocks; b++) ord[(size_t)b] = blk[(size_t)kb[(size_t)b].second];
-  M.desc_ord = (BlkDesc*)dev_alloc_exact(sizeof(BlkDesc) * (size_t)M.nblocks);
+  M.n_mb = partition_descs_host(ord);
   HIP_CHECK(hipMemcpy(M.desc_ord, ord.data(), sizeof(BlkDesc) * (size_t)M.nblocks, hipMemcpyHostToDevice));
   if (M.desc_int && M.desc_bnd) {
     // distributed operand with the interior / boundary split: both lists in the same spatial order
@@ -74,6 +77,7 @@ static void order_blocks_by_key(DevMat& M, const int32_t* dev_row_to_host, const
     devmat_boundary_flags(M, fl, s);
     std::vector<BlkDesc> li, lb; li.reserve((size_t)M.n_int); lb.reserve((size_t)M.n_bnd);
     for (int64_t b = 0; b < M.nblocks; b++) { const int32_t q = kb[(size_t)b].second; (fl[(size_t)q] ? lb : li).push_back(blk[(size_t)q]); }
+    M.n_mb_int = partition_descs_host(li); M.n_mb_bnd = partition_descs_host(lb);
     if (!li.empty()) HIP_CHECK(hipMemcpy(M.desc_int, li.data(), sizeof(BlkDesc) * li.size(), hipMemcpyHostToDevice));
     if (!lb.empty()) HIP_CHECK(hipMemcpy(M.desc_bnd, lb.data(), sizeof(BlkDesc) * lb.size(), hipMemcpyHostToDevice));
   }
@@ -151,16 +155,30 @@ void DevPCAIR::spmv(const DevMat& A, const double* x, const SpmvEpi& e, const ch
   if (profile_) { id = stat_id(name, level, bytes_override >= 0 ? bytes_override : A.s_bytes()); stats_[id].kernel = "k_rb_spmv"; }
   if (begin_exchange(A, x)) {
     if (profile_) begin_kernel(id);
-    launch_spmv(A, x, e, stream_, A.halo->recvbuf, A.desc_int, A.n_int);   // rows that read no ghost value
+    launch_spmv(A, x, e, stream_, A.halo->recvbuf, RB_INTERIOR);   // rows that read no ghost value
     wait_exchange();
-    launch_spmv(A, x, e, stream_, A.halo->recvbuf, A.desc_bnd, A.n_bnd);
+    launch_spmv(A, x, e, stream_, A.halo->recvbuf, RB_BOUNDARY);
     if (profile_) end_kernel();
     return;
   }
   const double* xg = halo_update(A, x);
-  if (profile_) begin_kernel(id);      // times the product, not the exchange
-  launch_spmv(A, x, e, stream_, xg);
-  if (profile_) end_kernel();
+  if (!profile_) { launch_spmv(A, x, e, stream_, xg); return; }
+  // times the product, not the exchange; the blocks outside the multi-base form run in a kernel of their own
+  // (k_rb_spmv_g) and are accounted for under that name, with their share of the operator's bytes
+  const double bytes = bytes_override >= 0 ? bytes_override : A.s_bytes(), share = A.mb_share();
+  if (A.n_mb > 0) {
+    stats_[id].alg_bytes = A.n_mb < A.nblocks ? bytes * share : bytes;
+    begin_kernel(id);
+    launch_spmv(A, x, e, stream_, xg, RB_ALL, RB_MB);
+    end_kernel();
+  }
+  if (A.n_mb < A.nblocks) {
+    const int idg = A.n_mb > 0 ? stat_id((std::string(name) + " [other blocks]").c_str(), level, bytes * (1.0 - share)) : id;
+    stats_[idg].kernel = "k_rb_spmv_g";
+    begin_kernel(idg);
+    launch_spmv(A, x, e, stream_, xg, RB_ALL, RB_GENERAL);
+    end_kernel();
+  }
 }
 
 // Starts the neighbour exchange of a distributed operand on the communication stream.  Ordering: the
@@ -223,8 +241,8 @@ void DevPCAIR::attach_halo(DevMat& M, const HaloHost* h, const int32_t* host_col
     std::vector<int32_t> li, lb;
     for (int64_t b = 0; b < M.nblocks; b++) (fl[b] ? lb : li).push_back((int32_t)b);
     M.n_int = (int64_t)li.size(); M.n_bnd = (int64_t)lb.size();
-    M.desc_int = devmat_desc_list(M, li.data(), M.n_int, stream_);
-    M.desc_bnd = devmat_desc_list(M, lb.data(), M.n_bnd, stream_);
+    M.desc_int = devmat_desc_list(M, li.data(), M.n_int, stream_, &M.n_mb_int);
+    M.desc_bnd = devmat_desc_list(M, lb.data(), M.n_bnd, stream_, &M.n_mb_bnd);
   }
 }
 
@@ -461,8 +479,28 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
       levels_.push_back(std::move(dl));
       continue;
     }
-    upload_mat(h.A_fc, Frow, pc.p, d.A_fc, stream_, ng(hl ? &hl->A_fc : nullptr));   // rows F block, cols permuted coarse
-    attach_halo(d.A_fc, hl ? &hl->A_fc : nullptr, perm[l + 1].data());
+    // columns of A_fc (and of the one-point prolongator): positions in x_c = the level-(l+1) vector, or - single device,
+    // set_fc_spatial - positions in the copy of x_c that f_smooths keeps in the spatial order of the C points
+    std::vector<int32_t> csp;              // coarse index -> spatial rank (empty: not used)
+    const bool fc_spatial = g_fc_spatial && !dist && (g_fc_spatial >= 2 || h.n_c >= 4096);
+    if (fc_spatial) {
+      const std::vector<int64_t>& kc = level_keys[l + 1];
+      std::vector<int32_t> ord((size_t)h.n_c), src((size_t)h.n_c);
+      csp.resize((size_t)h.n_c);
+#pragma omp parallel for schedule(static)
+      for (int64_t i = 0; i < h.n_c; i++) ord[(size_t)i] = (int32_t)i;
+      __gnu_parallel::sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) { return kc[(size_t)a] != kc[(size_t)b] ? kc[(size_t)a] < kc[(size_t)b] : a < b; });
+      const int32_t* pn = perm[l + 1].data();
+#pragma omp parallel for schedule(static)
+      for (int64_t r = 0; r < h.n_c; r++) { csp[(size_t)ord[(size_t)r]] = (int32_t)r; src[(size_t)r] = pn[ord[(size_t)r]]; }
+      d.xs_src.upload(src.data(), h.n_c);
+      d.xs.alloc(h.n_c);
+      DBuf<int32_t> cspd; cspd.upload(csp.data(), h.n_c);
+      upload_mat(h.A_fc, Frow, cspd.p, d.A_fc, stream_, 0);
+    } else {
+      upload_mat(h.A_fc, Frow, pc.p, d.A_fc, stream_, ng(hl ? &hl->A_fc : nullptr));   // rows F block, cols permuted coarse
+      attach_halo(d.A_fc, hl ? &hl->A_fc : nullptr, perm[l + 1].data());
+    }
     upload_mat(h.Z, ipc.p, Fcol, d.Z, stream_, ng(hl ? &hl->Z : nullptr));           // rows permuted coarse, cols F block
     attach_halo(d.Z, hl ? &hl->Z : nullptr, fph);
     if (order_blocks) order_blocks_by_key(d.Z, ipn.data(), level_keys[l + 1].data(), stream_);
@@ -489,7 +527,7 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
       const int32_t* pn = perm[l + 1].data();
       // distributed: columns >= n_c are ghost columns of A_fc and keep their index
 #pragma omp parallel for schedule(static)
-      for (int64_t i = 0; i < h.n_f; i++) { const int32_t c = h.wcol[i]; wc[fph ? fph[i] : i] = c < 0 ? -1 : (c < h.n_c ? pn[c] : c); }
+      for (int64_t i = 0; i < h.n_f; i++) { const int32_t c = h.wcol[i]; wc[fph ? fph[i] : i] = c < 0 ? -1 : (c < h.n_c ? (fc_spatial ? csp[(size_t)c] : pn[c]) : c); }
       d.wcol.upload(wc.data(), h.n_f);
     } else {
       upload_mat(h.W, Frow, pc.p, d.W, stream_, ng(hl ? &hl->W : nullptr));
@@ -697,6 +735,14 @@ void DevPCAIR::f_smooths(DevLevel& L, int li, bool first, int its) {
   double* x_f = xvec(li); double* x_c = x_f + L.n_f;
   const double* b_f = bvec(li);
   const bool diag_inv = L.aff_diag && L.inv_ff.kind == InvOp::DIAG;
+  const double* x_c_nat = x_c;       // x_c as the level-(l+1) vector: what a general W multiplies
+  if (L.xs.p) {
+    // x_c in the spatial order of the C points, for A_fc and the one-point prolongator
+    prof_begin("x_c to spatial order", li, 20.0 * L.n_c, "k_gather");
+    launch_gather(L.n_c, L.xs_src.p, x_c, L.xs.p, stream_);
+    prof_end();
+    x_c = L.xs.p;
+  }
   if (first && L.one_point && !g_fc_fuse && !L.A_fc.halo && !(diag_inv && its == 1)) {
     // diagnostic: the two steps apart
     launch_gather(L.n_f, L.wcol.p, x_c, x_f, stream_);
@@ -711,9 +757,9 @@ void DevPCAIR::f_smooths(DevLevel& L, int li, bool first, int its) {
     const double* ad = full ? L.aff_d.p : nullptr; const double* mi = full ? L.inv_ff.d.p : nullptr;
     if (begin_exchange(L.A_fc, x_c)) {
       if (profile_) begin_kernel(id);
-      launch_fc_first(L.A_fc, L.wcol.p, b_f, x_c, ad, mi, L.t4.p, x_f, stream_, L.A_fc.halo->recvbuf, L.A_fc.desc_int, L.A_fc.n_int);
+      launch_fc_first(L.A_fc, L.wcol.p, b_f, x_c, ad, mi, L.t4.p, x_f, stream_, L.A_fc.halo->recvbuf, RB_INTERIOR);
       wait_exchange();
-      launch_fc_first(L.A_fc, L.wcol.p, b_f, x_c, ad, mi, L.t4.p, x_f, stream_, L.A_fc.halo->recvbuf, L.A_fc.desc_bnd, L.A_fc.n_bnd);
+      launch_fc_first(L.A_fc, L.wcol.p, b_f, x_c, ad, mi, L.t4.p, x_f, stream_, L.A_fc.halo->recvbuf, RB_BOUNDARY);
     } else {
       const double* xg = halo_update(L.A_fc, x_c);
       if (profile_) begin_kernel(id);
@@ -722,7 +768,7 @@ void DevPCAIR::f_smooths(DevLevel& L, int li, bool first, int its) {
     if (profile_) end_kernel();
     if (full) return;
   } else {
-    if (first) { SpmvEpi e; e.out = x_f; spmv(L.W, x_c, e, "prolong(W)", li); }
+    if (first) { SpmvEpi e; e.out = x_f; spmv(L.W, x_c_nat, e, "prolong(W)", li); }
     SpmvEpi e; e.out = L.t4.p; e.alpha = -1.0; e.z = b_f; e.beta = 1.0;
     spmv(L.A_fc, x_c, e, "t4=b_f-A_fc*x_c", li);
   }
@@ -746,7 +792,9 @@ void DevPCAIR::c_smooths(DevLevel& L, int li, bool first, int its) {
   if (first) {   // prolongation has not been applied yet
     if (L.one_point) {
       if (L.A_fc.halo) throw std::runtime_error("a distributed cycle that starts with C smoothing needs a general W");
-      launch_gather(L.n_f, L.wcol.p, x_c, x_f, stream_);   // wcol < 0 -> 0 (no W entry)
+      const double* xw = x_c;
+      if (L.xs.p) { launch_gather(L.n_c, L.xs_src.p, x_c, L.xs.p, stream_); xw = L.xs.p; }   // wcol counts in the spatial order
+      launch_gather(L.n_f, L.wcol.p, xw, x_f, stream_);   // wcol < 0 -> 0 (no W entry)
     }
     else { SpmvEpi e; e.out = x_f; spmv(L.W, x_c, e, "prolong(W)", li); }
   }

@@ -31,6 +31,11 @@ void set_block_order_min(int64_t nblocks);
 // diagnostic (airhip_set_tuning "fc_fuse"): 0 runs the first stage of an F relaxation as a gather (one-point prolongation)
 // followed by a plain A_fc product instead of the fused k_rb_fc_first; same results, one more pass over the F vectors
 void set_fc_fuse(bool on);
+// (airhip_set_tuning "fc_spatial_x", acts at the next upload) A_fc x_c gathers from a copy of x_c in which the level's C points
+// lie in the order of their locality keys instead of section by section [F_{l+1} | F_{l+2} | ...]: the copy costs 20 bytes per
+// C point and cycle, the blocks of A_fc then touch half as many lines of x.  Same results bit for bit (the order of the
+// entries inside a row does not change).  Single device, one-point or general W; not for distributed hierarchies.
+void set_fc_spatial(int mode);      // 0 off, 1 (default) levels with at least 4096 C points, 2 every level
 
 // Upload a host CSR and convert it to SELL-64 on the device (rows/cols optionally permuted).
 void upload_mat(const Csr& A, const int32_t* d_rowsrc, const int32_t* d_colmap, DevMat& out, hipStream_t s, int64_t n_ghost = 0);
@@ -61,6 +66,9 @@ struct DevLevel {
   DevInv inv_ff, inv_cc;
   int smooth_order[10] = {0};
   DBuf<double> t4, r, t4c, rc;
+  // x_c in the spatial order of the level's C points (set_fc_spatial): A_fc and the one-point prolongator gather from this
+  // copy; xs_src[k] = position in x_c of the point with spatial rank k
+  DBuf<double> xs; DBuf<int32_t> xs_src;
   int64_t nnz_A = 0;
   // full up / down smoothing: the level operator in the level's hierarchical ordering (inv_ff is then n x n) and the
   // residual of the level, whose C part is the next level's right-hand side

@@ -27,9 +27,13 @@ struct RbView {
   int32_t nblocks;                        // how many
   int32_t per_class;                      // ceil(nblocks / 8): the blocks of one XCD class (see my_block)
 };
-inline RbView view_of(const DevMat& A, const BlkDesc* blks, int64_t nblks) {
-  if (!blks) { blks = A.desc_ord ? A.desc_ord : A.blk; nblks = A.nblocks; }
-  return RbView{blks, A.roff, A.idx, A.val, (int32_t)nblks, (int32_t)((nblks + 7) / 8)};
+// the multi-base (mb = true) or the other part of one of A's launch lists
+inline RbView view_of(const DevMat& A, int list, bool mb) {
+  const BlkDesc* d = list == RB_INTERIOR ? A.desc_int : list == RB_BOUNDARY ? A.desc_bnd : A.desc_ord;
+  const int64_t n = list == RB_INTERIOR ? A.n_int : list == RB_BOUNDARY ? A.n_bnd : A.nblocks;
+  const int64_t nm = list == RB_INTERIOR ? A.n_mb_int : list == RB_BOUNDARY ? A.n_mb_bnd : A.n_mb;
+  const int64_t cnt = mb ? nm : n - nm;
+  return RbView{d ? d + (mb ? 0 : nm) : nullptr, A.roff, A.idx, A.val, (int32_t)cnt, (int32_t)((cnt + 7) / 8)};
 }
 
 // Input vector of an SpMV.  Single device: DIST = false, plain x[c].  Row-block distributed

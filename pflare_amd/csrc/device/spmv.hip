@@ -68,16 +68,33 @@ __device__ __forceinline__ int my_block(const RbView& A) {
 
 // ---- tuning knobs (airhip_set_tuning): which blocks the conversion stores in the 16-bit multi-base form (dev.hpp).
 //   mb16          0: none (the round-3 format: packed or raw), 1 (default): see mb16_max_rows
-//   mb16_max_rows blocks of at most this many rows go multi-base (default 8; 128 = every block that can), blocks whose
-//                 columns span 2^19 or more (raw otherwise) always do.  Row-major order is free for a block of few long
-//                 rows; a block of many short rows gathers better in column order (the packed form).
+//   mb16_max_rows blocks of at most this many rows go multi-base (default 128 = every block that can), blocks whose
+//                 columns span 2^19 or more (raw otherwise) always do.  Measured at 464^3 (profiles/r04_mb16_rows.txt):
+//                 2 rows 20.7, 8 rows 21.3, 128 rows 21.5 iterations/s - the column order of the packed form buys the
+//                 short-row blocks less than its 4-byte words cost them.
 // They act when an operator is converted (upload of a hierarchy), not on operators that exist.
-static int g_mb16 = 1, g_mb16_max_rows = 8;
+//   occ_spmv / occ_fc  workgroups (of 4 waves) of the lean k_rb_spmv / k_rb_fc_first kernels that a CU may hold = waves per
+//                 SIMD (0: as many as the registers allow, 8).  Takes effect at the next launch: the launch asks for enough
+//                 dynamic LDS that no more fit.  More resident waves stream more, but they also share the L2 and the
+//                 address path: a kernel whose blocks gather many distinct lines (A_fc: columns in every section of the
+//                 coarse vector) loses what a streaming-bound one gains.
+static int g_mb16 = 1, g_mb16_max_rows = 128;
+static int g_occ_spmv = 6, g_occ_fc = 5;
 int spmv_set_tuning(const char* key, int value) {
   const std::string k(key);
   if (k == "mb16") { g_mb16 = value != 0; return 0; }
   if (k == "mb16_max_rows") { g_mb16_max_rows = value < 0 ? 0 : value; return 0; }
+  if (k == "occ_spmv") { g_occ_spmv = value < 0 ? 0 : value; return 0; }
+  if (k == "occ_fc") { g_occ_fc = value < 0 ? 0 : value; return 0; }
   return -1;
+}
+// dynamic LDS that limits a kernel with LDS_STATIC bytes of its own to `wgs` workgroups per CU (160 KB of LDS, allocated
+// in units of 1 KB here so that the rounding of the hardware's granule cannot cost a workgroup)
+static unsigned occ_pad(int wgs) {
+  constexpr int LDS_CU = 160 * 1024, LDS_STATIC = SPMV_WAVES * LDS_SLOTS * 8;
+  if (wgs <= 0 || wgs >= LDS_CU / LDS_STATIC) return 0;
+  const int alloc = LDS_CU / wgs / 1024 * 1024;
+  return alloc > LDS_STATIC ? (unsigned)(alloc - LDS_STATIC) : 0;
 }
 
 struct BlkInfo { int64_t p0, ip; int32_t r0, cbase, nb, nr; };
@@ -165,26 +182,29 @@ __device__ __forceinline__ void issue_stream(const RbView& A, const BlkInfo& d, 
 
 // 16-bit index words of a multi-base block: the words of every pair of full rounds are interleaved like the values (one
 // dword per lane holds slot 64 (2i) + lane in its low half and slot 64 (2i + 1) + lane in its high half), the rest is in
-// slot order; in front of them the table of windows, one per lane.  Then the values.
+// slot order; in front of them the table of windows, one per lane.  Then the values.  iw[i] keeps the two words of
+// rounds 2i / 2i + 1 packed (mb_word extracts them).
 template <int NF>
-__device__ __forceinline__ void issue_stream_mb(const RbView& A, const BlkInfo& d, int nwin, int lane, uint32_t& tab, uint32_t (&iw)[EPL], double (&vv)[EPL]) {
+__device__ __forceinline__ void issue_stream_mb(const RbView& A, const BlkInfo& d, int nwin, int lane, uint32_t& tab, uint32_t (&iw)[EPL / 2], double (&vv)[EPL]) {
   typedef Rounds<NF> R;
   const uint8_t* __restrict__ ib = A.idx + d.ip;
   tab = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc32(ib, nwin * 4), lane * 4, 0, 0);
   const rsrc_t ri = make_rsrc32(ib + nwin * 4, d.nb * 2);
 #pragma unroll
   for (int i = 0; i < EPL / 2; i++) {
-    iw[2 * i] = 0; iw[2 * i + 1] = 0;
-    if (i < R::npair) {
-      const uint32_t q = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(ri, lane * 4, i * 2 * WAVE * 2, 0);
-      iw[2 * i] = q & 0xffffu; iw[2 * i + 1] = q >> 16;
-    } else {
-      if (R::has(2 * i)) iw[2 * i] = (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(ri, lane * 2, 2 * i * WAVE * 2, 0);
-      if (R::has(2 * i + 1)) iw[2 * i + 1] = (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(ri, lane * 2, (2 * i + 1) * WAVE * 2, 0);
+    iw[i] = 0;
+    if (i < R::npair) iw[i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(ri, lane * 4, i * 2 * WAVE * 2, 0);
+    else {
+      uint32_t lo = 0, hi = 0;
+      if (R::has(2 * i)) lo = (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(ri, lane * 2, 2 * i * WAVE * 2, 0);
+      if (R::has(2 * i + 1)) hi = (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(ri, lane * 2, (2 * i + 1) * WAVE * 2, 0);
+      if (R::has(2 * i)) iw[i] = lo | (hi << 16);
     }
   }
   issue_values<NF>(A, d, d.nb, lane, vv);
 }
+template <int N>
+__device__ __forceinline__ uint32_t mb_word(const uint32_t (&iw)[N], int u) { return (u & 1) ? (iw[u >> 1] >> 16) : (iw[u >> 1] & 0xffffu); }
 
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -225,17 +245,20 @@ __device__ __forceinline__ void load_row_ranges(const RbView& A, const BlkInfo& 
   }
 }
 
-// phase 2 of a block whose products are staged in LDS at their row-major positions: the row sums, then the epilogue
-template <class Epi>
+// phase 2 of a block whose products are staged in LDS at their row-major positions: the row sums, then the epilogue.
+// pre[1] (the epilogue inputs of a lane's second row, blocks of more than 64 rows) may have been loaded by the caller
+// (late2 = false) or is loaded here, after the first row has been stored (late2 = true: the lean multi-base kernel does not
+// keep a second set of epilogue registers alive across its gather)
+template <bool LATE2, class Epi>
 __device__ __forceinline__ void sum_rows(const BlkInfo& d, const double* __restrict__ lds, const Epi& epi, int lane, bool two,
-                                         const int (&ra)[2], const int (&re)[2], const typename Epi::Pre (&pre)[2]) {
+                                         const int (&ra)[2], const int (&re)[2], typename Epi::Pre (&pre)[2]) {
   const int nr = d.nr;
   if (nr > 32) {
     // one lane per row, column order
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-      if (q == 1 && !two) break;
-      epi.store(d.r0, nr, lane + q * WAVE, row_sum(lds, ra[q], re[q], 1), pre[q]);
+    epi.store(d.r0, nr, lane, row_sum(lds, ra[0], re[0], 1), pre[0]);
+    if (two) {
+      if constexpr (LATE2) pre[1] = epi.load(d.r0, nr, lane + WAVE, epi.early(d.r0, nr, lane + WAVE));
+      epi.store(d.r0, nr, lane + WAVE, row_sum(lds, ra[1], re[1], 1), pre[1]);
     }
   } else {
     // few (longer) rows: T = 64 / 2^ceil(log2 nr) lanes share a row
@@ -292,7 +315,7 @@ __device__ __forceinline__ void rb_body(const RbView& A, const BlkInfo& d, const
       for (int u = 0; u < EPL; u++) if (R::has(u)) { const int k = lane + u * WAVE; lds[k < nb ? k + 1 : 0] = vv[u] * xx[u]; }
     }
     wave_lds_sync();
-    sum_rows(d, lds, epi, lane, two, ra, re, pre);
+    sum_rows<false>(d, lds, epi, lane, two, ra, re, pre);
   } else {
     // one long row: the whole wave reduces it.  The first 512 entries are already in registers (stream and
     // gather above: all eight rounds exist); the rest is read with four independent chains per lane
@@ -318,23 +341,28 @@ __device__ __forceinline__ void rb_body(const RbView& A, const BlkInfo& d, const
   }
 }
 
-// multi-base blocks (16-bit index words, row-major order; at most 512 entries)
-template <int NF, bool DIST, class Epi>
+// multi-base blocks (16-bit index words, row-major order; at most 512 entries).  The lean path: it runs in kernels of its
+// own (k_rb_spmv / k_rb_fc_first; the packed, raw and long-row blocks go through the *_g kernels) so that its register
+// budget - 16 for the values, 16 for the gathered x, 4 for the index words, one set of epilogue inputs - and not that of
+// the widest path decides how many waves a SIMD holds: the block code waits on memory three times in a row, and what it
+// streams per microsecond is the number of resident waves times a block.
+// RAW: the same path for a raw block of at most 512 entries (32-bit absolute columns; the few blocks that fit no table, e.g.
+// a block of one entry) - so that a launch of the *_g kernels is only needed for what is rare: raw long rows, and packed
+// blocks when the multi-base form is switched off
+template <int NF, bool RAW, bool DIST, class Epi>
 __device__ __forceinline__ void rb_body_mb(const RbView& A, const BlkInfo& d, const XVec<DIST> x, double* __restrict__ lds, const Epi& epi, int lane) {
   const int nr = d.nr;
   typedef Rounds<NF> R;
-  const int meta = -(d.cbase + 2);
+  const int meta = RAW ? 0 : -(d.cbase + 2);
   const int ob = meta & MB_OB_MASK, nwin = meta >> MB_WIN_SHIFT;
-  uint32_t tab; uint32_t iw[EPL]; double vv[EPL];
-  issue_stream_mb<NF>(A, d, nwin, lane, tab, iw, vv);
-  typename Epi::Early early[2];
+  uint32_t tab = 0; uint32_t iw[RAW ? EPL : EPL / 2]; double vv[EPL];
+  if constexpr (RAW) issue_stream<NF>(A, d, lane, iw, vv);
+  else issue_stream_mb<NF>(A, d, nwin, lane, tab, iw, vv);
   int ra[2], re[2];
   typename Epi::Pre pre[2];
   const bool two = nr > WAVE;
   const bool one = nr == 1;            // the common case on the deep levels: no staging, no row offsets
-  early[0] = epi.early(d.r0, nr, lane);
-  early[1] = early[0];
-  if (two) early[1] = epi.early(d.r0, nr, lane + WAVE);
+  const typename Epi::Early early0 = epi.early(d.r0, nr, lane);
   ra[0] = ra[1] = re[0] = re[1] = 0;
   if (!one) load_row_ranges(A, d, lane, two, ra, re);
   // column = window's first column + offset: the table lives in one register across the lanes (ds_bpermute)
@@ -344,13 +372,55 @@ __device__ __forceinline__ void rb_body_mb(const RbView& A, const BlkInfo& d, co
   for (int u = 0; u < EPL; u++) {
     xx[u] = 0.0;
     if (R::has(u)) {
-      const uint32_t base = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((iw[u] >> ob) << 2), (int)tab);
-      xx[u] = x.at_byte_offset(base + ((iw[u] & omask) << 3));
+      if constexpr (RAW) xx[u] = x.at_byte_offset(iw[u] << 3);
+      else {
+        const uint32_t w = mb_word(iw, u);
+        const uint32_t base = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((w >> ob) << 2), (int)tab);
+        xx[u] = x.at_byte_offset(base + ((w & omask) << 3));
+      }
     }
   }
-  pre[0] = epi.load(d.r0, nr, lane, early[0]);
-  pre[1] = pre[0];
-  if (two) pre[1] = epi.load(d.r0, nr, lane + WAVE, early[1]);
+  pre[0] = epi.load(d.r0, nr, lane, early0);
+  if constexpr (NF == EPL && !RAW) {
+    if (d.nb > BLK_NNZ) {
+      // one long row: the whole wave reduces it, with the arithmetic of the raw long-row path (rb_body).  The first 512
+      // entries are in registers; the words and values of the rest lie in plain order behind them
+      const unsigned short* __restrict__ wp = reinterpret_cast<const unsigned short*>(A.idx + d.ip + nwin * 4);
+      const double* __restrict__ vp = A.val + d.p0;
+      const int nb = d.nb;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+      for (int u = 0; u < EPL; u += 4) {
+        s0 = fma(vv[u], xx[u], s0); s1 = fma(vv[u + 1], xx[u + 1], s1);
+        s2 = fma(vv[u + 2], xx[u + 2], s2); s3 = fma(vv[u + 3], xx[u + 3], s3);
+      }
+      auto xat = [&](uint32_t w) {
+        const uint32_t base = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((w >> ob) << 2), (int)tab);
+        return x.at_byte_offset(base + ((w & omask) << 3));
+      };
+      // Wave-uniform trip counts with per-lane predicates: ds_bpermute only sees the table entries of ACTIVE lanes, so no
+      // lane may leave these loops before the last one does.  Per lane the entries go to the same chains as in rb_body's
+      // per-lane loops (four at a time while four remain for this lane, the rest to chain 0).
+      int j = BLK_NNZ + lane;
+      while (__any(j + 3 * WAVE < nb)) {
+        const bool p = j + 3 * WAVE < nb;
+        const int jj = p ? j : BLK_NNZ;      // (a valid position for the lanes that are done)
+        const uint32_t c0 = wp[jj], c1 = wp[jj + WAVE], c2 = wp[jj + 2 * WAVE], c3 = wp[jj + 3 * WAVE];
+        const double v0 = vp[jj], v1 = vp[jj + WAVE], v2 = vp[jj + 2 * WAVE], v3 = vp[jj + 3 * WAVE];
+        const double x0 = xat(c0), x1 = xat(c1), x2 = xat(c2), x3 = xat(c3);
+        if (p) { s0 = fma(v0, x0, s0); s1 = fma(v1, x1, s1); s2 = fma(v2, x2, s2); s3 = fma(v3, x3, s3); j += 4 * WAVE; }
+      }
+      for (; __any(j < nb); j += WAVE) {
+        const uint32_t w = j < nb ? (uint32_t)wp[j] : 0u;
+        const double xv = xat(w);
+        if (j < nb) s0 = fma(vp[j], xv, s0);
+      }
+      double s = (s0 + s1) + (s2 + s3);
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
+      epi.store(d.r0, nr, lane, s, pre[0]);
+      return;
+    }
+  }
   if (one) {
     // one row: lane l holds entries l, l + 64, ... - what it would read back from the staging area.  Same products, same
     // order of additions as the staged path (multiply, then add: no contraction)
@@ -368,44 +438,59 @@ __device__ __forceinline__ void rb_body_mb(const RbView& A, const BlkInfo& d, co
 #pragma unroll
   for (int u = 0; u < EPL; u++) if (R::has(u)) lds[lane + u * WAVE + 1] = vv[u] * xx[u];
   wave_lds_sync();
-  sum_rows(d, lds, epi, lane, two, ra, re, pre);
+  sum_rows<true>(d, lds, epi, lane, two, ra, re, pre);
 }
 
 // Epi interface (r0 = first row of the block, nr = its rows, lr = this lane's local row, may be >= nr):
 //   Early early(r0, nr, lr)            loads whose result feeds another load (issued with the stream)
 //   Pre   load(r0, nr, lr, Early)      the epilogue's inputs, issued before the gather is waited for
 //   void  store(r0, nr, lr, acc, Pre)  after the row sum is known; rows past the block's end are dropped
-template <bool DIST, class Epi>
+// MB: the launch holds multi-base blocks only (lean path) / none of them (the other kinds)
+template <bool MB, bool DIST, class Epi>
 __device__ __forceinline__ void rb_block(const RbView& A, const XVec<DIST> x, double* __restrict__ lds, const Epi& epi) {
   const int lane = threadIdx.x & (WAVE - 1);
   const int bi = my_block(A);
   if (bi < 0) return;
   const BlkInfo d = load_blk(A, bi);
   const int nf = (d.nb < BLK_NNZ ? d.nb : BLK_NNZ) >> 6;     // full rounds: one straight-line variant each (every long row: 8)
-  if (d.cbase <= -2) {
-    switch (nf) {
-      case 8: rb_body_mb<8, DIST>(A, d, x, lds, epi, lane); break;
-      case 7: rb_body_mb<7, DIST>(A, d, x, lds, epi, lane); break;
-      case 6: rb_body_mb<6, DIST>(A, d, x, lds, epi, lane); break;
-      case 5: rb_body_mb<5, DIST>(A, d, x, lds, epi, lane); break;
-      case 4: rb_body_mb<4, DIST>(A, d, x, lds, epi, lane); break;
-      case 3: rb_body_mb<3, DIST>(A, d, x, lds, epi, lane); break;
-      case 2: rb_body_mb<2, DIST>(A, d, x, lds, epi, lane); break;
-      case 1: rb_body_mb<1, DIST>(A, d, x, lds, epi, lane); break;
-      default: rb_body_mb<0, DIST>(A, d, x, lds, epi, lane); break;
+  if constexpr (MB) {
+    if (d.cbase == -1) {
+      switch (nf) {
+        case 8: rb_body_mb<8, true, DIST>(A, d, x, lds, epi, lane); break;
+        case 7: rb_body_mb<7, true, DIST>(A, d, x, lds, epi, lane); break;
+        case 6: rb_body_mb<6, true, DIST>(A, d, x, lds, epi, lane); break;
+        case 5: rb_body_mb<5, true, DIST>(A, d, x, lds, epi, lane); break;
+        case 4: rb_body_mb<4, true, DIST>(A, d, x, lds, epi, lane); break;
+        case 3: rb_body_mb<3, true, DIST>(A, d, x, lds, epi, lane); break;
+        case 2: rb_body_mb<2, true, DIST>(A, d, x, lds, epi, lane); break;
+        case 1: rb_body_mb<1, true, DIST>(A, d, x, lds, epi, lane); break;
+        default: rb_body_mb<0, true, DIST>(A, d, x, lds, epi, lane); break;
+      }
+      return;
     }
-    return;
-  }
-  switch (nf) {
-    case 8: rb_body<8, DIST>(A, d, x, lds, epi, lane); break;
-    case 7: rb_body<7, DIST>(A, d, x, lds, epi, lane); break;
-    case 6: rb_body<6, DIST>(A, d, x, lds, epi, lane); break;
-    case 5: rb_body<5, DIST>(A, d, x, lds, epi, lane); break;
-    case 4: rb_body<4, DIST>(A, d, x, lds, epi, lane); break;
-    case 3: rb_body<3, DIST>(A, d, x, lds, epi, lane); break;
-    case 2: rb_body<2, DIST>(A, d, x, lds, epi, lane); break;
-    case 1: rb_body<1, DIST>(A, d, x, lds, epi, lane); break;
-    default: rb_body<0, DIST>(A, d, x, lds, epi, lane); break;
+    switch (nf) {
+      case 8: rb_body_mb<8, false, DIST>(A, d, x, lds, epi, lane); break;
+      case 7: rb_body_mb<7, false, DIST>(A, d, x, lds, epi, lane); break;
+      case 6: rb_body_mb<6, false, DIST>(A, d, x, lds, epi, lane); break;
+      case 5: rb_body_mb<5, false, DIST>(A, d, x, lds, epi, lane); break;
+      case 4: rb_body_mb<4, false, DIST>(A, d, x, lds, epi, lane); break;
+      case 3: rb_body_mb<3, false, DIST>(A, d, x, lds, epi, lane); break;
+      case 2: rb_body_mb<2, false, DIST>(A, d, x, lds, epi, lane); break;
+      case 1: rb_body_mb<1, false, DIST>(A, d, x, lds, epi, lane); break;
+      default: rb_body_mb<0, false, DIST>(A, d, x, lds, epi, lane); break;
+    }
+  } else {
+    switch (nf) {
+      case 8: rb_body<8, DIST>(A, d, x, lds, epi, lane); break;
+      case 7: rb_body<7, DIST>(A, d, x, lds, epi, lane); break;
+      case 6: rb_body<6, DIST>(A, d, x, lds, epi, lane); break;
+      case 5: rb_body<5, DIST>(A, d, x, lds, epi, lane); break;
+      case 4: rb_body<4, DIST>(A, d, x, lds, epi, lane); break;
+      case 3: rb_body<3, DIST>(A, d, x, lds, epi, lane); break;
+      case 2: rb_body<2, DIST>(A, d, x, lds, epi, lane); break;
+      case 1: rb_body<1, DIST>(A, d, x, lds, epi, lane); break;
+      default: rb_body<0, DIST>(A, d, x, lds, epi, lane); break;
+    }
   }
 }
 
@@ -439,16 +524,27 @@ struct EpiAxpby {
   }
 };
 
+// k_rb_spmv: multi-base blocks (the lean path); k_rb_spmv_g: the blocks of the other kinds
 template <bool DIST, int F>
 __global__ __launch_bounds__(SPMV_BLOCK) void k_rb_spmv(RbView A, XVec<DIST> x, EpiAxpby<F> epi) {
   __shared__ double lds_all[SPMV_WAVES][LDS_SLOTS];
-  rb_block<DIST>(A, x, lds_all[threadIdx.x >> 6], epi);
+  rb_block<true, DIST>(A, x, lds_all[threadIdx.x >> 6], epi);
 }
-// the same kernel under another name for the products of the setup phase (SpmvEpi::setup_phase)
+template <bool DIST, int F>
+__global__ __launch_bounds__(SPMV_BLOCK) void k_rb_spmv_g(RbView A, XVec<DIST> x, EpiAxpby<F> epi) {
+  __shared__ double lds_all[SPMV_WAVES][LDS_SLOTS];
+  rb_block<false, DIST>(A, x, lds_all[threadIdx.x >> 6], epi);
+}
+// the same kernels under other names for the products of the setup phase (SpmvEpi::setup_phase)
 template <int F>
 __global__ __launch_bounds__(SPMV_BLOCK) void k_rb_spmv_setup(RbView A, XVec<false> x, EpiAxpby<F> epi) {
   __shared__ double lds_all[SPMV_WAVES][LDS_SLOTS];
-  rb_block<false>(A, x, lds_all[threadIdx.x >> 6], epi);
+  rb_block<true, false>(A, x, lds_all[threadIdx.x >> 6], epi);
+}
+template <int F>
+__global__ __launch_bounds__(SPMV_BLOCK) void k_rb_spmv_setup_g(RbView A, XVec<false> x, EpiAxpby<F> epi) {
+  __shared__ double lds_all[SPMV_WAVES][LDS_SLOTS];
+  rb_block<false, false>(A, x, lds_all[threadIdx.x >> 6], epi);
 }
 
 // Fused first stage of an F-point relaxation with a one-point prolongator (see dev.hpp)
@@ -493,7 +589,12 @@ struct EpiFcFirst {
 template <bool DIST, bool DIAG>
 __global__ __launch_bounds__(SPMV_BLOCK) void k_rb_fc_first(RbView A, XVec<DIST> x_c, EpiFcFirst<DIST, DIAG> epi) {
   __shared__ double lds_all[SPMV_WAVES][LDS_SLOTS];
-  rb_block<DIST>(A, x_c, lds_all[threadIdx.x >> 6], epi);
+  rb_block<true, DIST>(A, x_c, lds_all[threadIdx.x >> 6], epi);
+}
+template <bool DIST, bool DIAG>
+__global__ __launch_bounds__(SPMV_BLOCK) void k_rb_fc_first_g(RbView A, XVec<DIST> x_c, EpiFcFirst<DIST, DIAG> epi) {
+  __shared__ double lds_all[SPMV_WAVES][LDS_SLOTS];
+  rb_block<false, DIST>(A, x_c, lds_all[threadIdx.x >> 6], epi);
 }
 
 // grid: one wave per block, four waves per workgroup, a multiple of 8 workgroups (every XCD class gets
@@ -511,65 +612,84 @@ static void check_launch(const char* what) {
   if (e != hipSuccess) throw std::runtime_error(std::string("HIP error ") + hipGetErrorString(e) + " launching " + what);
 }
 
-template <bool DIST, int F>
-static void launch_spmv_f(const RbView& v, const XVec<DIST>& xv, const SpmvEpi& e, int64_t nb, hipStream_t s) {
+template <bool MB, bool DIST, int F>
+static void launch_spmv_f(const RbView& v, const XVec<DIST>& xv, const SpmvEpi& e, hipStream_t s) {
   const EpiAxpby<F> epi{e};
+  const dim3 g(grid_for(v.nblocks)), b(SPMV_BLOCK);
   if constexpr (!DIST && (F == 0 || F == 1 || F == 9)) {      // the epilogues the setup's Arnoldi / Newton apply use
-    if (e.setup_phase) { hipLaunchKernelGGL((k_rb_spmv_setup<F>), dim3(grid_for(nb)), dim3(SPMV_BLOCK), 0, s, v, xv, epi); return; }
+    if (e.setup_phase) {
+      if constexpr (MB) hipLaunchKernelGGL((k_rb_spmv_setup<F>), g, b, 0, s, v, xv, epi);
+      else hipLaunchKernelGGL((k_rb_spmv_setup_g<F>), g, b, 0, s, v, xv, epi);
+      return;
+    }
   }
-  hipLaunchKernelGGL((k_rb_spmv<DIST, F>), dim3(grid_for(nb)), dim3(SPMV_BLOCK), 0, s, v, xv, epi);
+  if constexpr (MB) hipLaunchKernelGGL((k_rb_spmv<DIST, F>), g, b, occ_pad(g_occ_spmv), s, v, xv, epi);
+  else hipLaunchKernelGGL((k_rb_spmv_g<DIST, F>), g, b, 0, s, v, xv, epi);
 }
-template <bool DIST>
-static void launch_spmv_d(const RbView& v, const XVec<DIST>& xv, const SpmvEpi& e, int64_t nb, hipStream_t s) {
+template <bool MB, bool DIST>
+static void launch_spmv_d(const RbView& v, const XVec<DIST>& xv, const SpmvEpi& e, hipStream_t s) {
+  if (v.nblocks == 0) return;
   const int f = (e.z ? EPI_Z : 0) | (e.w ? EPI_W : 0) | (e.dscale ? EPI_D : 0) | (e.y2 ? EPI_Y : 0);
   switch (f) {
-#define C(F) case F: launch_spmv_f<DIST, F>(v, xv, e, nb, s); break;
+#define C(F) case F: launch_spmv_f<MB, DIST, F>(v, xv, e, s); break;
     C(0) C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15)
 #undef C
   }
 }
 
-void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t s, const double* x_ghost,
-                 const BlkDesc* blks, int64_t nblks) {
-  if (A.m == 0 || (blks && nblks == 0)) return;
-  const RbView v = view_of(A, blks, nblks);
-  const int64_t nb = v.nblocks;
+void launch_spmv(const DevMat& A, const double* x, const SpmvEpi& e, hipStream_t s, const double* x_ghost, int list, int part) {
+  if (A.m == 0) return;
+  if (!A.desc_ord) throw std::logic_error("launch_spmv: operator without a launch list");
+  const RbView vm = view_of(A, list, true), vg = view_of(A, list, false);
   if (A.n == 0) x = A.val;     // no columns: blocks of empty rows still read element 0 of "x"
   if (A.n_ghost > 0) {
     // distributed operand: ghost columns start at A.n - A.n_ghost
     if (!x_ghost) throw std::runtime_error("launch_spmv: distributed operand without ghost values");
     const int32_t nl = (int32_t)(A.n - A.n_ghost);
-    launch_spmv_d<true>(v, XVec<true>{x, x_ghost - nl, nl}, e, nb, s);
+    const XVec<true> xv{x, x_ghost - nl, nl};
+    if (part != RB_GENERAL) launch_spmv_d<true, true>(vm, xv, e, s);
+    if (part != RB_MB) launch_spmv_d<false, true>(vg, xv, e, s);
   } else {
-    launch_spmv_d<false>(v, XVec<false>{x, nullptr, 0}, e, nb, s);
+    const XVec<false> xv{x, nullptr, 0};
+    if (part != RB_GENERAL) launch_spmv_d<true, false>(vm, xv, e, s);
+    if (part != RB_MB) launch_spmv_d<false, false>(vg, xv, e, s);
   }
   check_launch("k_rb_spmv");
 }
 
-template <bool DIST>
+template <bool MB, bool DIST>
 static void launch_fc_first_d(const RbView& v, const XVec<DIST>& xv, const int32_t* wcol, const double* b_f, const double* aff_d,
-                              const double* minv, double* t4_out, double* x_f, int64_t nb, hipStream_t s) {
-  if (aff_d) hipLaunchKernelGGL((k_rb_fc_first<DIST, true>), dim3(grid_for(nb)), dim3(SPMV_BLOCK), 0, s, v, xv,
-                                EpiFcFirst<DIST, true>{wcol, b_f, xv, aff_d, minv, t4_out, x_f});
-  else hipLaunchKernelGGL((k_rb_fc_first<DIST, false>), dim3(grid_for(nb)), dim3(SPMV_BLOCK), 0, s, v, xv,
-                          EpiFcFirst<DIST, false>{wcol, b_f, xv, aff_d, minv, t4_out, x_f});
+                              const double* minv, double* t4_out, double* x_f, hipStream_t s) {
+  if (v.nblocks == 0) return;
+  const dim3 g(grid_for(v.nblocks)), b(SPMV_BLOCK);
+  if (aff_d) {
+    const EpiFcFirst<DIST, true> epi{wcol, b_f, xv, aff_d, minv, t4_out, x_f};
+    if constexpr (MB) hipLaunchKernelGGL((k_rb_fc_first<DIST, true>), g, b, occ_pad(g_occ_fc), s, v, xv, epi);
+    else hipLaunchKernelGGL((k_rb_fc_first_g<DIST, true>), g, b, 0, s, v, xv, epi);
+  } else {
+    const EpiFcFirst<DIST, false> epi{wcol, b_f, xv, aff_d, minv, t4_out, x_f};
+    if constexpr (MB) hipLaunchKernelGGL((k_rb_fc_first<DIST, false>), g, b, occ_pad(g_occ_fc), s, v, xv, epi);
+    else hipLaunchKernelGGL((k_rb_fc_first_g<DIST, false>), g, b, 0, s, v, xv, epi);
+  }
 }
 
 void launch_fc_first(const DevMat& A_fc, const int32_t* wcol, const double* b_f, const double* x_c,
                      const double* aff_d, const double* minv, double* t4_out, double* x_f, hipStream_t s,
-                     const double* x_ghost, const BlkDesc* blks, int64_t nblks) {
-  if (A_fc.m == 0 || (blks && nblks == 0)) return;
+                     const double* x_ghost, int list, int part) {
+  if (A_fc.m == 0) return;
+  if (!A_fc.desc_ord) throw std::logic_error("launch_fc_first: operator without a launch list");
   if (A_fc.n == 0) x_c = A_fc.val;
-  const RbView v = view_of(A_fc, blks, nblks);
-  const int64_t nb = v.nblocks;
+  const RbView vm = view_of(A_fc, list, true), vg = view_of(A_fc, list, false);
   if (A_fc.n_ghost > 0) {
     if (!x_ghost) throw std::runtime_error("launch_fc_first: distributed operand without ghost values");
     const int32_t nl = (int32_t)(A_fc.n - A_fc.n_ghost);
     const XVec<true> xv{x_c, x_ghost - nl, nl};
-    launch_fc_first_d<true>(v, xv, wcol, b_f, aff_d, minv, t4_out, x_f, nb, s);
+    if (part != RB_GENERAL) launch_fc_first_d<true, true>(vm, xv, wcol, b_f, aff_d, minv, t4_out, x_f, s);
+    if (part != RB_MB) launch_fc_first_d<false, true>(vg, xv, wcol, b_f, aff_d, minv, t4_out, x_f, s);
   } else {
     const XVec<false> xv{x_c, nullptr, 0};
-    launch_fc_first_d<false>(v, xv, wcol, b_f, aff_d, minv, t4_out, x_f, nb, s);
+    if (part != RB_GENERAL) launch_fc_first_d<true, false>(vm, xv, wcol, b_f, aff_d, minv, t4_out, x_f, s);
+    if (part != RB_MB) launch_fc_first_d<false, false>(vg, xv, wcol, b_f, aff_d, minv, t4_out, x_f, s);
   }
   check_launch("k_rb_fc_first");
 }
@@ -725,12 +845,78 @@ __global__ __launch_bounds__(BLOCK) void k_block_pack(int64_t nblocks, int64_t n
     if (lane == 0) { blk[b].nb = (int32_t)nbl; blk[b].nr = nrows; blk[b].ip = 4 * nbl; }
     uint32_t* oidx = reinterpret_cast<uint32_t*>(col);
     if (nbl == 0 || nbl > BLK_NNZ) {
-      // row-major order, absolute columns (already in place); the first 512 values in the interleaved placement
+      // one long row (or an empty block): row-major order; the first 512 values in the interleaved placement
       const int n512 = (int)(nbl < BLK_NNZ ? nbl : BLK_NNZ);
       for (int64_t k = p0 + lane; k < p1; k += WAVE) {
         const int64_t q = k - p0;
         oval[q < n512 ? p0 + val_slot((int)q, n512) : k] = val[k];
       }
+      if (nbl == 0 || !mb_on) continue;      // raw: the absolute columns are in place already
+      // multi-base form of a long row: its distinct windows (column >> ob) are collected in a small hash set in LDS (the row
+      // is too long to sort here); a window's base is its smallest column, its number its rank among the row's windows
+      uint32_t* wkey = reinterpret_cast<uint32_t*>(keys);          // [128] window or EMPTY
+      uint32_t* wmin = wkey + 128;                                  // [128] smallest column of the window
+      uint32_t* wid = wmin + 128;                                   // [128] rank of the window
+      constexpr uint32_t EMPTY = 0xffffffffu;
+      int ob = 0, nwin = 0;
+      for (int t = 14; t >= 10 && ob == 0; t--) {
+        for (int i = lane; i < 128; i += WAVE) { wkey[i] = EMPTY; wmin[i] = EMPTY; }
+        lds_sync();
+        bool over = false;
+        for (int64_t k = p0 + lane; k < p1; k += WAVE) {
+          const uint32_t c = (uint32_t)col[k], w = c >> t;
+          uint32_t h = (w * 2654435761u) >> 25;
+          int probes = 0;
+          for (;;) {
+            const uint32_t old = atomicCAS(&wkey[h], EMPTY, w);
+            if (old == EMPTY || old == w) { atomicMin(&wmin[h], c); break; }
+            h = (h + 1) & 127u;
+            if (++probes == 128) { over = true; break; }
+          }
+        }
+        lds_sync();
+        int cnt = 0;
+        for (int i = lane; i < 128; i += WAVE) cnt += wkey[i] != EMPTY ? 1 : 0;
+        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, WAVE);
+        if (!__any(over) && cnt <= (1 << (16 - t)) && cnt <= MB_MAX_WIN) { ob = t; nwin = cnt; }
+      }
+      if (!ob) continue;
+      // ranks of the windows (deterministic: by value), table
+      for (int i = lane; i < 128; i += WAVE) {
+        const uint32_t me = wkey[i];
+        int r = 0;
+        if (me != EMPTY) for (int q = 0; q < 128; q++) r += wkey[q] < me ? 1 : 0;      // (EMPTY is the largest value)
+        wid[i] = (uint32_t)r;
+        if (me != EMPTY) tab[r] = wmin[i];
+      }
+      lds_sync();
+      // words, written in place over the columns: chunk k + 1 is in registers before chunk k's words are written (the
+      // words of chunk k end before the columns of chunk k + 2 begin; see the layout in dev.hpp)
+      unsigned short* wout = reinterpret_cast<unsigned short*>(oidx + p0 + nwin);
+      const int64_t nchunk = (nbl + WAVE - 1) / WAVE;
+      uint32_t cur = lane < nbl ? (uint32_t)col[p0 + lane] : 0u;
+      uint32_t tabreg = lane < nwin ? tab[lane] << 3 : 0u;
+      for (int64_t ch = 0; ch < nchunk; ch++) {
+        const int64_t i = ch * WAVE + lane, inext = i + WAVE;
+        const uint32_t nxt = inext < nbl ? (uint32_t)col[p0 + inext] : 0u;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (i < nbl) {
+          const uint32_t w = cur >> ob;
+          uint32_t h = (w * 2654435761u) >> 25;
+          while (wkey[h] != w) h = (h + 1) & 127u;
+          const uint32_t id = wid[h];
+          wout[i < BLK_NNZ ? val_slot((int)i, BLK_NNZ) : i] = (unsigned short)((id << ob) | (cur - wmin[h]));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        cur = nxt;
+      }
+      // the table last (its bytes were columns of chunk 0)
+      if (lane < nwin) oidx[p0 + lane] = tabreg;
+      if (lane == 0) { blk[b].cbase = -2 - (ob | (nwin << MB_WIN_SHIFT)); blk[b].ip = 4 * ((int64_t)nwin + ((nbl + 1) >> 1)); }
+      if ((nbl & 1) && lane == 0) wout[nbl] = 0;      // padding half of the last dword
+      lds_sync();
       continue;
     }
     const int nb = (int)nbl;
@@ -872,15 +1058,54 @@ __global__ __launch_bounds__(BLOCK) void k_desc_gather(int64_t n, const BlkDesc*
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) out[i] = blk[order[i]];
 }
 
-BlkDesc* devmat_desc_list(const DevMat& A, const int32_t* order_host, int64_t n, hipStream_t s) {
+// ---- launch lists: the blocks of the lean kernels first (stable), the rest after them
+__global__ __launch_bounds__(BLOCK) void k_mb_flags(int64_t n, const BlkDesc* __restrict__ d, int64_t* __restrict__ is_mb, int64_t* __restrict__ nz_mb) {
+  const int64_t stride = (int64_t)gridDim.x * BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+    const bool mb = lean_block(d[i]);
+    is_mb[i] = mb ? 1 : 0;
+    if (nz_mb) nz_mb[i] = mb ? d[i].nb : 0;
+  }
+}
+__global__ __launch_bounds__(BLOCK) void k_mb_scatter(int64_t n, int64_t n_mb, const BlkDesc* __restrict__ in, const int64_t* __restrict__ pos, BlkDesc* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+    const BlkDesc q = in[i];
+    out[lean_block(q) ? pos[i] : n_mb + (i - pos[i])] = q;
+  }
+}
+static int grid1d(int64_t n);
+// out (n descriptors, may not alias in) = in with the multi-base blocks first; returns their number, *nnz_mb their non-zeros
+static int64_t partition_descs_device(const BlkDesc* in, int64_t n, BlkDesc* out, hipStream_t s, int64_t* nnz_mb) {
+  if (nnz_mb) *nnz_mb = 0;
+  if (n == 0) return 0;
+  int64_t* fl = (int64_t*)dev_alloc(sizeof(int64_t) * (size_t)n);
+  int64_t* pos = (int64_t*)dev_alloc(sizeof(int64_t) * (size_t)n);
+  int64_t* nz = nnz_mb ? (int64_t*)dev_alloc(sizeof(int64_t) * (size_t)n) : nullptr;
+  hipLaunchKernelGGL(k_mb_flags, dim3(grid1d(n)), dim3(BLOCK), 0, s, n, in, fl, nz);
+  const int64_t n_mb = device_exclusive_scan(n, fl, pos, s);
+  hipLaunchKernelGGL(k_mb_scatter, dim3(grid1d(n)), dim3(BLOCK), 0, s, n, n_mb, in, pos, out);
+  if (nnz_mb) *nnz_mb = device_exclusive_scan(n, nz, fl, s);
+  HIP_CHECK(hipStreamSynchronize(s));
+  dev_free(fl); dev_free(pos); dev_free(nz);
+  return n_mb;
+}
+int64_t partition_descs_host(std::vector<BlkDesc>& v) {
+  auto mid = std::stable_partition(v.begin(), v.end(), [](const BlkDesc& q) { return lean_block(q); });
+  return (int64_t)(mid - v.begin());
+}
+
+BlkDesc* devmat_desc_list(const DevMat& A, const int32_t* order_host, int64_t n, hipStream_t s, int64_t* n_mb) {
   BlkDesc* out = (BlkDesc*)dev_alloc_exact(sizeof(BlkDesc) * (size_t)std::max<int64_t>(n, 1));
+  *n_mb = 0;
   if (n == 0) return out;
   int32_t* d_ord = (int32_t*)dev_alloc(sizeof(int32_t) * (size_t)n);
+  BlkDesc* tmp = (BlkDesc*)dev_alloc(sizeof(BlkDesc) * (size_t)n);
   HIP_CHECK(hipMemcpyAsync(d_ord, order_host, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, s));
   const int g = (int)std::min<int64_t>((n + BLOCK - 1) / BLOCK, MAX_BLOCKS);
-  hipLaunchKernelGGL(k_desc_gather, dim3(g), dim3(BLOCK), 0, s, n, A.blk, d_ord, out);
-  HIP_CHECK(hipStreamSynchronize(s));
-  dev_free(d_ord);
+  hipLaunchKernelGGL(k_desc_gather, dim3(g), dim3(BLOCK), 0, s, n, A.blk, d_ord, tmp);
+  *n_mb = partition_descs_device(tmp, n, out, s, nullptr);
+  dev_free(d_ord); dev_free(tmp);
   return out;
 }
 
@@ -934,13 +1159,16 @@ void devmat_from_csr_device(int64_t m, int64_t n, const int64_t* d_rp, const int
   out.idx = (uint8_t*)alloc_out((size_t)out.idx_bytes + 4);
   HIP_CHECK(hipMemsetAsync(out.idx + out.idx_bytes, 0, 4, s));
   hipLaunchKernelGGL(k_idx_compact, dim3(g < 1 ? 1 : g), dim3(BLOCK), 0, s, out.nblocks, out.blk, d_off, reinterpret_cast<const uint32_t*>(tcol), out.idx);
+  // the launch list in storage order (DevPCAIR::upload replaces it with a spatial order where that pays)
+  out.desc_ord = (BlkDesc*)alloc_out(sizeof(BlkDesc) * (size_t)out.nblocks);
+  out.n_mb = partition_descs_device(out.blk, out.nblocks, out.desc_ord, s, &out.nnz_mb);
   HIP_CHECK(hipStreamSynchronize(s));
   check_launch("row-block conversion");
   dev_free(d_nrp); dev_free(d_cnt); dev_free(d_first); dev_free(tcol); dev_free(tval); dev_free(d_sz); dev_free(d_off);
 }
 
 void devmat_free(DevMat& A) {
-  if (A.cached) { dev_free(A.blk); dev_free(A.roff); dev_free(A.idx); dev_free(A.val); A.blk = nullptr; A.roff = nullptr; A.idx = nullptr; A.val = nullptr; }
+  if (A.cached) { dev_free(A.blk); dev_free(A.roff); dev_free(A.idx); dev_free(A.val); dev_free(A.desc_ord); A.blk = nullptr; A.roff = nullptr; A.idx = nullptr; A.val = nullptr; A.desc_ord = nullptr; }
   dev_free_exact(A.blk);
   dev_free_exact(A.roff);
   dev_free_exact(A.idx);

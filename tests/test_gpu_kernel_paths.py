@@ -3,8 +3,8 @@
 
 * packed blocks (column-sorted, block-relative 19-bit columns: rb.hpp COL_BITS), raw blocks (row-major, absolute columns)
   and multi-base blocks (row-major, 16-bit window | offset words, dev.hpp BlkDesc) - every test of this file runs under
-  three conversion settings: the default (blocks of <= 8 rows and blocks that cannot be packed go multi-base), multi-base
-  off (the round-3 format) and multi-base wherever it fits; the three must agree BIT FOR BIT (same products, same order
+  three conversion settings: the default (multi-base wherever it fits), multi-base off (the round-3 format) and multi-base
+  for blocks of <= 4 rows and blocks that cannot be packed only; the three must agree BIT FOR BIT (same products, same order
   of additions) - the round-1 kernel switched formats on the operator width (2^22 columns) and the wide mode, the one
   the 464^3 benchmark runs, had no test;
 * every straight-line variant of the block code (0 ... 8 full rounds of 64 entries, with and without a partial round; values
@@ -70,7 +70,7 @@ def _rows(lengths, n, rng, local=None):
     return sp.csr_matrix((vals, cols, indptr), shape=(m, n))
 
 
-FORMATS = {"default": (1, 8), "mb16-off": (0, 8), "mb16-everywhere": (1, 128)}
+FORMATS = {"default": (1, 128), "mb16-off": (0, 128), "mb16-long-rows-only": (1, 4)}
 
 
 def _set_format(P, name):
@@ -268,11 +268,11 @@ def decode_blocks(dm):
             kinds["raw"] += 1
         else:
             meta = -(cbase + 2); ob = meta & 31; nwin = meta >> 5
-            assert nb <= 512 and 1 <= nwin <= 64 and nwin <= (1 << (16 - ob))
+            assert 1 <= nwin <= 64 and nwin <= (1 << (16 - ob))      # (a long row may be multi-base as well)
             tab = idx[ip:ip + 4 * nwin].view("<u4").astype(np.int64)
             assert np.all(tab % 8 == 0) and np.all(np.diff(tab) > 0)
             words = idx[ip + 4 * nwin:ip + 4 * nwin + 2 * nb].view("<u2").astype(np.int64)
-            wd = words[_val_slot(slot, nb)]                  # word of logical slot s = row-major position s
+            wd = words[vpos]                                 # word of logical slot s = row-major position s (placed like the values)
             assert np.all((wd >> ob) < nwin)
             c_rm = tab[wd >> ob] // 8 + (wd & ((1 << ob) - 1)); v_rm = v
             kinds["multi-base"] += 1
@@ -352,7 +352,7 @@ def test_the_three_conversions_agree_bit_for_bit(gpu):
                 y = torch.empty(A.shape[0], dtype=torch.float64, device="cuda")
                 dm.mult(x, y)
                 outs[name].append(y)
-        for name in ("mb16-off", "mb16-everywhere"):
+        for name in ("mb16-off", "mb16-long-rows-only"):
             for k, (a, b) in enumerate(zip(outs["default"], outs[name])):
                 assert torch.equal(a, b), (name, k)
     finally:

@@ -61,6 +61,7 @@ CASES = {
     "adv3d_10_full_mf": (dict(dim=3, M=10, N=10, P=10), dict(full_smoothing_up_and_down=True, matrix_free_polys=True, a_lump=True)),
     "diff2d_16_full_ideal_W": (dict(dim=2, M=16, N=16, u=0, v=0, alpha=1.0),
                                dict(full_smoothing_up_and_down=True, one_point_classical_prolong=False, inverse_type="neumann")),
+    "adv2d_16_ideal_W": (dict(dim=2, M=16, N=16), dict(one_point_classical_prolong=False)),
     "adv2d_16_fc": (dict(dim=2, M=16, N=16), dict(smooth_type="fc")),
     "adv2d_16_fcf": (dict(dim=2, M=16, N=16), dict(smooth_type="fcf")),
     "diff2d_12_diagscale": (dict(dim=2, M=12, N=12, u=0, v=0, alpha=1.0), dict(diag_scale_polys=True)),
@@ -241,6 +242,44 @@ def test_spatial_block_order_is_bitwise_neutral(torch_mod, case, hint):
             out.append((z, res["its"], res["rnorm"], pc))
     finally:
         lib.airhip_set_tuning(b"block_order_min_blocks", 4096)
+    assert torch.equal(out[0][0], out[1][0])
+    assert out[0][1] == out[1][1] and out[0][2] == out[1][2]
+    H = bridge.hierarchy_from_product(out[1][3], A)
+    assert relerr(out[1][0].cpu().numpy(), R.vcycle(H, x)) <= TOL_CYCLE
+
+
+@pytest.mark.parametrize("case", ["adv3d_12_lump", "adv2d_16_fcf", "adv2d_30_lair_ffc", "adv2d_16_ideal_W", "diff2d_16_neumann_mf"])
+@pytest.mark.parametrize("hint", [False, True])
+def test_spatial_copy_of_x_c_is_bitwise_neutral(torch_mod, case, hint):
+    """A_fc and the one-point prolongator gather from a copy of x_c in the spatial order of the level's C points
+    (DevLevel::xs, tuning key fc_spatial_x: 0 off, 1 levels of >= 4096 C points - the default -, 2 every level).  Only the
+    numbering of A_fc's columns changes, not the order of the entries inside a row: PCApply and the Krylov solve must not
+    change by a bit, with and without a layout hint, for one-point and general W and for cycles with C smoothing."""
+    torch = torch_mod
+    import pflare_amd as P
+    from oracle import air_ref as R, bridge
+    gen, opts = CASES[case]
+    hm = P.HostMat.adv_diff_fd(**gen)
+    A = bridge.to_scipy(hm.csr())
+    n = A.shape[0]
+    x = lcg_vector(n)
+    key = np.random.default_rng(9).permutation(n) if hint else None
+    out = []
+    lib = P.lib()
+    try:
+        for mode in (0, 2):
+            assert lib.airhip_set_tuning(b"fc_spatial_x", mode) == 0
+            pc = P.PCAIR(**opts)
+            if key is not None:
+                pc.set_ordering_hint(key)
+            pc.setup(A)
+            z = torch.empty(n, dtype=torch.float64, device="cuda")
+            pc.apply(dev(torch, x), z)
+            b = torch.zeros(n, dtype=torch.float64, device="cuda"); sol = torch.ones_like(b)
+            res = P.KSP("gmres", pc_side="right", rtol=1e-10, atol=1e-50, max_it=40).solve(b, sol, pc=pc)
+            out.append((z, res["its"], res["rnorm"], pc))
+    finally:
+        lib.airhip_set_tuning(b"fc_spatial_x", 1)
     assert torch.equal(out[0][0], out[1][0])
     assert out[0][1] == out[1][1] and out[0][2] == out[1][2]
     H = bridge.hierarchy_from_product(out[1][3], A)
