@@ -103,7 +103,13 @@ int airhip_set_num_threads(int n, int* prev);
  *   of the device SpGEMM at that many entries, 0 = sized from the operands; a small cap forces the multi-round path),
  *   "spgemm_pool_chunk" (entries a wave takes from that pool at a time, -1 = automatic), "block_order_min_blocks"
  *   (operators with at least this many row blocks are swept in the spatial order of their rows, default 4096), "fc_fuse"
- *   (default 1; 0 runs the one-point prolongation and the A_fc product of an F relaxation as two launches - diagnostic).
+ *   (default 1; 0 runs the one-point prolongation and the A_fc product of an F relaxation as two launches - diagnostic),
+ *   "mb16" / "mb16_max_rows" (default 1 / 128: row blocks of at most that many rows are stored with 16-bit multi-base index
+ *   words - 10 instead of 12 bytes per non-zero; 0 = the packed / raw 32-bit forms only; act at the next conversion),
+ *   "occ_spmv" / "occ_fc" (default 6 / 5: workgroups per CU = waves per SIMD of the SpMV / fused F-relaxation kernels, 0 =
+ *   what the registers allow; act at the next launch), "fc_spatial_x" (default 1: A_fc gathers from a copy of x_c in the
+ *   spatial order of the C points on the levels where that pays, 0 = never, 2 = every level; acts at the next upload).
+ *   None of them changes a result by a bit.
  * airhip_pcair_setup_host_only / airhip_pcinv_setup_host_only: build the hierarchy without touching a device (CPU-side
  *   tests of the setup, hierarchy export); apply / solve then fail with AIRHIP_ERR_STATE.
  * airhip_spgemm_filtered: C = filter(A*B) with the host (on_device = 0) or the device SpGEMM of the setup, drop / lump /

@@ -52,7 +52,7 @@ static int64_t g_block_order_min = 4096;      // smaller operators sit in the ca
 void set_block_order_min(int64_t nblocks) { g_block_order_min = nblocks > 0 ? nblocks : 1; }
 static bool g_fc_fuse = true;
 void set_fc_fuse(bool on) { g_fc_fuse = on; }
-static int g_fc_spatial = 1;       // 0 off, 1 levels with at least 4096 C points, 2 every level (tests)
+static int g_fc_spatial = 1;       // 0 off, 1 levels where it pays (upload), 2 every level (tests)
 void set_fc_spatial(int mode) { g_fc_spatial = mode; }
 
 static void order_blocks_by_key(DevMat& M, const int32_t* dev_row_to_host, const int64_t* key, hipStream_t s) {
@@ -482,7 +482,10 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
     // columns of A_fc (and of the one-point prolongator): positions in x_c = the level-(l+1) vector, or - single device,
     // set_fc_spatial - positions in the copy of x_c that f_smooths keeps in the spatial order of the C points
     std::vector<int32_t> csp;              // coarse index -> spatial rank (empty: not used)
-    const bool fc_spatial = g_fc_spatial && !dist && (g_fc_spatial >= 2 || h.n_c >= 4096);
+    // Worth it where A_fc's rows are long: the copy moves 20 bytes per C point, the product streams ~10 bytes per non-zero and
+    // gains ~8 % (464^3, profiles/r04_fc_spatial.txt: levels 5-10 gain 0.05-0.13 ms each for 0.01-0.06 ms of copy, levels 1-4
+    // lose 0.03-0.2 ms each) - from 25 non-zeros of A_fc per C point on
+    const bool fc_spatial = g_fc_spatial && !dist && (g_fc_spatial >= 2 || (h.n_c >= 4096 && h.A_fc.nnz() >= 25 * h.n_c));
     if (fc_spatial) {
       const std::vector<int64_t>& kc = level_keys[l + 1];
       std::vector<int32_t> ord((size_t)h.n_c), src((size_t)h.n_c);

@@ -35,7 +35,7 @@ void set_fc_fuse(bool on);
 // lie in the order of their locality keys instead of section by section [F_{l+1} | F_{l+2} | ...]: the copy costs 20 bytes per
 // C point and cycle, the blocks of A_fc then touch half as many lines of x.  Same results bit for bit (the order of the
 // entries inside a row does not change).  Single device, one-point or general W; not for distributed hierarchies.
-void set_fc_spatial(int mode);      // 0 off, 1 (default) levels with at least 4096 C points, 2 every level
+void set_fc_spatial(int mode);      // 0 off, 1 (default) levels where A_fc holds >= 25 non-zeros per C point, 2 every level
 
 // Upload a host CSR and convert it to SELL-64 on the device (rows/cols optionally permuted).
 void upload_mat(const Csr& A, const int32_t* d_rowsrc, const int32_t* d_colmap, DevMat& out, hipStream_t s, int64_t n_ghost = 0);
