@@ -378,15 +378,23 @@ static std::string memory_state() {
   std::string st = "driver reports " + std::to_string(free_b >> 20) + " MiB free of " + std::to_string(total_b >> 20) + ", block cache holds " +
                    std::to_string(c.idle_bytes >> 20) + " MiB idle";
   { size_t lb = 0; for (auto& kv : c.live) lb += kv.second; st += " and " + std::to_string(lb >> 20) + " MiB in use outside the arenas"; }
-  for (auto& a : arenas()) st += ", arena (" + std::string(a->closing ? "of a finished setup" : "active") + ") " + std::to_string(a->used >> 20) + " MiB in blocks / " +
-                                 std::to_string(a->vm.committed >> 20) + " MiB backed";
+  for (auto& a : arenas()) st += ", arena (" + std::string(a->release_pending ? "empty, waiting for its maker thread to free it" : a->closing ? "of a finished setup" : "active") + ") " +
+                                 std::to_string(a->used >> 20) + " MiB in blocks / " + std::to_string(a->vm.committed >> 20) + " MiB backed";
   return st;
 }
 static void* dev_alloc_once(size_t bytes, bool& failed);
 void* dev_alloc(size_t bytes) {
   bool failed = false;
   void* p = dev_alloc_once(bytes, failed);
-  if (failed && relieve_pressure() > 0) p = dev_alloc_once(bytes, failed);
+  if (failed) {
+    // (opt-in arenas) ranges whose last block came back on another thread still hold their memory until this thread - if
+    // it made them - frees them
+    dev_drain_releases();
+    const size_t got = relieve_pressure();
+    dev_drain_releases();
+    (void)got;
+    p = dev_alloc_once(bytes, failed);
+  }
   if (failed) throw std::runtime_error(std::string("hipMalloc of ") + std::to_string(bytes) + " bytes failed: out of memory (" + memory_state() + ")");
   return p;
 }
@@ -447,7 +455,8 @@ void* dev_alloc_exact(size_t bytes) {
   void* p = nullptr;
   hipError_t e = raw_alloc(&p, bytes ? bytes : 1);
   if (e != hipSuccess) { (void)hipGetLastError(); dev_cache_trim(); e = raw_alloc(&p, bytes ? bytes : 1); }
-  if (e != hipSuccess && relieve_pressure() > 0) {
+  if (e != hipSuccess) { dev_drain_releases(); (void)relieve_pressure(); dev_drain_releases(); }
+  if (e != hipSuccess) {
     (void)hipGetLastError();
     if (bytes >= CACHE_MIN) {
       DevCache& c = cache();

@@ -97,11 +97,13 @@ static int mpi_allreduce(void* user, double* vals, int n) {
 struct piece_mem { void** blocks; int n, cap; };
 static void* piece_alloc(struct piece_mem* pm, size_t bytes) {
   if (pm->n == pm->cap) {
-    pm->cap = pm->cap ? 2 * pm->cap : 256;
-    pm->blocks = (void**)realloc(pm->blocks, sizeof(void*) * (size_t)pm->cap);
+    const int cap = pm->cap ? 2 * pm->cap : 256;
+    void** b = (void**)realloc(pm->blocks, sizeof(void*) * (size_t)cap);
+    if (!b) return NULL;
+    pm->blocks = b; pm->cap = cap;
   }
   void* p = malloc(bytes ? bytes : 1);
-  pm->blocks[pm->n++] = p;
+  if (p) pm->blocks[pm->n++] = p;
   return p;
 }
 static void piece_free(struct piece_mem* pm) {
@@ -181,6 +183,7 @@ int airhip_mpi_pcair_setup(MPI_Comm user_comm, const airhip_csr* local, int nopt
   const int64_t nnz_local = local->m > 0 ? local->rowptr[local->m] - local->rowptr[0] : 0;
   /* ---- gather the operator on rank 0 (row lengths, columns, values; rank order = global row order) */
   counts = (int64_t*)malloc(sizeof(int64_t) * 2 * (size_t)h->size);
+  if (!counts) FAIL(AIRHIP_ERR_INTERNAL, "out of memory");      /* (before any rank waits for another) */
   {
     int64_t mine2[2] = {local->m, nnz_local};
     MPIC(MPI_Gather(mine2, 2, MPI_INT64_T, counts, 2, MPI_INT64_T, 0, h->comm));
@@ -194,7 +197,19 @@ int airhip_mpi_pcair_setup(MPI_Comm user_comm, const airhip_csr* local, int nopt
     g_v = (double*)malloc(sizeof(double) * (size_t)(nnz ? nnz : 1));
     owner = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n ? n : 1));
     if (hint) g_hint = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n ? n : 1));
-    if (!g_rp || !g_ci || !g_v || !owner || (hint && !g_hint)) FAIL(AIRHIP_ERR_INTERNAL, "out of memory gathering the operator");
+  }
+  int64_t* rel = NULL;               /* ranks > 0: row pointers relative to their first entry */
+  if (h->rank != 0) rel = (int64_t*)malloc(sizeof(int64_t) * (size_t)(local->m ? local->m : 1));
+  {
+    /* every rank learns whether all of them have their buffers BEFORE the first point-to-point message: a rank that gave
+     * up here used to leave the others blocked in their sends / receives */
+    int ok = h->rank != 0 ? rel != NULL : (g_rp && g_ci && g_v && owner && (!hint || g_hint)), all_ok = 0;
+    MPIC(MPI_Allreduce(&ok, &all_ok, 1, MPI_INT, MPI_MIN, h->comm));
+    if (!all_ok) { free(rel); FAIL(AIRHIP_ERR_INTERNAL, "out of memory gathering the operator on rank 0"); }
+  }
+  if (h->rank == 0) {
+    const int64_t n = local->n;
+    (void)n;
     int64_t row = 0, p = 0;
     g_rp[0] = 0;
     for (int r = 0; r < h->size; r++) {
@@ -215,7 +230,6 @@ int airhip_mpi_pcair_setup(MPI_Comm user_comm, const airhip_csr* local, int nopt
       row += mr; p += nr;
     }
   } else {
-    int64_t* rel = (int64_t*)malloc(sizeof(int64_t) * (size_t)(local->m ? local->m : 1));
     for (int64_t i = 0; i < local->m; i++) rel[i] = local->rowptr[i + 1] - local->rowptr[0];
     int bad = send_big(rel, 8 * local->m, 0, 70, h->comm);
     free(rel);
@@ -251,6 +265,7 @@ int airhip_mpi_pcair_setup(MPI_Comm user_comm, const airhip_csr* local, int nopt
           const char* name; int dt; const void* data; int64_t cnt;
           AIR(airhip_archive_item(ar, i, &name, &dt, &data, &cnt));
           void* p = piece_alloc(&pm, (size_t)(cnt * elem_size[dt]));
+          if (!p) FAIL(AIRHIP_ERR_INTERNAL, "out of memory keeping rank 0's piece");
           if (cnt) memcpy(p, data, (size_t)(cnt * elem_size[dt]));
           AIR(airhip_archive_add(mine, name, dt, p, cnt));
           piece_bytes += cnt * elem_size[dt];
