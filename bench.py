@@ -451,7 +451,8 @@ def main():
     value = args.steps / wall
     roofline = None
     if stats:
-        live = [s for s in stats if s["calls"] > 0]
+        exch = [s for s in stats if s["calls"] > 0 and s["kernel"] == "halo_exchange"]      # distributed: exposed exchange time, not a kernel
+        live = [s for s in stats if s["calls"] > 0 and s["kernel"] != "halo_exchange"]
         # aggregate the call sites by HIP kernel function: this is the row a rocprofv3
         # --kernel-trace --stats summary shows (profiles/), so the two can be compared directly
         kern = {}
@@ -519,6 +520,8 @@ def main():
         # complete accounting: kernels timed inside the solves / device time of the solves (the rest: host round trips
         # of the dot products, launch gaps)
         roofline["profiled_share_of_device_ms"] = (vc_ms + outer_ms + kry_ms) / ms_dev if ms_dev > 0 else None
+        if exch:
+            roofline["exposed_exchange_ms_per_step"] = sum(s["total_ms"] for s in exch) / args.steps
         if args.verbose:
             for s in sorted(live, key=lambda s: -s["total_ms"])[:60]:
                 a = s["total_ms"] / s["calls"]
