@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 # defaults of the airhip_set_tuning keys (include/airhip.h): what --variants restores after each variant
-TUNING_DEFAULTS = {"spgemm_pool_entries": 0, "spgemm_pool_chunk": -1, "block_order_min_blocks": 4096, "fc_fuse": 1, "occ_spmv": 6, "occ_fc": 5}
+TUNING_DEFAULTS = {"spgemm_pool_entries": 0, "spgemm_pool_chunk": -1, "block_order_min_blocks": 4096, "fc_fuse": 1, "occ_spmv": 6, "occ_fc": 5, "krylov_blocks": 512}
 
 RECIPES = {
     # reference GPU recipe: lumping + auto truncation + Newton matrix-free coarse solver
@@ -393,6 +393,13 @@ def main():
         before the driver's scaling run, so it must not be able to cost the line; the result goes to stderr."""
         if not (dist_mode and transport == "rccl" and not args.graph and os.environ.get("AIRHIP_BENCH_GRAPH_REHEARSAL", "1") == "1"):
             return
+        # a hang in here (a first run of captured RCCL groups on N > 1 devices) must not keep the ranks alive: the line is out,
+        # so after three minutes every rank ends itself with exit code 0
+        import threading
+        dog = threading.Timer(float(os.environ.get("AIRHIP_BENCH_GRAPH_REHEARSAL_TIMEOUT_S", "180")),
+                              lambda: (print(f"[bench] rank {rank}: graph rehearsal timed out", file=sys.stderr, flush=True), os._exit(0)))
+        dog.daemon = True
+        dog.start()
         try:
             pc.use_graph(True)
             r_ = P.KSP(max_it=200, **ksp_kw).solve(b, x.fill_(1.0), pc=pc)
@@ -406,6 +413,7 @@ def main():
         except Exception as e:      # noqa: BLE001 - a rehearsal
             print(f"[bench] rank {rank}: graph rehearsal failed: {e!r}", file=sys.stderr, flush=True)
         finally:
+            dog.cancel()
             pc.use_graph(False)
 
     run_iterations(args.warmup)

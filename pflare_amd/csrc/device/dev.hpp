@@ -134,6 +134,7 @@ void devmat_free(DevMat& A);
 
 // performance knobs (not part of the stable ABI; airhip_set_tuning): see spmv.hip
 int spmv_set_tuning(const char* key, int value);
+int kernels_set_tuning(const char* key, int value);      // kernels.hip: experiments on the Krylov kernels
 
 #define HIP_CHECK(expr)                                                                       \
   do {                                                                                        \

@@ -5,6 +5,7 @@
 #include "dev.hpp"
 #include "kcommon.hpp"
 #include <stdexcept>
+#include <string>
 
 namespace airhip {
 
@@ -173,9 +174,11 @@ __global__ __launch_bounds__(BLOCK) void k_mdot_final(int nblocks, int nv, const
   }
 }
 
+extern int g_stream_blocks_limit();
 static int stream_blocks(int64_t n) {
   int blocks = grid_for_n(n, 2);
-  return blocks > MDOT_BLOCKS ? MDOT_BLOCKS : blocks;
+  const int lim = g_stream_blocks_limit();
+  return blocks > lim ? lim : blocks;
 }
 static bool vec2_ok(int64_t n, int64_t ld, const void* a, const void* b) {
   return (n & 1) == 0 && (ld & 1) == 0 && (((uintptr_t)a | (uintptr_t)b) & 15) == 0;
@@ -239,6 +242,17 @@ __global__ __launch_bounds__(BLOCK) void k_maxpy(int64_t n, double* __restrict__
   if constexpr (NORM) block_sums<1>(ss, partial, 1, 0);
 }
 
+// Workgroups of the multi-dot / multi-axpy launches (airhip_set_tuning "krylov_blocks").  Measured at 464^3 over the 20 timed
+// iterations of bench.py (profiles/r04_krylov_blocks.txt): 2048 workgroups (8 per CU) multi-dot 20.0 ms / multi-axpy 27.1 ms,
+// 256 ... 768 workgroups 17.7 / 23.9-24.5 ms, 128 workgroups 26.0 / 28.3 ms - with K + 1 streams a gigabyte apart, fewer waves
+// walking them keep the DRAM pages open longer; non-temporal stores of the result changed nothing.
+static int g_stream_blocks = 512;
+int kernels_set_tuning(const char* key, int value) {
+  const std::string k(key);
+  if (k == "krylov_blocks") { g_stream_blocks = value < 64 ? 64 : (value > MDOT_BLOCKS ? MDOT_BLOCKS : value); return 0; }
+  return -1;
+}
+int g_stream_blocks_limit() { return g_stream_blocks; }
 template <bool VEC, bool ZERO, bool NORM>
 static void maxpy_dispatch(int k, int blocks, hipStream_t s, int64_t n, double* w, const double* V, int64_t ld, const double* coef, int k0, double* partial) {
   switch (k) {

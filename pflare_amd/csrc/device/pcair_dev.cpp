@@ -139,10 +139,13 @@ void DevPCAIR::end_kernel() {
 void DevPCAIR::resolve_events() {
   if (pending_.empty()) return;
   HIP_CHECK(hipStreamSynchronize(stream_));
+  if (comm_stream_) HIP_CHECK(hipStreamSynchronize(comm_stream_));      // (the exchange statistics pair events of both streams)
   for (auto& p : pending_) {
     float ms = 0.f;
-    HIP_CHECK(hipEventElapsedTime(&ms, p.a, p.b));
-    if (ms < 0.f) ms = 0.f;      // (an exchange that ended before the interior blocks did: nothing exposed)
+    // a pair across the two streams may be "in the wrong order" (an exchange that ended before the interior blocks did:
+    // nothing exposed) - a negative time or an error from the runtime both mean zero here
+    if (hipEventElapsedTime(&ms, p.a, p.b) != hipSuccess) { (void)hipGetLastError(); ms = 0.f; }
+    if (ms < 0.f) ms = 0.f;
     stats_[p.stat].calls++; stats_[p.stat].ms += ms;
     event_pool_.push_back(p.a); event_pool_.push_back(p.b);
   }

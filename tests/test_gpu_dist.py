@@ -66,6 +66,8 @@ def _worker(rank, world, port, case, out):
         comm = D.StagedComm()
         assert comm.selftest(1000)
         pc, gid = D.distribute(pcg, A, owner, comm)
+        if case == "adv3d_24_lump":
+            pc.profile(True)          # the per-kernel events, and the exposed-exchange statistic across the two streams
         xb = torch.from_numpy(b[gid]).cuda()
         z = torch.empty_like(xb)
         try:
@@ -79,6 +81,9 @@ def _worker(rank, world, port, case, out):
         rhs = torch.zeros_like(xb); x = torch.ones_like(xb)
         res = ksp.solve(rhs, x, pc=pc)
         assert comm.error is None, comm.error
+        if case == "adv3d_24_lump":
+            st = [s for s in pc.profile_stats() if s["calls"] > 0]
+            assert any(s["kernel"] == "halo_exchange" for s in st) and all(s["total_ms"] >= 0.0 for s in st), st
         payload = (gid, z.cpu().numpy(), x.cpu().numpy(), res["its"], res["reason"], comm.stats())
         if rank == 0:
             got = [payload]
