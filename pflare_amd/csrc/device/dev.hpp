@@ -31,8 +31,8 @@ namespace airhip {
 //                run through several sections of a hierarchical vector (A_fc), which were raw before round 4.
 struct alignas(32) BlkDesc { int64_t p0; int32_t row; int32_t cbase; int32_t nb; int32_t nr; int64_t ip; };
 constexpr int MB_OB_MASK = 31, MB_WIN_SHIFT = 5, MB_MAX_WIN = 64;
-// the blocks the lean kernels process (spmv.hip): multi-base blocks, and raw blocks of at most 512 entries
-__host__ __device__ inline bool lean_block(const BlkDesc& q) { return q.cbase <= -2 || (q.cbase == -1 && q.nb <= 512); }
+// the blocks the lean kernels process (spmv.hip): multi-base and raw blocks - everything but the packed form of rounds 2-3
+__host__ __device__ inline bool lean_block(const BlkDesc& q) { return q.cbase <= -1; }
 
 // Row-block CSR.  One wavefront streams a block's (index word, value) pairs with coalesced loads, gathers x,
 // stages the products a_ij * x_j in LDS at their row-major positions and then sums every row's LDS segment

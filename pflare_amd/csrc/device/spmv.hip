@@ -40,6 +40,7 @@
 #include "rb.hpp"
 #include "devmem.hpp"
 #include <stdexcept>
+#include <type_traits>
 #include <vector>
 #include <algorithm>
 #include <cstdlib>
@@ -346,9 +347,9 @@ __device__ __forceinline__ void rb_body(const RbView& A, const BlkInfo& d, const
 // budget - 16 for the values, 16 for the gathered x, 4 for the index words, one set of epilogue inputs - and not that of
 // the widest path decides how many waves a SIMD holds: the block code waits on memory three times in a row, and what it
 // streams per microsecond is the number of resident waves times a block.
-// RAW: the same path for a raw block of at most 512 entries (32-bit absolute columns; the few blocks that fit no table, e.g.
-// a block of one entry) - so that a launch of the *_g kernels is only needed for what is rare: raw long rows, and packed
-// blocks when the multi-base form is switched off
+// RAW: the same path for a raw block (32-bit absolute columns; the few blocks that fit no table, e.g. a block of one entry or
+// a long row whose columns lie in more than 64 windows) - so that a launch of the *_g kernels is only needed for packed
+// blocks, i.e. when the multi-base form is switched off
 template <int NF, bool RAW, bool DIST, class Epi>
 __device__ __forceinline__ void rb_body_mb(const RbView& A, const BlkInfo& d, const XVec<DIST> x, double* __restrict__ lds, const Epi& epi, int lane) {
   const int nr = d.nr;
@@ -381,11 +382,13 @@ __device__ __forceinline__ void rb_body_mb(const RbView& A, const BlkInfo& d, co
     }
   }
   pre[0] = epi.load(d.r0, nr, lane, early0);
-  if constexpr (NF == EPL && !RAW) {
+  if constexpr (NF == EPL) {
     if (d.nb > BLK_NNZ) {
-      // one long row: the whole wave reduces it, with the arithmetic of the raw long-row path (rb_body).  The first 512
-      // entries are in registers; the words and values of the rest lie in plain order behind them
-      const unsigned short* __restrict__ wp = reinterpret_cast<const unsigned short*>(A.idx + d.ip + nwin * 4);
+      // one long row: the whole wave reduces it, with the arithmetic of the general kernels' long-row path (rb_body).  The
+      // first 512 entries are in registers; the words (16-bit, or 32-bit absolute columns of a raw row) and values of the
+      // rest lie in plain order behind them
+      typedef typename std::conditional<RAW, uint32_t, unsigned short>::type word_t;
+      const word_t* __restrict__ wp = reinterpret_cast<const word_t*>(A.idx + d.ip + nwin * 4);
       const double* __restrict__ vp = A.val + d.p0;
       const int nb = d.nb;
       double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -395,8 +398,11 @@ __device__ __forceinline__ void rb_body_mb(const RbView& A, const BlkInfo& d, co
         s2 = fma(vv[u + 2], xx[u + 2], s2); s3 = fma(vv[u + 3], xx[u + 3], s3);
       }
       auto xat = [&](uint32_t w) {
-        const uint32_t base = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((w >> ob) << 2), (int)tab);
-        return x.at_byte_offset(base + ((w & omask) << 3));
+        if constexpr (RAW) return x.at_byte_offset(w << 3);
+        else {
+          const uint32_t base = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((w >> ob) << 2), (int)tab);
+          return x.at_byte_offset(base + ((w & omask) << 3));
+        }
       };
       // Wave-uniform trip counts with per-lane predicates: ds_bpermute only sees the table entries of ACTIVE lanes, so no
       // lane may leave these loops before the last one does.  Per lane the entries go to the same chains as in rb_body's
@@ -404,7 +410,7 @@ __device__ __forceinline__ void rb_body_mb(const RbView& A, const BlkInfo& d, co
       int j = BLK_NNZ + lane;
       while (__any(j + 3 * WAVE < nb)) {
         const bool p = j + 3 * WAVE < nb;
-        const int jj = p ? j : BLK_NNZ;      // (a valid position for the lanes that are done)
+        const int jj = p ? j : lane;         // (lanes that are done read positions inside the first 512: always the block's own)
         const uint32_t c0 = wp[jj], c1 = wp[jj + WAVE], c2 = wp[jj + 2 * WAVE], c3 = wp[jj + 3 * WAVE];
         const double v0 = vp[jj], v1 = vp[jj + WAVE], v2 = vp[jj + 2 * WAVE], v3 = vp[jj + 3 * WAVE];
         const double x0 = xat(c0), x1 = xat(c1), x2 = xat(c2), x3 = xat(c3);
