@@ -350,6 +350,8 @@ __device__ __forceinline__ void rb_body(const RbView& A, const BlkInfo& d, const
 // RAW: the same path for a raw block (32-bit absolute columns; the few blocks that fit no table, e.g. a block of one entry or
 // a long row whose columns lie in more than 64 windows) - so that a launch of the *_g kernels is only needed for packed
 // blocks, i.e. when the multi-base form is switched off
+// (The epilogue inputs of a lane's second row - blocks of more than 64 rows - are loaded only after the first row is stored:
+// loading them with the first row's was measured on the levels 1-3, whose blocks all have 128 rows: no difference.)
 template <int NF, bool RAW, bool DIST, class Epi>
 __device__ __forceinline__ void rb_body_mb(const RbView& A, const BlkInfo& d, const XVec<DIST> x, double* __restrict__ lds, const Epi& epi, int lane) {
   const int nr = d.nr;
@@ -987,7 +989,9 @@ __global__ __launch_bounds__(BLOCK) void k_block_pack(int64_t nblocks, int64_t n
       }
       for (int i = lane; i < nb; i += WAVE) oval[p0 + val_slot(i, nb)] = val[p0 + i];
       if (lane == 0) { blk[b].cbase = -2 - (ob | (nwin << MB_WIN_SHIFT)); blk[b].ip = 4 * (int64_t)(nwin + nd); }
-    } else if (can_pack) {
+    } else if (can_pack && !mb_on) {
+      // (with the multi-base form on, a block that fits no table stays raw: the lean kernels take it, and a launch of the
+      // *_g kernels for a handful of one-entry blocks per operator costs more than their 4-byte words)
       for (int i = lane; i < nb; i += WAVE) {
         const unsigned long long k = keys[i];
         const int pos = (int)(k & 0xffffull);
