@@ -1,5 +1,5 @@
 """The bench.py output contract, checked on the committed line of the round's final default run
-(profiles/r03_final3_bench464_default.json): every key the driver and the judge read is there with the right type,
+(profiles/r04_final_bench464_default.json): every key the driver and the judge read is there with the right type,
 the workload is BASELINE configs[2] (3D advection, 464^3), and the derived fields are consistent."""
 import json
 import os
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_honours_the_contract():
-    with open(os.path.join(ROOT, "profiles", "r03_final3_bench464_default.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r04_final_bench464_default.json")) as f:
         d = json.loads(f.read().strip().splitlines()[-1])
     for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                  ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
@@ -25,15 +25,16 @@ def test_committed_bench_line_honours_the_contract():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-12
     assert abs(r["achieved"] - r["alg_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) <= 1e-6 * r["achieved"]
-    assert r["traffic"] is None or r["traffic"] >= r["alg_bytes_per_launch"]     # measured HBM bytes >= algorithmic
-    assert r["traffic"] is None or r["traffic"] <= 1.15 * r["alg_bytes_per_launch"]   # ... and no wasted re-reads
-    assert r["frac"] >= 0.64
+    # measured HBM bytes against the algorithmic figure (12 bytes per non-zero by SURVEY 8d's definition): since round 4 the
+    # format stores 10.1, so the counters read BELOW it - but not below what the format holds, and without wasted re-reads
+    assert r["traffic"] is None or 0.80 * r["alg_bytes_per_launch"] <= r["traffic"] <= 1.15 * r["alg_bytes_per_launch"]
+    assert r["frac"] >= 0.70
     # the second kernel of the cycle, reported the same way (its PMC traffic is the committed k_rb_fc_first@464 entry)
     o = r["other_kernels"]["k_rb_fc_first"]
-    assert abs(o["frac"] - o["achieved"] / 8000.0) <= 1e-12 and o["frac"] >= 0.5
+    assert abs(o["frac"] - o["achieved"] / 8000.0) <= 1e-12 and o["frac"] >= 0.6
     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
         assert o["traffic"] == json.load(f)["k_rb_fc_first@464"]["bytes_per_launch"]
-    assert o["alg_bytes_per_launch"] <= o["traffic"] <= 1.15 * o["alg_bytes_per_launch"]
+    assert 0.80 * o["alg_bytes_per_launch"] <= o["traffic"] <= 1.15 * o["alg_bytes_per_launch"]
     # the traffic figure is a replay of the committed PMC passes: it must name them and the commit they were taken at
     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
         pmc = json.load(f)["k_rb_spmv@464"]
@@ -47,4 +48,7 @@ def test_committed_bench_line_honours_the_contract():
     # the oracle as the checker: the CPU sample's residual norms against the GPU solve's, entry by entry
     assert c["check"]["residual_norms_compared"] >= 2 and c["check"]["max_rel_diff_gpu_vs_cpu"] <= 1e-6
     # the setup as the caller sees it, and the library's host-mirror thread that runs after it (beside the solves)
-    assert 0 < d["config"]["setup_s"] < 30.0 and d["config"]["host_mirror_s"] >= 0.0
+    assert 0 < d["config"]["setup_s"] < 40.0 and d["config"]["host_mirror_s"] >= 0.0
+    # round 4: every kernel of a step is accounted for, both cycle denominators are reported
+    assert r["profiled_share_of_device_ms"] >= 0.97 and r["krylov_kernels_ms_per_step"] <= 3.0
+    assert r["vcycle_exec_GBs"] < r["vcycle_alg_GBs"] and r["vcycle_kernel_ms"] <= 37.0 and d["value"] >= 22.0
