@@ -515,6 +515,7 @@ static void finish_device(airhip_pcair pc, SetupAccel* accel = nullptr) {
   pc->dev->upload(*pc->H, pc->A_top);
   pc->dev->set_device_source(nullptr);
   pc->dev->set_use_graph(pc->use_graph);
+  pc->dev->set_before_capture([pc]() { mirror_join(pc); });
   pc->dev->set_profile(pc->profile);
   pc->ksp.reset();
   pc->kb.release(); pc->kx.release();
@@ -1162,6 +1163,7 @@ int airhip_pcair_load_distributed(airhip_pcair pc, airhip_archive piece, airhip_
   if (loc->hint.size() > 0) pc->dev->set_ordering_hint(loc->hint.data(), loc->hint.size());
   pc->dev->upload(loc->H, loc->A_top, loc.get(), comm->c.get());
   pc->dev->set_use_graph(pc->use_graph);      // effective only with a transport whose exchange is device work (DevPCAIR::graph_ok)
+  pc->dev->set_before_capture([pc]() { mirror_join(pc); });
   pc->dev->set_profile(pc->profile);
   pc->upload_s = now_s() - t0;
   pc->op_nnz_top = (double)loc->A_top.nnz();

@@ -889,9 +889,22 @@ bool DevPCAIR::graph_ok() const { return want_graph_ && !profile_ && (!comm_ || 
 void DevPCAIR::run_cycle() {
   if (graph_ok()) {
     if (!graph_exec_) {
-      hipGraph_t g;
-      HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
-      vcycle();
+      hipGraph_t g = nullptr;
+      // Found in round 4 with a captured PCApply right after setup(): the copies and frees of the library's own host-mirror
+      // thread invalidate a capture in progress on this stream ("operation failed due to a previous error during capture"),
+      // in thread-local and in relaxed mode alike.  So the owner first waits for that thread (before_capture_); relaxed mode
+      // stays for the application's other threads.
+      if (before_capture_) before_capture_();
+      HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeRelaxed));
+      try { vcycle(); }
+      catch (...) {
+        // leave the stream usable: end (and discard) the broken capture, run without a graph from here on
+        (void)hipStreamEndCapture(stream_, &g);
+        if (g) (void)hipGraphDestroy(g);
+        (void)hipGetLastError();
+        want_graph_ = false;
+        throw;
+      }
       HIP_CHECK(hipStreamEndCapture(stream_, &g));
       HIP_CHECK(hipGraphInstantiate(&graph_exec_, g, nullptr, nullptr, 0));
       HIP_CHECK(hipGraphDestroy(g));

@@ -119,6 +119,9 @@ class DevPCAIR {
   const std::vector<KernelStat>& stats() const { return stats_; }
 
   void set_use_graph(bool on) { want_graph_ = on; }
+  // called right before the cycle is recorded into a graph: the owner waits there for everything of its own that may issue
+  // HIP calls from another thread (the host-mirror thread of a setup: its copies and frees invalidate a capture in progress)
+  void set_before_capture(std::function<void()> f) { before_capture_ = std::move(f); }
   std::vector<std::unique_ptr<DevLevel>> levels_;
   DevInv coarse_inv_;
   DevMat coarse_A_;
@@ -200,6 +203,7 @@ class DevPCAIR {
   int cur_stat_ = -1; hipEvent_t cur_a_ = nullptr;
   // graph
   bool want_graph_ = false;
+  std::function<void()> before_capture_;
   hipGraphExec_t graph_exec_ = nullptr;
 };
 

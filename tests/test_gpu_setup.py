@@ -460,3 +460,21 @@ def test_two_setups_back_to_back_at_128_with_the_mirror_thread_alive(gpu):
     about 128^3, on the default device-memory path (no address-space covers, no handle recycling)."""
     v = _run_fallback({}, M=128)
     assert v["its"] == v["its2"] and v["same"] == 0.0 and v["its"] <= 10, v
+
+
+def test_graph_capture_right_after_a_setup_waits_for_the_mirror_thread(gpu):
+    """found in round 4: a PCApply recorded into a hipGraph while the library's host-mirror thread was still copying and
+    freeing device memory failed ("operation failed due to a previous error during capture").  The capture now waits for that
+    thread; the captured cycle must give the plain cycle's result bit for bit."""
+    import torch
+    import pflare_amd as P
+    A = P.HostMat.adv_diff_fd(dim=3, M=72, N=72, P=72)
+    n = A.shape[0]
+    pc = P.PCAIR(a_lump=True).setup(A)
+    pc.use_graph(True)                         # (no host_mirror_wait: the mirror thread of the 72^3 setup is still busy)
+    x = torch.ones(n, dtype=torch.float64, device="cuda")
+    yg = torch.empty_like(x); pc.apply(x, yg); pc.apply(x, yg)
+    pc.use_graph(False)
+    yp = torch.empty_like(x); pc.apply(x, yp)
+    assert torch.equal(yg, yp)
+    assert pc.host_mirror_wait() >= 0.0
