@@ -452,6 +452,22 @@ void* dev_alloc_exact(size_t bytes) {
     std::lock_guard<std::mutex> lock(c.mu);
     if (void* q = arena_alloc(active_arena(DEV_HIER), bytes)) return q;
   }
+  if (bytes >= CACHE_MIN) {
+    // A released block of the setup that fits closely (at most 1/8 larger) becomes the long-lived array: it is a plain
+    // hipMalloc block (hipFree takes it back like any other) whose memory the driver does not have to hand out afresh -
+    // 7-57 ms per GB for the 106 GB of a 464^3 hierarchy since the arenas are off by default.
+    DevCache& c = cache();
+    std::lock_guard<std::mutex> lock(c.mu);
+    int best = -1;
+    for (int k = 0; k < (int)c.idle.size(); k++)
+      if (c.idle[k].second >= bytes && c.idle[k].second - bytes <= bytes / 8 && (best < 0 || c.idle[k].second < c.idle[best].second)) best = k;
+    if (best >= 0) {
+      void* q = c.idle[best].first;
+      c.idle_bytes -= c.idle[best].second;
+      c.idle.erase(c.idle.begin() + best);
+      return q;
+    }
+  }
   void* p = nullptr;
   hipError_t e = raw_alloc(&p, bytes ? bytes : 1);
   if (e != hipSuccess) { (void)hipGetLastError(); dev_cache_trim(); e = raw_alloc(&p, bytes ? bytes : 1); }
