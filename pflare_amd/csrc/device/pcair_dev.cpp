@@ -638,6 +638,13 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
     for (auto& l : levels_) for (const DevMat* m : {&l->A_ff, &l->A_fc, &l->A_cf, &l->A_cc, &l->Z, &l->W, &l->inv_ff.mat, &l->inv_cc.mat, &l->A_full}) acc(*m);
     std::printf(" row blocks on the device: %.3g non-zeros, index regions %.2f bytes per non-zero (values 8), %.1f GB in all\n",
                 nz, nz > 0 ? ib / nz : 0.0, storage_bytes() * 1e-9);
+    // how full the blocks are (512 entries = full): rows of 257 ... 511 entries cannot share a block
+    std::printf(" non-zeros per row block (A_ff, M_ff, A_fc, Z) by level:");
+    for (size_t l = 0; l < levels_.size(); l++) {
+      auto f = [](const DevMat& m) { return m.valid() && m.nblocks > 0 ? (double)m.nnz / (double)m.nblocks : 0.0; };
+      std::printf(" %zu: %.0f %.0f %.0f %.0f;", l + 1, f(levels_[l]->A_ff), f(levels_[l]->inv_ff.mat), f(levels_[l]->A_fc), f(levels_[l]->Z));
+    }
+    std::printf(" coarse: %.0f\n", coarse_A_.valid() && coarse_A_.nblocks > 0 ? (double)coarse_A_.nnz / (double)coarse_A_.nblocks : 0.0);
     std::fflush(stdout);
   }
 }
