@@ -1,9 +1,9 @@
 // Device-side data structures and kernel launchers of the PCAIR solve phase (gfx950).
 //
 // Layout decisions:
-//  * matrices live in HBM as row-block CSR: CSR values / column words without padding, rows in vector
+//  * matrices live in HBM as row-block CSR: CSR values / index words without padding, rows in vector
 //    order, plus a partition of the rows into blocks of <= 512 non-zeros and <= 128 rows (a longer row is
-//    a block of its own).  One wavefront owns one block at a time and software-pipelines over its blocks.
+//    a block of its own).  One wavefront owns exactly one block (spmv.hip).
 //  * level vectors use a hierarchical F/C ordering: the level-l vector is [x_F | x_C] and
 //    x_C *is* the level-(l+1) vector, so the level-l vector is a suffix of the level-1
 //    vector.  Gathers/scatters (VecISCopy) and the identity blocks of R=[Z I], P=[W;I]

@@ -5,12 +5,19 @@
 //   * the matrix stays in CSR row order (no padding; SELL-64 padded the AIR operators by 1.75x, and
 //     length-sorted SELL-C-sigma destroyed the locality of the x gathers);
 //   * rows are partitioned into blocks of <= BLK_NNZ (512) non-zeros and <= BLK_ROWS (128) rows; a row
-//     longer than that is a block of its own.  Inside a block the (column, value) pairs are stored SORTED
-//     BY COLUMN (neighbouring lanes then gather neighbouring x entries: the gather is bound by distinct
-//     cache lines per wave instruction, profiles/r01_spmv_experiments.md) and the 32-bit index word is
-//     ((column - cbase) * 8) << 10 | (row-major position + 1) with a per-block column base: 12 B per non-zero
-//     for every operator width, the gather's byte offset one shift and the staging slot one mask away.  Blocks
-//     whose columns span 2^19 or more stay row-major with absolute columns;
+//     longer than that is a block of its own.  A block's index region has one of three forms (dev.hpp: BlkDesc).
+//     MULTI-BASE (round 4, the default wherever it fits): entries in row-major order, one 16-BIT word each,
+//     window << ob | offset, in front of them a table of up to 64 column windows (byte offset of a window's first
+//     column) - 10 B per non-zero; also for rows longer than a block.  RAW: row-major order, 32-bit absolute
+//     columns (blocks that fit no table).  PACKED (rounds 2-3, only with the multi-base form switched off): entries
+//     SORTED BY COLUMN, 32-bit word ((column - cbase) * 8) << 10 | (row-major position + 1).  Measured at 464^3: the
+//     column order of the packed form buys blocks of many short rows less than its 4-byte words cost them, and a
+//     block of few long rows is in column order anyway (profiles/r04_mb16_rows.txt);
+//   * the multi-base and raw blocks run in LEAN kernels of their own (k_rb_spmv, k_rb_fc_first: 57-76 VGPRs), the packed
+//     ones in the *_g kernels: the block code waits on memory three times in a row, so what a CU streams is resident
+//     waves x one block per wave lifetime, and the widest path of one kernel for all kinds had set the budget at 5
+//     waves per SIMD.  The lean kernels are launched with enough dynamic LDS that 6 (products) / 5 (fused first F stage)
+//     workgroups fit a CU - measured optima; 8 is slower again (profiles/r04_occupancy.txt);
 //   * one WAVE owns exactly one block: the grid has as many waves as the matrix has blocks, and the hardware
 //     dispatches workgroups in order, so the waves resident on an XCD at any moment cover one contiguous window
 //     of rows - the matrix stream is read front to back and the x lines a window gathers stay in that XCD's L2.
@@ -20,8 +27,8 @@
 //     round trips with SQ_WAIT_ANY at 82 %; here the descriptor is a scalar load, every vector the block needs
 //     (index words, values, row offsets, epilogue inputs) is requested before the first wait, and the gather is
 //     the only second round trip;
-//   * a block's 512 logical slots are 8 ROUNDS of 64 (slot 64 u + lane = register u of that lane).  Index words are stored
-//     in slot order (8 coalesced dword loads).  VALUES are stored with every pair of full rounds (2i, 2i+1) interleaved -
+//   * a block's 512 logical slots are 8 ROUNDS of 64 (slot 64 u + lane = register u of that lane).  32-bit index words are
+//     stored in slot order (8 coalesced dword loads), 16-bit ones interleaved like the values.  VALUES are stored with every pair of full rounds (2i, 2i+1) interleaved -
 //     memory position 128 i + 2 lane + t holds slot 64 (2i + t) + lane - so that one 16-byte load per lane fetches both
 //     rounds: a dwordx4 load costs the address path what a dwordx2 load does (tools/ta_probe.hip), and the value stream is
 //     the largest load of a block (tools/block_probe.hip: +5 % on a gather-bound block kernel).  Rounds that a block does
@@ -30,7 +37,8 @@
 //     returns 0 past the end (and drops stores), which replaces clamps, exec-mask branches and 64-bit addresses;
 //   * phase 1: products to LDS at their row-major positions (4 KB per wave); phase 2: lane l sums the LDS
 //     segment of rows r0+l and r0+l+64 in column order (the summation order of a sequential CSR loop), or
-//     T lanes share a row when the block holds <= 32 rows; the epilogue vectors are loaded before the
+//     T lanes share a row when the block holds <= 32 rows; a multi-base / raw block of ONE row is summed in
+//     registers (same products, same order) and never touches LDS; the epilogue vectors are loaded before the
 //     gather is waited for;
 //   * XCD-aware assignment: blocks b and b+8 of the grid share an XCD (observed round-robin
 //     dispatch; a speed assumption only), so each residue class of workgroups walks a contiguous
