@@ -109,7 +109,9 @@ int airhip_set_num_threads(int n, int* prev);
  *   "occ_spmv" / "occ_fc" (default 6 / 5: workgroups per CU = waves per SIMD of the SpMV / fused F-relaxation kernels, 0 =
  *   what the registers allow; act at the next launch), "fc_spatial_x" (default 1: A_fc gathers from a copy of x_c in the
  *   spatial order of the C points on the levels where that pays, 0 = never, 2 = every level; acts at the next upload),
- *   "krylov_blocks" (default 512: workgroups of the multi-dot / multi-axpy launches of the Krylov solvers).
+ *   "krylov_blocks" (default 512: workgroups of the multi-dot / multi-axpy launches of the Krylov solvers),
+ *   "ksp_unnormalised" (default 1: GMRES keeps its basis vectors unnormalised and their norms on the host - no scaling
+ *   pass per iteration; 0: normalised basis.  Same Hessenberg matrix up to rounding, identical iteration counts).
  *   None of them changes a result by a bit.
  * airhip_pcair_setup_host_only / airhip_pcinv_setup_host_only: build the hierarchy without touching a device (CPU-side
  *   tests of the setup, hierarchy export); apply / solve then fail with AIRHIP_ERR_STATE.

@@ -57,6 +57,7 @@ int airhip_set_tuning(const char* key, int value) {
   else if (std::string(key) == "fc_fuse") airhip::set_fc_fuse(value != 0);
   else if (std::string(key) == "fc_spatial_x") airhip::set_fc_spatial(value);
   else if (airhip::kernels_set_tuning(key, value) == 0) {}
+  else if (airhip::ksp_set_tuning(key, value) == 0) {}
   else if (airhip::spmv_set_tuning(key, value) != 0) { g_err = std::string("unknown tuning key ") + key; return AIRHIP_ERR_ARG; }
   API_END
 }

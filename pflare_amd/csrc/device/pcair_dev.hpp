@@ -235,6 +235,7 @@ struct KspOperator {
   std::function<void()> prof_end;
 };
 
+int ksp_set_tuning(const char* key, int value);      // ksp_dev.cpp
 class DevKSP {
  public:
   explicit DevKSP(int64_t n);
