@@ -106,7 +106,7 @@ int airhip_set_num_threads(int n, int* prev);
  *   (default 1; 0 runs the one-point prolongation and the A_fc product of an F relaxation as two launches - diagnostic),
  *   "mb16" / "mb16_max_rows" (default 1 / 128: row blocks of at most that many rows are stored with 16-bit multi-base index
  *   words - 10 instead of 12 bytes per non-zero; 0 = the packed / raw 32-bit forms only; act at the next conversion),
- *   "occ_spmv" / "occ_fc" (default 6 / 5: workgroups per CU = waves per SIMD of the SpMV / fused F-relaxation kernels, 0 =
+ *   "occ_spmv" / "occ_fc" (default 6 / 6: workgroups per CU = waves per SIMD of the SpMV / fused F-relaxation kernels, 0 =
  *   what the registers allow; act at the next launch), "fc_spatial_x" (default 1: A_fc gathers from a copy of x_c in the
  *   spatial order of the C points on the levels where that pays, 0 = never, 2 = every level; acts at the next upload),
  *   "krylov_blocks" (default 512: workgroups of the multi-dot / multi-axpy launches of the Krylov solvers),

@@ -88,7 +88,7 @@ __device__ __forceinline__ int my_block(const RbView& A) {
 //                 address path: a kernel whose blocks gather many distinct lines (A_fc: columns in every section of the
 //                 coarse vector) loses what a streaming-bound one gains.
 static int g_mb16 = 1, g_mb16_max_rows = 128;
-static int g_occ_spmv = 6, g_occ_fc = 5;
+static int g_occ_spmv = 6, g_occ_fc = 6;
 int spmv_set_tuning(const char* key, int value) {
   const std::string k(key);
   if (k == "mb16") { g_mb16 = value != 0; return 0; }
