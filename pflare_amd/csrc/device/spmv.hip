@@ -102,6 +102,7 @@ int spmv_set_tuning(const char* key, int value) {
 static unsigned occ_pad(int wgs) {
   constexpr int LDS_CU = 160 * 1024, LDS_STATIC = SPMV_WAVES * LDS_SLOTS * 8;
   if (wgs <= 0 || wgs >= LDS_CU / LDS_STATIC) return 0;
+  if (wgs < 3) wgs = 3;      // (a workgroup may not ask for more than 64 KB)
   const int alloc = LDS_CU / wgs / 1024 * 1024;
   return alloc > LDS_STATIC ? (unsigned)(alloc - LDS_STATIC) : 0;
 }
