@@ -96,7 +96,7 @@ struct DevCache {
   size_t idle_bytes = 0;
   size_t limit = [] {
     const char* e = std::getenv("AIRHIP_DEVICE_CACHE_GB");
-    return (size_t)(e ? std::atof(e) : 96.0) << 30;
+    return (size_t)(e ? std::atof(e) : 128.0) << 30;      // (profiles/r04_setup_cache.txt)
   }();
 };
 DevCache& cache() { static DevCache* c = new DevCache; return *c; }
@@ -510,6 +510,18 @@ void dev_cache_trim() {
   std::vector<std::pair<void*, size_t>> blocks;
   { std::lock_guard<std::mutex> lock(c.mu); blocks.swap(c.idle); c.idle_bytes = 0; }
   for (const auto& b : blocks) raw_free(b.first);
+}
+
+// gives idle blocks back, smallest first, until at most `keep_bytes` of them are left
+void dev_cache_trim_to(size_t keep_bytes) {
+  DevCache& c = cache();
+  std::vector<std::pair<void*, size_t>> drop;
+  {
+    std::lock_guard<std::mutex> lock(c.mu);
+    std::sort(c.idle.begin(), c.idle.end(), [](const std::pair<void*, size_t>& a, const std::pair<void*, size_t>& b) { return a.second > b.second; });
+    while (!c.idle.empty() && c.idle_bytes > keep_bytes) { drop.push_back(c.idle.back()); c.idle_bytes -= c.idle.back().second; c.idle.pop_back(); }
+  }
+  for (const auto& b : drop) raw_free(b.first);
 }
 
 size_t dev_arena_bytes_for(double nnz) {

@@ -18,6 +18,10 @@ void dev_free(void* p);                  // any pointer dev_alloc returned (null
 void* dev_alloc_exact(size_t bytes);
 void dev_free_exact(void* p);
 void dev_cache_trim();
+// the same down to `keep_bytes` of idle blocks (the largest stay).  The upload of a hierarchy calls it first: measured at 464^3
+// (profiles/r04_setup_cache.txt) the upload's hipMalloc calls of fresh memory take 3.9 / 4.2 / 5.5-6.6 / 7.7 s with 48 / 64 / 96 /
+// 128 GB of the device held idle by the cache, while the setup before it wants 64-128 GB there (20-21 s against 25 s with 48)
+void dev_cache_trim_to(size_t keep_bytes);
 // Owners of device memory that is only an optimisation (the setup's kept copies of finished operators) register a function
 // that frees it and returns the bytes; dev_alloc / dev_alloc_exact call them when the device is full and try once more.
 int dev_add_pressure_handler(std::function<size_t()> f);

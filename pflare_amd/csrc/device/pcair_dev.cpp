@@ -301,6 +301,7 @@ void DevPCAIR::upload_inv(const InvOp& h, DevInv& d, const DevMat* Aop, const do
 
 void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy* dist, Comm* comm) {
   dev_stage("upload of the hierarchy");
+  dev_cache_trim_to((size_t)40 << 30);      // (devmem.hpp: what the setup left idle slows the allocations of the arrays that stay)
   const int L = H.no_levels();
   const double t_upload0 = now_s();
   g_t_h2d = g_t_convert = 0.0; g_n_from_device = 0;
