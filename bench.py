@@ -12,8 +12,15 @@ auto-truncation and a matrix-free Newton-basis GMRES polynomial as coarse solver
 A "step" is one Krylov iteration = 1 SpMV with A + 1 AIR V-cycle (PCApply) + the classical
 Gram-Schmidt update.  Exactly K iterations are timed, spread over consecutive solves of the
 reference problem (each solve restarts from x0 = 1 and runs to convergence or to the remaining
-step budget), bracketed by barrier + device synchronisation.  Inputs are resident in HBM before
-the timed region starts.
+step budget, and ends with its solution update), bracketed by barrier + device synchronisation.
+Inputs are resident in HBM before the timed region starts.
+
+Solution update (round 5): the solver keeps the preconditioned basis z_j = M v_j it computes anyway
+and updates x += Z y, where PETSc's KSPGMRES computes x += M (V y) with one more PCApply per solve
+(csrc/device/ksp_dev.cpp: same Arnoldi process, residual norms and iteration count bit for bit).
+`config.pc_applies_per_step` says how many V-cycles a step of the timed region cost, and
+`config.iterations_per_s_petsc_solution_update` is the same measurement with PETSc's form
+(airhip_set_tuning "ksp_keep_preconditioned" = 0: 22 V-cycles for the default 20 steps, not 20).
 """
 import argparse
 import json
@@ -27,7 +34,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 # defaults of the airhip_set_tuning keys (include/airhip.h): what --variants restores after each variant
-TUNING_DEFAULTS = {"spgemm_pool_entries": 0, "spgemm_pool_chunk": -1, "block_order_min_blocks": 4096, "fc_fuse": 1, "occ_spmv": 6, "occ_fc": 6, "krylov_blocks": 512, "ksp_unnormalised": 1, "mb16": 1, "mb16_max_rows": 128, "fc_spatial_x": 1}
+TUNING_DEFAULTS = {"spgemm_pool_entries": 0, "spgemm_pool_chunk": -1, "block_order_min_blocks": 4096, "fc_fuse": 1, "occ_spmv": 6, "occ_fc": 6, "krylov_blocks": 512, "ksp_unnormalised": 1, "ksp_keep_preconditioned": 1, "mb16": 1, "mb16_max_rows": 128, "fc_spatial_x": 1}
 
 RECIPES = {
     # reference GPU recipe: lumping + auto truncation + Newton matrix-free coarse solver
@@ -102,6 +109,9 @@ def main():
         raise SystemExit(subprocess.call(cmd))
     if "AIRHIP_DEVICE_TRUNC" not in os.environ:
         os.environ["AIRHIP_DEVICE_TRUNC"] = str(1 if args.device_trunc else 0)
+    # a GPU memory fault aborts the process from the runtime's own thread: the library's SIGABRT note then names the step
+    # (async-signal-safe, no SIGSEGV handler)
+    os.environ.setdefault("AIRHIP_FAULT_STAGE", "1")
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -345,10 +355,13 @@ def main():
         cpu["check"] = {"residual_norms_compared": k, "max_rel_diff_gpu_vs_cpu": d}
         log(f"[bench] residual norms GPU vs CPU oracle over {k} entries: max relative difference {d}")
 
+    applies = [0]
+
     def run_iterations(k):
         """exactly k Krylov iterations over consecutive solves of the reference problem"""
         done = 0
         ms = 0.0
+        applies[0] = 0
         while done < k:
             x.fill_(1.0)
             r = P.KSP(max_it=k - done, **ksp_kw).solve(b, x, pc=pc)
@@ -356,6 +369,7 @@ def main():
                 raise RuntimeError("solver made no progress")
             done += r["its"]
             ms += r["solve_ms"]
+            applies[0] += r["pc_applies"]
         return ms
 
     if args.variants:
@@ -396,10 +410,12 @@ def main():
         if not (dist_mode and transport == "rccl" and not args.graph and os.environ.get("AIRHIP_BENCH_GRAPH_REHEARSAL", "0") == "1"):
             return
         # a hang in here (a first run of captured RCCL groups on N > 1 devices) must not keep the ranks alive: the line is out,
-        # so after three minutes every rank ends itself with exit code 0
+        # so after three minutes every rank ends itself - with a NON-ZERO exit code (3) and a marker line: a hang with device
+        # work in flight is a failure that needs a root cause, not a pass (the measured line above it stays readable)
         import threading
         dog = threading.Timer(float(os.environ.get("AIRHIP_BENCH_GRAPH_REHEARSAL_TIMEOUT_S", "180")),
-                              lambda: (print(f"[bench] rank {rank}: graph rehearsal timed out", file=sys.stderr, flush=True), os._exit(0)))
+                              lambda: (print(f"[bench] rank {rank}: GRAPH_REHEARSAL_HUNG (captured RCCL exchange did not finish); exit code 3",
+                                             file=sys.stderr, flush=True), os._exit(3)))
         dog.daemon = True
         dog.start()
         try:
@@ -433,24 +449,37 @@ def main():
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
     stats = pc.profile_stats() if args.profile_kernels else []
+    applies_timed = applies[0]
+    comm1 = comm.stats() if dist_mode else None      # the traffic counters at the end of the timed region
+    # the same steps with PETSc's solution update x += M (V y) (one more PCApply per solve), instrumented like the timed
+    # region: for information (config.iterations_per_s_petsc_solution_update)
+    petsc_form = None
+    if P.lib().airhip_set_tuning(b"ksp_keep_preconditioned", 0) == 0:
+        try:
+            barrier(); t1 = time.perf_counter()
+            run_iterations(args.steps)
+            barrier(); w1 = time.perf_counter() - t1
+            if dist_mode:
+                tw1 = torch.tensor([w1], dtype=torch.float64, device="cpu" if staged else "cuda")
+                dist.all_reduce(tw1, op=dist.ReduceOp.MAX)
+                w1 = float(tw1.item())
+            petsc_form = {"value": args.steps / w1, "pc_applies_per_step": applies[0] / args.steps}
+        finally:
+            P.lib().airhip_set_tuning(b"ksp_keep_preconditioned", TUNING_DEFAULTS["ksp_keep_preconditioned"])
     pc.profile(False)
     unprofiled = None
     if dist_mode and args.profile_kernels:
         # N > 1: the per-kernel events of the timed region (they are what `roofline` is made of) cost the short per-rank
         # kernels more than the 2 % they cost one GPU - the same iterations once more without them, for information
-        comm_before = comm.stats()
         barrier(); t1 = time.perf_counter()
         run_iterations(args.steps)
         barrier(); w1 = time.perf_counter() - t1
         tw1 = torch.tensor([w1], dtype=torch.float64, device="cpu" if staged else "cuda")
         dist.all_reduce(tw1, op=dist.ReduceOp.MAX)
         unprofiled = args.steps / float(tw1.item())
-        comm_extra = {k: comm.stats()[k] - comm_before[k] for k in comm_before}
     if dist_mode:
-        info["comm"] = comm.stats()
-        if unprofiled is not None:      # (the second pass is not part of the timed iterations' traffic)
-            info["comm"] = {k: info["comm"][k] - comm_extra[k] for k in comm_extra}
-        info["comm_timed"] = {k: info["comm"][k] - comm0[k] for k in comm0}      # the timed iterations only
+        info["comm"] = comm1      # (the passes after the timed region are not part of its traffic)
+        info["comm_timed"] = {k: comm1[k] - comm0[k] for k in comm0}      # the timed iterations only
         cab = torch.tensor([pc.cycle_alg_bytes()], dtype=torch.float64, device="cpu" if staged else "cuda")
         dist.all_reduce(cab)
         cx = dict(cx); cx["cycle_alg_bytes"] = float(cab.item())
@@ -575,7 +604,14 @@ def main():
                    # the library's thread that completes the HOST copy of the hierarchy after setup() has returned
                    # (the solve does not read it; runs beside the warm-up solves): how long it ran
                    "host_mirror_s": host_mirror_s,
-                   "device_ms_of_timed_solves": ms_dev, "hip_graph": bool(args.graph)},
+                   "device_ms_of_timed_solves": ms_dev, "hip_graph": bool(args.graph),
+                   # V-cycles per step of the timed region (1.0: the preconditioned basis is kept, x += Z y) and the same
+                   # steps with PETSc's solution update x += M (V y)
+                   "pc_applies_per_step": applies_timed / args.steps,
+                   "solution_update": "x += Z y with the preconditioned basis z_j = M v_j kept (same iterates as PETSc's "
+                                      "x += M (V y), one PCApply less per solve; airhip_set_tuning ksp_keep_preconditioned)",
+                   "iterations_per_s_petsc_solution_update": petsc_form["value"] if petsc_form else None,
+                   "pc_applies_per_step_petsc_solution_update": petsc_form["pc_applies_per_step"] if petsc_form else None},
         "roofline": roofline, "cpu_baseline": cpu,
     }
     # the residual history of the converged solve against the committed single-GPU history (same hierarchy for every N: the

@@ -111,8 +111,15 @@ int airhip_set_num_threads(int n, int* prev);
  *   spatial order of the C points on the levels where that pays, 0 = never, 2 = every level; acts at the next upload),
  *   "krylov_blocks" (default 512: workgroups of the multi-dot / multi-axpy launches of the Krylov solvers),
  *   "ksp_unnormalised" (default 1: GMRES keeps its basis vectors unnormalised and their norms on the host - no scaling
- *   pass per iteration; 0: normalised basis.  Same Hessenberg matrix up to rounding, identical iteration counts).
- *   None of them changes a result by a bit.
+ *   pass per iteration; 0: normalised basis.  Same Hessenberg matrix up to rounding, identical iteration counts),
+ *   "ksp_keep_preconditioned" (default 1: right-preconditioned GMRES keeps z_j = M v_j, restart more vectors, and updates
+ *   x += Z y without the extra PCApply of PETSc's x += M (V y); same Arnoldi process, Hessenberg matrix, residual norms and
+ *   iteration count bit for bit - the solution differs in its last rounding; 0: PETSc's form).
+ *   Bitwise neutral - not a bit of any result changes - are the FORMAT, OCCUPANCY and ORDER keys ("mb16", "mb16_max_rows",
+ *   "occ_spmv", "occ_fc", "fc_spatial_x", "block_order_min_blocks", "fc_fuse", the "spgemm_*" keys).  NOT bitwise neutral:
+ *   "ksp_unnormalised" (every Hessenberg entry is rounded differently), "krylov_blocks" (the grid sets the summation order
+ *   of every dot product and norm) and "ksp_keep_preconditioned" (the last rounding of x); they keep the iteration counts
+ *   and agree within the tolerances tests/test_gpu_ksp_variants.py states.
  * airhip_pcair_setup_host_only / airhip_pcinv_setup_host_only: build the hierarchy without touching a device (CPU-side
  *   tests of the setup, hierarchy export); apply / solve then fail with AIRHIP_ERR_STATE.
  * airhip_spgemm_filtered: C = filter(A*B) with the host (on_device = 0) or the device SpGEMM of the setup, drop / lump /
@@ -335,6 +342,10 @@ typedef struct {
   int reason;      /* KSPConvergedReason values: 2 RTOL, 3 ATOL, -3 ITS, -4 DTOL, -5 BREAKDOWN */
   double rnorm;
   double solve_ms; /* HIP-event time of the solve on the library stream                */
+  int pc_applies;  /* PCApply calls of the solve.  Right-preconditioned GMRES keeps the preconditioned basis z_j = M v_j
+                    * (airhip_set_tuning "ksp_keep_preconditioned", default 1) and updates x += Z y, so this equals `its`;
+                    * PETSc's form x += M (V y) (key = 0) applies M once more per restart cycle                          */
+  int reserved;
 } airhip_ksp_result;
 void airhip_ksp_default_options(airhip_ksp_options* o);
 /* Solve A x = b (natural ordering, device pointers; x holds the initial guess).  Exactly one

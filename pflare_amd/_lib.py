@@ -27,7 +27,8 @@ class airhip_ksp_options(C.Structure):
 
 
 class airhip_ksp_result(C.Structure):
-    _fields_ = [("its", C.c_int), ("reason", C.c_int), ("rnorm", C.c_double), ("solve_ms", C.c_double)]
+    _fields_ = [("its", C.c_int), ("reason", C.c_int), ("rnorm", C.c_double), ("solve_ms", C.c_double),
+                ("pc_applies", C.c_int), ("reserved", C.c_int)]
 
 
 # every symbol include/airhip.h declares (tests check that the library exports all of them)

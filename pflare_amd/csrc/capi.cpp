@@ -55,6 +55,7 @@ int airhip_set_tuning(const char* key, int value) {
   else if (std::string(key) == "spgemm_pool_chunk") airhip::spgemm_set_pool_chunk(value);
   else if (std::string(key) == "block_order_min_blocks") airhip::set_block_order_min(value);
   else if (std::string(key) == "fc_fuse") airhip::set_fc_fuse(value != 0);
+  else if (std::string(key) == "profile_chain") airhip::set_profile_chain(value != 0);
   else if (std::string(key) == "fc_spatial_x") airhip::set_fc_spatial(value);
   else if (airhip::kernels_set_tuning(key, value) == 0) {}
   else if (airhip::ksp_set_tuning(key, value) == 0) {}
@@ -100,7 +101,7 @@ static int library_team() {
   }();
   return team;
 }
-TeamGuard::TeamGuard() : prev(omp_get_max_threads()) { omp_set_num_threads(library_team()); dev_drain_releases(); }
+TeamGuard::TeamGuard() : prev(omp_get_max_threads()) { omp_set_num_threads(library_team()); }
 TeamGuard::~TeamGuard() { omp_set_num_threads(prev); }
 // fewer threads for small operators: one thread per ~32k non-zeros
 struct ThreadScope {
@@ -538,7 +539,6 @@ int airhip_pcair_setup(airhip_pcair pc, const airhip_csr* A) {
   view_csr(A, pc->A_top);
   ThreadScope threads(A->rowptr[A->m]);
   double t0 = now_s();
-  DevArena dev_arena(pc->setup_on_device ? dev_arena_bytes_for((double)A->rowptr[A->m]) : 0, dev_arena_front_for((double)A->rowptr[A->m]));   // the setup's temporaries, then the hierarchy
   std::unique_ptr<SetupAccel> accel;
   {
     if (pc->setup_on_device) accel = make_device_setup_accel(nullptr, pc->setup_device_min_nnz);
@@ -557,15 +557,12 @@ int airhip_pcair_setup(airhip_pcair pc, const airhip_csr* A) {
   pc->host_setup_s = now_s() - t0;
   pc->byo = false;
   pc->op_nnz_top = (double)pc->A_top.nnz();
-  // the temporaries of the setup are gone: their range of device memory goes back before the hierarchy takes its own
+  // the temporaries of the setup are gone before the hierarchy takes its own memory
   if (accel) accel->release_temporaries();
-  dev_arena.recycle_temporaries();
   if (pc->device_upload) finish_device(pc, accel.get());
   // the numbers print_stats and airhip_pcair_complexities report, while nothing else touches the hierarchy
   pc->cplx_valid = false;
   if (airhip_pcair_complexities(pc, &pc->cplx[0], &pc->cplx[1], &pc->cplx[2], &pc->cplx[3], &pc->cplx[4]) == 0) pc->cplx_valid = true;
-  dev_arena.finish();      // the ranges of this call that are empty go back now: not beside the thread below
-  (void)dev_check_covers();
   if (accel && hierarchy_has_stubs(*pc->H)) {
     // The operators whose download was deferred come to the host beside whatever the caller does next (the solve does
     // not need them); everything that reads the host hierarchy waits for this thread first (mirror_join).
@@ -578,7 +575,6 @@ int airhip_pcair_setup(airhip_pcair pc, const airhip_csr* A) {
       try {
         if (hipSetDevice(dev) != hipSuccess) throw std::runtime_error("host mirror: hipSetDevice failed");
         mirror_fetch(*pc->H, *pc->mirror_accel);
-        (void)dev_check_covers();
       } catch (...) { pc->mirror_error = std::current_exception(); }
       pc->mirror_s = now_s() - t0;
     });
@@ -1159,7 +1155,6 @@ int airhip_pcair_load_distributed(airhip_pcair pc, airhip_archive piece, airhip_
   load_local(piece->ar, *loc);
   REQUIRE(loc->nranks == comm->c->size && loc->rank == comm->c->rank, AIRHIP_ERR_ARG, "piece does not belong to this rank");
   double t0 = now_s();
-  DevArena dev_arena(dev_arena_bytes_for((double)loc->A_top.nnz()), 0);      // this rank's hierarchy in one contiguous range (its staging blocks in another)
   pc->dev = std::make_unique<DevPCAIR>();
   if (loc->hint.size() > 0) pc->dev->set_ordering_hint(loc->hint.data(), loc->hint.size());
   pc->dev->upload(loc->H, loc->A_top, loc.get(), comm->c.get());
@@ -1390,7 +1385,7 @@ int airhip_ksp_solve_on_stream(const airhip_ksp_options* o, airhip_mat A, airhip
     r = A->ksp->solve(op, ko, d_b, d_x);
     HIP_CHECK(hipStreamSynchronize(A->stream));
   }
-  res->its = r.its; res->reason = r.reason; res->rnorm = r.rnorm; res->solve_ms = r.solve_ms;
+  res->its = r.its; res->reason = r.reason; res->rnorm = r.rnorm; res->solve_ms = r.solve_ms; res->pc_applies = r.pc_applies; res->reserved = 0;
   int nh = (int)r.history.size();
   if (history && history_cap > 0) { int c = std::min(nh, history_cap); std::memcpy(history, r.history.data(), sizeof(double) * c); }
   if (history_len) *history_len = nh;

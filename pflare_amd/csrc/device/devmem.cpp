@@ -3,24 +3,20 @@
 #include <algorithm>
 #include <cstdlib>
 #include <mutex>
-#include <thread>
 #include <stdexcept>
 #include <chrono>
 #include <cstdio>
 #include <exception>
-#include <map>
-#include <deque>
-#include <memory>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
 #include <functional>
 #include <atomic>
+#include <string>
 #include <csignal>
 #include <cstring>
 #include <unistd.h>
 #include <execinfo.h>
-#include <sys/mman.h>
 
 namespace airhip {
 
@@ -29,30 +25,6 @@ std::atomic<const char*> g_stage{"(none)"};
 double trace_clock() {
   static const auto t0 = std::chrono::steady_clock::now();
   return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-}
-// post-mortem notes (fixed-size, written without locks by whoever holds the allocator's mutex / runs the copy)
-struct RangeNote { void* base; size_t size; int covered; };
-RangeNote g_released[16]; std::atomic<int> g_nreleased{0};
-std::atomic<void*> g_copy_host{nullptr}; std::atomic<size_t> g_copy_bytes{0};
-void hex_out(const char* label, uintptr_t v) {
-  char buf[160]; int n = 0;
-  for (const char* c = label; *c && n < 128; c++) buf[n++] = *c;
-  buf[n++] = '0'; buf[n++] = 'x';
-  for (int sh = 60; sh >= 0; sh -= 4) buf[n++] = "0123456789abcdef"[(v >> sh) & 15];
-  buf[n++] = '\n';
-  (void)!write(2, buf, (size_t)n);
-}
-extern "C" void airhip_segv_note(int sig, siginfo_t* info, void*) {
-  hex_out("[airhip] segmentation fault at address ", (uintptr_t)info->si_addr);
-  hex_out("[airhip]   host side of the copy in progress: ", (uintptr_t)g_copy_host.load());
-  hex_out("[airhip]   its bytes: ", (uintptr_t)g_copy_bytes.load());
-  const int n = std::min(g_nreleased.load(), 16);
-  for (int k = 0; k < n; k++) { hex_out("[airhip]   released range base ", (uintptr_t)g_released[k].base); hex_out("[airhip]     size ", g_released[k].size); hex_out("[airhip]     covered ", (uintptr_t)g_released[k].covered); }
-  void* frames[48];
-  const int nf = backtrace(frames, 48);
-  backtrace_symbols_fd(frames, nf, 2);
-  std::signal(sig, SIG_DFL);
-  std::raise(sig);
 }
 extern "C" void airhip_abort_note(int sig) {
   const char* s = g_stage.load(std::memory_order_relaxed);
@@ -68,18 +40,11 @@ extern "C" void airhip_abort_note(int sig) {
 }
 }  // namespace
 
-void dev_note_host_copy(void* host, size_t bytes) { g_copy_host.store(host); g_copy_bytes.store(bytes); }
-
 void dev_stage(const char* what) {
   static const bool on = [] {
     const char* e = std::getenv("AIRHIP_FAULT_STAGE");
     if (!(e && e[0] == '1')) return false;
     std::signal(SIGABRT, airhip_abort_note);
-    if (e[1] == '1') {      // AIRHIP_FAULT_STAGE=11: segmentation faults too (address, the copy in progress, released ranges, native backtrace)
-      struct sigaction sa; std::memset(&sa, 0, sizeof sa);
-      sa.sa_sigaction = airhip_segv_note; sa.sa_flags = SA_SIGINFO | SA_RESETHAND;
-      sigaction(SIGSEGV, &sa, nullptr);
-    }
     return true;
   }();
   if (on) g_stage.store(what, std::memory_order_relaxed);
@@ -101,227 +66,8 @@ struct DevCache {
 };
 DevCache& cache() { static DevCache* c = new DevCache; return *c; }
 
-// ---- the setup arenas: device memory straight from the virtual-memory interface (all of it guarded by DevCache::mu).
-// tools/vmm_probe.hip on the GPU box: backing a reserved range with hipMemCreate + hipMemMap + hipMemSetAccess costs
-// 0.6 - 2.5 ms per GB in 256-MB pieces (64 GB: 0.04 - 0.17 s; 30 ms per GB on memory nobody has used since the box came
-// up) where a plain hipMalloc of 64 GB took 0.5 .. 3.9 s from one call to the next (and holds the driver's lock meanwhile),
-// and a read+write stream runs as fast on memory mapped like this (5.19 vs 5.02 TB/s).
-// Two facts of this driver shape the design (tools/vmm_probe.hip, tools/vmm_stress.hip, profiles/r03_vmm_*.txt):
-//  * the memory under a range only goes back to the device when the whole range is freed (hipMemAddressFree) - unmapping
-//    and releasing pieces does not return it;
-//  * an address that is mapped a second time reads stale data: blocks filled by a copy and checked by a kernel right away
-//    came back wrong when their addresses had been backed before (one reservation whose pieces are unmapped and mapped
-//    again: 9 of 177 blocks; reservations that come and go: 19 of 177), never when every address was backed at most once.
-//    The device's addresses are the process's own (a reservation is an inaccessible CPU mapping), so a freed range is
-//    covered at once with an inaccessible mapping of our own and nobody is ever given those addresses again (0 of 177).
-// Hence: one range per class of blocks with a common lifetime, every piece backed at most once, the range freed as a whole
-// when its last block is gone.
-constexpr size_t GRANULE = 2u << 20;             // blocks of the arena
-constexpr size_t PIECE = (size_t)256 << 20;    // physical memory is created and mapped in pieces of this size
-constexpr size_t VA_BUDGET = (size_t)64 << 40;   // address space the process may use up this way (then: no more arenas)
-size_t g_va_used = 0;
-
-// The arenas are OFF by default since round 4.  Records of round 3 (464^3): 3 of 24 runs died in the host-mirror thread with a
-// segmentation fault whose address lay inside a host array that glibc had mapped inside a device range this file had freed
-// AND covered (PROT_NONE, MAP_FIXED_NOREPLACE) a moment before - so the cover went away after it had been laid, and then the
-// array's pages went too: somebody unmapped that range twice after hipMemAddressFree had returned.  The faults began with the
-// commit that left the physical handles of a freed range alive (Group::spare, re-mapped into the other ranges).  Reading of
-// that timeline (NOT confirmed by an experiment - the round's instruction was to stop experimenting with the allocator): the
-// runtime's bookkeeping of a physical handle keeps the address range it was first mapped at, and finishes that range's
-// teardown (a munmap / a fresh PROT_NONE MAP_FIXED mapping over it) only when the handle is unmapped again or released -
-// long after the range was handed back and covered, whatever then lives at those addresses.  Consequences: the plain path
-// (block cache + hipMalloc, ~2 s more per 464^3 setup, nothing in the solve) is the default; with AIRHIP_DEVICE_VMM=1 the
-// arenas no longer hand physical pieces from a freed range to the others (every handle is released before its range's
-// addresses are), the thread rules and the covers stay as they were.
-bool vm_supported() {
-  static const bool ok = [] {
-    // OPT-IN since round 4 (AIRHIP_DEVICE_VMM=1): see "the arenas are off by default" below
-    const char* e = std::getenv("AIRHIP_DEVICE_VMM");
-    if (!(e && e[0] == '1')) return false;
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeVirtualMemoryManagementSupported, dev) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return v != 0;
-  }();
-  return ok;
-}
-
-// what the arenas of one DevArena scope may back together
-// spare: physical pieces a freed range of the scope has left behind - the next piece any of its arenas backs takes one of
-// these (in the order they were created) instead of asking the driver for fresh memory, which it would first have to clear
-// (31 ms per GB right after a release, measured at 464^3: the hierarchy's 131 GB out of the temporaries' memory)
-struct Group { size_t committed = 0, limit = 0, peak = 0; std::deque<hipMemGenericAllocationHandle_t> spare; };
-
-// one reserved range; every piece is backed at most once
-struct VmRange {
-  char* base = nullptr; size_t reserved = 0; int dev = 0;
-  std::vector<hipMemGenericAllocationHandle_t> handle;
-  std::vector<char> state;                           // 0 never backed, 1 backed, 2 unusable
-  size_t committed = 0;
-  std::shared_ptr<Group> group;
-  bool reserve(size_t bytes, std::shared_ptr<Group> g) {
-    bytes = (bytes + PIECE - 1) / PIECE * PIECE;
-    if (g_va_used + bytes > VA_BUDGET) return false;
-    void* p = nullptr;
-    if (hipGetDevice(&dev) != hipSuccess || hipMemAddressReserve(&p, bytes, 0, nullptr, 0) != hipSuccess || !p) { (void)hipGetLastError(); return false; }
-    g_va_used += bytes;
-    base = (char*)p; reserved = bytes; group = std::move(g);
-    handle.assign(bytes / PIECE, hipMemGenericAllocationHandle_t{}); state.assign(bytes / PIECE, 0);
-    return true;
-  }
-  bool map_piece(size_t k) {
-    const bool reuse = !group->spare.empty();
-    if (!reuse && group->committed + PIECE > group->limit) return false;
-    if (reuse) { handle[k] = group->spare.front(); group->spare.pop_front(); group->committed -= PIECE; }      // (counted again below)
-    else {
-      hipMemAllocationProp prop = {};
-      prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
-      if (hipMemCreate(&handle[k], PIECE, &prop, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
-    }
-    hipMemAccessDesc acc = {};
-    acc.location.type = hipMemLocationTypeDevice; acc.location.id = dev; acc.flags = hipMemAccessFlagsProtReadWrite;
-    if (hipMemMap(base + k * PIECE, PIECE, 0, handle[k], 0) != hipSuccess) { (void)hipGetLastError(); (void)hipMemRelease(handle[k]); return false; }
-    if (hipMemSetAccess(base + k * PIECE, PIECE, &acc, 1) != hipSuccess) {
-      (void)hipGetLastError(); (void)hipMemUnmap(base + k * PIECE, PIECE); (void)hipMemRelease(handle[k]);
-      state[k] = 2;                                  // its addresses have been mapped once: never again
-      return false;
-    }
-    state[k] = 1; committed += PIECE; group->committed += PIECE;
-    if (group->committed > group->peak) group->peak = group->committed;
-    return true;
-  }
-  // every piece that [off, off + len) touches is backed afterwards, plus `ahead` more bytes beyond it while that is possible
-  // (pieces backed in one go); false: one of the pieces asked for cannot be (no memory, the limit) - pieces backed on the way
-  // stay backed (free space of the arena like any other)
-  bool commit(size_t off, size_t len, size_t ahead = 0) {
-    const size_t k0 = off / PIECE, k1 = (off + len + PIECE - 1) / PIECE;
-    bool fresh = false;
-    for (size_t k = k0; k < k1; k++) if (state[k] == 2) return false;
-    for (size_t k = k0; k < k1; k++) {
-      if (state[k] == 1) continue;
-      if (!map_piece(k)) return false;
-      fresh = true;
-    }
-    if (fresh) for (size_t k = k1; k < state.size() && k < k1 + ahead / PIECE; k++) if (state[k] == 0 && !map_piece(k)) break;
-    return true;
-  }
-  // Everything goes back: memory and addresses - and the addresses are taken out of circulation for good.  No kernel may
-  // still be using the range: unlike hipFree, unmapping does not wait for the device
-  // keep_pieces: the physical pieces stay with the scope (Group::spare) for the ranges that are still growing
-  void release(bool keep_pieces = false) {
-    if (!base) return;
-    (void)hipDeviceSynchronize();
-    for (size_t k = 0; k < state.size(); k++) {
-      if (state[k] != 1) continue;
-      (void)hipMemUnmap(base + k * PIECE, PIECE);
-      committed -= PIECE;
-      if (keep_pieces) group->spare.push_back(handle[k]);      // still counted in group->committed
-      else { (void)hipMemRelease(handle[k]); group->committed -= PIECE; }
-    }
-    (void)hipMemAddressFree(base, reserved);
-    void* t = mmap(base, reserved, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE | MAP_FIXED_NOREPLACE, -1, 0);
-    { const int k = g_nreleased.fetch_add(1); if (k < 16) g_released[k] = RangeNote{base, reserved, t == (void*)base ? 1 : 0}; }
-    if (t != (void*)base) {
-      // somebody was quicker (or the kernel is too old for MAP_FIXED_NOREPLACE): these addresses may come back - no more
-      // arenas in this process, the cache / hipMalloc path serves everything from here on
-      if (t != MAP_FAILED) (void)munmap(t, reserved);
-      g_va_used = VA_BUDGET;
-    }
-    *this = VmRange();
-  }
-};
-
 hipError_t raw_alloc(void** p, size_t bytes) { return hipMalloc(p, bytes); }
 void raw_free(void* p) { (void)hipFree(p); }
-
-// ---- one range per class of blocks (DevClass), backed as far as the blocks in use reach (first fit: the blocks gather at
-// the low end), freed as a whole when it has been closed and its last block is gone
-struct Arena {
-  VmRange vm;
-  char* base = nullptr; size_t size = 0;            // = vm.base / vm.reserved while the arena exists
-  int cls = 0;
-  const void* owner = nullptr;                      // the DevArena scope it belongs to
-  size_t ahead = 0;                                 // back this much beyond a request that needs fresh pieces
-  std::map<size_t, size_t> free_by_off;             // offset -> length, neighbours merged
-  std::unordered_map<void*, size_t> live;           // block -> length
-  bool closing = false;                             // no new blocks: release once the last block is back
-  bool leave_pieces = false;                        // ... and leave the physical pieces to the scope's other arenas
-  // A range is only ever freed by the thread that made it, and never while another thread of the library works: on the GPU
-  // box one 464^3 run in eight died in the host-mirror thread's copy loop - its destination array, which the C library had
-  // placed inside the address range the main thread had freed (and covered) a moment before, was gone.  What took the
-  // cover (and then the array) away was not found (a single thread freeing and covering ranges never loses a cover:
-  // tools/vmm_stress.hip mode 4); with the frees kept to one thread and away from the mirror's life the fault has not
-  // come back in 40 runs (it had in 3 of the 24 before), and dev_check_covers has not found a cover missing in any of them.
-  std::thread::id maker = std::this_thread::get_id();
-  bool release_pending = false;                     // its last block came back on another thread: dev_drain_releases
-  size_t peak = 0, used = 0, misses = 0, peak_committed = 0;
-};
-std::vector<std::unique_ptr<Arena>>& arenas() { static auto* v = new std::vector<std::unique_ptr<Arena>>; return *v; }
-// the arena of class c that serves requests: that of the innermost scope in progress
-Arena* active_arena(int c) {
-  auto& v = arenas();
-  for (size_t k = v.size(); k-- > 0;) if (v[k]->cls == c && !v[k]->closing) return v[k].get();
-  return nullptr;
-}
-
-void* arena_alloc(Arena* ap, size_t bytes) {
-  if (!ap) return nullptr;
-  Arena& a = *ap;
-  static const bool trace = std::getenv("AIRHIP_ALLOC_TRACE") != nullptr;
-  const size_t need = (bytes + GRANULE - 1) / GRANULE * GRANULE;
-  for (auto it = a.free_by_off.begin(); it != a.free_by_off.end(); ++it) {
-    if (it->second < need) continue;
-    const size_t off = it->first, len = it->second;
-    if (!a.vm.commit(off, need, a.ahead)) break;      // the device (or the limit) has no room for the pieces
-    a.free_by_off.erase(it);
-    if (len > need) a.free_by_off[off + need] = len - need;
-    a.live[a.base + off] = need;
-    a.used += need; if (a.used > a.peak) a.peak = a.used;
-    if (a.vm.committed > a.peak_committed) a.peak_committed = a.vm.committed;
-    return a.base + off;
-  }
-  if (trace) std::fprintf(stderr, "[devmem %.3f] arena %d: %.2f GB did not fit (in use %.1f GB, backed %.1f GB; the scope's arenas together %.1f of at most %.1f GB)\n",
-                          trace_clock(), a.cls, need * 1e-9, a.used * 1e-9, a.vm.committed * 1e-9, a.vm.group->committed * 1e-9, a.vm.group->limit * 1e-9);
-  a.misses++;
-  return nullptr;
-}
-// the arena a block belongs to (any of them), or null
-Arena* arena_of(void* p) {
-  for (auto& a : arenas()) if (a->live.count(p)) return a.get();
-  return nullptr;
-}
-void arena_free(Arena& a, void* p) {
-  auto it = a.live.find(p);
-  size_t off = (size_t)((char*)p - a.base), len = it->second;
-  a.live.erase(it);
-  a.used -= len;
-  auto nxt = a.free_by_off.lower_bound(off);
-  if (nxt != a.free_by_off.end() && off + len == nxt->first) { len += nxt->second; nxt = a.free_by_off.erase(nxt); }
-  if (nxt != a.free_by_off.begin()) {
-    auto prv = std::prev(nxt);
-    if (prv->first + prv->second == off) { off = prv->first; len += prv->second; a.free_by_off.erase(prv); }
-  }
-  a.free_by_off[off] = len;
-}
-void arena_release_if_done(Arena& a) {
-  if (!(a.closing && a.live.empty())) return;
-  if (std::this_thread::get_id() != a.maker) { a.release_pending = true; return; }
-  static const bool trace = std::getenv("AIRHIP_ALLOC_TRACE") != nullptr;
-  if (trace) std::fprintf(stderr, "[devmem %.3f] arena %d released: peak use %.1f GB, peak backing %.1f GB, %zu requests did not fit\n", trace_clock(), a.cls, a.peak * 1e-9,
-                          a.peak_committed * 1e-9, a.misses);
-  a.vm.release(a.leave_pieces);
-  auto& v = arenas();
-  for (size_t k = 0; k < v.size(); k++) if (v[k].get() == &a) { v.erase(v.begin() + (long)k); break; }
-}
-// dev_free / dev_free_exact: true when the block was an arena's
-bool arena_take_back(void* p) {
-  Arena* a = arena_of(p);
-  if (!a) return false;
-  arena_free(*a, p);
-  arena_release_if_done(*a);
-  return true;
-}
-
-thread_local int t_class = DEV_TEMP;
 
 // journals of the DevScopes alive on this thread, innermost last
 thread_local std::vector<std::unordered_set<void*>> t_scopes;
@@ -375,24 +121,17 @@ static std::string memory_state() {
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) (void)hipGetLastError();
   DevCache& c = cache();
   std::lock_guard<std::mutex> lock(c.mu);
-  std::string st = "driver reports " + std::to_string(free_b >> 20) + " MiB free of " + std::to_string(total_b >> 20) + ", block cache holds " +
-                   std::to_string(c.idle_bytes >> 20) + " MiB idle";
-  { size_t lb = 0; for (auto& kv : c.live) lb += kv.second; st += " and " + std::to_string(lb >> 20) + " MiB in use outside the arenas"; }
-  for (auto& a : arenas()) st += ", arena (" + std::string(a->release_pending ? "empty, waiting for its maker thread to free it" : a->closing ? "of a finished setup" : "active") + ") " +
-                                 std::to_string(a->used >> 20) + " MiB in blocks / " + std::to_string(a->vm.committed >> 20) + " MiB backed";
-  return st;
+  size_t lb = 0;
+  for (auto& kv : c.live) lb += kv.second;
+  return "driver reports " + std::to_string(free_b >> 20) + " MiB free of " + std::to_string(total_b >> 20) + ", block cache holds " +
+         std::to_string(c.idle_bytes >> 20) + " MiB idle and " + std::to_string(lb >> 20) + " MiB in use";
 }
 static void* dev_alloc_once(size_t bytes, bool& failed);
 void* dev_alloc(size_t bytes) {
   bool failed = false;
   void* p = dev_alloc_once(bytes, failed);
   if (failed) {
-    // (opt-in arenas) ranges whose last block came back on another thread still hold their memory until this thread - if
-    // it made them - frees them
-    dev_drain_releases();
-    const size_t got = relieve_pressure();
-    dev_drain_releases();
-    (void)got;
+    (void)relieve_pressure();
     p = dev_alloc_once(bytes, failed);
   }
   if (failed) throw std::runtime_error(std::string("hipMalloc of ") + std::to_string(bytes) + " bytes failed: out of memory (" + memory_state() + ")");
@@ -404,7 +143,6 @@ static void* dev_alloc_once(size_t bytes, bool& failed) {
   DevCache& c = cache();
   if (bytes >= CACHE_MIN) {
     std::lock_guard<std::mutex> lock(c.mu);
-    if (void* q = arena_alloc(active_arena(t_class), bytes)) { note_alloc(q); return q; }
     int best = -1;          // smallest idle block that holds the request and is at most twice its size
     for (int k = 0; k < (int)c.idle.size(); k++)
       if (c.idle[k].second >= bytes && c.idle[k].second / 2 <= bytes && (best < 0 || c.idle[k].second < c.idle[best].second)) best = k;
@@ -437,25 +175,14 @@ static void* dev_alloc_once(size_t bytes, bool& failed) {
 }
 
 void dev_free_exact(void* p) {
-  if (!p) return;
-  {
-    DevCache& c = cache();
-    std::lock_guard<std::mutex> lock(c.mu);
-    if (arena_take_back(p)) return;
-  }
-  raw_free(p);
+  if (p) raw_free(p);
 }
 
 void* dev_alloc_exact(size_t bytes) {
   if (bytes >= CACHE_MIN) {
-    DevCache& c = cache();
-    std::lock_guard<std::mutex> lock(c.mu);
-    if (void* q = arena_alloc(active_arena(DEV_HIER), bytes)) return q;
-  }
-  if (bytes >= CACHE_MIN) {
     // A released block of the setup that fits closely (at most 1/8 larger) becomes the long-lived array: it is a plain
     // hipMalloc block (hipFree takes it back like any other) whose memory the driver does not have to hand out afresh -
-    // 7-57 ms per GB for the 106 GB of a 464^3 hierarchy since the arenas are off by default.
+    // 7-57 ms per GB for the 106 GB of a 464^3 hierarchy.
     DevCache& c = cache();
     std::lock_guard<std::mutex> lock(c.mu);
     int best = -1;
@@ -471,16 +198,7 @@ void* dev_alloc_exact(size_t bytes) {
   void* p = nullptr;
   hipError_t e = raw_alloc(&p, bytes ? bytes : 1);
   if (e != hipSuccess) { (void)hipGetLastError(); dev_cache_trim(); e = raw_alloc(&p, bytes ? bytes : 1); }
-  if (e != hipSuccess) { dev_drain_releases(); (void)relieve_pressure(); dev_drain_releases(); }
-  if (e != hipSuccess) {
-    (void)hipGetLastError();
-    if (bytes >= CACHE_MIN) {
-      DevCache& c = cache();
-      std::lock_guard<std::mutex> lock(c.mu);
-      if (void* q = arena_alloc(active_arena(DEV_HIER), bytes)) return q;
-    }
-    e = raw_alloc(&p, bytes ? bytes : 1);
-  }
+  if (e != hipSuccess) { (void)hipGetLastError(); (void)relieve_pressure(); e = raw_alloc(&p, bytes ? bytes : 1); }
   if (e != hipSuccess) {
     (void)hipGetLastError();
     throw std::runtime_error(std::string("hipMalloc of ") + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e) + " (" + memory_state() + ")");
@@ -494,7 +212,6 @@ void dev_free(void* p) {
   DevCache& c = cache();
   {
     std::lock_guard<std::mutex> lock(c.mu);
-    if (arena_take_back(p)) return;
     auto it = c.live.find(p);
     if (it != c.live.end()) {
       const size_t bytes = it->second;
@@ -524,188 +241,12 @@ void dev_cache_trim_to(size_t keep_bytes) {
   for (const auto& b : drop) raw_free(b.first);
 }
 
-size_t dev_arena_bytes_for(double nnz) {
-  const char* e = std::getenv("AIRHIP_DEVICE_ARENA_GB");      // the limit, whatever the size of the problem (0 = no arena)
-  const size_t want = (size_t)(300.0 * std::max(nnz, 0.0));
-  if (!e && want < ((size_t)256 << 20)) return 0;              // small problems: the cache is all they need
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return 0; }
-  // the arena grows with the demand; the limit keeps it off the last GBs, and is the address space the arena uses up: a
-  // small problem does not take a device's worth of it (about 1 kB per non-zero is three times what the 464^3 setup needs)
-  size_t limit = std::min((size_t)(0.92 * (double)free_b), std::max((size_t)4 << 30, (size_t)(1000.0 * std::max(nnz, 0.0))));
-  if (e) limit = std::min((size_t)(0.92 * (double)free_b), (size_t)(std::atof(e) * 1e9));
-  return limit / GRANULE * GRANULE;
-}
-
-DevClassScope::DevClassScope(int cls) : prev_(t_class) { t_class = cls; }
-DevClassScope::~DevClassScope() { t_class = prev_; }
-
-namespace {
-// a fresh arena of class c for the scope `owner`; null when there is no address space to be had
-Arena* open_arena(int c, const void* owner, std::shared_ptr<Group> g, size_t va_bytes, size_t ahead) {
-  auto a = std::make_unique<Arena>();
-  if (!a->vm.reserve(std::max(va_bytes, PIECE), std::move(g))) return nullptr;
-  a->base = a->vm.base; a->size = a->vm.reserved; a->cls = c; a->owner = owner; a->ahead = ahead;
-  a->free_by_off[0] = a->size;
-  static const bool trace = std::getenv("AIRHIP_ALLOC_TRACE") != nullptr;
-  if (trace) std::fprintf(stderr, "[devmem %.3f] arena %d: %.1f GB of address space reserved (%.2f TB used so far)\n", trace_clock(), c, a->size * 1e-9, g_va_used * 1e-12);
-  arenas().push_back(std::move(a));
-  return arenas().back().get();
-}
-void close_arenas(const void* owner, int c, bool leave_pieces = false) {      // c < 0: all classes
-  auto& v = arenas();
-  for (size_t k = v.size(); k-- > 0;) {
-    Arena& a = *v[k];
-    if (a.owner != owner || a.closing || (c >= 0 && a.cls != c)) continue;
-    a.closing = true; a.leave_pieces = leave_pieces;
-    arena_release_if_done(a);                       // (erases v[k]: the loop runs downwards)
-  }
-}
-}  // namespace
-
-struct DevArena::Impl {
-  std::shared_ptr<Group> group;
-  size_t bytes = 0;
-  std::thread helper;
-  std::atomic<bool> stop{false};
-};
-
-DevArena::DevArena(size_t bytes, size_t front_bytes) {
-  if (bytes == 0 || !vm_supported()) return;             // (a limit below one piece: arenas that can back nothing)
-  DevCache& c = cache();
-  std::lock_guard<std::mutex> lock(c.mu);
-  if (active_arena(DEV_TEMP) || active_arena(DEV_HIER) || active_arena(DEV_KEPT)) return;      // an enclosing call's arenas are in use
-  impl_ = new Impl;
-  impl_->bytes = bytes;
-  impl_->group = std::make_shared<Group>();
-  impl_->group->limit = bytes;
-  // three ranges (address space only), one per class of blocks; together they may back `bytes`.  The long-lived arrays get
-  // their pieces 8 GB at a time (pieces backed in one go are where the cycle's kernels run fastest: the products ran 1.5 %
-  // slower, and one operator in twenty runs six times slower, on pieces backed one by one between other work -
-  // profiles/r03_arena_backing.txt)
-  Arena* tmp = open_arena(DEV_TEMP, this, impl_->group, bytes, 0);
-  open_arena(DEV_KEPT, this, impl_->group, bytes, 0);
-  open_arena(DEV_HIER, this, impl_->group, bytes, (size_t)8 << 30);
-  if (!tmp) { close_arenas(this, -1); delete impl_; impl_ = nullptr; return; }
-  // The low end of the temporaries' range is backed piece after piece by a helper thread right away instead of whenever a
-  // block first reaches a piece: on a box whose memory has not been used before a piece costs 8 ms, and the setup would
-  // pay that in its products (464^3: R*A*P 7.3 -> 9.5 s).  The memory would be backed during the setup anyway; the setup
-  // takes a piece the helper has not reached yet by backing it itself.
-  size_t ahead = std::min(bytes, front_bytes) / PIECE * PIECE;
-  start_helper(DEV_TEMP, ahead);
-}
-
-// backs the first `ahead` bytes of the scope's arena of class cls piece after piece (the caller holds no lock of the cache)
-void DevArena::start_helper(int cls, size_t ahead) {
-  if (!impl_ || ahead < PIECE) return;
-  int dev = 0; (void)hipGetDevice(&dev);
-  Impl* im = impl_;
-  const void* owner = this;
-  im->stop.store(false);
-  impl_->helper = std::thread([im, owner, ahead, dev, cls] {
-    if (hipSetDevice(dev) != hipSuccess) { (void)hipGetLastError(); return; }
-    const double t0 = trace_clock();
-    size_t done = 0;
-    for (size_t k = 0; k < ahead / PIECE && !im->stop.load(); k++) {
-      {
-        std::lock_guard<std::mutex> lk(cache().mu);
-        Arena* ap = nullptr;
-        for (auto& a : arenas()) if (a->owner == owner && a->cls == cls && !a->closing) ap = a.get();
-        if (!ap || k >= ap->vm.state.size()) break;         // the arena is gone (recycled, scope over)
-        if (ap->vm.state[k] != 0) continue;
-        if (!ap->vm.map_piece(k)) break;
-        done += PIECE;
-        if (ap->vm.committed > ap->peak_committed) ap->peak_committed = ap->vm.committed;
-      }
-      // the mutex is not fair: without a pause the caller's own requests wait until this loop is through
-      std::this_thread::sleep_for(std::chrono::microseconds(150));
-    }
-    static const bool tr = std::getenv("AIRHIP_ALLOC_TRACE") != nullptr;
-    if (tr) std::fprintf(stderr, "[devmem %.3f] arena %d: helper backed %.1f GB of the first %.1f GB in %.3f s\n", trace_clock(), cls, done * 1e-9, ahead * 1e-9, trace_clock() - t0);
-  });
-}
-void DevArena::wait() { if (impl_ && impl_->helper.joinable()) impl_->helper.join(); }
-
-void DevArena::recycle_temporaries(size_t hier_front) {
-  if (!impl_) return;
-  impl_->stop.store(true);
-  wait();
-  {
-    DevCache& c = cache();
-    std::lock_guard<std::mutex> lock(c.mu);
-    // (empty by now in the normal course: freed here and now; an arena that still holds a block when the scope ends must
-    // not leave pieces to a scope that no longer exists - ~DevArena clears the flag)
-    close_arenas(this, DEV_TEMP, false);      // (no physical pieces are handed on any more: see vm_supported)
-    open_arena(DEV_TEMP, this, impl_->group, impl_->bytes, 0);
-  }
-  // (hier_front: measured at 464^3, a helper that backs the hierarchy's 131 GB at once out of the memory that has just come
-  // back takes 4.1 s - 31 ms per GB, the driver is still clearing what was freed - and holds up the upload's own requests
-  // meanwhile (upload 4.4 -> 5.8 s); backed 8 GB at a time as the arrays come, the same memory costs 0.85 s.  Off by default.)
-  if (hier_front) start_helper(DEV_HIER, std::min(impl_->bytes, hier_front) / PIECE * PIECE);
-}
-
-DevArena::~DevArena() { finish(); }
-
-void DevArena::finish() {
-  if (!impl_) return;
-  impl_->stop.store(true);
-  wait();
-  {
-    DevCache& c = cache();
-    std::lock_guard<std::mutex> lock(c.mu);
-    static const bool trace = std::getenv("AIRHIP_ALLOC_TRACE") != nullptr;
-    if (trace) std::fprintf(stderr, "[devmem %.3f] setup scope over: its arenas backed %.1f GB at the peak\n", trace_clock(), impl_->group->peak * 1e-9);
-    close_arenas(this, -1);
-    for (auto& a : arenas()) if (a->owner == this) a->leave_pieces = false;
-    // the pieces nobody took
-    for (auto h : impl_->group->spare) { (void)hipMemRelease(h); impl_->group->committed -= PIECE; }
-    impl_->group->spare.clear();
-  }
-  delete impl_;
-  impl_ = nullptr;
-}
-
-// The covers of the ranges freed so far: one that can be laid a second time had gone (what takes a cover away is not known -
-// see Arena::maker); it is put back and the fact reported.  Returns the number of covers that had to be put back.
-int dev_check_covers() {
-  DevCache& c = cache();
-  std::lock_guard<std::mutex> lock(c.mu);
-  int gone = 0;
-  const int n = std::min(g_nreleased.load(), 16);
-  for (int k = 0; k < n; k++) {
-    if (!g_released[k].covered) continue;
-    void* t = mmap(g_released[k].base, g_released[k].size, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE | MAP_FIXED_NOREPLACE, -1, 0);
-    if (t == g_released[k].base) {
-      gone++;
-      std::fprintf(stderr, "[airhip] the cover of a freed device address range (%p, %.1f GB) had gone; put back\n", g_released[k].base, g_released[k].size * 1e-9);
-    } else if (t != MAP_FAILED) (void)munmap(t, g_released[k].size);
-  }
-  return gone;
-}
-
-void dev_drain_releases() {
-  DevCache& c = cache();
-  std::lock_guard<std::mutex> lock(c.mu);
-  auto& v = arenas();
-  for (size_t k = v.size(); k-- > 0;)
-    if (v[k]->release_pending && v[k]->maker == std::this_thread::get_id()) { v[k]->release_pending = false; arena_release_if_done(*v[k]); }
-}
-
-int dev_class_of(void* p) {
-  DevCache& c = cache();
-  std::lock_guard<std::mutex> lock(c.mu);
-  const Arena* a = arena_of(p);
-  return a ? a->cls : -1;
-}
-
 size_t dev_available_bytes() {
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return 0; }
   DevCache& c = cache();
   std::lock_guard<std::mutex> lock(c.mu);
-  size_t v = free_b + c.idle_bytes;
-  for (auto& a : arenas()) if (!a->closing) v += a->vm.committed - a->used;      // backed, but no block on it
-  return v;
+  return free_b + c.idle_bytes;
 }
 
 size_t dev_cache_idle_bytes() {

@@ -89,10 +89,10 @@ KspResult DevKSP::richardson(const KspOperator& op, const KspOptions& o, const d
   double* r = w_.p; double* z = t_.p;
   ConvState st;
   double bn = norm2(op, b, s);
-  if (prec && bn != 0.0) { if (op.pc) op.pc(b, z); else HIP_CHECK(hipMemcpyAsync(z, b, 8 * (size_t)n_, hipMemcpyDeviceToDevice, s)); bn = norm2(op, z, s); }
+  if (prec && bn != 0.0) { if (op.pc) { op.pc(b, z); R.pc_applies++; } else HIP_CHECK(hipMemcpyAsync(z, b, 8 * (size_t)n_, hipMemcpyDeviceToDevice, s)); bn = norm2(op, z, s); }
   st.bnorm = bn;
   auto apply_pc = [&](const double* in, double* out) {
-    if (op.pc) op.pc(in, out); else HIP_CHECK(hipMemcpyAsync(out, in, 8 * (size_t)n_, hipMemcpyDeviceToDevice, s));
+    if (op.pc) { op.pc(in, out); R.pc_applies++; } else HIP_CHECK(hipMemcpyAsync(out, in, 8 * (size_t)n_, hipMemcpyDeviceToDevice, s));
   };
   residual(op, b, x, r);
   double rnorm = 0.0;
@@ -124,8 +124,20 @@ KspResult DevKSP::richardson(const KspOperator& op, const KspOptions& o, const d
 // rounding (each entry differs by a few ulp from the normalised run, like any other order of the sums); sig_k shrinks with
 // the residual (1e-10 at convergence), far from the range limits of a double.
 static int g_unnormalised = 1;
+// Right-preconditioned GMRES KEEPS THE PRECONDITIONED BASIS when g_keep_pc is set (airhip_set_tuning
+// "ksp_keep_preconditioned", default 1): z_j = M v_j, which every Arnoldi step computes anyway on its way to A M v_j, is
+// written into a second basis Z instead of a work vector, and the solution update is x += Z y - one multi-axpy - instead of
+// PETSc's x += M (V y) (KSPGMRESBuildSoln -> KSPUnwindPreconditioner), which costs one more PCApply per restart cycle and
+// per solve: 13 V-cycles instead of 12 for the 12 iterations of the 464^3 solve.  M is a fixed linear operator (the AIR
+// V-cycle: fixed polynomials, no inner convergence test), so Z y = M (V y) exactly in exact arithmetic; the Arnoldi
+// process, the Hessenberg matrix, every residual norm and the iteration count are untouched - only the last rounding of x
+// differs (tests/test_gpu_ksp_variants.py).  This is what PETSc's KSPFGMRES stores; for a linear preconditioner the two
+// methods generate the same iterates.  Price: restart more vectors of device memory (24 GB at 464^3); when that allocation
+// fails the solver falls back to PETSc's form.  Left preconditioning never had the extra application.
+static int g_keep_pc = 1;
 int ksp_set_tuning(const char* key, int value) {
   if (std::string(key) == "ksp_unnormalised") { g_unnormalised = value != 0; return 0; }
+  if (std::string(key) == "ksp_keep_preconditioned") { g_keep_pc = value != 0; return 0; }
   return -1;
 }
 
@@ -137,8 +149,17 @@ KspResult DevKSP::gmres(const KspOperator& op, const KspOptions& o, const double
   const bool right = (o.pc_side == 1);
   if (v_alloc_ < m + 1) { V_.alloc((int64_t)(m + 1) * n_); v_alloc_ = m + 1; }
   auto Vk = [&](int k) { return V_.p + (int64_t)k * n_; };
+  // the preconditioned basis (see g_keep_pc): right preconditioning with a real preconditioner only
+  bool keep = right && g_keep_pc != 0 && (bool)op.pc;
+  if (keep && z_alloc_ < m) {
+    try { Z_.alloc((int64_t)m * n_); z_alloc_ = m; }
+    catch (const std::exception&) { (void)hipGetLastError(); Z_.release(); z_alloc_ = 0; keep = false; }      // no room: PETSc's form
+  }
+  if (!keep && z_alloc_ > 0 && g_keep_pc == 0) { Z_.release(); z_alloc_ = 0; }
+  auto Zk = [&](int k) { return Z_.p + (int64_t)k * n_; };
+  R.pc_applies = 0;
   auto apply_pc = [&](const double* in, double* out) {
-    if (op.pc) op.pc(in, out); else HIP_CHECK(hipMemcpyAsync(out, in, 8 * (size_t)n_, hipMemcpyDeviceToDevice, s));
+    if (op.pc) { op.pc(in, out); R.pc_applies++; } else HIP_CHECK(hipMemcpyAsync(out, in, 8 * (size_t)n_, hipMemcpyDeviceToDevice, s));
   };
   ConvState st;
   double bn = norm2(op, b, s);
@@ -172,7 +193,7 @@ KspResult DevKSP::gmres(const KspOperator& op, const KspOptions& o, const double
     bool hapend = false;
     while (!reason && it < m && its < o.max_it) {
       double* w = Vk(it + 1);
-      if (right) { apply_pc(Vk(it), t_.p); SpmvEpi e; e.out = w; op_mult(op, t_.p, e); }
+      if (right) { double* z = keep ? Zk(it) : t_.p; apply_pc(Vk(it), z); SpmvEpi e; e.out = w; op_mult(op, z, e); }
       else { SpmvEpi e; e.out = t_.p; op_mult(op, Vk(it), e); apply_pc(t_.p, w); }
       // classical Gram-Schmidt: one multi-dot and one multi-axpy, each a single pass over w and the basis; the norm of
       // the orthogonalised vector rides along in the multi-axpy
@@ -229,7 +250,11 @@ KspResult DevKSP::gmres(const KspOperator& op, const KspOptions& o, const double
       }
       for (int j = 0; j < it; j++) nrs[j] /= sig[j];      // coefficients of the stored (unnormalised) vectors
       HIP_CHECK(hipMemcpyAsync(dcoef_.p, nrs.data(), sizeof(double) * it, hipMemcpyHostToDevice, s));
-      if (right) {
+      if (right && keep) {
+        // x += Z y: the preconditioned vectors are at hand, no further PCApply
+        Timed t(op, ("Krylov solution multi-axpy (" + std::to_string(it) + ")").c_str(), 8.0 * n_ * (it + 2), "k_maxpy");
+        launch_maxpy(n_, x, Z_.p, n_, it, dcoef_.p, s);
+      } else if (right) {
         { Timed t(op, ("Krylov solution multi-axpy (" + std::to_string(it) + ")").c_str(), 8.0 * n_ * (it + 1), "k_maxpy"); launch_maxpy(n_, w_.p, V_.p, n_, it, dcoef_.p, s, true); }
         apply_pc(w_.p, t_.p);
         Timed t(op, "Krylov x+=z", 24.0 * n_, "k_axpby");

@@ -52,6 +52,10 @@ static int64_t g_block_order_min = 4096;      // smaller operators sit in the ca
 void set_block_order_min(int64_t nblocks) { g_block_order_min = nblocks > 0 ? nblocks : 1; }
 static bool g_fc_fuse = true;
 void set_fc_fuse(bool on) { g_fc_fuse = on; }
+// (airhip_set_tuning "profile_chain") the per-kernel events of the profile: 1 = inside the cycle the stop event of a kernel
+// is the start event of the next (half as many events in the stream), 0 = a pair of events per kernel
+static bool g_profile_chain = true;
+void set_profile_chain(bool on) { g_profile_chain = on; }
 static int g_fc_spatial = 1;       // 0 off, 1 levels where it pays (upload), 2 every level (tests)
 void set_fc_spatial(int mode) { g_fc_spatial = mode; }
 
@@ -102,7 +106,7 @@ DevPCAIR::DevPCAIR() {
 DevPCAIR::~DevPCAIR() {
   if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
   for (auto e : event_pool_) (void)hipEventDestroy(e);
-  for (auto& p : pending_) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+  for (auto& p : pending_) { if (!p.a_shared) (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   devmat_free(A_perm_); devmat_free(coarse_A_);
   if (stream_) (void)hipStreamDestroy(stream_);
   if (comm_stream_) (void)hipStreamDestroy(comm_stream_);
@@ -122,19 +126,27 @@ int DevPCAIR::stat_id(const char* name, int level, double bytes) {
   stat_index_[key] = (int)stats_.size() - 1;
   return (int)stats_.size() - 1;
 }
+// Inside the cycle (statistics of level >= 0, one device) the kernels follow one another on the stream with nothing in
+// between, so the stop event of one is the start event of the next: half as many events in the stream.  A kernel's time
+// then includes the few microseconds between the end of the kernel before it and its own start - what a step pays for
+// it.  The Krylov method's kernels (level -1) have host round trips between them and keep their own pair of events, as do
+// the kernels of a distributed cycle (exchanges on a second stream in between).
 void DevPCAIR::begin_kernel(int stat) {
   if (!profile_) return;
+  cur_stat_ = stat;
+  if (g_profile_chain && chain_armed_ && !comm_ && last_level_ >= 0 && stats_[stat].level >= 0) { cur_a_ = last_b_; cur_a_shared_ = true; return; }
   hipEvent_t a;
   if (!event_pool_.empty()) { a = event_pool_.back(); event_pool_.pop_back(); } else HIP_CHECK(hipEventCreate(&a));
   HIP_CHECK(hipEventRecord(a, stream_));
-  cur_a_ = a; cur_stat_ = stat;
+  cur_a_ = a; cur_a_shared_ = false;
 }
 void DevPCAIR::end_kernel() {
   if (!profile_) return;
   hipEvent_t b;
   if (!event_pool_.empty()) { b = event_pool_.back(); event_pool_.pop_back(); } else HIP_CHECK(hipEventCreate(&b));
   HIP_CHECK(hipEventRecord(b, stream_));
-  pending_.push_back({cur_a_, b, cur_stat_});
+  pending_.push_back({cur_a_, b, cur_stat_, cur_a_shared_});
+  last_b_ = b; last_level_ = stats_[cur_stat_].level; chain_armed_ = true;
 }
 void DevPCAIR::resolve_events() {
   if (pending_.empty()) return;
@@ -147,9 +159,11 @@ void DevPCAIR::resolve_events() {
     if (hipEventElapsedTime(&ms, p.a, p.b) != hipSuccess) { (void)hipGetLastError(); ms = 0.f; }
     if (ms < 0.f) ms = 0.f;
     stats_[p.stat].calls++; stats_[p.stat].ms += ms;
-    event_pool_.push_back(p.a); event_pool_.push_back(p.b);
+    if (!p.a_shared) event_pool_.push_back(p.a);
+    event_pool_.push_back(p.b);
   }
   pending_.clear();
+  chain_armed_ = false; last_b_ = nullptr;
 }
 void DevPCAIR::reset_stats() { resolve_events(); for (auto& s : stats_) { s.calls = 0; s.ms = 0.0; } }
 
@@ -214,7 +228,7 @@ void DevPCAIR::wait_exchange() {
     HIP_CHECK(hipEventRecord(a, stream_));
     const int id = stat_id("halo exchange, exposed", -2, 0.0);
     stats_[id].kernel = "halo_exchange";
-    pending_.push_back({a, exch_end_, id});
+    pending_.push_back({a, exch_end_, id, false});
     exch_end_ = nullptr;
   }
   HIP_CHECK(hipStreamWaitEvent(stream_, ev_recv_, 0));
@@ -255,11 +269,11 @@ const double* DevPCAIR::halo_update(const DevMat& A, const double* x) {
   if (!A.halo) return nullptr;
   HaloPlan& p = *A.halo;
   // (not overlapped: the whole exchange, pack kernel included, is exposed)
-  hipEvent_t saved_a = cur_a_; const int saved_stat = cur_stat_;
+  hipEvent_t saved_a = cur_a_; const int saved_stat = cur_stat_; const bool saved_shared = cur_a_shared_;
   if (profile_) { const int id = stat_id("halo exchange, exposed", -2, 0.0); stats_[id].kernel = "halo_exchange"; begin_kernel(id); }
   if (p.n_send) launch_gather(p.n_send, p.send_idx, x, p.sendbuf, stream_);
   comm_->exchange(p, stream_);
-  if (profile_) { end_kernel(); cur_a_ = saved_a; cur_stat_ = saved_stat; }
+  if (profile_) { end_kernel(); cur_a_ = saved_a; cur_stat_ = saved_stat; cur_a_shared_ = saved_shared; }
   return p.recvbuf;
 }
 
@@ -671,7 +685,7 @@ void DevPCAIR::apply_inv(DevInv& I, const double* r, double* x, bool add, int lv
   }
   if (I.kind == InvOp::DIAG) {
     int id = -1;
-    if (profile_) { id = stat_id(tag, lvl, I.alg_bytes()); stats_[id].kernel = "k_pointwise_mult"; begin_kernel(id); }
+    if (profile_) { id = stat_id(tag, lvl, I.alg_bytes()); stats_[id].kernel = "k_pmult"; begin_kernel(id); }
     launch_pointwise_mult(n, 1.0, I.d.p, r, 1.0, add ? x : nullptr, x, stream_);
     if (profile_) end_kernel();
     return;
@@ -679,6 +693,7 @@ void DevPCAIR::apply_inv(DevInv& I, const double* r, double* x, bool add, int lv
   const DevMat& A = *I.Aop;
   const double* rr = r;
   if (I.diag_scale) {   // MF_VEC_RHS = D^-1 x  (src/Gmres_Poly.F90:1406)
+    Aux t(this, "polynomial rhs = D^-1 r", lvl, 24.0 * n, "k_pmult");
     launch_pointwise_mult(n, 1.0, I.dinv.p, r, 0.0, nullptr, I.rhs.p, stream_);
     rr = I.rhs.p;
   }
@@ -687,7 +702,7 @@ void DevPCAIR::apply_inv(DevInv& I, const double* r, double* x, bool add, int lv
     const int m = (int)c.size() - 1;
     std::vector<int> steps;
     for (int k = m - 1; k >= 0; k--) if (c[k] != 0.0) steps.push_back(k);
-    if (steps.empty()) { launch_axpby(n, c[m], rr, 1.0, add ? x : nullptr, x, stream_); return; }
+    if (steps.empty()) { Aux t(this, "polynomial of order 0", lvl, 24.0 * n, "k_axpby"); launch_axpby(n, c[m], rr, 1.0, add ? x : nullptr, x, stream_); return; }
     const double* cur = rr;       // holds y / lead, with `lead` the scalar still to be applied
     double lead = c[m];
     for (size_t si = 0; si < steps.size(); si++) {
@@ -708,7 +723,7 @@ void DevPCAIR::apply_inv(DevInv& I, const double* r, double* x, bool add, int lv
   // Newton basis (Loe et al. Alg. 3); y accumulates straight into x
   const std::vector<double>& re = I.re; const std::vector<double>& im = I.im;
   const int nr = (int)re.size();
-  if (!add) launch_fill(n, 0.0, x, stream_);
+  if (!add) { Aux ta(this, "Newton apply: x = 0", lvl, 8.0 * n, "k_fill"); launch_fill(n, 0.0, x, stream_); }
   const double* t = rr;
   auto next_t = [&]() { return (t == I.t1.p) ? I.t2.p : I.t1.p; };
   int i = 0;
@@ -738,8 +753,10 @@ void DevPCAIR::apply_inv(DevInv& I, const double* r, double* x, bool add, int lv
       i += 2;
     }
   }
-  if (im[nr - 1] == 0.0 && std::fabs(re[nr - 1]) > TOL_ZERO)
+  if (im[nr - 1] == 0.0 && std::fabs(re[nr - 1]) > TOL_ZERO) {
+    Aux ta(this, "Newton apply: last real root", lvl, 24.0 * n, "k_axpby");
     launch_axpby(n, 1.0 / re[nr - 1], t, 1.0, x, x, stream_);
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -759,7 +776,7 @@ void DevPCAIR::f_smooths(DevLevel& L, int li, bool first, int its) {
   }
   if (first && L.one_point && !g_fc_fuse && !L.A_fc.halo && !(diag_inv && its == 1)) {
     // diagnostic: the two steps apart
-    launch_gather(L.n_f, L.wcol.p, x_c, x_f, stream_);
+    { Aux t(this, "prolong(one point)", li, 20.0 * L.n_f, "k_gather"); launch_gather(L.n_f, L.wcol.p, x_c, x_f, stream_); }
     SpmvEpi e; e.out = L.t4.p; e.alpha = -1.0; e.z = b_f; e.beta = 1.0;
     spmv(L.A_fc, x_c, e, "t4=b_f-A_fc*x_c", li);
   } else if (first && L.one_point) {
@@ -788,10 +805,11 @@ void DevPCAIR::f_smooths(DevLevel& L, int li, bool first, int its) {
   }
   for (int it = 0; it < its; it++) {
     if (diag_inv) {
+      Aux t(this, "x_f+=M(t4-D*x_f) diagonal", li, 40.0 * L.n_f, "k_diag_resid_update");
       launch_diag_residual_update(L.n_f, L.aff_d.p, L.inv_ff.d.p, L.t4.p, x_f, stream_);
       continue;
     }
-    if (L.aff_diag) launch_pointwise_mult(L.n_f, -1.0, L.aff_d.p, x_f, 1.0, L.t4.p, L.r.p, stream_);
+    if (L.aff_diag) { Aux t(this, "r=t4-D*x_f", li, 32.0 * L.n_f, "k_pmult"); launch_pointwise_mult(L.n_f, -1.0, L.aff_d.p, x_f, 1.0, L.t4.p, L.r.p, stream_); }
     else {
       SpmvEpi e; e.out = L.r.p; e.alpha = -1.0; e.z = L.t4.p; e.beta = 1.0;
       spmv(L.A_ff, x_f, e, "r=t4-A_ff*x_f", li);
@@ -807,7 +825,8 @@ void DevPCAIR::c_smooths(DevLevel& L, int li, bool first, int its) {
     if (L.one_point) {
       if (L.A_fc.halo) throw std::runtime_error("a distributed cycle that starts with C smoothing needs a general W");
       const double* xw = x_c;
-      if (L.xs.p) { launch_gather(L.n_c, L.xs_src.p, x_c, L.xs.p, stream_); xw = L.xs.p; }   // wcol counts in the spatial order
+      if (L.xs.p) { Aux t(this, "x_c to spatial order", li, 20.0 * L.n_c, "k_gather"); launch_gather(L.n_c, L.xs_src.p, x_c, L.xs.p, stream_); xw = L.xs.p; }   // wcol counts in the spatial order
+      Aux t(this, "prolong(one point)", li, 20.0 * L.n_f, "k_gather");
       launch_gather(L.n_f, L.wcol.p, xw, x_f, stream_);   // wcol < 0 -> 0 (no W entry)
     }
     else { SpmvEpi e; e.out = x_f; spmv(L.W, x_c, e, "prolong(W)", li); }
@@ -825,7 +844,7 @@ void DevPCAIR::c_smooths(DevLevel& L, int li, bool first, int its) {
 void DevPCAIR::coarse_solve(const double* bL, double* xL) {
   const int L = no_levels();
   if (coarse_richardson_its_ <= 0) { apply_inv(coarse_inv_, bL, xL, false, L - 1, "coarse x=M*b"); return; }
-  launch_fill(coarse_inv_.n, 0.0, xL, stream_);
+  { Aux t(this, "coarse x = 0", L - 1, 8.0 * coarse_inv_.n, "k_fill"); launch_fill(coarse_inv_.n, 0.0, xL, stream_); }
   for (int it = 0; it < coarse_richardson_its_; it++) {
     const double* r = bL;
     if (it > 0) {
@@ -856,7 +875,7 @@ void DevPCAIR::vcycle_full() {
   coarse_solve(B(L - 1), X(L - 1));
   for (int l = L - 2; l >= 0; l--) {
     DevLevel& Lv = *levels_[l];
-    launch_axpby(Lv.n_c, 1.0, X(l + 1), 1.0, X(l) + Lv.n_f, X(l) + Lv.n_f, stream_);   // x_c += e
+    { Aux t(this, "x_c+=e", l, 24.0 * Lv.n_c, "k_axpby"); launch_axpby(Lv.n_c, 1.0, X(l + 1), 1.0, X(l) + Lv.n_f, X(l) + Lv.n_f, stream_); }   // x_c += e
     SpmvEpi e; e.out = X(l); e.alpha = 1.0; e.z = X(l); e.beta = 1.0;
     spmv(Lv.W, X(l + 1), e, "prolong(x_f+=W*e)", l);
     SpmvEpi e2; e2.out = Lv.rfull.p; e2.alpha = -1.0; e2.z = B(l); e2.beta = 1.0;

@@ -31,6 +31,7 @@ void set_block_order_min(int64_t nblocks);
 // diagnostic (airhip_set_tuning "fc_fuse"): 0 runs the first stage of an F relaxation as a gather (one-point prolongation)
 // followed by a plain A_fc product instead of the fused k_rb_fc_first; same results, one more pass over the F vectors
 void set_fc_fuse(bool on);
+void set_profile_chain(bool on);      // pcair_dev.cpp: begin_kernel
 // (airhip_set_tuning "fc_spatial_x", acts at the next upload) A_fc x_c gathers from a copy of x_c in which the level's C points
 // lie in the order of their locality keys instead of section by section [F_{l+1} | F_{l+2} | ...]: the copy costs 20 bytes per
 // C point and cycle, the blocks of A_fc then touch half as many lines of x.  Same results bit for bit (the order of the
@@ -81,7 +82,7 @@ struct DevLevel {
 // rocprofv3 kernel trace aggregates by)
 struct KernelStat { std::string name; int level; double alg_bytes; int64_t calls = 0; double ms = 0.0; const char* kernel = ""; };
 
-struct PendingEvent { hipEvent_t a, b; int stat; };
+struct PendingEvent { hipEvent_t a, b; int stat; bool a_shared; };      // a_shared: `a` is the entry before's `b`
 
 class DevPCAIR {
  public:
@@ -136,7 +137,7 @@ class DevPCAIR {
     stats_[id].kernel = kernel;
     begin_kernel(id);
   }
-  void prof_end() { end_kernel(); }
+  void prof_end() { if (profile_) end_kernel(); }
   // SpMV on the library stream, timed under (name, level) when profiling is on
   void spmv(const DevMat& A, const double* x, const SpmvEpi& e, const char* name, int level, double bytes_override = -1);
 
@@ -201,6 +202,10 @@ class DevPCAIR {
   std::vector<PendingEvent> pending_;
   std::vector<hipEvent_t> event_pool_;
   int cur_stat_ = -1; hipEvent_t cur_a_ = nullptr;
+  // chained events (pcair_dev.cpp: begin_kernel): the stop event of one cycle kernel is the start event of the next
+  bool cur_a_shared_ = false, chain_armed_ = false; hipEvent_t last_b_ = nullptr; int last_level_ = -1;
+  // RAII timed section for the cycle's small vector kernels
+  struct Aux { DevPCAIR* p; Aux(DevPCAIR* q, const char* name, int level, double bytes, const char* kernel) : p(q) { p->prof_begin(name, level, bytes, kernel); } ~Aux() { p->prof_end(); } };
   // graph
   bool want_graph_ = false;
   std::function<void()> before_capture_;
@@ -218,7 +223,7 @@ struct KspOptions {
   int max_it = 10000;
   int restart = 30;
 };
-struct KspResult { int its = 0; int reason = 0; double rnorm = 0.0; double solve_ms = 0.0; std::vector<double> history; };
+struct KspResult { int its = 0; int reason = 0; double rnorm = 0.0; double solve_ms = 0.0; std::vector<double> history; int pc_applies = 0; };
 
 // Generic preconditioner callback in whatever ordering the operator uses.
 struct KspOperator {
@@ -250,8 +255,8 @@ class DevKSP {
   KspResult richardson(const KspOperator& op, const KspOptions& o, const double* b, double* x);
   KspResult gmres(const KspOperator& op, const KspOptions& o, const double* b, double* x);
   int64_t n_;
-  DBuf<double> V_, w_, t_, scratch_, ddots_, dcoef_, dnorm_;
-  int v_alloc_ = 0;
+  DBuf<double> V_, Z_, w_, t_, scratch_, ddots_, dcoef_, dnorm_;      // Z_: the preconditioned basis (ksp_dev.cpp: g_keep_pc)
+  int v_alloc_ = 0, z_alloc_ = 0;
 };
 
 }  // namespace airhip

@@ -94,9 +94,7 @@ struct DevSetupAccel final : SetupAccel {
     if (!d.rp) return;
     std::lock_guard<std::mutex> lk(mu_kept);
     const bool only_copy = tag && host_missing.count(tag);
-    // (a copy in the temporaries' range - an operand uploaded from the host - would hold that whole range back: not kept)
-    const bool pins_temporaries = dev_class_of(d.v ? (void*)d.v : (void*)d.rp) == DEV_TEMP;
-    if (tag && !kept.count(tag) && (only_copy || (keeping && !pins_temporaries && kept_bytes + bytes_of(d) <= kept_limit))) { kept[tag] = d; kept_bytes += bytes_of(d); d = DCsr(); }
+    if (tag && !kept.count(tag) && (only_copy || (keeping && kept_bytes + bytes_of(d) <= kept_limit))) { kept[tag] = d; kept_bytes += bytes_of(d); d = DCsr(); }
     else if (only_copy) throw std::logic_error("setup accelerator: two device copies of an operator that is not on the host");
     else dcsr_free(d);
   }
@@ -189,7 +187,7 @@ struct DevSetupAccel final : SetupAccel {
     retire(inverse, inverse_tag); inverse_key = nullptr; inverse_tag = 0;
     const double t0 = now_s();
     dev_stage("setup: product (Z = -A_cf * M or A * B)");
-    DCsr dC = dev_spgemm(dA, dB, drop.enabled, drop.tol, drop.lump, drop.negate, stream, nullptr, keep && keeping ? DEV_KEPT : DEV_TEMP);
+    DCsr dC = dev_spgemm(dA, dB, drop.enabled, drop.tol, drop.lump, drop.negate, stream, nullptr);
     t_compute += now_s() - t0;
     // the C-F block is only kept when the host has not got it yet; the inverse is an operator of the hierarchy
     { bool only; { std::lock_guard<std::mutex> lk(mu_kept); only = a_tag && host_missing.count(a_tag); } if (only) retire(dA, a_tag); else dcsr_free(dA); }
@@ -248,7 +246,7 @@ struct DevSetupAccel final : SetupAccel {
     const double t0 = now_s();
     dev_stage("setup: polynomial assembly");
     bool ok;
-    { DevClassScope cls(final_values && keeping ? DEV_KEPT : DEV_TEMP); ok = dev_poly_assemble(dA, c.data(), (int)c.size(), dM, stream); }
+    ok = dev_poly_assemble(dA, c.data(), (int)c.size(), dM, stream);
     t_poly += now_s() - t0;
     retire(dA, A.device_tag);              // A_ff itself is an operator of the hierarchy
     if (!ok) return false;
@@ -523,7 +521,7 @@ struct DevSetupAccel final : SetupAccel {
     t0 = now_s();
     DCsr dff, dfc, dcf, dcc;
     dev_stage("setup: F / C block extraction");
-    { DevClassScope cls(keeping ? DEV_KEPT : DEV_TEMP); dev_split_fc(resident, d_code, n_f, n_c, dff, dfc, dcf, A_cc ? &dcc : nullptr, stream); }
+    dev_split_fc(resident, d_code, n_f, n_c, dff, dfc, dcf, A_cc ? &dcc : nullptr, stream);
     dev_free(d_code);
     dev_stage("setup: F / C blocks, downloads");
     t_extract += now_s() - t0;

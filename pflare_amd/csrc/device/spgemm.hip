@@ -775,7 +775,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather_rows(int64_t nrows, const int3
 // totals.  Only when rows fail (LDS table too small -> global table; pool exhausted -> another round with a fresh
 // pool) are the counts downloaded and the failed rows listed.
 DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, bool lump, bool negate, hipStream_t s,
-                SpgemmStats* stats, int out_class) {
+                SpgemmStats* stats) {
   if (A.n != B.m) throw std::runtime_error("dev_spgemm: shape mismatch");
   DevScope scope;      // every block below is a raw dev_alloc pointer: an exception on the way returns them all
   static const bool trace = std::getenv("AIRHIP_SPGEMM_TRACE") != nullptr;
@@ -783,7 +783,7 @@ DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, boo
   const double t_begin = now();
   const int64_t m = A.m;
   DCsr C; C.m = m; C.n = B.n;
-  { DevClassScope cls(out_class); C.rp = dmalloc<int64_t>(m + 1); }
+  C.rp = dmalloc<int64_t>(m + 1);
   if (m == 0) { int64_t z = 0; HIP_CHECK(hipMemcpy(C.rp, &z, sizeof(int64_t), hipMemcpyHostToDevice)); return C; }
   const CsrView av = cview(A), bv = cview(B);
   const DropParams dp{drop_enabled ? 1 : 0, tol, lump ? 1 : 0, negate ? 1 : 0};
@@ -984,7 +984,7 @@ DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, boo
   const double tg0 = now();
   C.nnz = device_exclusive_scan(m, d_cnt, C.rp, s);
   HIP_CHECK(hipMemcpyAsync(C.rp + m, &C.nnz, sizeof(int64_t), hipMemcpyHostToDevice, s));
-  { DevClassScope cls(out_class); C.ci = dmalloc<int32_t>(C.nnz); C.v = dmalloc<double>(C.nnz); }
+  C.ci = dmalloc<int32_t>(C.nnz); C.v = dmalloc<double>(C.nnz);
   for (Round& rd : rounds) {
     const int64_t nr = rd.all_rows ? m : (int64_t)rd.done.size();
     if (nr) {

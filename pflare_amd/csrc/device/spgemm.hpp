@@ -29,9 +29,8 @@ void dcsr_download(const DCsr& d, int64_t* rp, int32_t* ci, double* v);
 // C = filter(A * B).  With drop_enabled: entries with |c_ij| < tol * max_j |c_ij| are removed
 // (the diagonal i==j is never removed; with lump the removed entries are added to it), negate
 // flips the sign of the product first.  Rows come out sorted by column; values are bit-identical
-// to the host spgemm (host/spops.cpp).  out_class: the allocation class of the result's arrays (devmem.hpp: DEV_TEMP, or
-// DEV_KEPT for an operator that stays on the device after the setup); everything else the product allocates is temporary.
+// to the host spgemm (host/spops.cpp).
 DCsr dev_spgemm(const DCsr& A, const DCsr& B, bool drop_enabled, double tol, bool lump, bool negate, hipStream_t s,
-                SpgemmStats* stats = nullptr, int out_class = 0);
+                SpgemmStats* stats = nullptr);
 
 }  // namespace airhip

@@ -998,9 +998,11 @@ __global__ __launch_bounds__(BLOCK) void k_block_pack(int64_t nblocks, int64_t n
       }
       for (int i = lane; i < nb; i += WAVE) oval[p0 + val_slot(i, nb)] = val[p0 + i];
       if (lane == 0) { blk[b].cbase = -2 - (ob | (nwin << MB_WIN_SHIFT)); blk[b].ip = 4 * (int64_t)(nwin + nd); }
-    } else if (can_pack && !mb_on) {
-      // (with the multi-base form on, a block that fits no table stays raw: the lean kernels take it, and a launch of the
-      // *_g kernels for a handful of one-entry blocks per operator costs more than their 4-byte words)
+    } else if (can_pack && (!mb_on || nrows > mb_max_rows)) {
+      // packed: the multi-base form is off, or the block has more rows than mb16_max_rows admits to it (the documented
+      // meaning of that knob: such blocks keep the packed form of rounds 2-3 and run in the *_g kernels).  With the
+      // multi-base form on, a block that was ADMITTED but fits no table stays raw: the lean kernels take it, and a launch
+      // of the *_g kernels for a handful of one-entry blocks per operator costs more than their 4-byte words.
       for (int i = lane; i < nb; i += WAVE) {
         const unsigned long long k = keys[i];
         const int pos = (int)(k & 0xffffull);

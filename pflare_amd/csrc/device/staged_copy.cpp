@@ -56,7 +56,6 @@ static int copy_mode() {
 constexpr size_t PIN_MIN = 32ull << 20;
 static bool pinned_copy(void* dst, const void* src, size_t bytes, bool to_device) {
   void* host = to_device ? const_cast<void*>(src) : dst;
-  dev_note_host_copy(host, bytes);
   if (!to_device) {
     // a fresh destination: fault the pages in with all threads first (registering would do it with one)
     char* p = (char*)host;

@@ -558,4 +558,4 @@ class KSP:
         check(lib().airhip_ksp_solve_on_stream(C.byref(self.o), amat, pcair, pcinv, _ptr(b), _ptr(x), C.byref(res), hist,
                                                4096, C.byref(hl), _caller_stream(x)))
         return dict(its=res.its, reason=res.reason, reason_name=KSP_REASONS.get(res.reason, str(res.reason)),
-                    rnorm=res.rnorm, solve_ms=res.solve_ms, history=[hist[i] for i in range(min(hl.value, 4096))])
+                    rnorm=res.rnorm, solve_ms=res.solve_ms, pc_applies=res.pc_applies, history=[hist[i] for i in range(min(hl.value, 4096))])

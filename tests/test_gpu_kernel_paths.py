@@ -70,7 +70,10 @@ def _rows(lengths, n, rng, local=None):
     return sp.csr_matrix((vals, cols, indptr), shape=(m, n))
 
 
-FORMATS = {"default": (1, 128), "mb16-off": (0, 128), "mb16-long-rows-only": (1, 4)}
+# "mb16-mixed-with-packed": blocks of at most 4 rows (and blocks that cannot be packed) go multi-base, the others keep the
+# packed form of rounds 2-3: one operator then holds both kinds and both launch parts (the lean kernels and the *_g kernels)
+# run for one product
+FORMATS = {"default": (1, 128), "mb16-off": (0, 128), "mb16-mixed-with-packed": (1, 4)}
 
 
 def _set_format(P, name):
@@ -352,7 +355,7 @@ def test_the_three_conversions_agree_bit_for_bit(gpu):
                 y = torch.empty(A.shape[0], dtype=torch.float64, device="cuda")
                 dm.mult(x, y)
                 outs[name].append(y)
-        for name in ("mb16-off", "mb16-long-rows-only"):
+        for name in ("mb16-off", "mb16-mixed-with-packed"):
             for k, (a, b) in enumerate(zip(outs["default"], outs[name])):
                 assert torch.equal(a, b), (name, k)
     finally:

@@ -441,14 +441,14 @@ def _run_fallback(env_extra, M=96):
 
 
 def test_setup_fallback_paths_in_a_process_of_their_own(gpu):
-    """The switches that stay are read once per process, so each runs in a child: the virtual-memory arenas
-    (AIRHIP_DEVICE_VMM=1, opt-in since round 4), R / P assembled on the host (AIRHIP_DEVICE_RP=0), no operator kept on the device
-    for the upload (AIRHIP_KEEP_DEVICE_COPIES=0).  3D advection 96^3 (3.5 M non-zeros: every device path of the setup is taken,
+    """The switches that stay are read once per process, so each runs in a child: R / P assembled on the host
+    (AIRHIP_DEVICE_RP=0), no operator kept on the device for the upload (AIRHIP_KEEP_DEVICE_COPIES=0), downloads not deferred
+    to the mirror thread (AIRHIP_DEFER_DOWNLOADS=0).  (The virtual-memory arenas of rounds 3-4 are gone: round 5 removed them.)  3D advection 96^3 (3.5 M non-zeros: every device path of the setup is taken,
     the mirror thread runs), two setups back to back in each process with the host mirror alive and host allocations in
     between.  Every variant must build the same hierarchy and solve it the same way as the default path."""
     base = _run_fallback({})
     assert base["its"] == base["its2"] and base["same"] == 0.0 and base["its"] <= 9, base
-    for env in ({"AIRHIP_DEVICE_VMM": "1"}, {"AIRHIP_DEVICE_RP": "0"}, {"AIRHIP_KEEP_DEVICE_COPIES": "0"}):
+    for env in ({"AIRHIP_DEVICE_RP": "0"}, {"AIRHIP_KEEP_DEVICE_COPIES": "0"}, {"AIRHIP_DEFER_DOWNLOADS": "0"}):
         v = _run_fallback(env)
         assert v["levels"] == base["levels"] and v["nnz"] == base["nnz"] and v["cx"] == base["cx"], (env, v, base)
         assert v["its"] == base["its"] == v["its2"] and v["same"] == 0.0, (env, v, base)
