@@ -308,6 +308,10 @@ int airhip_pcinv_setup(airhip_pcinv pc, const airhip_csr* A);
 int airhip_pcinv_setup_host_only(airhip_pcinv pc, const airhip_csr* A);
 int airhip_spgemm_filtered(const airhip_csr* A, const airhip_csr* B, int drop, double tol, int lump, int negate,
                            int on_device, airhip_hostmat* out, int64_t* stats);
+/* inspection hook, not part of the stable ABI: G = A_fc + A_ff W for the one-point prolongator W (wcol[i] = W's column of F
+ * point i, -1 = none) - the operator the fused first F sweep of the cycle runs on (airhip_set_tuning "fuse_first_sweep"),
+ * built by the host code (on_device = 0) or by the device code of the upload; both give the same bits */
+int airhip_fused_first_operator(const airhip_csr* A_ff, const airhip_csr* A_fc, const int32_t* wcol, int on_device, airhip_hostmat* out);
 int airhip_pcinv_apply(airhip_pcinv pc, const double* d_x, double* d_y);      /* PCApply_PFLAREINV_c, src/PCPFLAREINV.c:618-626 */
 int airhip_pcinv_apply_on_stream(airhip_pcinv pc, const double* d_x, double* d_y, void* stream);
 /* the zero-level PCAIR object a PCPFLAREINV is built on - BORROWED, valid while pc is; what airhip_partition_create takes

@@ -34,7 +34,7 @@ class airhip_ksp_result(C.Structure):
 # every symbol include/airhip.h declares (tests check that the library exports all of them)
 DECLARED_SYMBOLS = [
     "airhip_last_error", "airhip_version", "airhip_device_count", "airhip_set_device", "airhip_set_num_threads",
-    "airhip_set_tuning", "airhip_pcair_setup_host_only", "airhip_pcinv_setup_host_only", "airhip_spgemm_filtered",
+    "airhip_set_tuning", "airhip_pcair_setup_host_only", "airhip_pcinv_setup_host_only", "airhip_spgemm_filtered", "airhip_fused_first_operator",
     "airhip_gen_adv_1d", "airhip_gen_adv_diff_fd", "airhip_hostmat_from_csr", "airhip_hostmat_get",
     "airhip_hostmat_destroy",
     "airhip_pcair_create", "airhip_pcair_set_option", "airhip_pcair_set_ordering_hint", "airhip_pcair_setup", "airhip_pcair_begin_levels",

@@ -4,6 +4,7 @@
 #include "device/pcair_dev.hpp"
 #include "device/setup_accel.hpp"
 #include "device/spgemm.hpp"
+#include "device/extract.hpp"
 #include "device/comm.hpp"
 #include "device/devmem.hpp"
 #include "host/dist.hpp"
@@ -56,6 +57,8 @@ int airhip_set_tuning(const char* key, int value) {
   else if (std::string(key) == "block_order_min_blocks") airhip::set_block_order_min(value);
   else if (std::string(key) == "fc_fuse") airhip::set_fc_fuse(value != 0);
   else if (std::string(key) == "profile_chain") airhip::set_profile_chain(value != 0);
+  else if (std::string(key) == "fuse_first_sweep") airhip::set_fuse_first_sweep(value);
+  else if (std::string(key) == "fuse_first_sweep_run") airhip::set_fuse_first_sweep_run(value != 0);
   else if (std::string(key) == "fc_spatial_x") airhip::set_fc_spatial(value);
   else if (airhip::kernels_set_tuning(key, value) == 0) {}
   else if (airhip::ksp_set_tuning(key, value) == 0) {}
@@ -305,6 +308,31 @@ int airhip_spgemm_filtered(const airhip_csr* A, const airhip_csr* B, int drop, d
     if (stats) { stats[0] = st.rows_reg; stats[1] = st.rows_1k; stats[2] = st.rows_2k; stats[3] = st.rows_4k; stats[4] = st.rows_global; }
   }
   *out = h;
+  API_END
+}
+// Inspection hook: G = A_fc + A_ff W (one-point W given by wcol) built by the host code (host/spops.cpp) or by the device
+// code (device/extract.hip) - the operator of the fused first F sweep
+int airhip_fused_first_operator(const airhip_csr* A_ff, const airhip_csr* A_fc, const int32_t* wcol, int on_device, airhip_hostmat* out) {
+  API_BEGIN
+  REQUIRE(A_ff && A_fc && wcol && out && A_ff->m == A_fc->m && A_ff->n == A_ff->m, AIRHIP_ERR_ARG, "bad arguments");
+  REQUIRE_CSR(A_ff, true); REQUIRE_CSR(A_fc, false);
+  for (int64_t i = 0; i < A_fc->m; i++) REQUIRE(wcol[i] >= -1 && wcol[i] < A_fc->n, AIRHIP_ERR_ARG, "wcol out of range");
+  Csr a, b; view_csr(A_ff, a); view_csr(A_fc, b);
+  auto h = std::make_unique<airhip_hostmat_s>();
+  if (!on_device) h->A = fused_first_operator(a, b, wcol);
+  else {
+    DevScope scope(true);
+    DCsr da = dcsr_upload(a.m, a.n, a.rp.data(), a.ci.data(), a.v.data());
+    DCsr db = dcsr_upload(b.m, b.n, b.rp.data(), b.ci.data(), b.v.data());
+    int32_t* dw = (int32_t*)dev_alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(a.m, 1));
+    staged_h2d(dw, wcol, sizeof(int32_t) * (size_t)a.m);
+    DCsr dg = dev_fused_first_operator(da, db, dw, nullptr);
+    h->A.m = dg.m; h->A.n = dg.n;
+    h->A.rp.alloc(dg.m + 1); h->A.ci.alloc(dg.nnz); h->A.v.alloc(dg.nnz);
+    dcsr_download(dg, h->A.rp.data(), h->A.ci.data(), h->A.v.data());
+    dcsr_free(da); dcsr_free(db); dcsr_free(dg); dev_free(dw);
+  }
+  *out = h.release();
   API_END
 }
 int airhip_hostmat_destroy(airhip_hostmat* A) {

@@ -141,6 +141,51 @@ DCsr dev_build_R(const DCsr& Z, const int32_t* d_F, const int32_t* d_C, int64_t 
   return R;
 }
 
+namespace {
+__global__ __launch_bounds__(BLOCK) void k_cat_rp(int64_t m, const int64_t* __restrict__ a, const int64_t* __restrict__ b, int64_t* __restrict__ rp) {
+  const int64_t stride = (int64_t)gridDim.x * BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i <= m; i += stride) rp[i] = a[i] + b[i];
+}
+// one wave per row of [A | B]: A's entries, then B's with their columns moved by `shift`
+__global__ __launch_bounds__(BLOCK) void k_cat_fill(Src A, Src B, int32_t shift, const int64_t* __restrict__ rp, int32_t* __restrict__ ci, double* __restrict__ v) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * BLOCK) >> 6;
+  for (int64_t i = wave; i < A.m; i += nw) {
+    const int64_t a0 = A.rp[i], a1 = A.rp[i + 1], b0 = B.rp[i], b1 = B.rp[i + 1], o = rp[i];
+    for (int64_t k = a0 + lane; k < a1; k += WAVE) { ci[o + (k - a0)] = A.ci[k]; v[o + (k - a0)] = A.v[k]; }
+    const int64_t ob = o + (a1 - a0);
+    for (int64_t k = b0 + lane; k < b1; k += WAVE) { ci[ob + (k - b0)] = B.ci[k] + shift; v[ob + (k - b0)] = B.v[k]; }
+  }
+}
+// the code array of the index space [F points | C points] (dev_split_fc's convention)
+__global__ __launch_bounds__(BLOCK) void k_cat_code(int64_t nf, int64_t nc, uint32_t* __restrict__ code) {
+  const int64_t stride = (int64_t)gridDim.x * BLOCK;
+  for (int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x; r < nf + nc; r += stride) code[r] = r < nf ? ((uint32_t)r | FBIT) : (uint32_t)(r - nf);
+}
+}  // namespace
+
+DCsr dev_fused_first_operator(const DCsr& A_ff, const DCsr& A_fc, const int32_t* d_wcol, hipStream_t s) {
+  const int64_t nf = A_fc.m, nc = A_fc.n;
+  if (A_ff.m != nf || A_ff.n != nf) throw std::runtime_error("dev_fused_first_operator: A_ff / A_fc shape mismatch");
+  DCsr cat; cat.m = nf; cat.n = nf + nc; cat.nnz = A_ff.nnz + A_fc.nnz;
+  cat.rp = dalloc<int64_t>(nf + 1); cat.ci = dalloc<int32_t>(cat.nnz); cat.v = dalloc<double>(cat.nnz);
+  const int g1 = (int)std::max<int64_t>(1, std::min<int64_t>((nf + 1 + BLOCK - 1) / BLOCK, MAX_BLOCKS));
+  hipLaunchKernelGGL(k_cat_rp, dim3(g1), dim3(BLOCK), 0, s, nf, A_ff.rp, A_fc.rp, cat.rp);
+  if (nf > 0) {
+    const int g2 = (int)std::max<int64_t>(1, std::min<int64_t>((nf + 3) / 4, MAX_BLOCKS));
+    hipLaunchKernelGGL(k_cat_fill, dim3(g2), dim3(BLOCK), 0, s, Src{nf, A_ff.rp, A_ff.ci, A_ff.v}, Src{nf, A_fc.rp, A_fc.ci, A_fc.v}, (int32_t)nf, cat.rp, cat.ci, cat.v);
+  }
+  uint32_t* code = dalloc<uint32_t>(nf + nc);
+  const int g3 = (int)std::max<int64_t>(1, std::min<int64_t>((nf + nc + BLOCK - 1) / BLOCK, MAX_BLOCKS));
+  hipLaunchKernelGGL(k_cat_code, dim3(g3), dim3(BLOCK), 0, s, nf, nc, code);
+  DCsr P = dev_build_P_one_point(nf + nc, nc, code, d_wcol, s);
+  dev_free(code);
+  DCsr G = dev_spgemm(cat, P, false, 0.0, false, false, s);
+  dcsr_free(cat); dcsr_free(P);
+  return G;
+}
+
 DCsr dev_build_P_one_point(int64_t n, int64_t n_c, const uint32_t* d_code, const int32_t* d_wcol, hipStream_t s) {
   DCsr P; P.m = n; P.n = n_c;
   int64_t* cnt = dalloc<int64_t>(n);

@@ -23,5 +23,9 @@ DCsr dev_build_P_one_point(int64_t n, int64_t n_c, const uint32_t* d_code, const
 // the one-point classical prolongator's column per F point (host twin: air_setup.cpp one_point_W; src/Grid_Transfer.F90:
 // 329-461): the column of the largest |entry| of the row of A_fc, the first one on ties, -1 for an empty row
 void dev_one_point_w(const DCsr& A_fc, int32_t* d_wcol, hipStream_t s);
+// G = A_fc + A_ff W for the one-point prolongator W: the operator of the fused first F sweep (host twin, with the reasons:
+// host/spops.hpp fused_first_operator; same bits).  [A_ff | A_fc] and [W; I] are assembled on the device and multiplied by
+// dev_spgemm.  d_wcol: W's column per F point on the device (-1 = none).
+DCsr dev_fused_first_operator(const DCsr& A_ff, const DCsr& A_fc, const int32_t* d_wcol, hipStream_t s);
 
 }  // namespace airhip

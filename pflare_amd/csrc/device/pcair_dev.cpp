@@ -7,43 +7,55 @@
 // src/Gmres_Poly_Newton.F90:763-875; Neumann shell src/Neumann_Poly.F90:19-55.
 #include "pcair_dev.hpp"
 #include "devmem.hpp"
+#include "extract.hpp"
 #include <parallel/algorithm>
 #include <cstdio>
 
 namespace airhip {
 
 // where the upload of a hierarchy spends its time (printed with -pc_air_print_stats_timings)
-static double g_t_h2d = 0.0, g_t_convert = 0.0;
+static double g_t_h2d = 0.0, g_t_convert = 0.0, g_t_fuse = 0.0;
 
 // the setup accelerator that built the hierarchy being uploaded (DevPCAIR::set_device_source), or null
 static thread_local SetupAccel* t_source = nullptr;
 static int64_t g_n_from_device = 0;
 
-void upload_mat(const Csr& A, const int32_t* d_rowsrc, const int32_t* d_colmap, DevMat& out, hipStream_t s, int64_t n_ghost) {
-  // an operator the setup left on this device is converted where it is
-  if (t_source && A.device_tag) {
-    const int64_t* rp = nullptr; const int32_t* ci = nullptr; const double* v = nullptr;
-    if (t_source->device_copy(A.device_tag, A.m, A.nnz(), &rp, &ci, &v)) {
-      const double t0 = now_s();
-      devmat_from_csr_device(A.m, A.n, rp, ci, v, d_rowsrc, d_colmap, out, s, n_ghost);
-      t_source->drop_device_copy(A.device_tag);
-      g_t_convert += now_s() - t0;
-      g_n_from_device++;
-      return;
-    }
+// The CSR arrays of an operator of the host hierarchy on the device, for as long as the upload needs them: the copy the
+// setup left here (lent by the accelerator, handed back - or dropped - at the end) or a staged copy of the host arrays
+// (blocks from the cache, back to it afterwards).
+struct DevCsrLease {
+  int64_t m = 0, n = 0, nnz = 0;
+  const int64_t* rp = nullptr; const int32_t* ci = nullptr; const double* v = nullptr;
+  uint64_t tag = 0;                          // != 0: the accelerator's copy
+  void *s_rp = nullptr, *s_ci = nullptr, *s_v = nullptr;
+  explicit DevCsrLease(const Csr& A) : m(A.m), n(A.n), nnz(A.nnz()) {
+    if (t_source && A.device_tag && t_source->device_copy(A.device_tag, A.m, A.nnz(), &rp, &ci, &v)) { tag = A.device_tag; g_n_from_device++; return; }
+    if (!A.on_host()) throw std::logic_error("upload of an operator that is neither on the host nor kept on the device");
+    const double t0 = now_s();
+    try {
+      s_rp = dev_alloc(sizeof(int64_t) * (size_t)(m + 1)); s_ci = dev_alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(nnz, 1));
+      s_v = dev_alloc(sizeof(double) * (size_t)std::max<int64_t>(nnz, 1));
+      staged_h2d(s_rp, A.rp.data(), sizeof(int64_t) * (size_t)(m + 1));
+      if (nnz > 0) { staged_h2d(s_ci, A.ci.data(), sizeof(int32_t) * (size_t)nnz); staged_h2d(s_v, A.v.data(), sizeof(double) * (size_t)nnz); }
+    } catch (...) { dev_free(s_rp); dev_free(s_ci); dev_free(s_v); throw; }
+    rp = (const int64_t*)s_rp; ci = (const int32_t*)s_ci; v = (const double*)s_v;
+    g_t_h2d += now_s() - t0;
   }
-  if (!A.on_host()) throw std::logic_error("upload of an operator that is neither on the host nor kept on the device");
-  // the CSR arrays are only staged on the device: blocks from the cache, back to it afterwards
-  struct Staged { void* p; explicit Staged(size_t bytes) : p(dev_alloc(bytes)) {} ~Staged() { dev_free(p); } };
-  const int64_t nnz = A.nnz();
-  Staged rp(sizeof(int64_t) * (size_t)(A.m + 1)), ci(sizeof(int32_t) * (size_t)std::max<int64_t>(nnz, 1)), v(sizeof(double) * (size_t)std::max<int64_t>(nnz, 1));
-  double t0 = now_s();
-  staged_h2d(rp.p, A.rp.data(), sizeof(int64_t) * (size_t)(A.m + 1));
-  if (nnz > 0) { staged_h2d(ci.p, A.ci.data(), sizeof(int32_t) * (size_t)nnz); staged_h2d(v.p, A.v.data(), sizeof(double) * (size_t)nnz); }
-  g_t_h2d += now_s() - t0;
-  t0 = now_s();
-  devmat_from_csr_device(A.m, A.n, (const int64_t*)rp.p, (const int32_t*)ci.p, (const double*)v.p, d_rowsrc, d_colmap, out, s, n_ghost);
-  g_t_convert += now_s() - t0;
+  ~DevCsrLease() {
+    if (tag) t_source->drop_device_copy(tag);
+    dev_free(s_rp); dev_free(s_ci); dev_free(s_v);
+  }
+  DevCsrLease(const DevCsrLease&) = delete; DevCsrLease& operator=(const DevCsrLease&) = delete;
+  void convert(const int32_t* d_rowsrc, const int32_t* d_colmap, DevMat& out, hipStream_t s, int64_t n_ghost) const {
+    const double t0 = now_s();
+    devmat_from_csr_device(m, n, rp, ci, v, d_rowsrc, d_colmap, out, s, n_ghost);
+    g_t_convert += now_s() - t0;
+  }
+};
+
+void upload_mat(const Csr& A, const int32_t* d_rowsrc, const int32_t* d_colmap, DevMat& out, hipStream_t s, int64_t n_ghost) {
+  DevCsrLease lease(A);
+  lease.convert(d_rowsrc, d_colmap, out, s, n_ghost);
 }
 
 // Processing order of an operator's row blocks by the locality key of each block's first row (host arrays:
@@ -56,6 +68,10 @@ void set_fc_fuse(bool on) { g_fc_fuse = on; }
 // is the start event of the next (half as many events in the stream), 0 = a pair of events per kernel
 static bool g_profile_chain = true;
 void set_profile_chain(bool on) { g_profile_chain = on; }
+static int g_fuse_first = 1;          // pcair_dev.hpp: set_fuse_first_sweep
+static bool g_fuse_first_run = true;
+void set_fuse_first_sweep(int mode) { g_fuse_first = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }
+void set_fuse_first_sweep_run(bool on) { g_fuse_first_run = on; }
 static int g_fc_spatial = 1;       // 0 off, 1 levels where it pays (upload), 2 every level (tests)
 void set_fc_spatial(int mode) { g_fc_spatial = mode; }
 
@@ -318,7 +334,7 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
   dev_cache_trim_to((size_t)40 << 30);      // (devmem.hpp: what the setup left idle slows the allocations of the arrays that stay)
   const int L = H.no_levels();
   const double t_upload0 = now_s();
-  g_t_h2d = g_t_convert = 0.0; g_n_from_device = 0;
+  g_t_h2d = g_t_convert = g_t_fuse = 0.0; g_n_from_device = 0;
   struct SourceScope { SetupAccel* prev; explicit SourceScope(SetupAccel* a) : prev(t_source) { t_source = a; } ~SourceScope() { t_source = prev; } } source_scope(dist ? nullptr : source_);
   comm_ = dist ? comm : nullptr;
   if (dist && !comm) throw std::runtime_error("a distributed hierarchy needs a communicator");
@@ -504,6 +520,14 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
     // gains ~8 % (464^3, profiles/r04_fc_spatial.txt: levels 5-10 gain 0.05-0.13 ms each for 0.01-0.06 ms of copy, levels 1-4
     // lose 0.03-0.2 ms each) - from 25 non-zeros of A_fc per C point on
     const bool fc_spatial = g_fc_spatial && !dist && (g_fc_spatial >= 2 || (h.n_c >= 4096 && h.A_fc.nnz() >= 25 * h.n_c));
+    // The first F sweep on G = A_fc + A_ff W (set_fuse_first_sweep): relaxation that starts with F sweeps, one-point W,
+    // sparse A_ff, assembled A_ff inverse; one device (a distributed hierarchy keeps the reference's sequence).
+    const bool fuse_first = g_fuse_first && !dist && h.one_point && !h.aff_diag && h.smooth_order[0] > 0 && h.inv_ff.kind == InvOp::ASSEMBLED &&
+                            h.A_fc.nnz() > 0 && h.A_ff.nnz() > 0;      // (nnz(): also for operators whose host arrays are still on the device)
+    bool later_f_group = false;
+    for (int i = 1; i < 10 && h.smooth_order[i] != 0; i++) later_f_group |= h.smooth_order[i] > 0;
+    const bool need_fc = !fuse_first || g_fuse_first == 2 || later_f_group;
+    DBuf<int32_t> cspd;
     if (fc_spatial) {
       const std::vector<int64_t>& kc = level_keys[l + 1];
       std::vector<int32_t> ord((size_t)h.n_c), src((size_t)h.n_c);
@@ -516,7 +540,26 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
       for (int64_t r = 0; r < h.n_c; r++) { csp[(size_t)ord[(size_t)r]] = (int32_t)r; src[(size_t)r] = pn[ord[(size_t)r]]; }
       d.xs_src.upload(src.data(), h.n_c);
       d.xs.alloc(h.n_c);
-      DBuf<int32_t> cspd; cspd.upload(csp.data(), h.n_c);
+      cspd.upload(csp.data(), h.n_c);
+    }
+    if (fuse_first) {
+      // A_fc and A_ff as CSR on the device (the setup's copies, or staged), G built from them there, then all three
+      // converted to row blocks - A_fc only where something still reads it
+      const int32_t* fc_colmap = fc_spatial ? cspd.p : pc.p;
+      DevCsrLease lfc(h.A_fc), lff(h.A_ff);
+      {
+        DBuf<int32_t> dw; dw.upload(h.wcol.data(), h.n_f);
+        DCsr aff; aff.m = lff.m; aff.n = lff.n; aff.nnz = lff.nnz; aff.rp = const_cast<int64_t*>(lff.rp); aff.ci = const_cast<int32_t*>(lff.ci); aff.v = const_cast<double*>(lff.v);
+        DCsr afc; afc.m = lfc.m; afc.n = lfc.n; afc.nnz = lfc.nnz; afc.rp = const_cast<int64_t*>(lfc.rp); afc.ci = const_cast<int32_t*>(lfc.ci); afc.v = const_cast<double*>(lfc.v);
+        const double t0 = now_s();
+        DCsr G = dev_fused_first_operator(aff, afc, dw.p, stream_);
+        g_t_fuse += now_s() - t0;
+        devmat_from_csr_device(G.m, G.n, G.rp, G.ci, G.v, Frow, fc_colmap, d.G, stream_, 0);
+        dcsr_free(G);
+      }
+      if (need_fc) lfc.convert(Frow, fc_colmap, d.A_fc, stream_, 0);
+      lff.convert(Frow, Fcol, d.A_ff, stream_, 0);
+    } else if (fc_spatial) {
       upload_mat(h.A_fc, Frow, cspd.p, d.A_fc, stream_, 0);
     } else {
       upload_mat(h.A_fc, Frow, pc.p, d.A_fc, stream_, ng(hl ? &hl->A_fc : nullptr));   // rows F block, cols permuted coarse
@@ -535,7 +578,7 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
         upload_mat(D, nullptr, nullptr, d.A_ff, stream_);
       }
     } else {
-      upload_mat(h.A_ff, Frow, Fcol, d.A_ff, stream_, ng(hl ? &hl->A_ff : nullptr));
+      if (!fuse_first) upload_mat(h.A_ff, Frow, Fcol, d.A_ff, stream_, ng(hl ? &hl->A_ff : nullptr));
       attach_halo(d.A_ff, hl ? &hl->A_ff : nullptr, fph);
       if (mf && h.inv_ff.diag_scale) {
         std::vector<double> nat(h.n_f); get_diagonal(h.A_ff, nat.data());
@@ -597,7 +640,8 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
     int g = 0, sf = 0, gc = 0, sc = 0;
     for (int i = 0; i < 10; i++) { int s = h.smooth_order[i]; if (s > 0) { g++; sf += s; } else if (s < 0) { gc++; sc += -s; } }
     double affB = h.aff_diag ? S(h.n_f, h.n_f, h.n_f) : d.A_ff.s_bytes();
-    cycle_bytes_ += g * d.A_fc.s_bytes() + sf * (affB + d.inv_ff.alg_bytes());
+    // (the reference's count whatever the device executes: on a fused level A_fc may not even be there)
+    cycle_bytes_ += g * (d.A_fc.valid() ? d.A_fc.s_bytes() : S((double)h.A_fc.nnz(), h.n_f, h.n_c)) + sf * (affB + d.inv_ff.alg_bytes());
     if (any_c_) cycle_bytes_ += gc * d.A_cf.s_bytes() + sc * (d.A_cc.s_bytes() + d.inv_cc.alg_bytes());
     levels_.push_back(std::move(dl));
   }
@@ -644,13 +688,13 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
   HIP_CHECK(hipStreamSynchronize(stream_));
   dev_cache_trim();       // the staging blocks
   if (H.opt.print_stats_timings) {
-    std::printf(" hierarchy to the device: %.2f s (orderings %.2f s, host -> device copies of the operators %.2f s, conversion to row blocks %.2f s; %lld operators were on the device already)\n",
-                now_s() - t_upload0, t_order, g_t_h2d, g_t_convert, (long long)g_n_from_device);
+    std::printf(" hierarchy to the device: %.2f s (orderings %.2f s, host -> device copies of the operators %.2f s, conversion to row blocks %.2f s, fused first-sweep operators %.2f s; %lld operators were on the device already)\n",
+                now_s() - t_upload0, t_order, g_t_h2d, g_t_convert, g_t_fuse, (long long)g_n_from_device);
     // what the index streams hold (12 bytes per non-zero = 8 of value + 4 of index in the packed / raw forms)
     double nz = 0, ib = 0;
     auto acc = [&](const DevMat& m) { if (m.valid()) { nz += (double)m.nnz; ib += (double)m.idx_bytes; } };
     acc(A_perm_); acc(coarse_A_); acc(coarse_inv_.mat);
-    for (auto& l : levels_) for (const DevMat* m : {&l->A_ff, &l->A_fc, &l->A_cf, &l->A_cc, &l->Z, &l->W, &l->inv_ff.mat, &l->inv_cc.mat, &l->A_full}) acc(*m);
+    for (auto& l : levels_) for (const DevMat* m : {&l->A_ff, &l->A_fc, &l->G, &l->A_cf, &l->A_cc, &l->Z, &l->W, &l->inv_ff.mat, &l->inv_cc.mat, &l->A_full}) acc(*m);
     std::printf(" row blocks on the device: %.3g non-zeros, index regions %.2f bytes per non-zero (values 8), %.1f GB in all\n",
                 nz, nz > 0 ? ib / nz : 0.0, storage_bytes() * 1e-9);
     // how full the blocks are (512 entries = full): rows of 257 ... 511 entries cannot share a block
@@ -668,7 +712,7 @@ double DevPCAIR::storage_bytes() const {
   double b = 0;
   auto sb = [&](const DevMat& m) { if (m.valid()) b += m.stored_bytes(); };
   sb(A_perm_); sb(coarse_A_); sb(coarse_inv_.mat);
-  for (auto& l : levels_) { sb(l->A_ff); sb(l->A_fc); sb(l->A_cf); sb(l->A_cc); sb(l->Z); sb(l->W); sb(l->inv_ff.mat); sb(l->inv_cc.mat); sb(l->A_full); }
+  for (auto& l : levels_) { sb(l->A_ff); sb(l->A_fc); sb(l->G); sb(l->A_cf); sb(l->A_cc); sb(l->Z); sb(l->W); sb(l->inv_ff.mat); sb(l->inv_cc.mat); sb(l->A_full); }
   return b;
 }
 
@@ -773,6 +817,42 @@ void DevPCAIR::f_smooths(DevLevel& L, int li, bool first, int its) {
     launch_gather(L.n_c, L.xs_src.p, x_c, L.xs.p, stream_);
     prof_end();
     x_c = L.xs.p;
+  }
+  if (first && L.G.valid() && (g_fuse_first_run || !L.A_fc.valid())) {
+    // The first sweep on G = A_fc + A_ff W (host/spops.hpp: fused_first_operator): with x0 = W x_c
+    //   r0 = b_f - A_fc x_c - A_ff x0 = b_f - G x_c                      (one product instead of two)
+    //   sweep k:  d = M r_k ; x += d ; r_{k+1} = r_k - A_ff d            (= t4 - A_ff x_{k+1}, the reference's residual)
+    //   (two sweeps: x_2 = x_0 + M (r_0 + r_1), below)
+    // - the reference's iterates x_1, x_2, ... (src/FC_Smooth.F90:541-559) with its + 1 + (its - 1) products instead of
+    // 2 its + 1; sums re-associated, so the results agree to rounding, not bit for bit.
+    if (g_fc_fuse) {
+      int id = -1;
+      if (profile_) { id = stat_id("fc_first(G=A_fc+A_ff*W)", li, L.G.s_bytes()); stats_[id].kernel = "k_rb_fc_first"; begin_kernel(id); }
+      launch_fc_first(L.G, L.wcol.p, b_f, x_c, nullptr, nullptr, L.r.p, x_f, stream_, nullptr);
+      if (profile_) end_kernel();
+    } else {
+      { Aux t(this, "prolong(one point)", li, 20.0 * L.n_f, "k_gather"); launch_gather(L.n_f, L.wcol.p, x_c, x_f, stream_); }
+      SpmvEpi e; e.out = L.r.p; e.alpha = -1.0; e.z = b_f; e.beta = 1.0;
+      spmv(L.G, x_c, e, "r=b_f-G*x_c", li);
+    }
+    if (its == 2) {
+      // two sweeps (the default "ff"): x_2 = x_0 + M r_0 + M r_1 = x_0 + M (r_0 + r_1) with r_1 = r_0 - A_ff M r_0 - M is
+      // linear -, so the first inverse product needs no update of x riding along and the last one is the plain x += M s
+      SpmvEpi e; e.out = L.t4.p;                                                        // d = M r_0
+      spmv(L.inv_ff.mat, L.r.p, e, "d=M_ff*r", li);
+      SpmvEpi e2; e2.out = L.r.p; e2.alpha = -1.0; e2.z = L.r.p; e2.beta = 2.0;      // s = r_0 + r_1 = 2 r_0 - A_ff d (row i reads and writes r_i only)
+      spmv(L.A_ff, L.t4.p, e2, "s=2r-A_ff*d", li);
+      apply_inv(L.inv_ff, L.r.p, x_f, true, li, "x_f+=M_ff*s");
+      return;
+    }
+    for (int it = 0; it < its; it++) {
+      if (it + 1 == its) { apply_inv(L.inv_ff, L.r.p, x_f, true, li, "x_f+=M_ff*r"); break; }
+      SpmvEpi e; e.out = L.t4.p; e.y2 = x_f; e.delta = 1.0; e.aux_out = 1;             // d = M r, x_f += d
+      spmv(L.inv_ff.mat, L.r.p, e, "d=M_ff*r,x_f+=d", li);
+      SpmvEpi e2; e2.out = L.r.p; e2.alpha = -1.0; e2.z = L.r.p; e2.beta = 1.0;      // r -= A_ff d (row i reads and writes r_i only)
+      spmv(L.A_ff, L.t4.p, e2, "r-=A_ff*d", li);
+    }
+    return;
   }
   if (first && L.one_point && !g_fc_fuse && !L.A_fc.halo && !(diag_inv && its == 1)) {
     // diagnostic: the two steps apart

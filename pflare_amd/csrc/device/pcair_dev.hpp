@@ -32,6 +32,12 @@ void set_block_order_min(int64_t nblocks);
 // followed by a plain A_fc product instead of the fused k_rb_fc_first; same results, one more pass over the F vectors
 void set_fc_fuse(bool on);
 void set_profile_chain(bool on);      // pcair_dev.cpp: begin_kernel
+// (airhip_set_tuning "fuse_first_sweep", acts at the next upload) 1 (default): on the levels whose relaxation starts with F
+// sweeps, with a one-point prolongator, a sparse A_ff and an assembled A_ff inverse, the first sweep runs on
+// G = A_fc + A_ff W: four products per level instead of five.  0: the reference's sequence of products.  2: as 1, and A_fc
+// stays on the device everywhere (lets "fuse_first_sweep_run" switch between the two sequences on one hierarchy).
+void set_fuse_first_sweep(int mode);
+void set_fuse_first_sweep_run(bool on);
 // (airhip_set_tuning "fc_spatial_x", acts at the next upload) A_fc x_c gathers from a copy of x_c in which the level's C points
 // lie in the order of their locality keys instead of section by section [F_{l+1} | F_{l+2} | ...]: the copy costs 20 bytes per
 // C point and cycle, the blocks of A_fc then touch half as many lines of x.  Same results bit for bit (the order of the
@@ -62,6 +68,10 @@ struct DevLevel {
   bool aff_diag = false;
   DBuf<double> aff_d;
   DevMat A_ff, A_fc, A_cf, A_cc, Z, W;
+  // G = A_fc + A_ff W (one-point W): the operator of the fused first F sweep, r0 = b_f - G x_c (pcair_dev.cpp: f_smooths,
+  // host/spops.hpp: fused_first_operator).  Valid on the levels where the sweep is fused; A_fc is then only on the device
+  // when a later smoothing group needs it (or the tuning key asks to keep it).
+  DevMat G;
   bool one_point = true;
   DBuf<int32_t> wcol;
   DevInv inv_ff, inv_cc;
@@ -75,7 +85,7 @@ struct DevLevel {
   // residual of the level, whose C part is the next level's right-hand side
   DevMat A_full;
   DBuf<double> rfull;
-  ~DevLevel() { devmat_free(A_ff); devmat_free(A_fc); devmat_free(A_cf); devmat_free(A_cc); devmat_free(Z); devmat_free(W); devmat_free(A_full); }
+  ~DevLevel() { devmat_free(A_ff); devmat_free(A_fc); devmat_free(A_cf); devmat_free(A_cc); devmat_free(Z); devmat_free(W); devmat_free(A_full); devmat_free(G); }
 };
 
 // one record per call site; `kernel` names the HIP kernel function the site launches (what a

@@ -456,6 +456,39 @@ Csr spgemm(const Csr& A, const Csr& B, const SpgemmDrop& drop) {
   return C;
 }
 
+Csr fused_first_operator(const Csr& A_ff, const Csr& A_fc, const int32_t* wcol) {
+  const int64_t nf = A_fc.m, nc = A_fc.n;
+  if (A_ff.m != nf || A_ff.n != nf) throw std::runtime_error("fused_first_operator: A_ff / A_fc shape mismatch");
+  // [A_ff | A_fc]: the entries of A_ff, then those of A_fc with their columns moved behind the F columns
+  Csr cat; cat.m = nf; cat.n = nf + nc;
+  cat.rp.alloc(nf + 1);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i <= nf; i++) cat.rp[i] = A_ff.rp[i] + A_fc.rp[i];
+  cat.ci.alloc(cat.rp[nf]); cat.v.alloc(cat.rp[nf]);
+#pragma omp parallel for schedule(dynamic, 1024)
+  for (int64_t i = 0; i < nf; i++) {
+    int64_t o = cat.rp[i];
+    for (int64_t k = A_ff.rp[i]; k < A_ff.rp[i + 1]; k++, o++) { cat.ci[o] = A_ff.ci[k]; cat.v[o] = A_ff.v[k]; }
+    for (int64_t k = A_fc.rp[i]; k < A_fc.rp[i + 1]; k++, o++) { cat.ci[o] = (int32_t)(A_fc.ci[k] + nf); cat.v[o] = A_fc.v[k]; }
+  }
+  // [W; I]
+  Csr P; P.m = nf + nc; P.n = nc;
+  P.rp.alloc(P.m + 1);
+  {
+    Arr<int64_t> cnt(P.m);
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < P.m; r++) cnt[r] = r < nf ? (wcol[r] >= 0 ? 1 : 0) : 1;
+    exclusive_scan(cnt.data(), P.m, P.rp.data());
+  }
+  P.ci.alloc(P.rp[P.m]); P.v.alloc(P.rp[P.m]);
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < P.m; r++) {
+    const int32_t c = r < nf ? wcol[r] : (int32_t)(r - nf);
+    if (c >= 0) { P.ci[P.rp[r]] = c; P.v[P.rp[r]] = 1.0; }
+  }
+  return spgemm(cat, P);
+}
+
 void spmv(const Csr& A, const double* x, double* y) {
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < A.m; i++) {

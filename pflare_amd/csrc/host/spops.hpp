@@ -111,6 +111,14 @@ struct SetupAccel {
 // the accelerator the polynomial assembly may use (set by setup_air for its duration; null = host only)
 extern thread_local SetupAccel* g_setup_accel;
 
+// The operator of the fused first F sweep with a one-point prolongator W (wcol[j] = W's column of F point j, -1 = none):
+//   G = A_fc + A_ff W,   so that   b_f - A_fc x_c - A_ff (W x_c) = b_f - G x_c
+// - the two products that open the reference's F-point relaxation (src/FC_Smooth.F90:533-548 after the prolongation
+// src/AIR_MG_Setup.F90:1005) in one.  G is the F-row block of the A P product the setup forms for R A P; it is computed as
+// [A_ff | A_fc] * [W; I] with spgemm(), so every entry is the Gustavson sum in the order of the row's entries (those of A_ff
+// first) and the device twin (device/extract.hip: dev_fused_first_operator) gives the same bits.
+Csr fused_first_operator(const Csr& A_ff, const Csr& A_fc, const int32_t* wcol);
+
 void spmv(const Csr& A, const double* x, double* y);
 // y = (A x) ./ d
 void spmv_dscale(const Csr& A, const double* d, const double* x, double* y);
