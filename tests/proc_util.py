@@ -17,9 +17,13 @@ def rank_threads(world):
     return max(1, total // max(1, world))
 
 
-def spawn(fn, args, nprocs, deadline=180):
-    """torch.multiprocessing.spawn joined with a deadline: on expiry the ranks (exact PIDs) are killed and the
-    test fails instead of hanging in gloo's 30-minute default."""
+def free_port():
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _spawn_once(fn, args, nprocs, deadline):
     import torch.multiprocessing as mp
     ctx = mp.spawn(fn, args=args, nprocs=nprocs, join=False)
     t_end = time.time() + deadline
@@ -33,6 +37,21 @@ def spawn(fn, args, nprocs, deadline=180):
             for p in ctx.processes:
                 p.join(10)
             raise TimeoutError(f"spawned ranks did not finish within {deadline}s")
+
+
+def spawn(fn, args, nprocs, deadline=180, port_index=1):
+    """torch.multiprocessing.spawn joined with a deadline: on expiry the ranks (exact PIDs) are killed and the
+    test fails instead of hanging in gloo's 30-minute default.  args[port_index] is the rendezvous port (a port found free a
+    moment ago): when the store cannot listen on it after all (EADDRINUSE - the system handed the port to an outgoing
+    connection in between; seen once in the GPU suite, round 5) the ranks are started again on a fresh port, twice at most.
+    Only that error is retried."""
+    for attempt in range(3):
+        try:
+            return _spawn_once(fn, args, nprocs, deadline)
+        except Exception as e:      # noqa: BLE001 - re-raised unless it is the port race
+            if attempt == 2 or "EADDRINUSE" not in str(e) or port_index is None:
+                raise
+            args = tuple(free_port() if k == port_index else a for k, a in enumerate(args))
 
 
 def init_rank_env(rank, world, port):
