@@ -1067,6 +1067,11 @@ int airhip_partition_create(airhip_pcair pc, const airhip_csr* A_top, int nranks
   auto* h = new airhip_partition_s;
   view_csr(A_top, h->A_view);
   REQUIRE(pc->hint.empty() || (int64_t)pc->hint.size() == A_top->m, AIRHIP_ERR_ARG, "ordering hint: one key per row of the operator is required");
+  // the operators of the fused first F sweep (one device builds them at upload time from its own copies of A_fc / A_ff;
+  // a cut hierarchy gets them here, cut like every other operand)
+  if (fuse_first_sweep_mode() != 0)
+    for (auto& lv : pc->H->levels)
+      if (lv->G.empty() && lv->fuses_first_sweep() && lv->A_fc.on_host() && lv->A_ff.on_host()) lv->G = fused_first_operator(lv->A_ff, lv->A_fc, lv->wcol.data());
   try { h->p = std::make_unique<Partitioner>(*pc->H, h->A_view, nranks, owner, pc->hint.empty() ? nullptr : pc->hint.data()); }
   catch (...) { delete h; throw; }
   *out = h;

@@ -72,6 +72,7 @@ static int g_fuse_first = 1;          // pcair_dev.hpp: set_fuse_first_sweep
 static bool g_fuse_first_run = true;
 void set_fuse_first_sweep(int mode) { g_fuse_first = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }
 void set_fuse_first_sweep_run(bool on) { g_fuse_first_run = on; }
+int fuse_first_sweep_mode() { return g_fuse_first; }
 static int g_fc_spatial = 1;       // 0 off, 1 levels where it pays (upload), 2 every level (tests)
 void set_fc_spatial(int mode) { g_fc_spatial = mode; }
 
@@ -522,8 +523,8 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
     const bool fc_spatial = g_fc_spatial && !dist && (g_fc_spatial >= 2 || (h.n_c >= 4096 && h.A_fc.nnz() >= 25 * h.n_c));
     // The first F sweep on G = A_fc + A_ff W (set_fuse_first_sweep): relaxation that starts with F sweeps, one-point W,
     // sparse A_ff, assembled A_ff inverse; one device (a distributed hierarchy keeps the reference's sequence).
-    const bool fuse_first = g_fuse_first && !dist && h.one_point && !h.aff_diag && h.smooth_order[0] > 0 && h.inv_ff.kind == InvOp::ASSEMBLED &&
-                            h.A_fc.nnz() > 0 && h.A_ff.nnz() > 0;      // (nnz(): also for operators whose host arrays are still on the device)
+    // (a piece of a cut hierarchy brings its rows of G along, or keeps the reference's sequence)
+    const bool fuse_first = g_fuse_first && h.fuses_first_sweep() && (!dist || !h.G.empty());
     bool later_f_group = false;
     for (int i = 1; i < 10 && h.smooth_order[i] != 0; i++) later_f_group |= h.smooth_order[i] > 0;
     const bool need_fc = !fuse_first || g_fuse_first == 2 || later_f_group;
@@ -542,7 +543,15 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
       d.xs.alloc(h.n_c);
       cspd.upload(csp.data(), h.n_c);
     }
-    if (fuse_first) {
+    if (fuse_first && dist) {
+      upload_mat(h.G, Frow, pc.p, d.G, stream_, ng(&hl->G));
+      attach_halo(d.G, &hl->G, perm[l + 1].data());
+      if (need_fc) {
+        upload_mat(h.A_fc, Frow, pc.p, d.A_fc, stream_, ng(&hl->A_fc));
+        attach_halo(d.A_fc, &hl->A_fc, perm[l + 1].data());
+      }
+      upload_mat(h.A_ff, Frow, Fcol, d.A_ff, stream_, ng(&hl->A_ff));
+    } else if (fuse_first) {
       // A_fc and A_ff as CSR on the device (the setup's copies, or staged), G built from them there, then all three
       // converted to row blocks - A_fc only where something still reads it
       const int32_t* fc_colmap = fc_spatial ? cspd.p : pc.p;
@@ -589,9 +598,10 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
     if (h.one_point) {
       std::vector<int32_t> wc(h.n_f);
       const int32_t* pn = perm[l + 1].data();
-      // distributed: columns >= n_c are ghost columns of A_fc and keep their index
+      // distributed: columns >= n_c are ghost columns of A_fc - of G on a level whose first sweep is fused - and keep their index
+      const int32_t* wsrc = (dist && fuse_first) ? h.wcol_g.data() : h.wcol.data();
 #pragma omp parallel for schedule(static)
-      for (int64_t i = 0; i < h.n_f; i++) { const int32_t c = h.wcol[i]; wc[fph ? fph[i] : i] = c < 0 ? -1 : (c < h.n_c ? (fc_spatial ? csp[(size_t)c] : pn[c]) : c); }
+      for (int64_t i = 0; i < h.n_f; i++) { const int32_t c = wsrc[i]; wc[fph ? fph[i] : i] = c < 0 ? -1 : (c < h.n_c ? (fc_spatial ? csp[(size_t)c] : pn[c]) : c); }
       d.wcol.upload(wc.data(), h.n_f);
     } else {
       upload_mat(h.W, Frow, pc.p, d.W, stream_, ng(hl ? &hl->W : nullptr));
@@ -818,17 +828,26 @@ void DevPCAIR::f_smooths(DevLevel& L, int li, bool first, int its) {
     prof_end();
     x_c = L.xs.p;
   }
-  if (first && L.G.valid() && (g_fuse_first_run || !L.A_fc.valid())) {
+  if (first && L.G.valid() && (g_fuse_first_run || !L.A_fc.valid() || comm_)) {
     // The first sweep on G = A_fc + A_ff W (host/spops.hpp: fused_first_operator): with x0 = W x_c
     //   r0 = b_f - A_fc x_c - A_ff x0 = b_f - G x_c                      (one product instead of two)
     //   sweep k:  d = M r_k ; x += d ; r_{k+1} = r_k - A_ff d            (= t4 - A_ff x_{k+1}, the reference's residual)
     //   (two sweeps: x_2 = x_0 + M (r_0 + r_1), below)
     // - the reference's iterates x_1, x_2, ... (src/FC_Smooth.F90:541-559) with its + 1 + (its - 1) products instead of
     // 2 its + 1; sums re-associated, so the results agree to rounding, not bit for bit.
-    if (g_fc_fuse) {
+    if (g_fc_fuse || L.G.halo) {
       int id = -1;
-      if (profile_) { id = stat_id("fc_first(G=A_fc+A_ff*W)", li, L.G.s_bytes()); stats_[id].kernel = "k_rb_fc_first"; begin_kernel(id); }
-      launch_fc_first(L.G, L.wcol.p, b_f, x_c, nullptr, nullptr, L.r.p, x_f, stream_, nullptr);
+      if (profile_) { id = stat_id("fc_first(G=A_fc+A_ff*W)", li, L.G.s_bytes()); stats_[id].kernel = "k_rb_fc_first"; }
+      if (begin_exchange(L.G, x_c)) {
+        if (profile_) begin_kernel(id);
+        launch_fc_first(L.G, L.wcol.p, b_f, x_c, nullptr, nullptr, L.r.p, x_f, stream_, L.G.halo->recvbuf, RB_INTERIOR);
+        wait_exchange();
+        launch_fc_first(L.G, L.wcol.p, b_f, x_c, nullptr, nullptr, L.r.p, x_f, stream_, L.G.halo->recvbuf, RB_BOUNDARY);
+      } else {
+        const double* xg = halo_update(L.G, x_c);
+        if (profile_) begin_kernel(id);
+        launch_fc_first(L.G, L.wcol.p, b_f, x_c, nullptr, nullptr, L.r.p, x_f, stream_, xg);
+      }
       if (profile_) end_kernel();
     } else {
       { Aux t(this, "prolong(one point)", li, 20.0 * L.n_f, "k_gather"); launch_gather(L.n_f, L.wcol.p, x_c, x_f, stream_); }

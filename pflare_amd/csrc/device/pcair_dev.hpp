@@ -37,6 +37,7 @@ void set_profile_chain(bool on);      // pcair_dev.cpp: begin_kernel
 // G = A_fc + A_ff W: four products per level instead of five.  0: the reference's sequence of products.  2: as 1, and A_fc
 // stays on the device everywhere (lets "fuse_first_sweep_run" switch between the two sequences on one hierarchy).
 void set_fuse_first_sweep(int mode);
+int fuse_first_sweep_mode();
 void set_fuse_first_sweep_run(bool on);
 // (airhip_set_tuning "fc_spatial_x", acts at the next upload) A_fc x_c gathers from a copy of x_c in which the level's C points
 // lie in the order of their locality keys instead of section by section [F_{l+1} | F_{l+2} | ...]: the copy costs 20 bytes per

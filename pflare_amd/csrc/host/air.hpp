@@ -80,6 +80,15 @@ struct Level {
   bool one_point = true;
   Arr<int32_t> wcol;             // one-point W: coarse column per F row (-1: none)
   Csr W;                         // general W (n_f x n_c) when !one_point
+  // Only in hierarchies that are cut for a multi-GPU run (and in the pieces): G = A_fc + A_ff W, the operator of the fused
+  // first F sweep (host/spops.hpp: fused_first_operator), and - pieces only - W's columns in the numbering of G's column
+  // space [local | ghosts of G].  On one device the upload builds G from the device copies of A_fc and A_ff instead.
+  Csr G;
+  Arr<int32_t> wcol_g;
+  // the cycle may run its first F sweep on G: relaxation that starts with F sweeps, one-point W, sparse A_ff, assembled A_ff inverse
+  bool fuses_first_sweep() const {
+    return one_point && !aff_diag && smooth_order[0] > 0 && inv_ff.kind == InvOp::ASSEMBLED && A_fc.nnz() > 0 && A_ff.nnz() > 0 && !full;
+  }
   int smooth_order[10] = {0};
   int64_t nnz_A = 0;             // nnz of the level operator (for complexities)
   bool full = false;             // full up / down smoothing: inv_ff is n x n and A_full holds the level operator

@@ -198,7 +198,7 @@ struct Partitioner::Impl {
   const int64_t* hint = nullptr;
   int N = 1;
   std::vector<Space> full, fsp;        // full[l]: level l rows; fsp[l]: F points of level l (C points = full[l+1])
-  struct LevelOps { OpRef A_ff, A_fc, A_cf, A_cc, Z, W, M_ff, M_cc; };
+  struct LevelOps { OpRef A_ff, A_fc, A_cf, A_cc, Z, W, M_ff, M_cc, G; };
   std::vector<LevelOps> ops;
   OpRef top, coarse_A, coarse_M;
   int64_t max_n = 0;
@@ -246,6 +246,7 @@ Partitioner::Partitioner(const Hierarchy& G, const Csr& A_top, int nranks, const
     const bool any_c = G.opt.any_c_smooths();
     o.A_cf = mk(any_c ? Lv.A_cf : none, C, F); o.A_cc = mk(any_c ? Lv.A_cc : none, C, C);
     o.Z = mk(Lv.Z, C, F); o.W = mk(Lv.W, F, C);
+    o.G = mk(Lv.G, F, C);
     o.M_ff = mk(Lv.inv_ff.mat, F, F); o.M_cc = mk(Lv.inv_cc.mat, C, C);
   }
   I.top = mk(A_top, I.full[0], I.full[0]);
@@ -324,6 +325,26 @@ void Partitioner::extract(int rank, Archive& ar) const {
       put_csr(ar, p + ".A_fc", loc, h.n_ghost);
       put_halo(ar, p + ".A_fc", h);
       if (Lv.one_point) ar.add_copy(p + ".wcol", Archive::I32, wc.data(), nf);
+    }
+    // the operator of the fused first F sweep, with W's columns once more in ITS column numbering (its ghosts are those of
+    // A_fc and the W columns of the F points the rank's rows of A_ff reach)
+    if (!Lv.G.empty()) {
+      Csr loc; HaloHost h;
+      std::vector<int32_t> wc;
+      extract_op(I.ops[l].G, rank, N, gmap, loc, h, [&](int64_t nlc) {
+        const auto& fm = F.members[rank];
+        wc.resize((size_t)nf);
+        for (int64_t k = 0; k < nf; k++) {
+          const int32_t c = Lv.wcol[fm[k]];
+          // (a W column of a local F point is a column of its row of G whenever the row of A_ff holds its diagonal; an F
+          // point without it gets no prolongated value from a ghost it does not receive)
+          wc[k] = c < 0 ? -1 : (C.own[c] == rank ? C.loc[c] : (gmap[c] >= 0 ? (int32_t)(nlc + gmap[c]) : -2));
+        }
+      });
+      for (int32_t c : wc) if (c == -2) throw std::runtime_error("partition: a one-point prolongator column is not a column of the fused operator's row (A_ff without its diagonal)");
+      put_csr(ar, p + ".G", loc, h.n_ghost);
+      put_halo(ar, p + ".G", h);
+      ar.add_copy(p + ".wcol_g", Archive::I32, wc.data(), nf);
     }
     if (G.opt.any_c_smooths()) {     // only the C-point relaxation reads these
       emit(p + ".A_cf", I.ops[l].A_cf);
@@ -459,6 +480,13 @@ void load_local(const Archive& ar, LocalHierarchy& out) {
       if (w.count != Lv.n_f) throw std::runtime_error("archive: wcol size mismatch in " + p);
       for (int64_t i = 0; i < w.count; i++)
         if (Lv.wcol[i] >= Lv.A_fc.n) throw std::runtime_error("archive: wcol out of range in " + p);
+    }
+    if (get_csr(ar, p + ".G", Lv.G, H.G)) {
+      const auto& w = need(ar, p + ".wcol_g", Archive::I32);
+      Lv.wcol_g.view((const int32_t*)w.ptr, w.count);
+      if (w.count != Lv.n_f || Lv.G.m != Lv.n_f) throw std::runtime_error("archive: fused operator size mismatch in " + p);
+      for (int64_t i = 0; i < w.count; i++)
+        if (Lv.wcol_g[i] >= Lv.G.n || Lv.wcol_g[i] < -1) throw std::runtime_error("archive: wcol_g out of range in " + p);
     }
     if (Lv.F.size() != Lv.n_f || Lv.C.size() != Lv.n_c || Lv.n_f + Lv.n_c != Lv.n || Lv.A_fc.m != Lv.n_f || Lv.Z.m != Lv.n_c)
       throw std::runtime_error("archive: level size mismatch in " + p);

@@ -25,7 +25,7 @@ struct HaloHost {
   bool active() const { return !peers.empty(); }
 };
 
-struct LevelHalos { HaloHost A_ff, A_fc, A_cf, A_cc, Z, W, M_ff, M_cc; };
+struct LevelHalos { HaloHost A_ff, A_fc, A_cf, A_cc, Z, W, M_ff, M_cc, G; };
 
 // The piece of a hierarchy one rank owns.  Matrices have n = n_local_cols + n_ghost columns.
 struct LocalHierarchy {

@@ -136,6 +136,22 @@ class Cluster:
             for r, q in self.p.items():
                 wc = q.d[f"L{l}.wcol"]
                 x_f[r] = np.where(wc >= 0, xc_ext[r][np.maximum(wc, 0)], 0.0)
+            if any_q.has(f"L{l}.G"):
+                # the pieces of the fused first sweep's operator G = A_fc + A_ff W and their halo plan: with x0 = W x_c (taken
+                # through G's own column numbering, wcol_g)   b_f - G x_c   must be the reference's   t4 - A_ff x0
+                ghg = self.ghosts(f"L{l}.G", x)
+                self.nexch -= 1                                   # (a check, not an exchange of the cycle)
+                ax0 = self.spmv(f"L{l}.A_ff", x_f)
+                self.nexch -= 1
+                for r, q in self.p.items():
+                    xg = np.concatenate([x[r], ghg[r]])
+                    wg = q.d[f"L{l}.wcol_g"]
+                    np.testing.assert_array_equal(np.where(wg >= 0, xg[np.maximum(wg, 0)], 0.0), x_f[r])
+                    r0 = b_f[r] - q.mat(f"L{l}.G") @ xg
+                    ref = t4[r] - ax0[r]
+                    scale = max(np.linalg.norm(b_f[r]), np.linalg.norm(ref), 1e-300)
+                    assert np.linalg.norm(r0 - ref) <= 1e-12 * scale, (l, r, np.linalg.norm(r0 - ref), scale)
+                self.fused_levels_checked = getattr(self, "fused_levels_checked", 0) + 1
             for _ in range(its):
                 if lv["aff_diag"]:
                     res = {r: t4[r] - self.p[r].d[f"L{l}.aff_d"] * x_f[r] for r in self.p}

@@ -95,6 +95,10 @@ def test_pieces_reproduce_global_vcycle_in_process(case, nranks):
         z[q.gid] = zs[r]
     zref = R.vcycle(H, b)
     assert np.linalg.norm(z - zref) <= 1e-12 * np.linalg.norm(zref)
+    # the pieces of the fused first sweep's operator were there and consistent on every level that fuses
+    # (assembled A_ff inverse, sparse A_ff, F sweeps first: not the matrix-free case)
+    want = sum(1 for l in range(pieces[0].L - 1) if not pieces[0].level(l)["aff_diag"] and pieces[0].inv(f"L{l}.inv_ff")["kind"] == 1)
+    assert getattr(cl, "fused_levels_checked", 0) == want, (getattr(cl, "fused_levels_checked", 0), want)
 
 
 def _free_port():
