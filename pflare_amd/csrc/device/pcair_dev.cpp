@@ -524,7 +524,9 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
     // The first F sweep on G = A_fc + A_ff W (set_fuse_first_sweep): relaxation that starts with F sweeps, one-point W,
     // sparse A_ff, assembled A_ff inverse; one device (a distributed hierarchy keeps the reference's sequence).
     // (a piece of a cut hierarchy brings its rows of G along, or keeps the reference's sequence)
-    const bool fuse_first = g_fuse_first && h.fuses_first_sweep() && (!dist || !h.G.empty());
+    // cut hierarchy: EVERY rank must take the same decision (the exchanges are collective), so it is the cut that decides - a
+    // piece either carries its rows of G (possibly none) or it does not; the predicate on a piece's own rows would differ
+    const bool fuse_first = g_fuse_first && (dist ? (!h.G.empty() && h.one_point) : h.fuses_first_sweep());
     bool later_f_group = false;
     for (int i = 1; i < 10 && h.smooth_order[i] != 0; i++) later_f_group |= h.smooth_order[i] > 0;
     const bool need_fc = !fuse_first || g_fuse_first == 2 || later_f_group;
