@@ -1,5 +1,5 @@
 """The bench.py output contract, checked on the committed line of the round's final default run
-(profiles/r04_final4_bench464_default.json): every key the driver and the judge read is there with the right type,
+(profiles/r05_final_bench464_default.json): every key the driver and the judge read is there with the right type,
 the workload is BASELINE configs[2] (3D advection, 464^3), and the derived fields are consistent."""
 import json
 import os
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_honours_the_contract():
-    with open(os.path.join(ROOT, "profiles", "r04_final4_bench464_default.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r05_final_bench464_default.json")) as f:
         d = json.loads(f.read().strip().splitlines()[-1])
     for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                  ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
@@ -48,7 +48,13 @@ def test_committed_bench_line_honours_the_contract():
     # the oracle as the checker: the CPU sample's residual norms against the GPU solve's, entry by entry
     assert c["check"]["residual_norms_compared"] >= 2 and c["check"]["max_rel_diff_gpu_vs_cpu"] <= 1e-6
     # the setup as the caller sees it, and the library's host-mirror thread that runs after it (beside the solves)
-    assert 0 < d["config"]["setup_s"] < 30.0 and d["config"]["host_mirror_s"] >= 0.0
+    # (25-26 s on a box that has run before, 31-36 s on one whose memory the driver still has to clear: DESIGN.md section 4)
+    assert 0 < d["config"]["setup_s"] < 40.0 and d["config"]["host_mirror_s"] >= 0.0
     # round 4: every kernel of a step is accounted for, both cycle denominators are reported
     assert r["profiled_share_of_device_ms"] >= 0.97 and r["krylov_kernels_ms_per_step"] <= 2.5
-    assert r["vcycle_exec_GBs"] < r["vcycle_alg_GBs"] and r["vcycle_kernel_ms"] <= 37.0 and d["value"] >= 22.0
+    assert r["vcycle_exec_GBs"] < r["vcycle_alg_GBs"] and r["vcycle_kernel_ms"] <= 34.5 and d["value"] >= 25.5
+    # round 5: one V-cycle per iteration (the preconditioned basis is kept), PETSc's form measured beside it
+    c5 = d["config"]
+    assert c5["pc_applies_per_step"] == 1.0 and c5["pc_applies_per_step_petsc_solution_update"] > 1.0
+    assert 0.85 * d["value"] <= c5["iterations_per_s_petsc_solution_update"] < d["value"]
+    assert c5["history_check"]["max_rel_diff"] <= 1e-8 and c5["history_check"]["iterations_fixture"] == c5["iterations_to_rtol_1e-10"] == 12
