@@ -112,14 +112,21 @@ int airhip_set_num_threads(int n, int* prev);
  *   "krylov_blocks" (default 512: workgroups of the multi-dot / multi-axpy launches of the Krylov solvers),
  *   "ksp_unnormalised" (default 1: GMRES keeps its basis vectors unnormalised and their norms on the host - no scaling
  *   pass per iteration; 0: normalised basis.  Same Hessenberg matrix up to rounding, identical iteration counts),
+ *   "fuse_first_sweep" (default 1, acts at the next upload: on the levels whose relaxation starts with F sweeps - one-point W,
+ *   sparse A_ff, assembled A_ff inverse - the first sweep runs on G = A_fc + A_ff W, four products per level instead of the
+ *   reference's five; same iterates up to rounding (1e-13 per cycle), NOT bit for bit; 0 = the reference's sequence; 2 = as 1
+ *   and A_fc stays on the device, so that "fuse_first_sweep_run" (default 1) can switch between the two sequences on one
+ *   hierarchy), "profile_chain" (default 1: inside the cycle the stop event of one profiled kernel is the start event of the
+ *   next; 0 = a pair of events per kernel),
  *   "ksp_keep_preconditioned" (default 1: right-preconditioned GMRES keeps z_j = M v_j, restart more vectors, and updates
  *   x += Z y without the extra PCApply of PETSc's x += M (V y); same Arnoldi process, Hessenberg matrix, residual norms and
  *   iteration count bit for bit - the solution differs in its last rounding; 0: PETSc's form).
  *   Bitwise neutral - not a bit of any result changes - are the FORMAT, OCCUPANCY and ORDER keys ("mb16", "mb16_max_rows",
  *   "occ_spmv", "occ_fc", "fc_spatial_x", "block_order_min_blocks", "fc_fuse", the "spgemm_*" keys).  NOT bitwise neutral:
  *   "ksp_unnormalised" (every Hessenberg entry is rounded differently), "krylov_blocks" (the grid sets the summation order
- *   of every dot product and norm) and "ksp_keep_preconditioned" (the last rounding of x); they keep the iteration counts
- *   and agree within the tolerances tests/test_gpu_ksp_variants.py states.
+ *   of every dot product and norm), "ksp_keep_preconditioned" (the last rounding of x) and "fuse_first_sweep" (the sums of the
+ *   first F sweep are re-associated); they keep the iteration counts and agree within the tolerances
+ *   tests/test_gpu_ksp_variants.py and tests/test_fused_first_sweep.py state.
  * airhip_pcair_setup_host_only / airhip_pcinv_setup_host_only: build the hierarchy without touching a device (CPU-side
  *   tests of the setup, hierarchy export); apply / solve then fail with AIRHIP_ERR_STATE.
  * airhip_spgemm_filtered: C = filter(A*B) with the host (on_device = 0) or the device SpGEMM of the setup, drop / lump /
