@@ -247,7 +247,7 @@ int airhip_compute_cf_splitting_on_device(const airhip_csr* A, int symmetric, do
   Csr view; view_csr(A, view);
   auto accel = make_device_setup_accel(nullptr, 0);
   Arr<int32_t> m;
-  REQUIRE(accel->cf_splitting(view, o, m), AIRHIP_ERR_STATE, "the device CF splitting is disabled (AIRHIP_DEVICE_CFSPLIT=0)");
+  REQUIRE(accel->cf_splitting(view, o, m), AIRHIP_ERR_STATE, "the device CF splitting declined this operator");
   for (int64_t i = 0; i < A->m; i++) markers[i] = m[i];
   accel.reset();
   dev_cache_trim();

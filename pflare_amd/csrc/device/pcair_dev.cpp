@@ -360,7 +360,7 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
   std::vector<std::vector<int32_t>> fpos(L > 0 ? L - 1 : 0);
   std::vector<int32_t> cpos;       // coarsest level: natural index -> position (empty = identity)
   std::vector<std::vector<int64_t>> level_keys;   // locality key of every point of every level (level-local numbering)
-  const bool order_blocks = !(std::getenv("AIRHIP_BLOCK_ORDER") && std::atoi(std::getenv("AIRHIP_BLOCK_ORDER")) == 0);
+  const bool order_blocks = true;      // (order_blocks_by_key itself skips operators below set_block_order_min's size: the switch)
   // level_keys[l][i]: locality key of point i of level l (level-local numbering) - the caller's hint on the top level, the
   // row's own index without one (the reference numbering is lexicographic, which is a locality key as well); a coarse
   // point inherits the key of its parent C point.  Used for the layout (with a hint) and for the processing order of

@@ -209,8 +209,7 @@ struct DevSetupAccel final : SetupAccel {
   // CF splitting of the level operator where it already is (the previous level's R*A*P; the top level is uploaded
   // once and stays resident for its own R*A*P)
   bool cf_splitting(const Csr& A, const AirOptions& o, Arr<int32_t>& markers) override {
-    static const bool enabled = [] { const char* e = std::getenv("AIRHIP_DEVICE_CFSPLIT"); return !(e && e[0] == '0'); }();
-    if (!enabled || o.cf_splitting_type != 0 || A.nnz() < min_nnz) return false;
+    if (o.cf_splitting_type != 0 || A.nnz() < min_nnz) return false;
     if (!is_resident(A)) { drop_resident(); resident = up(A); resident_key = (const void*)A.rp.data(); }
     const double t0 = now_s();
     markers.alloc(A.m);
@@ -238,8 +237,7 @@ struct DevSetupAccel final : SetupAccel {
   }
 
   bool poly_assemble(const Csr& A, const std::vector<double>& c, Csr& M, bool final_values) override {
-    static const bool enabled = [] { const char* e = std::getenv("AIRHIP_DEVICE_POLY"); return !(e && e[0] == '0'); }();
-    if (!enabled || A.nnz() < min_nnz || c.size() < 3) return false;
+    if (A.nnz() < min_nnz || c.size() < 3) return false;
     DCsr dA, dM;
     if (A.device_tag && A.device_tag == ff_tag && res_ff.rp && res_ff.nnz == A.nnz()) { dA = res_ff; res_ff = DCsr(); ff_tag = 0; }
     else dA = up(A);                       // (a fresh copy of the same host arrays: as good for the upload later)

@@ -39,16 +39,9 @@ void par_memcpy(char* dst, const char* src, size_t n) {
 
 }  // namespace
 
-// AIRHIP_HOST_COPY = pin (default) | staged | plain
-static int copy_mode() {
-  static const int mode = [] {
-    const char* e = std::getenv("AIRHIP_HOST_COPY");
-    if (e && std::strcmp(e, "staged") == 0) return 1;
-    if (e && std::strcmp(e, "plain") == 0) return 2;
-    return 0;
-  }();
-  return mode;
-}
+// 0: large arrays pinned in place (falls back to the bounce buffers when the registration fails); 1: bounce buffers; 2: plain
+// hipMemcpy.  Fixed at 0 since round 5 (the AIRHIP_HOST_COPY switch measured the three once: profiles/r02_thp_probe.txt).
+static int copy_mode() { return 0; }
 
 // Large arrays are pinned where they are for the duration of the copy: on the GPU box hipHostRegister of 2 MiB-paged
 // memory runs at 600 GB/s (68 GB/s on 4 KiB pages) and the copy then moves at 57 GB/s either way, against 47 / 25 GB/s

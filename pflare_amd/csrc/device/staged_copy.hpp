@@ -1,7 +1,7 @@
 // Large host <-> device copies of pageable host memory (the setup moves every level operator once in each direction).
-// Arrays of 32 MiB and more are pinned in place for the copy (hipHostRegister; 57 GB/s); if that is refused, and for
-// AIRHIP_HOST_COPY=staged, the copy goes through two pinned bounce buffers, the DMA of chunk k+1 overlapping a
-// multi-threaded memcpy of chunk k (~30 GB/s); AIRHIP_HOST_COPY=plain is a bare hipMemcpy.
+// Arrays of 32 MiB and more are pinned in place for the copy (hipHostRegister; 57 GB/s); if that is refused
+// the copy goes through two pinned bounce buffers, the DMA of chunk k+1 overlapping a
+// multi-threaded memcpy of chunk k (~30 GB/s); the third mode is a bare hipMemcpy (small arrays).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstddef>
