@@ -155,7 +155,16 @@ KspResult DevKSP::gmres(const KspOperator& op, const KspOptions& o, const double
     try { Z_.alloc((int64_t)m * n_); z_alloc_ = m; }
     catch (const std::exception&) { (void)hipGetLastError(); Z_.release(); z_alloc_ = 0; keep = false; }      // no room: PETSc's form
   }
-  if (!keep && z_alloc_ > 0 && g_keep_pc == 0) { Z_.release(); z_alloc_ = 0; }
+  if (comm_ && right && g_keep_pc != 0 && (bool)op.pc) {
+    // distributed: the form of the solution update decides how many PCApply calls (collective exchanges) a solve makes,
+    // so every rank must take the same one - all keep the basis, or none (a rank whose allocation failed decides for all)
+    const double mine = keep ? 1.0 : 0.0;
+    double all = 0.0;
+    HIP_CHECK(hipMemcpyAsync(dnorm_.p, &mine, sizeof(double), hipMemcpyHostToDevice, s));
+    fetch_dots(dnorm_.p, &all, 1, s);
+    if (all < (double)comm_->size - 0.5) keep = false;
+  }
+  if (!keep && z_alloc_ > 0) { Z_.release(); z_alloc_ = 0; }
   auto Zk = [&](int k) { return Z_.p + (int64_t)k * n_; };
   R.pc_applies = 0;
   auto apply_pc = [&](const double* in, double* out) {
