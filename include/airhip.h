@@ -106,6 +106,10 @@ int airhip_set_num_threads(int n, int* prev);
  *   (default 1; 0 runs the one-point prolongation and the A_fc product of an F relaxation as two launches - diagnostic),
  *   "mb16" / "mb16_max_rows" (default 1 / 128: row blocks of at most that many rows are stored with 16-bit multi-base index
  *   words - 10 instead of 12 bytes per non-zero; 0 = the packed / raw 32-bit forms only; act at the next conversion),
+ *   "vdict" (default 1: a multi-base block whose values take at most 256 distinct bit patterns stores them once and one-byte
+ *   indices - the operators of the first levels of a constant-coefficient problem: 8 nd + 512 bytes of values per block
+ *   instead of 8 per non-zero; lossless, the same doubles are multiplied in the same order; 0 = plain values; acts at the next
+ *   conversion),
  *   "occ_spmv" / "occ_fc" (default 6 / 6: workgroups per CU = waves per SIMD of the SpMV / fused F-relaxation kernels, 0 =
  *   what the registers allow; act at the next launch), "fc_spatial_x" (default 1: A_fc gathers from a copy of x_c in the
  *   spatial order of the C points on the levels where that pays, 0 = never, 2 = every level; acts at the next upload),
@@ -121,7 +125,7 @@ int airhip_set_num_threads(int n, int* prev);
  *   "ksp_keep_preconditioned" (default 1: right-preconditioned GMRES keeps z_j = M v_j, restart more vectors, and updates
  *   x += Z y without the extra PCApply of PETSc's x += M (V y); same Arnoldi process, Hessenberg matrix, residual norms and
  *   iteration count bit for bit - the solution differs in its last rounding; 0: PETSc's form).
- *   Bitwise neutral - not a bit of any result changes - are the FORMAT, OCCUPANCY and ORDER keys ("mb16", "mb16_max_rows",
+ *   Bitwise neutral - not a bit of any result changes - are the FORMAT, OCCUPANCY and ORDER keys ("mb16", "mb16_max_rows", "vdict",
  *   "occ_spmv", "occ_fc", "fc_spatial_x", "block_order_min_blocks", "fc_fuse", the "spgemm_*" keys).  NOT bitwise neutral:
  *   "ksp_unnormalised" (every Hessenberg entry is rounded differently), "krylov_blocks" (the grid sets the summation order
  *   of every dot product and norm), "ksp_keep_preconditioned" (the last rounding of x) and "fuse_first_sweep" (the sums of the

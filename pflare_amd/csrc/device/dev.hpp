@@ -29,8 +29,18 @@ namespace airhip {
 //                ob (bits 0-4) and the number of windows (bits 5-).  10 bytes per non-zero + the table: blocks of few long
 //                rows (the deep levels: a row's sorted columns are its row-major order anyway) and blocks whose columns
 //                run through several sections of a hierarchical vector (A_fc), which were raw before round 4.
+//                meta bits 12- (round 5): nd, the size of the block's VALUE DICTIONARY, 0 = plain values.  A multi-base block
+//                of at most 512 entries whose values take nd <= 256 distinct bit patterns (the operators of the first levels
+//                of a constant-coefficient problem: 1-5 distinct values on levels 1-2, ~150 per block on level 3) keeps, in its
+//                own 8 nb bytes of the value array, the nd distinct values (ascending bit patterns) followed by 512 bytes of
+//                indices - byte 8 l + u = the index of entry 64 u + l, so that a lane fetches its eight indices with one
+//                8-byte load: 8 nd + 512 bytes of values per block instead of 8 nb.  Lossless: the kernels multiply the very
+//                same doubles in the very same order.
 struct alignas(32) BlkDesc { int64_t p0; int32_t row; int32_t cbase; int32_t nb; int32_t nr; int64_t ip; };
-constexpr int MB_OB_MASK = 31, MB_WIN_SHIFT = 5, MB_MAX_WIN = 64;
+constexpr int MB_OB_MASK = 31, MB_WIN_SHIFT = 5, MB_WIN_MASK = 127, MB_MAX_WIN = 64, MB_ND_SHIFT = 12, MB_MAX_ND = 256;
+__host__ __device__ inline int mb_meta(const BlkDesc& q) { return -(q.cbase + 2); }
+__host__ __device__ inline int mb_nwin(int meta) { return (meta >> MB_WIN_SHIFT) & MB_WIN_MASK; }
+__host__ __device__ inline int mb_nd(int meta) { return meta >> MB_ND_SHIFT; }
 // the blocks the lean kernels process (spmv.hip): multi-base and raw blocks - everything but the packed form of rounds 2-3
 __host__ __device__ inline bool lean_block(const BlkDesc& q) { return q.cbase <= -1; }
 
@@ -60,6 +70,7 @@ struct DevMat {
   BlkDesc* desc_int = nullptr; BlkDesc* desc_bnd = nullptr;
   int64_t n_int = 0, n_bnd = 0, n_mb_int = 0, n_mb_bnd = 0;
   int64_t nnz_mb = 0;            // non-zeros in multi-base blocks
+  int64_t val_bytes = 0;         // bytes of the value array a product reads: 8 per non-zero, or 8 nd + 512 for a block with a value dictionary
   // transient operator (the setup's truncation test): its four arrays come from the block cache of device/devmem.hpp and go
   // back to it - a hipMalloc that follows the release of multi-GB blocks stalls for seconds every so often
   bool cached = false;

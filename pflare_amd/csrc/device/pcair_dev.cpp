@@ -703,12 +703,12 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
     std::printf(" hierarchy to the device: %.2f s (orderings %.2f s, host -> device copies of the operators %.2f s, conversion to row blocks %.2f s, fused first-sweep operators %.2f s; %lld operators were on the device already)\n",
                 now_s() - t_upload0, t_order, g_t_h2d, g_t_convert, g_t_fuse, (long long)g_n_from_device);
     // what the index streams hold (12 bytes per non-zero = 8 of value + 4 of index in the packed / raw forms)
-    double nz = 0, ib = 0;
-    auto acc = [&](const DevMat& m) { if (m.valid()) { nz += (double)m.nnz; ib += (double)m.idx_bytes; } };
+    double nz = 0, ib = 0, vb = 0;
+    auto acc = [&](const DevMat& m) { if (m.valid()) { nz += (double)m.nnz; ib += (double)m.idx_bytes; vb += (double)m.val_bytes; } };
     acc(A_perm_); acc(coarse_A_); acc(coarse_inv_.mat);
     for (auto& l : levels_) for (const DevMat* m : {&l->A_ff, &l->A_fc, &l->G, &l->A_cf, &l->A_cc, &l->Z, &l->W, &l->inv_ff.mat, &l->inv_cc.mat, &l->A_full}) acc(*m);
-    std::printf(" row blocks on the device: %.3g non-zeros, index regions %.2f bytes per non-zero (values 8), %.1f GB in all\n",
-                nz, nz > 0 ? ib / nz : 0.0, storage_bytes() * 1e-9);
+    std::printf(" row blocks on the device: %.3g non-zeros, index regions %.2f bytes per non-zero, values %.2f read per non-zero (8 stored; value dictionaries where a block's values repeat), %.1f GB in all\n",
+                nz, nz > 0 ? ib / nz : 0.0, nz > 0 ? vb / nz : 0.0, storage_bytes() * 1e-9);
     // how full the blocks are (512 entries = full): rows of 257 ... 511 entries cannot share a block
     std::printf(" non-zeros per row block (A_ff, M_ff, A_fc, Z) by level:");
     for (size_t l = 0; l < levels_.size(); l++) {

@@ -88,11 +88,15 @@ __device__ __forceinline__ int my_block(const RbView& A) {
 //                 address path: a kernel whose blocks gather many distinct lines (A_fc: columns in every section of the
 //                 coarse vector) loses what a streaming-bound one gains.
 static int g_mb16 = 1, g_mb16_max_rows = 128;
+//   vdict         1 (default): multi-base blocks whose values take at most 256 distinct bit patterns store a dictionary and
+//                 one-byte indices instead of the values (dev.hpp); 0: plain values everywhere.  Lossless either way.
+static int g_vdict = 1;
 static int g_occ_spmv = 6, g_occ_fc = 6;
 int spmv_set_tuning(const char* key, int value) {
   const std::string k(key);
   if (k == "mb16") { g_mb16 = value != 0; return 0; }
   if (k == "mb16_max_rows") { g_mb16_max_rows = value < 0 ? 0 : value; return 0; }
+  if (k == "vdict") { g_vdict = value != 0; return 0; }
   if (k == "occ_spmv") { g_occ_spmv = value < 0 ? 0 : value; return 0; }
   if (k == "occ_fc") { g_occ_fc = value < 0 ? 0 : value; return 0; }
   return -1;
@@ -195,7 +199,7 @@ __device__ __forceinline__ void issue_stream(const RbView& A, const BlkInfo& d, 
 // slot order; in front of them the table of windows, one per lane.  Then the values.  iw[i] keeps the two words of
 // rounds 2i / 2i + 1 packed (mb_word extracts them).
 template <int NF>
-__device__ __forceinline__ void issue_stream_mb(const RbView& A, const BlkInfo& d, int nwin, int lane, uint32_t& tab, uint32_t (&iw)[EPL / 2], double (&vv)[EPL]) {
+__device__ __forceinline__ void issue_index_mb(const RbView& A, const BlkInfo& d, int nwin, int lane, uint32_t& tab, uint32_t (&iw)[EPL / 2]) {
   typedef Rounds<NF> R;
   const uint8_t* __restrict__ ib = A.idx + d.ip;
   tab = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc32(ib, nwin * 4), lane * 4, 0, 0);
@@ -211,7 +215,39 @@ __device__ __forceinline__ void issue_stream_mb(const RbView& A, const BlkInfo& 
       if (R::has(2 * i)) iw[i] = lo | (hi << 16);
     }
   }
+}
+template <int NF>
+__device__ __forceinline__ void issue_stream_mb(const RbView& A, const BlkInfo& d, int nwin, int lane, uint32_t& tab, uint32_t (&iw)[EPL / 2], double (&vv)[EPL]) {
+  issue_index_mb<NF>(A, d, nwin, lane, tab, iw);
   issue_values<NF>(A, d, d.nb, lane, vv);
+}
+__device__ __forceinline__ void wave_lds_sync();
+// a block with a value dictionary (dev.hpp): its nd <= 256 distinct values (lane l takes entries l, l + 64, l + 128, l + 192;
+// past the end the range check returns zero) and this lane's eight one-byte indices
+__device__ __forceinline__ void issue_dictionary(const RbView& A, const BlkInfo& d, int nd, int lane, double (&tq)[4], unsigned long long& vi) {
+  const rsrc_t rt = make_rsrc32(A.val + d.p0, nd * 8);
+#pragma unroll
+  for (int k = 0; k < 4; k++) tq[k] = buf_f64(rt, lane * 8, k * WAVE * 8);
+  const rsrc_t rv = make_rsrc32(A.val + d.p0 + nd, WAVE * 8);
+  vi = __builtin_bit_cast(unsigned long long, buf_f64(rv, lane * 8));
+}
+// ... into the wave's staging area, and from there the values of this lane's slots (entries past the block's end: zero, as
+// the range check gives for plain values).  The staging area is free until the products are parked in it.
+template <int NF>
+__device__ __forceinline__ void values_from_dictionary(const BlkInfo& d, double* __restrict__ lds, int lane, const double (&tq)[4], unsigned long long vi, double (&vv)[EPL]) {
+  typedef Rounds<NF> R;
+#pragma unroll
+  for (int k = 0; k < 4; k++) lds[lane + k * WAVE] = tq[k];
+  wave_lds_sync();
+#pragma unroll
+  for (int u = 0; u < EPL; u++) {
+    vv[u] = 0.0;
+    if (R::has(u)) {
+      const double t = lds[(int)((vi >> (8 * u)) & 255ull)];
+      vv[u] = (u < NF || lane + u * WAVE < d.nb) ? t : 0.0;      // (u < NF: a full round, decided at compile time)
+    }
+  }
+  wave_lds_sync();
 }
 template <int N>
 __device__ __forceinline__ uint32_t mb_word(const uint32_t (&iw)[N], int u) { return (u & 1) ? (iw[u >> 1] >> 16) : (iw[u >> 1] & 0xffffu); }
@@ -361,14 +397,17 @@ __device__ __forceinline__ void rb_body(const RbView& A, const BlkInfo& d, const
 // blocks, i.e. when the multi-base form is switched off
 // (The epilogue inputs of a lane's second row - blocks of more than 64 rows - are loaded only after the first row is stored:
 // loading them with the first row's was measured on the levels 1-3, whose blocks all have 128 rows: no difference.)
-template <int NF, bool RAW, bool DIST, class Epi>
+// DICT: the block's values come out of its dictionary (dev.hpp; never a raw block, never a row longer than a block)
+template <int NF, bool RAW, bool DIST, bool DICT, class Epi>
 __device__ __forceinline__ void rb_body_mb(const RbView& A, const BlkInfo& d, const XVec<DIST> x, double* __restrict__ lds, const Epi& epi, int lane) {
   const int nr = d.nr;
   typedef Rounds<NF> R;
   const int meta = RAW ? 0 : -(d.cbase + 2);
-  const int ob = meta & MB_OB_MASK, nwin = meta >> MB_WIN_SHIFT;
+  const int ob = meta & MB_OB_MASK, nwin = (meta >> MB_WIN_SHIFT) & MB_WIN_MASK;
   uint32_t tab = 0; uint32_t iw[RAW ? EPL : EPL / 2]; double vv[EPL];
+  double tq[4]; unsigned long long vi = 0;
   if constexpr (RAW) issue_stream<NF>(A, d, lane, iw, vv);
+  else if constexpr (DICT) { issue_index_mb<NF>(A, d, nwin, lane, tab, iw); issue_dictionary(A, d, meta >> MB_ND_SHIFT, lane, tq, vi); }
   else issue_stream_mb<NF>(A, d, nwin, lane, tab, iw, vv);
   int ra[2], re[2];
   typename Epi::Pre pre[2];
@@ -393,7 +432,8 @@ __device__ __forceinline__ void rb_body_mb(const RbView& A, const BlkInfo& d, co
     }
   }
   pre[0] = epi.load(d.r0, nr, lane, early0);
-  if constexpr (NF == EPL) {
+  if constexpr (DICT) values_from_dictionary<NF>(d, lds, lane, tq, vi, vv);      // (while the gathers are in flight)
+  if constexpr (NF == EPL && !DICT) {
     if (d.nb > BLK_NNZ) {
       // one long row: the whole wave reduces it, with the arithmetic of the general kernels' long-row path (rb_body).  The
       // first 512 entries are in registers; the words (16-bit, or 32-bit absolute columns of a raw row) and values of the
@@ -473,28 +513,43 @@ __device__ __forceinline__ void rb_block(const RbView& A, const XVec<DIST> x, do
   if constexpr (MB) {
     if (d.cbase == -1) {
       switch (nf) {
-        case 8: rb_body_mb<8, true, DIST>(A, d, x, lds, epi, lane); break;
-        case 7: rb_body_mb<7, true, DIST>(A, d, x, lds, epi, lane); break;
-        case 6: rb_body_mb<6, true, DIST>(A, d, x, lds, epi, lane); break;
-        case 5: rb_body_mb<5, true, DIST>(A, d, x, lds, epi, lane); break;
-        case 4: rb_body_mb<4, true, DIST>(A, d, x, lds, epi, lane); break;
-        case 3: rb_body_mb<3, true, DIST>(A, d, x, lds, epi, lane); break;
-        case 2: rb_body_mb<2, true, DIST>(A, d, x, lds, epi, lane); break;
-        case 1: rb_body_mb<1, true, DIST>(A, d, x, lds, epi, lane); break;
-        default: rb_body_mb<0, true, DIST>(A, d, x, lds, epi, lane); break;
+        case 8: rb_body_mb<8, true, DIST, false>(A, d, x, lds, epi, lane); break;
+        case 7: rb_body_mb<7, true, DIST, false>(A, d, x, lds, epi, lane); break;
+        case 6: rb_body_mb<6, true, DIST, false>(A, d, x, lds, epi, lane); break;
+        case 5: rb_body_mb<5, true, DIST, false>(A, d, x, lds, epi, lane); break;
+        case 4: rb_body_mb<4, true, DIST, false>(A, d, x, lds, epi, lane); break;
+        case 3: rb_body_mb<3, true, DIST, false>(A, d, x, lds, epi, lane); break;
+        case 2: rb_body_mb<2, true, DIST, false>(A, d, x, lds, epi, lane); break;
+        case 1: rb_body_mb<1, true, DIST, false>(A, d, x, lds, epi, lane); break;
+        default: rb_body_mb<0, true, DIST, false>(A, d, x, lds, epi, lane); break;
+      }
+      return;
+    }
+    if ((-(d.cbase + 2)) >> MB_ND_SHIFT) {
+      // a block with a value dictionary: straight-line variants of its own
+      switch (nf) {
+        case 8: rb_body_mb<8, false, DIST, true>(A, d, x, lds, epi, lane); break;
+        case 7: rb_body_mb<7, false, DIST, true>(A, d, x, lds, epi, lane); break;
+        case 6: rb_body_mb<6, false, DIST, true>(A, d, x, lds, epi, lane); break;
+        case 5: rb_body_mb<5, false, DIST, true>(A, d, x, lds, epi, lane); break;
+        case 4: rb_body_mb<4, false, DIST, true>(A, d, x, lds, epi, lane); break;
+        case 3: rb_body_mb<3, false, DIST, true>(A, d, x, lds, epi, lane); break;
+        case 2: rb_body_mb<2, false, DIST, true>(A, d, x, lds, epi, lane); break;
+        case 1: rb_body_mb<1, false, DIST, true>(A, d, x, lds, epi, lane); break;
+        default: rb_body_mb<0, false, DIST, true>(A, d, x, lds, epi, lane); break;
       }
       return;
     }
     switch (nf) {
-      case 8: rb_body_mb<8, false, DIST>(A, d, x, lds, epi, lane); break;
-      case 7: rb_body_mb<7, false, DIST>(A, d, x, lds, epi, lane); break;
-      case 6: rb_body_mb<6, false, DIST>(A, d, x, lds, epi, lane); break;
-      case 5: rb_body_mb<5, false, DIST>(A, d, x, lds, epi, lane); break;
-      case 4: rb_body_mb<4, false, DIST>(A, d, x, lds, epi, lane); break;
-      case 3: rb_body_mb<3, false, DIST>(A, d, x, lds, epi, lane); break;
-      case 2: rb_body_mb<2, false, DIST>(A, d, x, lds, epi, lane); break;
-      case 1: rb_body_mb<1, false, DIST>(A, d, x, lds, epi, lane); break;
-      default: rb_body_mb<0, false, DIST>(A, d, x, lds, epi, lane); break;
+      case 8: rb_body_mb<8, false, DIST, false>(A, d, x, lds, epi, lane); break;
+      case 7: rb_body_mb<7, false, DIST, false>(A, d, x, lds, epi, lane); break;
+      case 6: rb_body_mb<6, false, DIST, false>(A, d, x, lds, epi, lane); break;
+      case 5: rb_body_mb<5, false, DIST, false>(A, d, x, lds, epi, lane); break;
+      case 4: rb_body_mb<4, false, DIST, false>(A, d, x, lds, epi, lane); break;
+      case 3: rb_body_mb<3, false, DIST, false>(A, d, x, lds, epi, lane); break;
+      case 2: rb_body_mb<2, false, DIST, false>(A, d, x, lds, epi, lane); break;
+      case 1: rb_body_mb<1, false, DIST, false>(A, d, x, lds, epi, lane); break;
+      default: rb_body_mb<0, false, DIST, false>(A, d, x, lds, epi, lane); break;
     }
   } else {
     switch (nf) {
@@ -843,8 +898,10 @@ __device__ __forceinline__ int val_slot(int s, int n) {
 //     values of column >> ob over the block's sorted columns, ob the largest of 14 ... 10 for which there are at most
 //     2^(16 - ob) (<= 64) of them; a window's base is its smallest column;
 //   raw: the rest (and rows longer than 512).
+//   value dictionary (vdict_on; multi-base blocks of <= 512 entries): the block's values have at most MB_MAX_ND distinct bit
+//     patterns and the dictionary form (8 nd + 512 bytes) is at most 5/8 of the plain values: dev.hpp.
 __global__ __launch_bounds__(BLOCK) void k_block_pack(int64_t nblocks, int64_t nnz, int64_t m, BlkDesc* __restrict__ blk, int32_t* col,
-                                                     const double* __restrict__ val, double* __restrict__ oval, int mb_on, int mb_max_rows) {
+                                                     const double* __restrict__ val, double* __restrict__ oval, int mb_on, int mb_max_rows, int vdict_on) {
   __shared__ unsigned long long keys_all[WAVES_PER_BLOCK][BLK_NNZ];
   __shared__ uint32_t tab_all[WAVES_PER_BLOCK][MB_MAX_WIN];
   __shared__ unsigned short word_all[WAVES_PER_BLOCK][BLK_NNZ];
@@ -996,8 +1053,63 @@ __global__ __launch_bounds__(BLOCK) void k_block_pack(int64_t nblocks, int64_t n
         const uint32_t lo = word[2 * k], hi = 2 * k + 1 < nb ? word[2 * k + 1] : 0u;
         reg[nwin + k] = lo | (hi << 16);
       }
-      for (int i = lane; i < nb; i += WAVE) oval[p0 + val_slot(i, nb)] = val[p0 + i];
-      if (lane == 0) { blk[b].cbase = -2 - (ob | (nwin << MB_WIN_SHIFT)); blk[b].ip = 4 * (int64_t)(nwin + nd); }
+      // the values: plain, or - few distinct bit patterns - a dictionary.  The distinct patterns are collected in a hash set
+      // (the keys array, free by now), counted (more than MB_MAX_ND: plain), sorted (ascending: the table does not depend
+      // on the order of insertion) and every entry finds its index by bisection
+      int ndv = 0;
+      if (vdict_on && nb >= 2 * WAVE) {
+        constexpr unsigned long long EMPTYV = ~0ull;
+        const unsigned long long* vbits = reinterpret_cast<const unsigned long long*>(val + p0);
+        for (int i = lane; i < BLK_NNZ; i += WAVE) keys[i] = EMPTYV;
+        lds_sync();
+        bool bad = false;
+        for (int i = lane; i < nb; i += WAVE) {
+          const unsigned long long v = vbits[i];
+          if (v == EMPTYV) { bad = true; continue; }
+          uint32_t h = (uint32_t)((v * 0x9E3779B97F4A7C15ull) >> 55);      // 9 bits
+          for (;;) {
+            const unsigned long long old = atomicCAS(&keys[h], EMPTYV, v);
+            if (old == EMPTYV || old == v) break;
+            h = (h + 1) & (BLK_NNZ - 1);
+          }
+        }
+        lds_sync();
+        int cnt = 0;
+        for (int i = lane; i < BLK_NNZ; i += WAVE) cnt += keys[i] != EMPTYV ? 1 : 0;
+        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, WAVE);
+        if (!__any(bad) && cnt <= MB_MAX_ND && 8 * (cnt + WAVE) <= 5 * nb) {
+          // ascending (bitonic over the 512 slots; EMPTYV is the largest pattern): the first cnt entries are the table
+          for (int size = 2; size <= BLK_NNZ; size <<= 1)
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+              for (int i = lane; i < BLK_NNZ / 2; i += WAVE) {
+                const int a = 2 * i - (i & (stride - 1));
+                const int bb = a + stride;
+                const bool asc = (a & size) == 0;
+                const unsigned long long ka = keys[a], kb = keys[bb];
+                if ((ka > kb) == asc) { keys[a] = kb; keys[bb] = ka; }
+              }
+              lds_sync();
+            }
+          ndv = cnt;
+          unsigned long long* otab = reinterpret_cast<unsigned long long*>(oval + p0);
+          for (int k = lane; k < ndv; k += WAVE) otab[k] = keys[k];
+          // byte 8 l + u = index of entry 64 u + l (entries past the end: 0); assembled eight to a lane, one store each
+          unsigned long long packed = 0;
+          for (int u = 0; u < EPL; u++) {
+            const int i = u * WAVE + lane;
+            if (i < nb) {
+              const unsigned long long v = vbits[i];
+              int lo = 0, hi = ndv - 1;
+              while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < v) lo = mid + 1; else hi = mid; }
+              packed |= (unsigned long long)lo << (8 * u);
+            }
+          }
+          otab[ndv + lane] = packed;
+        }
+        lds_sync();
+      }
+      if (!ndv) for (int i = lane; i < nb; i += WAVE) oval[p0 + val_slot(i, nb)] = val[p0 + i];
+      if (lane == 0) { blk[b].cbase = -2 - (ob | (nwin << MB_WIN_SHIFT) | (ndv << MB_ND_SHIFT)); blk[b].ip = 4 * (int64_t)(nwin + nd); }
     } else if (can_pack && (!mb_on || nrows > mb_max_rows)) {
       // packed: the multi-base form is off, or the block has more rows than mb16_max_rows admits to it (the documented
       // meaning of that knob: such blocks keep the packed form of rounds 2-3 and run in the *_g kernels).  With the
@@ -1043,7 +1155,7 @@ __device__ __forceinline__ int32_t stored_column(const BlkDesc& d, const uint8_t
   const uint32_t* __restrict__ w = reinterpret_cast<const uint32_t*>(idx + d.ip);
   if (d.cbase >= 0) return d.cbase + (int32_t)(w[k] >> (POS_BITS + 3));
   if (d.cbase == -1) return (int32_t)w[k];
-  const int meta = -(d.cbase + 2), ob = meta & MB_OB_MASK, nwin = meta >> MB_WIN_SHIFT;
+  const int meta = -(d.cbase + 2), ob = meta & MB_OB_MASK, nwin = (meta >> MB_WIN_SHIFT) & MB_WIN_MASK;
   const uint32_t q = (w[nwin + (k >> 1)] >> ((k & 1) * 16)) & 0xffffu;
   return (int32_t)((w[q >> ob] >> 3) + (q & ((1u << ob) - 1u)));
 }
@@ -1096,6 +1208,14 @@ __global__ __launch_bounds__(BLOCK) void k_mb_scatter(int64_t n, int64_t n_mb, c
   }
 }
 static int grid1d(int64_t n);
+// bytes of the value array a product reads for each block (dev.hpp: value dictionary)
+__global__ __launch_bounds__(BLOCK) void k_val_bytes(int64_t n, const BlkDesc* __restrict__ d, int64_t* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+    const int nd = d[i].cbase <= -2 ? mb_nd(mb_meta(d[i])) : 0;
+    out[i] = nd ? 8 * (int64_t)nd + 8 * WAVE : 8 * (int64_t)d[i].nb;
+  }
+}
 // out (n descriptors, may not alias in) = in with the multi-base blocks first; returns their number, *nnz_mb their non-zeros
 static int64_t partition_descs_device(const BlkDesc* in, int64_t n, BlkDesc* out, hipStream_t s, int64_t* nnz_mb) {
   if (nnz_mb) *nnz_mb = 0;
@@ -1172,7 +1292,7 @@ void devmat_from_csr_device(int64_t m, int64_t n, const int64_t* d_rp, const int
   HIP_CHECK(hipMemsetAsync(out.val + out.nnz, 0, sizeof(double), s));
   const int g = (int)std::min<int64_t>((out.nblocks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 4096);
   // kinds, values and index regions (in place over tcol), then the regions back to back
-  hipLaunchKernelGGL(k_block_pack, dim3(g < 1 ? 1 : g), dim3(BLOCK), 0, s, out.nblocks, out.nnz, m, out.blk, tcol, tval, out.val, g_mb16, g_mb16_max_rows);
+  hipLaunchKernelGGL(k_block_pack, dim3(g < 1 ? 1 : g), dim3(BLOCK), 0, s, out.nblocks, out.nnz, m, out.blk, tcol, tval, out.val, g_mb16, g_mb16_max_rows, g_vdict);
   int64_t* d_sz = (int64_t*)dev_alloc(sizeof(int64_t) * (size_t)out.nblocks);
   int64_t* d_off = (int64_t*)dev_alloc(sizeof(int64_t) * (size_t)out.nblocks);
   hipLaunchKernelGGL(k_region_sizes, dim3(grid1d(out.nblocks)), dim3(BLOCK), 0, s, out.nblocks, out.blk, d_sz);
@@ -1183,6 +1303,8 @@ void devmat_from_csr_device(int64_t m, int64_t n, const int64_t* d_rp, const int
   // the launch list in storage order (DevPCAIR::upload replaces it with a spatial order where that pays)
   out.desc_ord = (BlkDesc*)alloc_out(sizeof(BlkDesc) * (size_t)out.nblocks);
   out.n_mb = partition_descs_device(out.blk, out.nblocks, out.desc_ord, s, &out.nnz_mb);
+  hipLaunchKernelGGL(k_val_bytes, dim3(grid1d(out.nblocks)), dim3(BLOCK), 0, s, out.nblocks, out.blk, d_sz);
+  out.val_bytes = device_exclusive_scan(out.nblocks, d_sz, d_off, s);
   HIP_CHECK(hipStreamSynchronize(s));
   check_launch("row-block conversion");
   dev_free(d_nrp); dev_free(d_cnt); dev_free(d_first); dev_free(tcol); dev_free(tval); dev_free(d_sz); dev_free(d_off);

@@ -247,7 +247,7 @@ def decode_blocks(dm):
     m = dm.shape[0]
     indptr = np.zeros(m + 1, dtype=np.int64)
     cols_out, vals_out = [], []
-    kinds = {"packed": 0, "raw": 0, "multi-base": 0}
+    kinds = {"packed": 0, "raw": 0, "multi-base": 0, "dictionary": 0}
     for d in desc:
         p0, row, cbase, nb, nr, ip = (int(d[k]) for k in ("p0", "row", "cbase", "nb", "nr", "ip"))
         if nb == 0:
@@ -270,8 +270,23 @@ def decode_blocks(dm):
             c_rm = idx[ip:ip + 4 * nb].view("<u4").astype(np.int64); v_rm = v
             kinds["raw"] += 1
         else:
-            meta = -(cbase + 2); ob = meta & 31; nwin = meta >> 5
+            meta = -(cbase + 2); ob = meta & 31; nwin = (meta >> 5) & 127; ndv = meta >> 12
             assert 1 <= nwin <= 64 and nwin <= (1 << (16 - ob))      # (a long row may be multi-base as well)
+            if ndv:
+                # value dictionary (dev.hpp): ndv distinct values in ascending bit pattern order, then 512 bytes of indices,
+                # byte 8 l + u = index of entry 64 u + l - inside the block's own 8 nb bytes of the value array
+                assert nb <= 512 and 1 <= ndv <= 256 and 8 * (ndv + 64) <= 5 * nb
+                table = val[p0:p0 + ndv]
+                tb = table.view("<u8")
+                assert np.all(np.diff(tb.astype(object)) > 0), "dictionary not in ascending bit pattern order"
+                ib = val[p0 + ndv:p0 + ndv + 64].view("u1")
+                e = np.arange(nb)
+                vid = ib[(e & 63) * 8 + (e >> 6)]
+                assert np.all(vid < ndv)
+                pad = np.arange(nb, 512)
+                assert np.all(ib[(pad & 63) * 8 + (pad >> 6)] == 0)
+                v = table[vid]
+                kinds["dictionary"] += 1
             tab = idx[ip:ip + 4 * nwin].view("<u4").astype(np.int64)
             assert np.all(tab % 8 == 0) and np.all(np.diff(tab) > 0)
             words = idx[ip + 4 * nwin:ip + 4 * nwin + 2 * nb].view("<u2").astype(np.int64)
@@ -318,7 +333,7 @@ def test_row_blocks_decode_to_the_matrix_that_went_in(env):
     A5 = sp.csr_matrix((rng.standard_normal(indptr[-1]), cols, indptr), shape=(m, 2_000_000))
     A5.sum_duplicates(); A5.sort_indices()
     mats.append(A5)
-    seen = {"packed": 0, "raw": 0, "multi-base": 0}
+    seen = {"packed": 0, "raw": 0, "multi-base": 0, "dictionary": 0}
     for A in mats:
         A = sp.csr_matrix(A); A.sum_duplicates(); A.sort_indices()
         dm = P.DeviceMat(A)
@@ -360,3 +375,54 @@ def test_the_three_conversions_agree_bit_for_bit(gpu):
                 assert torch.equal(a, b), (name, k)
     finally:
         _set_format(P, "default")
+
+
+def test_value_dictionary_blocks_give_the_plain_blocks_bits(gpu):
+    """operators whose values repeat (the first levels of a constant-coefficient problem): the blocks that take the
+    dictionary form decode to the matrix that went in, and the product is the plain-value product bit for bit; blocks with
+    too many distinct values, small blocks and rows longer than a block keep their plain values"""
+    import torch
+    import pflare_amd as P
+    rng = np.random.default_rng(5)
+    lib = P.lib()
+
+    def few_values(A, k):
+        A = A.copy()
+        pool = rng.standard_normal(k) * 10.0 ** rng.integers(-3, 3, size=k)
+        if k > 2:
+            pool[1] = -pool[0]; pool[2] = 0.0           # -x / x and an explicit zero among the values
+        A.data = pool[rng.integers(0, k, size=A.nnz)]
+        return A
+    mats = []
+    for per_row, k in ((4, 2), (3, 1), (8, 5), (40, 43), (64, 150), (100, 256), (100, 257), (200, 300), (511, 3), (512, 7), (1, 2)):
+        mats.append(few_values(_rows([per_row] * 700, 70_000, rng, local=30_000), k))
+    mats.append(few_values(_rows(rng.integers(0, 60, size=4000), 500_000, rng, local=9000), 17))          # ragged rows, empty rows
+    mats.append(few_values(_rows([5, 513, 700, 2, 4097, 1, 512, 511, 0, 0, 3] * 20, 40_000, rng), 4))        # long rows: plain
+    x_cache = {}
+    try:
+        got = {}
+        for mode in (1, 0):
+            assert lib.airhip_set_tuning(b"vdict", mode) == 0
+            got[mode] = []
+            for A in mats:
+                dm = P.DeviceMat(A)
+                if mode == 1:
+                    indptr, cols, vals, kinds = decode_blocks(dm)
+                    B = sp.csr_matrix((vals, cols, indptr), shape=A.shape)
+                    assert (B != A).nnz == 0 and np.array_equal(B.indptr, A.indptr)
+                    assert np.array_equal(np.asarray(vals).view("<u8"), A.data.view("<u8"))      # bit patterns (signed zeros too)
+                    got.setdefault("kinds", []).append(kinds)
+                n = A.shape[1]
+                x = x_cache.setdefault(n, torch.from_numpy(lcg_vector(n)).cuda())
+                y = torch.empty(A.shape[0], dtype=torch.float64, device="cuda")
+                dm.mult(x, y)
+                got[mode].append(y)
+        for k, (a, b) in enumerate(zip(got[1], got[0])):
+            assert torch.equal(a, b), k
+        kinds = got["kinds"]
+        assert kinds[0]["dictionary"] > 0 and kinds[0]["dictionary"] == kinds[0]["multi-base"]      # 2 values: every block
+        assert kinds[7]["dictionary"] == 0            # 300 values over blocks of two 200-entry rows: ~220 distinct, 8 (220 + 64) > 5/8 of 3200 bytes
+        assert kinds[10]["dictionary"] > 0            # one entry per row, two values: a 128-entry block pays already (528 against 1024 bytes)
+        assert kinds[12]["multi-base"] + kinds[12]["raw"] > kinds[12]["dictionary"]      # rows longer than a block keep plain values
+    finally:
+        lib.airhip_set_tuning(b"vdict", 1)
