@@ -1067,9 +1067,11 @@ __global__ __launch_bounds__(BLOCK) void k_block_pack(int64_t nblocks, int64_t n
           const unsigned long long v = vbits[i];
           if (v == EMPTYV) { bad = true; continue; }
           uint32_t h = (uint32_t)((v * 0x9E3779B97F4A7C15ull) >> 55);      // 9 bits
-          for (;;) {
+          // (the set has as many slots as a block has entries, so every pattern finds one; the probe count is bounded all the same)
+          for (int probes = 0;; probes++) {
             const unsigned long long old = atomicCAS(&keys[h], EMPTYV, v);
             if (old == EMPTYV || old == v) break;
+            if (probes == BLK_NNZ) { bad = true; break; }
             h = (h + 1) & (BLK_NNZ - 1);
           }
         }
