@@ -104,7 +104,14 @@ int spmv_set_tuning(const char* key, int value) {
 // dynamic LDS that limits a kernel with LDS_STATIC bytes of its own to `wgs` workgroups per CU (160 KB of LDS, allocated
 // in units of 1 KB here so that the rounding of the hardware's granule cannot cost a workgroup)
 static unsigned occ_pad(int wgs) {
-  constexpr int LDS_CU = 160 * 1024, LDS_STATIC = SPMV_WAVES * LDS_SLOTS * 8;
+  // the LDS of one CU from the device (160 KB on gfx950, the only target; a part with 64 KB would otherwise be held to two
+  // workgroups per CU by a padding computed for 160)
+  static const int LDS_CU = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) != hipSuccess || v <= 0) { (void)hipGetLastError(); v = 160 * 1024; }
+    return v;
+  }();
+  constexpr int LDS_STATIC = SPMV_WAVES * LDS_SLOTS * 8;
   if (wgs <= 0 || wgs >= LDS_CU / LDS_STATIC) return 0;
   if (wgs < 3) wgs = 3;      // (a workgroup may not ask for more than 64 KB)
   const int alloc = LDS_CU / wgs / 1024 * 1024;
