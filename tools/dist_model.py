@@ -17,7 +17,7 @@ work:
         the cycle's bytes those levels hold;
       - communication avoidance (ghost layers deep enough for the whole F relaxation of a level, 2 exchanges per level
         instead of 6): |N_4(owned)| / |owned| with N_k the distance-k neighbourhood in the pattern of A_ff / M_ff.
-The numbers quoted in DESIGN.md section 6 come from this script (profiles/r03_dist_model_*.txt)."""
+The numbers quoted in DESIGN.md section 6 come from this script (profiles/r03_dist_model_*.txt, r05_dist_model_*.txt)."""
 import argparse
 import os
 import sys
@@ -46,7 +46,13 @@ def model(pieces, L, args, vol, surf, title):
     rows = []
     tot = dict(kernel=0.0, exch=0.0, exposed_overlap=0.0, exposed_plain=0.0, nexch=0, msgs=0, bytes=0.0)
     level_bytes = np.zeros(L)
-    ops = [(l, f"L{l}.{nm}", times) for l in range(L - 1) for nm, times in (("Z", 1), ("A_fc", 1), ("A_ff", 2), ("inv_ff.mat", 2))]
+    # the products of one cycle: round 5 runs the first F sweep on G = A_fc + A_ff W where the pieces carry it (G, M, A_ff, M);
+    # the reference's sequence (A_fc, 2 x A_ff, 2 x M) elsewhere and with --unfused
+    ops = []
+    for l in range(L - 1):
+        fused = (not args.unfused) and pieces[0].has(f"L{l}.G")
+        seq = (("Z", 1), ("G", 1), ("A_ff", 1), ("inv_ff.mat", 2)) if fused else (("Z", 1), ("A_fc", 1), ("A_ff", 2), ("inv_ff.mat", 2))
+        ops += [(l, f"L{l}.{nm}", times) for nm, times in seq]
     ops.append((L - 1, "coarse.A", 10))
     for l, name, times in ops:
         st = [op_stats(q, name) for q in pieces]
@@ -85,11 +91,12 @@ def main():
     ap.add_argument("--size", type=int, default=96)
     ap.add_argument("--ranks", type=int, default=8)
     ap.add_argument("--scale-to", type=int, default=0)
-    ap.add_argument("--bw", type=float, default=5.2e12, help="achieved HBM bandwidth of the SpMV kernels (B/s)")
+    ap.add_argument("--bw", type=float, default=5.8e12, help="achieved HBM bandwidth of the SpMV kernels (B/s)")
     ap.add_argument("--latency", type=float, default=15e-6, help="one send / receive group, small messages (s)")
     ap.add_argument("--link", type=float, default=50e9, help="effective bandwidth to one peer (B/s)")
     ap.add_argument("--launch", type=float, default=4e-6, help="fixed cost of one kernel launch on the stream (s)")
     ap.add_argument("--min-interior", type=float, default=10e-6, help="interior kernel time below which no overlap is attempted (s)")
+    ap.add_argument("--unfused", action="store_true", help="model the reference's sequence of products (rounds 1-4) instead of the fused first sweep")
     args = ap.parse_args()
     import pflare_amd as P
     from pflare_amd import dist as D
