@@ -66,6 +66,33 @@ def test_host_builder_is_a_fc_plus_a_ff_w(nf, nc, kff, kfc):
         assert np.all(np.diff(c) > 0)               # sorted, no duplicates
 
 
+def test_fused_operator_on_a_real_hierarchy_is_little_larger_than_a_fc():
+    """G = A_fc + A_ff W holds 1.0-1.3 x the non-zeros of A_fc on the levels of a 3D advection hierarchy (the W images of
+    a row's F neighbours mostly are its C neighbours), far fewer than nnz(A_fc) + nnz(A_ff) - which is why one product with G
+    replaces two; and it is A_fc + A_ff W on every level (host builder against scipy)"""
+    import pflare_amd as P
+    A = P.HostMat.adv_diff_fd(dim=3, M=40, N=40, P=40)
+    pc = P.PCAIR(a_lump=True, auto_truncate_start_level=1, auto_truncate_tol=1e-1, coarsest_inverse_type="newton",
+                 coarsest_matrix_free_polys=True, coarsest_poly_order=10)
+    pc.setup_host_only(A)
+    seen = 0
+    for l in range(pc.num_levels - 1):
+        lv = pc.export_level(l)
+        if "A_ff" not in lv:
+            continue                               # diagonal A_ff: that level's sweep is one launch already
+        a_ff = sp.csr_matrix((lv["A_ff"].val, lv["A_ff"].col, lv["A_ff"].rowptr), shape=lv["A_ff"].shape)
+        a_fc = sp.csr_matrix((lv["A_fc"].val, lv["A_fc"].col, lv["A_fc"].rowptr), shape=lv["A_fc"].shape)
+        wcol = np.asarray(lv["wcol"], dtype=np.int32)
+        g = _fused(P, a_ff, a_fc, wcol, on_device=False)
+        G = sp.csr_matrix((g.val, g.col, g.rowptr), shape=g.shape)
+        D = (G - _scipy_G(a_ff, a_fc, wcol)).tocsr()
+        assert D.nnz == 0 or np.max(np.abs(D.data)) <= 1e-12 * np.max(np.abs(G.data))
+        assert a_fc.nnz <= G.nnz <= 1.35 * a_fc.nnz, (l, a_fc.nnz, a_ff.nnz, G.nnz)
+        assert G.nnz <= 0.9 * (a_fc.nnz + a_ff.nnz), (l, a_fc.nnz, a_ff.nnz, G.nnz)
+        seen += 1
+    assert seen >= 3
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("nf,nc,kff,kfc", [(300, 500, 4, 3), (1, 1, 1, 1), (5000, 3000, 30, 45), (200, 9000, 2, 700), (40000, 30000, 9, 12)])
 def test_device_builder_gives_the_host_builders_bits(gpu, nf, nc, kff, kfc):
