@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 # defaults of the airhip_set_tuning keys (include/airhip.h): what --variants restores after each variant
-TUNING_DEFAULTS = {"spgemm_pool_entries": 0, "spgemm_pool_chunk": -1, "block_order_min_blocks": 4096, "fc_fuse": 1, "occ_spmv": 6, "occ_fc": 6, "krylov_blocks": 512, "ksp_unnormalised": 1, "ksp_keep_preconditioned": 1, "fuse_first_sweep": 1, "fuse_first_sweep_run": 1, "profile_chain": 1, "vdict": 1, "mb16": 1, "mb16_max_rows": 128, "fc_spatial_x": 1}
+TUNING_DEFAULTS = {"spgemm_pool_entries": 0, "spgemm_pool_chunk": -1, "block_order_min_blocks": 4096, "fc_fuse": 1, "occ_spmv": 6, "occ_fc": 6, "krylov_blocks": 512, "ksp_unnormalised": 1, "ksp_keep_preconditioned": 1, "fuse_first_sweep": 1, "fuse_first_sweep_run": 1, "profile_chain": 1, "perm_chunks": 1, "vdict": 1, "mb16": 1, "mb16_max_rows": 128, "fc_spatial_x": 1}
 
 RECIPES = {
     # reference GPU recipe: lumping + auto truncation + Newton matrix-free coarse solver

@@ -122,6 +122,9 @@ int airhip_set_num_threads(int n, int* prev);
  *   and A_fc stays on the device, so that "fuse_first_sweep_run" (default 1) can switch between the two sequences on one
  *   hierarchy), "profile_chain" (default 1: inside the cycle the stop event of one profiled kernel is the start event of the
  *   next; 0 = a pair of events per kernel),
+ *   "perm_chunks" (default 1: the natural <-> hierarchical permutation of PCApply / KSPSolve vectors walks the key range chunk
+ *   by chunk - every section's share of a chunk in one workgroup - instead of one plain gather; 0 = plain gathers; bitwise
+ *   neutral),
  *   "ksp_keep_preconditioned" (default 1: right-preconditioned GMRES keeps z_j = M v_j, restart more vectors, and updates
  *   x += Z y without the extra PCApply of PETSc's x += M (V y); same Arnoldi process, Hessenberg matrix, residual norms and
  *   iteration count bit for bit - the solution differs in its last rounding; 0: PETSc's form).

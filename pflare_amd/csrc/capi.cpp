@@ -57,6 +57,7 @@ int airhip_set_tuning(const char* key, int value) {
   else if (std::string(key) == "block_order_min_blocks") airhip::set_block_order_min(value);
   else if (std::string(key) == "fc_fuse") airhip::set_fc_fuse(value != 0);
   else if (std::string(key) == "profile_chain") airhip::set_profile_chain(value != 0);
+  else if (std::string(key) == "perm_chunks") airhip::set_perm_chunks(value != 0);
   else if (std::string(key) == "fuse_first_sweep") airhip::set_fuse_first_sweep(value);
   else if (std::string(key) == "fuse_first_sweep_run") airhip::set_fuse_first_sweep_run(value != 0);
   else if (std::string(key) == "fc_spatial_x") airhip::set_fc_spatial(value);

@@ -127,6 +127,11 @@ void launch_diag_residual_update(int64_t n, const double* d, const double* minv,
 void launch_gather(int64_t n, const int32_t* idx, const double* in, double* out, hipStream_t s);   // out[i] = in[idx[i]]
 void launch_scatter(int64_t n, const int32_t* idx, const double* in, double* out, hipStream_t s);  // out[idx[i]] = in[i]
 void launch_fill(int64_t n, double v, double* out, hipStream_t s);
+// natural <-> hierarchical permutation chunk by chunk of the locality key (kernels.hip): key_h[p] = key[iperm[p]]; the chunk
+// table starts[(nchunks + 1) * nsec]; out[p] = in[iperm[p]] (to_natural = false) or out[iperm[p]] = in[p]
+void launch_keys_at(int64_t n, const int32_t* iperm, const int64_t* key, int64_t* out, hipStream_t s);
+void launch_chunk_starts(int64_t nchunks, int nsec, int64_t chunk, const int64_t* sec_off, const int64_t* key_h, int32_t* starts, hipStream_t s);
+void launch_permute_chunks(int64_t nchunks, int nsec, const int32_t* starts, const int32_t* iperm, const double* in, double* out, bool to_natural, hipStream_t s);
 // dots[k] = <w, V_k>, k < nv (V_k = V + k*ld); two-stage deterministic reduction using `scratch`
 void launch_mdot(int64_t n, const double* w, const double* V, int64_t ld, int nv, double* scratch, double* dots, hipStream_t s);
 // w += sum_k coef[k] V_k  (coef on device); zero_first: w = sum_k ... (w is not read); norm_scratch / norm_out (device):

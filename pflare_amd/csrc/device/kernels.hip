@@ -75,6 +75,55 @@ void launch_gather(int64_t n, const int32_t* idx, const double* in, double* out,
   if (n == 0) return;
   hipLaunchKernelGGL(k_gather, dim3(grid_for_n(n)), dim3(BLOCK), 0, s, n, idx, in, out);
 }
+// ---- the natural <-> hierarchical permutation of a level-1 vector, chunk by chunk of the locality key.
+// A hierarchical vector is a row of sections [F_1 | F_2 | ... | coarsest], each in key order, so a plain gather over the
+// positions walks the natural vector once PER SECTION and fetches every natural line again for each section that holds one of
+// its points (1.8 TB/s on 20 bytes per element at 464^3).  Here a workgroup takes one chunk of the key range - in every section
+// the positions whose keys fall into it, starts[c * nsec + s] ... starts[(c + 1) * nsec + s] - so the natural lines a chunk
+// touches are used up within one workgroup's lifetime.  iperm[p] = natural index of hierarchical position p.
+// k_keys_at: key_h[p] = key[iperm[p]]; k_chunk_starts: the first position of section s whose key is >= the key at position
+// c * chunk of section 0 (binary search; row nchunks = the sections' ends).
+__global__ __launch_bounds__(BLOCK) void k_keys_at(int64_t n, const int32_t* __restrict__ iperm, const int64_t* __restrict__ key, int64_t* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * BLOCK;
+  for (int64_t p = (int64_t)blockIdx.x * BLOCK + threadIdx.x; p < n; p += stride) out[p] = key[iperm[p]];
+}
+__global__ __launch_bounds__(BLOCK) void k_chunk_starts(int64_t nchunks, int nsec, int64_t chunk, const int64_t* __restrict__ sec_off, const int64_t* __restrict__ key_h,
+                                                       int32_t* __restrict__ starts) {
+  const int64_t stride = (int64_t)gridDim.x * BLOCK, total = (nchunks + 1) * nsec;
+  for (int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x; t < total; t += stride) {
+    const int64_t c = t / nsec; const int s = (int)(t % nsec);
+    int64_t lo = sec_off[s], hi = sec_off[s + 1];
+    if (c == nchunks) { starts[t] = (int32_t)hi; continue; }
+    if (c == 0) { starts[t] = (int32_t)lo; continue; }
+    const int64_t k = key_h[sec_off[0] + c * chunk];
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (key_h[mid] < k) lo = mid + 1; else hi = mid; }
+    starts[t] = (int32_t)lo;
+  }
+}
+template <bool TO_NATURAL>
+__global__ __launch_bounds__(BLOCK) void k_permute_chunks(int nsec, const int32_t* __restrict__ starts, const int32_t* __restrict__ iperm,
+                                                         const double* __restrict__ in, double* __restrict__ out) {
+  const int32_t* s0 = starts + (int64_t)blockIdx.x * nsec;
+  for (int s = 0; s < nsec; s++) {
+    const int32_t a = s0[s], e = s0[nsec + s];
+    for (int32_t p = a + (int32_t)threadIdx.x; p < e; p += BLOCK) {
+      const int32_t nat = iperm[p];
+      if (TO_NATURAL) out[nat] = in[p]; else out[p] = in[nat];
+    }
+  }
+}
+void launch_keys_at(int64_t n, const int32_t* iperm, const int64_t* key, int64_t* out, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(k_keys_at, dim3(grid_for_n(n)), dim3(BLOCK), 0, s, n, iperm, key, out);
+}
+void launch_chunk_starts(int64_t nchunks, int nsec, int64_t chunk, const int64_t* sec_off, const int64_t* key_h, int32_t* starts, hipStream_t s) {
+  hipLaunchKernelGGL(k_chunk_starts, dim3(grid_for_n((nchunks + 1) * nsec)), dim3(BLOCK), 0, s, nchunks, nsec, chunk, sec_off, key_h, starts);
+}
+void launch_permute_chunks(int64_t nchunks, int nsec, const int32_t* starts, const int32_t* iperm, const double* in, double* out, bool to_natural, hipStream_t s) {
+  if (nchunks == 0) return;
+  if (to_natural) hipLaunchKernelGGL((k_permute_chunks<true>), dim3((unsigned)nchunks), dim3(BLOCK), 0, s, nsec, starts, iperm, in, out);
+  else hipLaunchKernelGGL((k_permute_chunks<false>), dim3((unsigned)nchunks), dim3(BLOCK), 0, s, nsec, starts, iperm, in, out);
+}
+
 __global__ __launch_bounds__(BLOCK) void k_scatter(int64_t n, const int32_t* __restrict__ idx, const double* __restrict__ in,
                                                   double* __restrict__ out) {
   const int64_t stride = (int64_t)gridDim.x * BLOCK;

@@ -68,6 +68,8 @@ void set_fc_fuse(bool on) { g_fc_fuse = on; }
 // is the start event of the next (half as many events in the stream), 0 = a pair of events per kernel
 static bool g_profile_chain = true;
 void set_profile_chain(bool on) { g_profile_chain = on; }
+static bool g_perm_chunks = true;     // (airhip_set_tuning "perm_chunks", acts at the next launch) 0: the plain gathers
+void set_perm_chunks(bool on) { g_perm_chunks = on; }
 static int g_fuse_first = 1;          // pcair_dev.hpp: set_fuse_first_sweep
 static bool g_fuse_first_run = true;
 void set_fuse_first_sweep(int mode) { g_fuse_first = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }
@@ -438,6 +440,24 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
     upload_mat(A_top, iperm_.p, perm_.p, A_perm_, stream_, ng(dist ? &dist->h_top : nullptr));
     attach_halo(A_perm_, dist ? &dist->h_top : nullptr, perm[0].data());
     if (order_blocks) order_blocks_by_key(A_perm_, ip.data(), level_keys[0].data(), stream_);
+    // the permutation of level-1 vectors chunk by chunk of the key range (kernels.hip: k_permute_chunks): sections = the F
+    // blocks of the levels and the coarsest level, each in key order; chunks of 1024 positions of the first section
+    perm_nchunks_ = 0; perm_nsec_ = 0; chunk_starts_.release();
+    constexpr int64_t PERM_CHUNK = 1024;
+    if (L >= 2 && H.levels[0]->n_f >= 64 * PERM_CHUNK) {
+      std::vector<int64_t> sec(L + 1);
+      for (int l = 0; l < L; l++) sec[l] = off_[l];
+      sec[L] = n_;
+      // (a section's positions are in key order: rank_by with a hint, the ascending F / C lists without one)
+      DBuf<int64_t> d_key, d_keyh, d_sec;
+      d_key.upload(level_keys[0].data(), n_); d_keyh.alloc(n_); d_sec.upload(sec.data(), L + 1);
+      const int64_t nch = (H.levels[0]->n_f + PERM_CHUNK - 1) / PERM_CHUNK;
+      chunk_starts_.alloc((nch + 1) * L);
+      launch_keys_at(n_, iperm_.p, d_key.p, d_keyh.p, stream_);
+      launch_chunk_starts(nch, L, PERM_CHUNK, d_sec.p, d_keyh.p, chunk_starts_.p, stream_);
+      HIP_CHECK(hipStreamSynchronize(stream_));
+      perm_nchunks_ = nch; perm_nsec_ = L;
+    }
   }
 
   cycle_bytes_ = 0.0;
@@ -1054,14 +1074,20 @@ void DevPCAIR::apply_permuted(const double* r, double* z) {
   HIP_CHECK(hipMemcpyAsync(z, cx_.p, sizeof(double) * (size_t)n_, hipMemcpyDeviceToDevice, stream_));
 }
 
-void DevPCAIR::to_permuted(const double* nat, double* perm) { launch_gather(n_, iperm_.p, nat, perm, stream_); }
-void DevPCAIR::to_natural(const double* perm, double* nat) { launch_gather(n_, perm_.p, perm, nat, stream_); }
+void DevPCAIR::to_permuted(const double* nat, double* perm) {
+  if (perm_nchunks_ > 0 && g_perm_chunks) launch_permute_chunks(perm_nchunks_, perm_nsec_, chunk_starts_.p, iperm_.p, nat, perm, false, stream_);
+  else launch_gather(n_, iperm_.p, nat, perm, stream_);
+}
+void DevPCAIR::to_natural(const double* perm, double* nat) {
+  if (perm_nchunks_ > 0 && g_perm_chunks) launch_permute_chunks(perm_nchunks_, perm_nsec_, chunk_starts_.p, iperm_.p, perm, nat, true, stream_);
+  else launch_gather(n_, perm_.p, perm, nat, stream_);
+}
 
 void DevPCAIR::apply_natural(const double* d_x, double* d_y) {
   b0_ = cb_.p; xbase_ = cx_.p;
-  launch_gather(n_, iperm_.p, d_x, cb_.p, stream_);
+  to_permuted(d_x, cb_.p);
   run_cycle();
-  launch_gather(n_, perm_.p, cx_.p, d_y, stream_);
+  to_natural(cx_.p, d_y);
 }
 
 }  // namespace airhip

@@ -32,6 +32,7 @@ void set_block_order_min(int64_t nblocks);
 // followed by a plain A_fc product instead of the fused k_rb_fc_first; same results, one more pass over the F vectors
 void set_fc_fuse(bool on);
 void set_profile_chain(bool on);      // pcair_dev.cpp: begin_kernel
+void set_perm_chunks(bool on);        // pcair_dev.cpp: to_permuted / to_natural
 // (airhip_set_tuning "fuse_first_sweep", acts at the next upload) 1 (default): on the levels whose relaxation starts with F
 // sweeps, with a one-point prolongator, a sparse A_ff and an assembled A_ff inverse, the first sweep runs on
 // G = A_fc + A_ff W: four products per level instead of five.  0: the reference's sequence of products.  2: as 1, and A_fc
@@ -203,6 +204,8 @@ class DevPCAIR {
   std::vector<DBuf<double>> b_sep_;   // separate rhs per level when C smoothing keeps b_c alive
   std::vector<double*> b_ptr_;
   DBuf<int32_t> perm_, iperm_;    // natural -> hierarchical and back (level 1)
+  // the same permutation walked chunk by chunk of the locality key (kernels.hip: k_permute_chunks): chunk_starts_[c * nsec + s]
+  DBuf<int32_t> chunk_starts_; int64_t perm_nchunks_ = 0; int perm_nsec_ = 0;
   DevMat A_perm_;
   DBuf<double> coarse_r_;
   double cycle_bytes_ = 0.0;

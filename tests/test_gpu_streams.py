@@ -96,3 +96,38 @@ def test_mat_mult_on_stream(env):
         out.copy_(y + 1.0, non_blocking=True)
     side.synchronize()
     assert torch.equal(out, ref + 1.0)
+
+
+def test_chunked_permutation_is_the_plain_gather(gpu):
+    """PCApply and KSPSolve take vectors in the caller's (natural) numbering; the permutation to the hierarchical layout and
+    back runs chunk by chunk of the locality key (kernels.hip: k_permute_chunks) on operators large enough - bit for bit what
+    the plain gathers give, with and without an ordering hint"""
+    import numpy as np
+    import torch
+    import pflare_amd as P
+    lib = P.lib()
+    M = 64
+    A = P.HostMat.adv_diff_fd(dim=3, M=M, N=M, P=M)
+    n = A.shape[0]
+    rng = np.random.default_rng(3)
+    x = torch.from_numpy(rng.standard_normal(n)).cuda()
+    try:
+        for hinted in (False, True):
+            pc = P.PCAIR(a_lump=True)
+            if hinted:
+                ax = np.arange(M, dtype=np.int64)
+                key = ((ax[:, None, None] // 8) * 64 + (ax[None, :, None] // 8) * 8 + (ax[None, None, :] // 8)) * 512 + \
+                      ((ax[:, None, None] % 8) * 64 + (ax[None, :, None] % 8) * 8 + (ax[None, None, :] % 8))
+                pc.set_ordering_hint(key.reshape(-1))
+            pc.setup(A)
+            out = {}
+            for mode in (1, 0):
+                assert lib.airhip_set_tuning(b"perm_chunks", mode) == 0
+                y = torch.empty_like(x)
+                pc.apply(x, y)
+                b = torch.zeros(n, dtype=torch.float64, device="cuda"); sol = torch.ones_like(b)
+                r = P.KSP("gmres", pc_side="right", rtol=1e-10, atol=1e-50, max_it=30).solve(b, sol, pc=pc)
+                out[mode] = (y, sol, r["history"])
+            assert torch.equal(out[1][0], out[0][0]) and torch.equal(out[1][1], out[0][1]) and out[1][2] == out[0][2], hinted
+    finally:
+        lib.airhip_set_tuning(b"perm_chunks", 1)
