@@ -1070,9 +1070,32 @@ int airhip_partition_create(airhip_pcair pc, const airhip_csr* A_top, int nranks
   REQUIRE(pc->hint.empty() || (int64_t)pc->hint.size() == A_top->m, AIRHIP_ERR_ARG, "ordering hint: one key per row of the operator is required");
   // the operators of the fused first F sweep (one device builds them at upload time from its own copies of A_fc / A_ff;
   // a cut hierarchy gets them here, cut like every other operand)
-  if (fuse_first_sweep_mode() != 0)
-    for (auto& lv : pc->H->levels)
-      if (lv->G.empty() && lv->fuses_first_sweep() && lv->A_fc.on_host() && lv->A_ff.on_host()) lv->G = fused_first_operator(lv->A_ff, lv->A_fc, lv->wcol.data());
+  if (fuse_first_sweep_mode() != 0) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) { (void)hipGetLastError(); ndev = 0; }
+    for (auto& lv : pc->H->levels) {
+      if (!(lv->G.empty() && lv->fuses_first_sweep() && lv->A_fc.on_host() && lv->A_ff.on_host())) continue;
+      // on this rank's device when there is one (the same bits as the host code, in a fraction of its time: the cut of a
+      // 464^3 hierarchy builds 2.9e9 non-zeros of G), on the host otherwise
+      bool done = false;
+      if (ndev > 0 && lv->A_fc.nnz() + lv->A_ff.nnz() >= 2000000) {
+        try {
+          DevScope scope(true);
+          DCsr da = dcsr_upload(lv->A_ff.m, lv->A_ff.n, lv->A_ff.rp.data(), lv->A_ff.ci.data(), lv->A_ff.v.data());
+          DCsr db = dcsr_upload(lv->A_fc.m, lv->A_fc.n, lv->A_fc.rp.data(), lv->A_fc.ci.data(), lv->A_fc.v.data());
+          int32_t* dw = (int32_t*)dev_alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(lv->n_f, 1));
+          staged_h2d(dw, lv->wcol.data(), sizeof(int32_t) * (size_t)lv->n_f);
+          DCsr dg = dev_fused_first_operator(da, db, dw, nullptr);
+          lv->G = Csr(); lv->G.m = dg.m; lv->G.n = dg.n;
+          lv->G.rp.alloc(dg.m + 1); lv->G.ci.alloc(dg.nnz); lv->G.v.alloc(dg.nnz);
+          dcsr_download(dg, lv->G.rp.data(), lv->G.ci.data(), lv->G.v.data());
+          dcsr_free(da); dcsr_free(db); dcsr_free(dg); dev_free(dw);
+          done = true;
+        } catch (const std::exception&) { (void)hipGetLastError(); lv->G = Csr(); }      // (no room on the device: the host code)
+      }
+      if (!done) lv->G = fused_first_operator(lv->A_ff, lv->A_fc, lv->wcol.data());
+    }
+  }
   try { h->p = std::make_unique<Partitioner>(*pc->H, h->A_view, nranks, owner, pc->hint.empty() ? nullptr : pc->hint.data()); }
   catch (...) { delete h; throw; }
   *out = h;
