@@ -254,7 +254,8 @@ def main():
     if dist_mode:
         from pflare_amd import dist as D
         px, py, pz = D.box_dims(world, (M, M, M))
-        parallelism = (f"row-block: {px}x{py}x{pz} boxes of the {M}^3 grid, one rank per GPU, hierarchy built on rank 0 "
+        parallelism = (f"row-block: {px}x{py}x{pz} boxes of the {M}^3 grid with equal WORK (non-zeros of an iteration's products; equal "
+                       f"boxes leave the downstream corner 1.85 x the upstream one's), one rank per GPU, hierarchy built on rank 0 "
                        f"and cut; RCCL halo exchange per sparse product, all-reduce for Krylov dots")
         # ranks > 0 get here minutes before rank 0 (which has been building the hierarchy): wait on the host
         # (gloo) rather than inside an RCCL collective that would spin on their GPUs for the whole setup
@@ -283,7 +284,26 @@ def main():
                 transport = "staged-fallback"
                 parallelism += " [RCCL self-test failed: host-staged halo transport over gloo]"
         t0 = time.time()
-        owner = D.box_owner(M, M, M, world) if rank == 0 else None
+        owner = None
+        if rank == 0:
+            # boxes of equal work, not of equal size (pflare_amd/dist.py: balanced_box_owner); AIRHIP_BENCH_EQUAL_BOXES=1 for
+            # the DMDA-style equal boxes
+            import numpy as np
+            equal = D.box_owner(M, M, M, world)
+            if os.environ.get("AIRHIP_BENCH_EQUAL_BOXES", "0") == "1":
+                owner = equal
+            else:
+                tw = time.time()
+                wpt = D.point_work(pc, hm)
+                owner = D.balanced_box_owner(wpt, (M, M, M), world)
+                per = [np.bincount(o, weights=wpt, minlength=world) for o in (equal, owner)]
+                info["balance"] = {"work_busiest_over_mean_equal_boxes": float(per[0].max() / per[0].mean()),
+                                   "work_busiest_over_mean": float(per[1].max() / per[1].mean()),
+                                   "rows_per_rank": [int(v) for v in np.bincount(owner, minlength=world)],
+                                   "seconds": time.time() - tw}
+                log(f"[bench] work-balanced boxes: {info['balance']}")
+                del wpt, per
+            del equal
         # the bulk arrays travel GPU -> GPU over RCCL only when RCCL has just proved itself; otherwise over gloo
         pcl, gid = D.distribute(pc, hm, owner, comm, src=0, meta_group=meta, bulk_group=None if transport == "rccl" else meta,
                                 bulk_on_gpu=(transport == "rccl"), log=log)
@@ -643,6 +663,7 @@ def main():
         except Exception:      # noqa: BLE001 - diagnostic only
             pass
         out["config"]["distribute_s"] = info["t_distribute"]
+        out["config"]["balance"] = info.get("balance")
         if unprofiled is not None:
             out["config"]["iterations_per_s_without_kernel_events"] = unprofiled
         out["config"]["halo_exchanges_rank0"] = info["comm"]["exchanges"]

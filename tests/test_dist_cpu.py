@@ -16,6 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 CASES = {
     "adv2d_40": (dict(dim=2, M=40, N=40), {}, "box2d"),
     "adv3d_14_lump": (dict(dim=3, M=14, N=14, P=14), dict(a_lump=True), "box3d"),
+    "adv3d_14_balanced": (dict(dim=3, M=14, N=14, P=14), dict(a_lump=True), "balanced3d"),      # boxes of equal work (bench.py, N > 1)
     "advdiff2d_30": (dict(dim=2, M=30, N=30, alpha=0.05), {}, "block"),
     "adv2d_30_mf_trunc": (dict(dim=2, M=30, N=30), dict(matrix_free_polys=True, max_levels=3,
                                                          coarsest_inverse_type="power", coarsest_poly_order=4,
@@ -29,10 +30,63 @@ CASES = {
 }
 
 
+def test_balanced_boxes_are_boxes_of_equal_work():
+    """bench.py's decomposition for N > 1: boxes of equal WORK (non-zeros of an iteration's products in the rows that live with
+    a point).  Equal boxes leave the downstream corner of the 3D upwind problem with far more than the mean; the balanced
+    ones are still boxes, differ in size, and the weight they are cut by IS the per-rank work the partitioner's pieces hold."""
+    import pflare_amd as P
+    from pflare_amd import dist as D
+    from dist_util import Piece
+    M = 28
+    A = P.HostMat.adv_diff_fd(dim=3, M=M, N=M, P=M)
+    pc = P.PCAIR(a_lump=True)
+    pc.setup_host_only(A)
+    w = D.point_work(pc, A)
+    assert w.shape == (M ** 3,) and np.all(w >= 1.0)
+    for nranks in (2, 4, 8, 3):
+        eq = D.box_owner(M, M, M, nranks)
+        bal = D.balanced_box_owner(w, (M, M, M), nranks)
+        assert bal.shape == eq.shape and set(np.unique(bal)) == set(range(nranks))
+        k, j, i = np.meshgrid(np.arange(M), np.arange(M), np.arange(M), indexing="ij")
+        for r in range(nranks):                                  # every rank owns a box
+            m = (bal == r).reshape(M, M, M)
+            ext = [(a[m].min(), a[m].max()) for a in (k, j, i)]
+            assert int(m.sum()) == int(np.prod([hi - lo + 1 for lo, hi in ext])), (nranks, r)
+        pe = np.bincount(eq, weights=w, minlength=nranks); pb = np.bincount(bal, weights=w, minlength=nranks)
+        assert pb.max() / pb.mean() <= 1.12 and pb.max() / pb.mean() <= pe.max() / pe.mean() + 1e-12, (nranks, pe, pb)
+    # the weight is the work: per-rank non-zeros of the pieces' products on 8 balanced boxes
+    part = D.Partition(pc, A, 8, bal)
+    tot = np.zeros(8)
+    L = pc.num_levels
+    for r in range(8):
+        ar = part.extract(r)
+        q = Piece((k_, v.copy()) for k_, v in ar.items())
+        ar.close()
+        for l in range(L - 1):
+            for nm, t in (("Z", 1), ("A_fc", 1), ("A_ff", 1), ("inv_ff.mat", 2)):
+                if q.has(f"L{l}.{nm}"):
+                    tot[r] += t * q.mat(f"L{l}.{nm}").nnz
+            if not q.has(f"L{l}.A_ff"):
+                tot[r] += q.level(l)["n_f"]                         # diagonal A_ff: one entry per row
+            if not q.has(f"L{l}.inv_ff.mat"):
+                tot[r] += 2 * q.level(l)["n_f"]
+        kind = q.inv("coarse.inv")["kind"]
+        tot[r] += (1 * q.mat("coarse.inv.mat").nnz) if kind == 1 else 10 * q.mat("coarse.A").nnz
+        tot[r] += q.mat("top.A").nnz
+    part.close()
+    np.testing.assert_allclose(tot, np.bincount(bal, weights=w, minlength=8), rtol=1e-12)
+
+
 def _owner(kind, gen, nranks):
     from pflare_amd import dist as D
     if kind == "box3d":
         return D.box_owner(gen["M"], gen["N"], gen["P"], nranks)
+    if kind == "balanced3d":
+        import pflare_amd as P
+        A = P.HostMat.adv_diff_fd(**gen)
+        pc = P.PCAIR(**CASES["adv3d_14_balanced"][1])
+        pc.setup_host_only(A)
+        return D.balanced_box_owner(D.point_work(pc, A), (gen["M"], gen["N"], gen["P"]), nranks)
     if kind == "box2d":
         return D.box_owner(gen["M"], gen["N"], 1, nranks)
     n = gen["M"] * gen["N"] * gen.get("P", 1)
