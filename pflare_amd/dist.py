@@ -54,12 +54,14 @@ def box_owner(M, N=1, P=1, nranks=1):
     return np.ascontiguousarray(own.reshape(-1).astype(np.int32))
 
 
-def point_work(pc, A_top=None):
+def point_work(pc, A_top=None, vector_work=True):
     """Per fine point, the non-zeros of one Krylov iteration's products in the rows that live with it: a level's rows stay
     with their parent C points (the reference's row ownership, src/Grid_Transfer.F90:745-746), so the rows of every level
     are rows of some fine point.  Counted: the restriction Z, the F-C product (A_fc, or the slightly larger G of the fused
     first sweep), A_ff and twice the A_ff inverse per level, ten products with the coarsest operator (the truncated recipe's
-    polynomial; an assembled inverse counts once) and the outer operator.  This is the weight balanced_box_owner cuts by."""
+    polynomial; an assembled inverse counts once) and the outer operator.  vector_work: plus what a row costs in vectors, in
+    units of one non-zero (10 bytes): 6 per row and level for the cycle's vectors (~60 bytes), 15 per fine row for the Krylov
+    method's (GMRES(30), ~150 bytes per iteration on average).  This is the weight balanced_box_owner cuts by."""
     from .pc import as_csr
     L = pc.num_levels
     comp = None
@@ -80,8 +82,8 @@ def point_work(pc, A_top=None):
             rf += 2.0 * np.diff(np.asarray(inv["mat"].rowptr))
         else:
             rf += 2.0
-        w[comp[F]] += rf
-        w[comp[C]] += np.diff(np.asarray(lv["Z"].rowptr))
+        w[comp[F]] += rf + (6.0 if vector_work else 0.0)
+        w[comp[C]] += np.diff(np.asarray(lv["Z"].rowptr)) + (6.0 if vector_work else 0.0)
         comp = comp[C]
     A_co, inv = pc.export_coarse(copy=False)
     if comp is None:
@@ -92,6 +94,8 @@ def point_work(pc, A_top=None):
     w[comp] += reps * np.diff(np.asarray(op.rowptr))
     if A_top is not None:
         w += np.diff(np.asarray(as_csr(A_top).rowptr))
+    if vector_work:
+        w += 15.0
     return w
 
 

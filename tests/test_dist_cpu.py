@@ -74,7 +74,7 @@ def test_balanced_boxes_are_boxes_of_equal_work():
         tot[r] += (1 * q.mat("coarse.inv.mat").nnz) if kind == 1 else 10 * q.mat("coarse.A").nnz
         tot[r] += q.mat("top.A").nnz
     part.close()
-    np.testing.assert_allclose(tot, np.bincount(bal, weights=w, minlength=8), rtol=1e-12)
+    np.testing.assert_allclose(tot, np.bincount(bal, weights=D.point_work(pc, A, vector_work=False), minlength=8), rtol=1e-12)
 
 
 def _owner(kind, gen, nranks):
