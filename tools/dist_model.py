@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--link", type=float, default=50e9, help="effective bandwidth to one peer (B/s)")
     ap.add_argument("--launch", type=float, default=4e-6, help="fixed cost of one kernel launch on the stream (s)")
     ap.add_argument("--min-interior", type=float, default=10e-6, help="interior kernel time below which no overlap is attempted (s)")
+    ap.add_argument("--equal-boxes", action="store_true", help="DMDA-style boxes of equal size instead of the boxes of equal work bench.py cuts (round 5)")
     ap.add_argument("--unfused", action="store_true", help="model the reference's sequence of products (rounds 1-4) instead of the fused first sweep")
     args = ap.parse_args()
     import pflare_amd as P
@@ -109,7 +110,7 @@ def main():
                  coarsest_matrix_free_polys=True, coarsest_poly_order=10)
     pc.setup_host_only(hm)
     L = pc.num_levels
-    owner = D.box_owner(M, M, M, args.ranks)
+    owner = D.box_owner(M, M, M, args.ranks) if args.equal_boxes else D.balanced_box_owner(D.point_work(pc, hm), (M, M, M), args.ranks)
     part = D.Partition(pc, hm, args.ranks, owner)
     pieces = []
     for r in range(args.ranks):
@@ -117,7 +118,8 @@ def main():
         pieces.append(Piece([(k, v.copy()) for k, v in ar.items()]))
         ar.close()
     part.close()
-    print(f"# {M}^3 = {M**3} rows, {L} levels, {args.ranks} ranks in boxes {D.box_dims(args.ranks, (M, M, M))}")
+    print(f"# {M}^3 = {M**3} rows, {L} levels, {args.ranks} ranks in boxes {D.box_dims(args.ranks, (M, M, M))} of equal {'size' if args.equal_boxes else 'work'}"
+          f" ({np.bincount(owner).min()} ... {np.bincount(owner).max()} rows per rank)")
     print(f"# model: kernels at {args.bw / 1e12:.1f} TB/s + {args.launch * 1e6:.0f} us per launch, exchange = {args.latency * 1e6:.0f} us + "
           f"bytes / {args.link / 1e9:.0f} GB/s per peer, overlap only above {args.min_interior * 1e6:.0f} us of interior work")
     level_bytes = model(pieces, L, args, 1.0, 1.0, f"as built: {M}^3")
