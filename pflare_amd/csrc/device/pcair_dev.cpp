@@ -542,9 +542,8 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
     // lose 0.03-0.2 ms each) - from 25 non-zeros of A_fc per C point on
     const bool fc_spatial = g_fc_spatial && !dist && (g_fc_spatial >= 2 || (h.n_c >= 4096 && h.A_fc.nnz() >= 25 * h.n_c));
     // The first F sweep on G = A_fc + A_ff W (set_fuse_first_sweep): relaxation that starts with F sweeps, one-point W,
-    // sparse A_ff, assembled A_ff inverse; one device (a distributed hierarchy keeps the reference's sequence).
-    // (a piece of a cut hierarchy brings its rows of G along, or keeps the reference's sequence)
-    // cut hierarchy: EVERY rank must take the same decision (the exchanges are collective), so it is the cut that decides - a
+    // sparse A_ff, assembled A_ff inverse.  One device: G is built below from the device copies of A_fc and A_ff.  Cut
+    // hierarchy: EVERY rank must take the same decision (the exchanges are collective), so it is the cut that decides - a
     // piece either carries its rows of G (possibly none) or it does not; the predicate on a piece's own rows would differ
     const bool fuse_first = g_fuse_first && (dist ? (!h.G.empty() && h.one_point) : h.fuses_first_sweep());
     bool later_f_group = false;
