@@ -342,7 +342,9 @@ int airhip_mat_mult_on_stream(airhip_mat A, const double* d_x, double* d_y, void
 /* diagnostic (the format tests decode it and compare with the CSR that went in, entry for entry): the row-block form of the
  * matrix as it lies on the device.  Sizes first (desc == NULL), then the arrays: desc = nblocks descriptors of 32 bytes
  * {int64 first value, int32 first row, int32 kind / base, int32 non-zeros, int32 rows, int64 byte offset of the index region},
- * idx = the index regions (idx_bytes), val = nnz values, roff = one 16-bit offset per row (csrc/device/dev.hpp). */
+ * idx = the index regions (idx_bytes), val = the value regions back to back - *nnz returns their length in doubles: the number
+ * of non-zeros unless blocks hold value dictionaries (table + 64 doubles of one-byte indices instead of the block's values);
+ * roff = one 16-bit offset per row (csrc/device/dev.hpp). */
 int airhip_mat_blocks(airhip_mat A, int64_t* nblocks, int64_t* idx_bytes, int64_t* nnz, void* desc, void* idx, double* val, void* roff);
 int airhip_mat_destroy(airhip_mat* A);
 

@@ -1374,13 +1374,13 @@ int airhip_mat_blocks(airhip_mat A, int64_t* nblocks, int64_t* idx_bytes, int64_
   API_BEGIN
   REQUIRE(A && nblocks && idx_bytes && nnz, AIRHIP_ERR_ARG, "null argument");
   const DevMat& M = A->A;
-  *nblocks = M.nblocks; *idx_bytes = M.idx_bytes; *nnz = M.nnz;
+  *nblocks = M.nblocks; *idx_bytes = M.idx_bytes; *nnz = M.val_len;      // (doubles of the value array: nnz unless blocks hold value dictionaries)
   if (desc) {
     REQUIRE(idx && val && roff, AIRHIP_ERR_ARG, "null argument");
     HIP_CHECK(hipStreamSynchronize(A->stream));
     if (M.nblocks) HIP_CHECK(hipMemcpy(desc, M.blk, sizeof(BlkDesc) * (size_t)M.nblocks, hipMemcpyDeviceToHost));
     if (M.idx_bytes) HIP_CHECK(hipMemcpy(idx, M.idx, (size_t)M.idx_bytes, hipMemcpyDeviceToHost));
-    if (M.nnz) HIP_CHECK(hipMemcpy(val, M.val, sizeof(double) * (size_t)M.nnz, hipMemcpyDeviceToHost));
+    if (M.val_len) HIP_CHECK(hipMemcpy(val, M.val, sizeof(double) * (size_t)M.val_len, hipMemcpyDeviceToHost));
     if (M.m) HIP_CHECK(hipMemcpy(roff, M.roff, sizeof(uint16_t) * (size_t)M.m, hipMemcpyDeviceToHost));
   }
   API_END

@@ -31,8 +31,8 @@ namespace airhip {
 //                run through several sections of a hierarchical vector (A_fc), which were raw before round 4.
 //                meta bits 12- (round 5): nd, the size of the block's VALUE DICTIONARY, 0 = plain values.  A multi-base block
 //                of at most 512 entries whose values take nd <= 256 distinct bit patterns (the operators of the first levels
-//                of a constant-coefficient problem: 1-5 distinct values on levels 1-2, ~150 per block on level 3) keeps, in its
-//                own 8 nb bytes of the value array, the nd distinct values (ascending bit patterns) followed by 512 bytes of
+//                of a constant-coefficient problem: 1-5 distinct values on levels 1-2, ~150 per block on level 3) keeps, as
+//                its region of the value array, the nd distinct values (ascending bit patterns) followed by 512 bytes of
 //                indices - byte 8 l + u = the index of entry 64 u + l, so that a lane fetches its eight indices with one
 //                8-byte load: 8 nd + 512 bytes of values per block instead of 8 nb.  Lossless: the kernels multiply the very
 //                same doubles in the very same order.
@@ -58,7 +58,9 @@ struct DevMat {
   uint16_t* roff = nullptr;      // [m] start of row r relative to its block's first non-zero
   uint8_t* idx = nullptr;        // [idx_bytes + 4] the blocks' index regions back to back (BlkDesc::ip), one readable padding word
   int64_t idx_bytes = 0;
-  double* val = nullptr;         // [nnz+1]
+  double* val = nullptr;         // [val_len + 1] the blocks' value regions back to back (BlkDesc::p0): 8 bytes per non-zero, or - a block with
+                                 // a value dictionary - nd values + 512 bytes of indices
+  int64_t val_len = 0;           // doubles in val (= nnz when no block has a dictionary)
   // Launch lists: copies of the descriptors in processing order, the multi-base blocks FIRST (they run in the lean kernels,
   // the other kinds in the *_g kernels - spmv.hip): [0, n_mb*) multi-base, [n_mb*, n*) the rest, each part in order.
   //  desc_ord  all nblocks blocks.  Storage order, or - operators whose rows run through the sections of a hierarchical
@@ -78,7 +80,7 @@ struct DevMat {
   // algorithmic bytes of one SpMV with this operator: S(X) of SURVEY 8(d)
   double s_bytes() const { return 12.0 * nnz + 4.0 * (m + 1) + 8.0 * m + 8.0 * n; }
   // bytes the format actually holds
-  double stored_bytes() const { return 8.0 * (nnz + 1) + (double)idx_bytes + 4.0 + 2.0 * m + 32.0 * nblocks * (desc_ord ? 2 : 1); }
+  double stored_bytes() const { return 8.0 * (val_len + 1) + (double)idx_bytes + 4.0 + 2.0 * m + 32.0 * nblocks * (desc_ord ? 2 : 1); }
   // share of s_bytes() that the lean kernels' launches carry
   double mb_share() const { return nnz > 0 ? (double)nnz_mb / (double)nnz : 1.0; }
 };

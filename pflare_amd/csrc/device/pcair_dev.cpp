@@ -726,7 +726,7 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
     auto acc = [&](const DevMat& m) { if (m.valid()) { nz += (double)m.nnz; ib += (double)m.idx_bytes; vb += (double)m.val_bytes; } };
     acc(A_perm_); acc(coarse_A_); acc(coarse_inv_.mat);
     for (auto& l : levels_) for (const DevMat* m : {&l->A_ff, &l->A_fc, &l->G, &l->A_cf, &l->A_cc, &l->Z, &l->W, &l->inv_ff.mat, &l->inv_cc.mat, &l->A_full}) acc(*m);
-    std::printf(" row blocks on the device: %.3g non-zeros, index regions %.2f bytes per non-zero, values %.2f read per non-zero (8 stored; value dictionaries where a block's values repeat), %.1f GB in all\n",
+    std::printf(" row blocks on the device: %.3g non-zeros, index regions %.2f bytes per non-zero, values %.2f bytes per non-zero (8 plain; value dictionaries where a block's values repeat), %.1f GB in all\n",
                 nz, nz > 0 ? ib / nz : 0.0, nz > 0 ? vb / nz : 0.0, storage_bytes() * 1e-9);
     // how full the blocks are (512 entries = full): rows of 257 ... 511 entries cannot share a block
     std::printf(" non-zeros per row block (A_ff, M_ff, A_fc, Z) by level:");

@@ -908,8 +908,11 @@ __device__ __forceinline__ int val_slot(int s, int n) {
 //   value dictionary (vdict_on; multi-base blocks of <= 512 entries): the block's values have at most MB_MAX_ND distinct bit
 //     patterns and the dictionary form (8 nd + 512 bytes) is at most 5/8 of the plain values: dev.hpp.
 __global__ __launch_bounds__(BLOCK) void k_block_pack(int64_t nblocks, int64_t nnz, int64_t m, BlkDesc* __restrict__ blk, int32_t* col,
-                                                     const double* __restrict__ val, double* __restrict__ oval, int mb_on, int mb_max_rows, int vdict_on) {
+                                                     double* val, int mb_on, int mb_max_rows, int vdict_on) {
+  // (the values are rearranged IN PLACE: a block's values are all in registers - eight a lane - before its first store)
   __shared__ unsigned long long keys_all[WAVES_PER_BLOCK][BLK_NNZ];
+  __shared__ double vals_all[WAVES_PER_BLOCK][BLK_NNZ];
+  double* const oval = val;
   __shared__ uint32_t tab_all[WAVES_PER_BLOCK][MB_MAX_WIN];
   __shared__ unsigned short word_all[WAVES_PER_BLOCK][BLK_NNZ];
   unsigned long long* keys = keys_all[threadIdx.x >> 6];
@@ -927,10 +930,10 @@ __global__ __launch_bounds__(BLOCK) void k_block_pack(int64_t nblocks, int64_t n
     uint32_t* oidx = reinterpret_cast<uint32_t*>(col);
     if (nbl == 0 || nbl > BLK_NNZ) {
       // one long row (or an empty block): row-major order; the first 512 values in the interleaved placement
-      const int n512 = (int)(nbl < BLK_NNZ ? nbl : BLK_NNZ);
-      for (int64_t k = p0 + lane; k < p1; k += WAVE) {
-        const int64_t q = k - p0;
-        oval[q < n512 ? p0 + val_slot((int)q, n512) : k] = val[k];
+      if (nbl) {
+        double head[EPL];
+        for (int u = 0; u < EPL; u++) head[u] = val[p0 + u * WAVE + lane];
+        for (int u = 0; u < EPL; u++) oval[p0 + val_slot(u * WAVE + lane, BLK_NNZ)] = head[u];
       }
       if (nbl == 0 || !mb_on) continue;      // raw: the absolute columns are in place already
       // multi-base form of a long row: its distinct windows (column >> ob) are collected in a small hash set in LDS (the row
@@ -1001,6 +1004,8 @@ __global__ __launch_bounds__(BLOCK) void k_block_pack(int64_t nblocks, int64_t n
       continue;
     }
     const int nb = (int)nbl;
+    double vreg[EPL];
+    for (int u = 0; u < EPL; u++) vreg[u] = u * WAVE + lane < nb ? val[p0 + u * WAVE + lane] : 0.0;
     int P2 = WAVE; while (P2 < nb) P2 <<= 1;
     for (int i = lane; i < P2; i += WAVE)
       keys[i] = i < nb ? (((unsigned long long)(uint32_t)col[p0 + i]) << 16) | (unsigned long long)i : ~0ull;
@@ -1066,12 +1071,12 @@ __global__ __launch_bounds__(BLOCK) void k_block_pack(int64_t nblocks, int64_t n
       int ndv = 0;
       if (vdict_on && nb >= 2 * WAVE) {
         constexpr unsigned long long EMPTYV = ~0ull;
-        const unsigned long long* vbits = reinterpret_cast<const unsigned long long*>(val + p0);
         for (int i = lane; i < BLK_NNZ; i += WAVE) keys[i] = EMPTYV;
         lds_sync();
         bool bad = false;
-        for (int i = lane; i < nb; i += WAVE) {
-          const unsigned long long v = vbits[i];
+        for (int u = 0; u < EPL; u++) {
+          if (u * WAVE + lane >= nb) continue;
+          const unsigned long long v = (unsigned long long)__double_as_longlong(vreg[u]);
           if (v == EMPTYV) { bad = true; continue; }
           uint32_t h = (uint32_t)((v * 0x9E3779B97F4A7C15ull) >> 55);      // 9 bits
           // (the set has as many slots as a block has entries, so every pattern finds one; the probe count is bounded all the same)
@@ -1107,7 +1112,7 @@ __global__ __launch_bounds__(BLOCK) void k_block_pack(int64_t nblocks, int64_t n
           for (int u = 0; u < EPL; u++) {
             const int i = u * WAVE + lane;
             if (i < nb) {
-              const unsigned long long v = vbits[i];
+              const unsigned long long v = (unsigned long long)__double_as_longlong(vreg[u]);
               int lo = 0, hi = ndv - 1;
               while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < v) lo = mid + 1; else hi = mid; }
               packed |= (unsigned long long)lo << (8 * u);
@@ -1117,22 +1122,25 @@ __global__ __launch_bounds__(BLOCK) void k_block_pack(int64_t nblocks, int64_t n
         }
         lds_sync();
       }
-      if (!ndv) for (int i = lane; i < nb; i += WAVE) oval[p0 + val_slot(i, nb)] = val[p0 + i];
+      if (!ndv) for (int u = 0; u < EPL; u++) if (u * WAVE + lane < nb) oval[p0 + val_slot(u * WAVE + lane, nb)] = vreg[u];
       if (lane == 0) { blk[b].cbase = -2 - (ob | (nwin << MB_WIN_SHIFT) | (ndv << MB_ND_SHIFT)); blk[b].ip = 4 * (int64_t)(nwin + nd); }
     } else if (can_pack && (!mb_on || nrows > mb_max_rows)) {
       // packed: the multi-base form is off, or the block has more rows than mb16_max_rows admits to it (the documented
       // meaning of that knob: such blocks keep the packed form of rounds 2-3 and run in the *_g kernels).  With the
       // multi-base form on, a block that was ADMITTED but fits no table stays raw: the lean kernels take it, and a launch
       // of the *_g kernels for a handful of one-entry blocks per operator costs more than their 4-byte words.
+      double* vl = vals_all[threadIdx.x >> 6];
+      for (int u = 0; u < EPL; u++) if (u * WAVE + lane < nb) vl[u * WAVE + lane] = vreg[u];
+      lds_sync();
       for (int i = lane; i < nb; i += WAVE) {
         const unsigned long long k = keys[i];
         const int pos = (int)(k & 0xffffull);
         oidx[p0 + i] = ((uint32_t)((int32_t)(k >> 16) - cmin) << (POS_BITS + 3)) | (uint32_t)(pos + 1);
-        oval[p0 + val_slot(i, nb)] = val[p0 + pos];
+        oval[p0 + val_slot(i, nb)] = vl[pos];
       }
       if (lane == 0) blk[b].cbase = cmin;
     } else {
-      for (int i = lane; i < nb; i += WAVE) oval[p0 + val_slot(i, nb)] = val[p0 + i];
+      for (int u = 0; u < EPL; u++) if (u * WAVE + lane < nb) oval[p0 + val_slot(u * WAVE + lane, nb)] = vreg[u];
     }
     lds_sync();
   }
@@ -1225,6 +1233,19 @@ __global__ __launch_bounds__(BLOCK) void k_val_bytes(int64_t n, const BlkDesc* _
     out[i] = nd ? 8 * (int64_t)nd + 8 * WAVE : 8 * (int64_t)d[i].nb;
   }
 }
+// the value regions back to back: k_val_bytes gave each block's bytes; the region is copied from where k_block_pack left it
+// (the block's first non-zero in `src`) to its offset in the compact array, and the descriptor follows
+__global__ __launch_bounds__(BLOCK) void k_val_compact(int64_t nblocks, BlkDesc* __restrict__ blk, const int64_t* __restrict__ sz, const int64_t* __restrict__ off,
+                                                      const double* __restrict__ src, double* __restrict__ dst) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * BLOCK) >> 6;
+  for (int64_t b = wave; b < nblocks; b += nwaves) {
+    const int64_t nd = sz[b] >> 3, o = off[b] >> 3, p0 = blk[b].p0;
+    for (int64_t k = lane; k < nd; k += WAVE) dst[o + k] = src[p0 + k];
+    if (lane == 0) blk[b].p0 = o;
+  }
+}
 // out (n descriptors, may not alias in) = in with the multi-base blocks first; returns their number, *nnz_mb their non-zeros
 static int64_t partition_descs_device(const BlkDesc* in, int64_t n, BlkDesc* out, hipStream_t s, int64_t* nnz_mb) {
   if (nnz_mb) *nnz_mb = 0;
@@ -1297,11 +1318,10 @@ void devmat_from_csr_device(int64_t m, int64_t n, const int64_t* d_rp, const int
   hipLaunchKernelGGL((k_chunk_blocks<true>), dim3(grid1d(nchunks)), dim3(BLOCK), 0, s, m, d_nrp, d_cnt, d_first, out.blk, out.roff);
   const BlkDesc end{out.nnz, (int32_t)m, 0, 0, 0, 0};            // readable padding entry (empty block)
   HIP_CHECK(hipMemcpyAsync(out.blk + out.nblocks, &end, sizeof(BlkDesc), hipMemcpyHostToDevice, s));
-  out.val = (double*)alloc_out(sizeof(double) * (size_t)(out.nnz + 1));
-  HIP_CHECK(hipMemsetAsync(out.val + out.nnz, 0, sizeof(double), s));
+  // (the values are rearranged in place in tval and then laid back to back in the final array)
   const int g = (int)std::min<int64_t>((out.nblocks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 4096);
   // kinds, values and index regions (in place over tcol), then the regions back to back
-  hipLaunchKernelGGL(k_block_pack, dim3(g < 1 ? 1 : g), dim3(BLOCK), 0, s, out.nblocks, out.nnz, m, out.blk, tcol, tval, out.val, g_mb16, g_mb16_max_rows, g_vdict);
+  hipLaunchKernelGGL(k_block_pack, dim3(g < 1 ? 1 : g), dim3(BLOCK), 0, s, out.nblocks, out.nnz, m, out.blk, tcol, tval, g_mb16, g_mb16_max_rows, g_vdict);
   int64_t* d_sz = (int64_t*)dev_alloc(sizeof(int64_t) * (size_t)out.nblocks);
   int64_t* d_off = (int64_t*)dev_alloc(sizeof(int64_t) * (size_t)out.nblocks);
   hipLaunchKernelGGL(k_region_sizes, dim3(grid1d(out.nblocks)), dim3(BLOCK), 0, s, out.nblocks, out.blk, d_sz);
@@ -1311,9 +1331,16 @@ void devmat_from_csr_device(int64_t m, int64_t n, const int64_t* d_rp, const int
   hipLaunchKernelGGL(k_idx_compact, dim3(g < 1 ? 1 : g), dim3(BLOCK), 0, s, out.nblocks, out.blk, d_off, reinterpret_cast<const uint32_t*>(tcol), out.idx);
   // the launch list in storage order (DevPCAIR::upload replaces it with a spatial order where that pays)
   out.desc_ord = (BlkDesc*)alloc_out(sizeof(BlkDesc) * (size_t)out.nblocks);
-  out.n_mb = partition_descs_device(out.blk, out.nblocks, out.desc_ord, s, &out.nnz_mb);
+  // the value regions back to back (a block with a dictionary keeps nd + 64 doubles, the others their non-zeros); BEFORE the
+  // launch list is derived: the descriptors' p0 move
   hipLaunchKernelGGL(k_val_bytes, dim3(grid1d(out.nblocks)), dim3(BLOCK), 0, s, out.nblocks, out.blk, d_sz);
   out.val_bytes = device_exclusive_scan(out.nblocks, d_sz, d_off, s);
+  out.val_len = out.val_bytes >> 3;
+  out.val = (double*)alloc_out(sizeof(double) * (size_t)(out.val_len + 1));
+  HIP_CHECK(hipMemsetAsync(out.val + out.val_len, 0, sizeof(double), s));
+  hipLaunchKernelGGL(k_val_compact, dim3(g < 1 ? 1 : g), dim3(BLOCK), 0, s, out.nblocks, out.blk, d_sz, d_off, tval, out.val);
+  { const BlkDesc end2{out.val_len, (int32_t)m, 0, 0, 0, 0}; HIP_CHECK(hipMemcpyAsync(out.blk + out.nblocks, &end2, sizeof(BlkDesc), hipMemcpyHostToDevice, s)); HIP_CHECK(hipStreamSynchronize(s)); }
+  out.n_mb = partition_descs_device(out.blk, out.nblocks, out.desc_ord, s, &out.nnz_mb);
   HIP_CHECK(hipStreamSynchronize(s));
   check_launch("row-block conversion");
   dev_free(d_nrp); dev_free(d_cnt); dev_free(d_first); dev_free(tcol); dev_free(tval); dev_free(d_sz); dev_free(d_off);

@@ -248,15 +248,19 @@ def decode_blocks(dm):
     indptr = np.zeros(m + 1, dtype=np.int64)
     cols_out, vals_out = [], []
     kinds = {"packed": 0, "raw": 0, "multi-base": 0, "dictionary": 0}
+    q0 = 0              # non-zeros before the block (p0 is its place in the value array, where dictionary blocks are shorter)
+    expect_p0 = 0
     for d in desc:
         p0, row, cbase, nb, nr, ip = (int(d[k]) for k in ("p0", "row", "cbase", "nb", "nr", "ip"))
         if nb == 0:
             continue
         assert ip % 4 == 0
+        assert p0 == expect_p0, "the value regions are not back to back"
         n512 = min(nb, 512)
         slot = np.arange(nb)
         vpos = np.where(slot < n512, _val_slot(np.minimum(slot, n512 - 1), n512), slot)
-        v = val[p0 + vpos]                                   # value of logical slot s
+        has_dict = cbase <= -2 and ((-(cbase + 2)) >> 12) > 0
+        v = None if has_dict else val[p0 + vpos]             # value of logical slot s (a dictionary block: decoded below)
         if cbase >= 0:
             w = idx[ip:ip + 4 * nb].view("<u4")
             col = cbase + (w >> 13).astype(np.int64)
@@ -274,7 +278,7 @@ def decode_blocks(dm):
             assert 1 <= nwin <= 64 and nwin <= (1 << (16 - ob))      # (a long row may be multi-base as well)
             if ndv:
                 # value dictionary (dev.hpp): ndv distinct values in ascending bit pattern order, then 512 bytes of indices,
-                # byte 8 l + u = index of entry 64 u + l - inside the block's own 8 nb bytes of the value array
+                # byte 8 l + u = index of entry 64 u + l - the block's region of the value array is these ndv + 64 doubles
                 assert nb <= 512 and 1 <= ndv <= 256 and 8 * (ndv + 64) <= 5 * nb
                 table = val[p0:p0 + ndv]
                 tb = table.view("<u8")
@@ -302,7 +306,10 @@ def decode_blocks(dm):
         ends = np.concatenate([ro[1:], [nb]])
         assert ro[0] == 0 and np.all(ends >= ro)
         indptr[row + 1:row + nr + 1] = ends - ro
-        cols_out.append((p0, c_rm)); vals_out.append(v_rm)
+        cols_out.append((q0, c_rm)); vals_out.append(v_rm)
+        q0 += nb
+        expect_p0 += (ndv + 64) if (cbase <= -2 and ndv) else nb
+    assert expect_p0 == val.size, (expect_p0, val.size)
     np.cumsum(indptr, out=indptr)
     nnz = int(indptr[-1])
     cols = np.zeros(nnz, dtype=np.int64); vals = np.zeros(nnz)
