@@ -155,6 +155,20 @@ __device__ __forceinline__ rsrc_t make_rsrc32(const void* base, int bytes) {
 __device__ __forceinline__ double buf_f64(rsrc_t r, int voff, int soff = 0) {
   return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
 }
+// Cache policy of the loads of the matrix stream (values, index words, dictionaries: bytes one wave reads once per product) -
+// the `aux` operand of the buffer loads: 0 = default, 2 = nt (non-temporal: the line is the first to leave the caches, so the
+// stream does not push the x lines the gathers share out of the XCD's L2).  The gathers and the vectors keep the default.
+#ifndef AIRHIP_STREAM_AUX
+#define AIRHIP_STREAM_AUX 0
+#endif
+constexpr int STREAM_AUX = AIRHIP_STREAM_AUX;
+__device__ __forceinline__ double stream_f64(rsrc_t r, int voff, int soff = 0) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, STREAM_AUX));
+}
+template <typename T> __device__ __forceinline__ T stream_ld(const T* p) {
+  if constexpr (STREAM_AUX == 2) return __builtin_nontemporal_load(p);
+  else return *p;
+}
 __device__ __forceinline__ void buf_store_f64(rsrc_t r, int voff, double v) {
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((__vector_size__(2 * sizeof(unsigned int)))) unsigned int, v), r, voff, 0, 0);
 }
@@ -179,13 +193,13 @@ __device__ __forceinline__ void issue_values(const RbView& A, const BlkInfo& d, 
 #pragma unroll
   for (int i = 0; i < EPL / 2; i++) {
     if (i < R::npair) {
-      const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rv, lane * 16, i * 2 * WAVE * 8, 0);
+      const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rv, lane * 16, i * 2 * WAVE * 8, STREAM_AUX);
       vv[2 * i] = __builtin_bit_cast(double, (unsigned long long)q.x | ((unsigned long long)q.y << 32));
       vv[2 * i + 1] = __builtin_bit_cast(double, (unsigned long long)q.z | ((unsigned long long)q.w << 32));
     } else {
       vv[2 * i] = 0.0; vv[2 * i + 1] = 0.0;
-      if (R::has(2 * i)) vv[2 * i] = buf_f64(rv, lane * 8, 2 * i * WAVE * 8);
-      if (R::has(2 * i + 1)) vv[2 * i + 1] = buf_f64(rv, lane * 8, (2 * i + 1) * WAVE * 8);
+      if (R::has(2 * i)) vv[2 * i] = stream_f64(rv, lane * 8, 2 * i * WAVE * 8);
+      if (R::has(2 * i + 1)) vv[2 * i + 1] = stream_f64(rv, lane * 8, (2 * i + 1) * WAVE * 8);
     }
   }
 }
@@ -197,7 +211,7 @@ __device__ __forceinline__ void issue_stream(const RbView& A, const BlkInfo& d, 
   const int n = d.nb < BLK_NNZ ? d.nb : BLK_NNZ;
   const rsrc_t ri = make_rsrc32(A.idx + d.ip, n * 4);
 #pragma unroll
-  for (int u = 0; u < EPL; u++) { ix[u] = 0; if (R::has(u)) ix[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(ri, lane * 4, u * WAVE * 4, 0); }
+  for (int u = 0; u < EPL; u++) { ix[u] = 0; if (R::has(u)) ix[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(ri, lane * 4, u * WAVE * 4, STREAM_AUX); }
   issue_values<NF>(A, d, n, lane, vv);
 }
 
@@ -209,16 +223,16 @@ template <int NF>
 __device__ __forceinline__ void issue_index_mb(const RbView& A, const BlkInfo& d, int nwin, int lane, uint32_t& tab, uint32_t (&iw)[EPL / 2]) {
   typedef Rounds<NF> R;
   const uint8_t* __restrict__ ib = A.idx + d.ip;
-  tab = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc32(ib, nwin * 4), lane * 4, 0, 0);
+  tab = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc32(ib, nwin * 4), lane * 4, 0, STREAM_AUX);
   const rsrc_t ri = make_rsrc32(ib + nwin * 4, d.nb * 2);
 #pragma unroll
   for (int i = 0; i < EPL / 2; i++) {
     iw[i] = 0;
-    if (i < R::npair) iw[i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(ri, lane * 4, i * 2 * WAVE * 2, 0);
+    if (i < R::npair) iw[i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(ri, lane * 4, i * 2 * WAVE * 2, STREAM_AUX);
     else {
       uint32_t lo = 0, hi = 0;
-      if (R::has(2 * i)) lo = (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(ri, lane * 2, 2 * i * WAVE * 2, 0);
-      if (R::has(2 * i + 1)) hi = (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(ri, lane * 2, (2 * i + 1) * WAVE * 2, 0);
+      if (R::has(2 * i)) lo = (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(ri, lane * 2, 2 * i * WAVE * 2, STREAM_AUX);
+      if (R::has(2 * i + 1)) hi = (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(ri, lane * 2, (2 * i + 1) * WAVE * 2, STREAM_AUX);
       if (R::has(2 * i)) iw[i] = lo | (hi << 16);
     }
   }
@@ -234,9 +248,9 @@ __device__ __forceinline__ void wave_lds_sync();
 __device__ __forceinline__ void issue_dictionary(const RbView& A, const BlkInfo& d, int nd, int lane, double (&tq)[4], unsigned long long& vi) {
   const rsrc_t rt = make_rsrc32(A.val + d.p0, nd * 8);
 #pragma unroll
-  for (int k = 0; k < 4; k++) tq[k] = buf_f64(rt, lane * 8, k * WAVE * 8);
+  for (int k = 0; k < 4; k++) tq[k] = stream_f64(rt, lane * 8, k * WAVE * 8);
   const rsrc_t rv = make_rsrc32(A.val + d.p0 + nd, WAVE * 8);
-  vi = __builtin_bit_cast(unsigned long long, buf_f64(rv, lane * 8));
+  vi = __builtin_bit_cast(unsigned long long, stream_f64(rv, lane * 8));
 }
 // ... into the wave's staging area, and from there the values of this lane's slots (entries past the block's end: zero, as
 // the range check gives for plain values).  The staging area is free until the products are parked in it.
@@ -382,12 +396,12 @@ __device__ __forceinline__ void rb_body(const RbView& A, const BlkInfo& d, const
     }
     int j = BLK_NNZ + lane;
     for (; j + 3 * WAVE < nb; j += 4 * WAVE) {
-      const uint32_t c0 = ip[j], c1 = ip[j + WAVE], c2 = ip[j + 2 * WAVE], c3 = ip[j + 3 * WAVE];
-      const double v0 = vp[j], v1 = vp[j + WAVE], v2 = vp[j + 2 * WAVE], v3 = vp[j + 3 * WAVE];
+      const uint32_t c0 = stream_ld(ip + j), c1 = stream_ld(ip + j + WAVE), c2 = stream_ld(ip + j + 2 * WAVE), c3 = stream_ld(ip + j + 3 * WAVE);
+      const double v0 = stream_ld(vp + j), v1 = stream_ld(vp + j + WAVE), v2 = stream_ld(vp + j + 2 * WAVE), v3 = stream_ld(vp + j + 3 * WAVE);
       const double x0 = x.at_byte_offset(c0 << 3), x1 = x.at_byte_offset(c1 << 3), x2 = x.at_byte_offset(c2 << 3), x3 = x.at_byte_offset(c3 << 3);
       s0 = fma(v0, x0, s0); s1 = fma(v1, x1, s1); s2 = fma(v2, x2, s2); s3 = fma(v3, x3, s3);
     }
-    for (; j < nb; j += WAVE) s0 = fma(vp[j], x.at_byte_offset(ip[j] << 3), s0);
+    for (; j < nb; j += WAVE) s0 = fma(stream_ld(vp + j), x.at_byte_offset(stream_ld(ip + j) << 3), s0);
     double s = (s0 + s1) + (s2 + s3);
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
     epi.store(d.r0, nr, lane, s, pre[0]);      // nr = 1: only lane 0 is inside the block
@@ -469,15 +483,15 @@ __device__ __forceinline__ void rb_body_mb(const RbView& A, const BlkInfo& d, co
       while (__any(j + 3 * WAVE < nb)) {
         const bool p = j + 3 * WAVE < nb;
         const int jj = p ? j : lane;         // (lanes that are done read positions inside the first 512: always the block's own)
-        const uint32_t c0 = wp[jj], c1 = wp[jj + WAVE], c2 = wp[jj + 2 * WAVE], c3 = wp[jj + 3 * WAVE];
-        const double v0 = vp[jj], v1 = vp[jj + WAVE], v2 = vp[jj + 2 * WAVE], v3 = vp[jj + 3 * WAVE];
+        const uint32_t c0 = stream_ld(wp + jj), c1 = stream_ld(wp + jj + WAVE), c2 = stream_ld(wp + jj + 2 * WAVE), c3 = stream_ld(wp + jj + 3 * WAVE);
+        const double v0 = stream_ld(vp + jj), v1 = stream_ld(vp + jj + WAVE), v2 = stream_ld(vp + jj + 2 * WAVE), v3 = stream_ld(vp + jj + 3 * WAVE);
         const double x0 = xat(c0), x1 = xat(c1), x2 = xat(c2), x3 = xat(c3);
         if (p) { s0 = fma(v0, x0, s0); s1 = fma(v1, x1, s1); s2 = fma(v2, x2, s2); s3 = fma(v3, x3, s3); j += 4 * WAVE; }
       }
       for (; __any(j < nb); j += WAVE) {
-        const uint32_t w = j < nb ? (uint32_t)wp[j] : 0u;
+        const uint32_t w = j < nb ? (uint32_t)stream_ld(wp + j) : 0u;
         const double xv = xat(w);
-        if (j < nb) s0 = fma(vp[j], xv, s0);
+        if (j < nb) s0 = fma(stream_ld(vp + j), xv, s0);
       }
       double s = (s0 + s1) + (s2 + s3);
       for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
