@@ -117,8 +117,8 @@ int airhip_set_num_threads(int n, int* prev);
  *   "ksp_unnormalised" (default 1: GMRES keeps its basis vectors unnormalised and their norms on the host - no scaling
  *   pass per iteration; 0: normalised basis.  Same Hessenberg matrix up to rounding, identical iteration counts),
  *   "fuse_first_sweep" (default 1, acts at the next upload: on the levels whose relaxation starts with F sweeps - one-point W,
- *   sparse A_ff, assembled A_ff inverse - the first sweep runs on G = A_fc + A_ff W, four products per level instead of the
- *   reference's five; same iterates up to rounding (1e-13 per cycle), NOT bit for bit; 0 = the reference's sequence; 2 = as 1
+ *   sparse A_ff, A_ff inverse assembled or a matrix-free polynomial - the first sweep runs on G = A_fc + A_ff W, four products
+ *   per level instead of the reference's five (matrix-free: one product with A_ff less); same iterates up to rounding (1e-13 per cycle), NOT bit for bit; 0 = the reference's sequence; 2 = as 1
  *   and A_fc stays on the device, so that "fuse_first_sweep_run" (default 1) can switch between the two sequences on one
  *   hierarchy), "profile_chain" (default 1: inside the cycle the stop event of one profiled kernel is the start event of the
  *   next; 0 = a pair of events per kernel),

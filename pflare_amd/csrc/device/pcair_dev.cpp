@@ -542,7 +542,7 @@ void DevPCAIR::upload(const Hierarchy& H, const Csr& A_top, const LocalHierarchy
     // lose 0.03-0.2 ms each) - from 25 non-zeros of A_fc per C point on
     const bool fc_spatial = g_fc_spatial && !dist && (g_fc_spatial >= 2 || (h.n_c >= 4096 && h.A_fc.nnz() >= 25 * h.n_c));
     // The first F sweep on G = A_fc + A_ff W (set_fuse_first_sweep): relaxation that starts with F sweeps, one-point W,
-    // sparse A_ff, assembled A_ff inverse.  One device: G is built below from the device copies of A_fc and A_ff.  Cut
+    // sparse A_ff, an A_ff inverse applied as a linear operator (assembled or matrix-free).  One device: G is built below from the device copies of A_fc and A_ff.  Cut
     // hierarchy: EVERY rank must take the same decision (the exchanges are collective), so it is the cut that decides - a
     // piece either carries its rows of G (possibly none) or it does not; the predicate on a piece's own rows would differ
     const bool fuse_first = g_fuse_first && (dist ? (!h.G.empty() && h.one_point) : h.fuses_first_sweep());
@@ -878,8 +878,7 @@ void DevPCAIR::f_smooths(DevLevel& L, int li, bool first, int its) {
     if (its == 2) {
       // two sweeps (the default "ff"): x_2 = x_0 + M r_0 + M r_1 = x_0 + M (r_0 + r_1) with r_1 = r_0 - A_ff M r_0 - M is
       // linear -, so the first inverse product needs no update of x riding along and the last one is the plain x += M s
-      SpmvEpi e; e.out = L.t4.p;                                                        // d = M r_0
-      spmv(L.inv_ff.mat, L.r.p, e, "d=M_ff*r", li);
+      apply_inv(L.inv_ff, L.r.p, L.t4.p, false, li, "d=M_ff*r");                          // d = M r_0 (assembled: one product; matrix-free: the polynomial)
       SpmvEpi e2; e2.out = L.r.p; e2.alpha = -1.0; e2.z = L.r.p; e2.beta = 2.0;      // s = r_0 + r_1 = 2 r_0 - A_ff d (row i reads and writes r_i only)
       spmv(L.A_ff, L.t4.p, e2, "s=2r-A_ff*d", li);
       apply_inv(L.inv_ff, L.r.p, x_f, true, li, "x_f+=M_ff*s");
@@ -887,8 +886,14 @@ void DevPCAIR::f_smooths(DevLevel& L, int li, bool first, int its) {
     }
     for (int it = 0; it < its; it++) {
       if (it + 1 == its) { apply_inv(L.inv_ff, L.r.p, x_f, true, li, "x_f+=M_ff*r"); break; }
-      SpmvEpi e; e.out = L.t4.p; e.y2 = x_f; e.delta = 1.0; e.aux_out = 1;             // d = M r, x_f += d
-      spmv(L.inv_ff.mat, L.r.p, e, "d=M_ff*r,x_f+=d", li);
+      if (L.inv_ff.kind == InvOp::ASSEMBLED) {
+        SpmvEpi e; e.out = L.t4.p; e.y2 = x_f; e.delta = 1.0; e.aux_out = 1;           // d = M r, x_f += d
+        spmv(L.inv_ff.mat, L.r.p, e, "d=M_ff*r,x_f+=d", li);
+      } else {
+        apply_inv(L.inv_ff, L.r.p, L.t4.p, false, li, "d=M_ff*r");
+        Aux t(this, "x_f+=d", li, 24.0 * L.n_f, "k_axpby");
+        launch_axpby(L.n_f, 1.0, L.t4.p, 1.0, x_f, x_f, stream_);
+      }
       SpmvEpi e2; e2.out = L.r.p; e2.alpha = -1.0; e2.z = L.r.p; e2.beta = 1.0;      // r -= A_ff d (row i reads and writes r_i only)
       spmv(L.A_ff, L.t4.p, e2, "r-=A_ff*d", li);
     }

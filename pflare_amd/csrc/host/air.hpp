@@ -85,9 +85,11 @@ struct Level {
   // space [local | ghosts of G].  On one device the upload builds G from the device copies of A_fc and A_ff instead.
   Csr G;
   Arr<int32_t> wcol_g;
-  // the cycle may run its first F sweep on G: relaxation that starts with F sweeps, one-point W, sparse A_ff, assembled A_ff inverse
+  // the cycle may run its first F sweep on G: relaxation that starts with F sweeps, one-point W, sparse A_ff, an A_ff inverse that
+  // is a linear operator applied as such (assembled, or a matrix-free polynomial in A_ff)
   bool fuses_first_sweep() const {
-    return one_point && !aff_diag && smooth_order[0] > 0 && inv_ff.kind == InvOp::ASSEMBLED && A_fc.nnz() > 0 && A_ff.nnz() > 0 && !full;
+    const bool lin = inv_ff.kind == InvOp::ASSEMBLED || inv_ff.kind == InvOp::HORNER || inv_ff.kind == InvOp::NEWTON;
+    return one_point && !aff_diag && smooth_order[0] > 0 && lin && A_fc.nnz() > 0 && A_ff.nnz() > 0 && !full;
   }
   int smooth_order[10] = {0};
   int64_t nnz_A = 0;             // nnz of the level operator (for complexities)

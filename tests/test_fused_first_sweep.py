@@ -116,6 +116,11 @@ CYCLE_CASES = {
     "adv2d_40_fcf": (dict(dim=2, M=40, N=40), dict(smooth_type="fcf")),          # the second F group needs A_fc itself
     "adv2d_40_fc": (dict(dim=2, M=40, N=40), dict(smooth_type="fc")),
     "diff2d_30_diagscale": (dict(dim=2, M=30, N=30, u=0.0, v=0.0, alpha=1.0), dict(diag_scale_polys=True)),
+    # matrix-free polynomial inverses (Horner / Newton / Neumann): d = M r is the polynomial, one A_ff product less per level
+    "adv2d_50_mf": (dict(dim=2, M=50, N=50), dict(matrix_free_polys=True)),
+    "adv2d_50_mf_fff": (dict(dim=2, M=50, N=50), dict(matrix_free_polys=True, smooth_type="fff")),
+    "adv2d_40_newton_mf": (dict(dim=2, M=40, N=40), dict(inverse_type="newton", matrix_free_polys=True)),
+    "diff2d_30_neumann_mf": (dict(dim=2, M=30, N=30, u=0.0, v=0.0, alpha=1.0), dict(inverse_type="neumann", matrix_free_polys=True)),
     "adv3d_20_trunc": (dict(dim=3, M=20, N=20, P=20), dict(a_lump=True, auto_truncate_start_level=1, auto_truncate_tol=1e-1,
                                                            coarsest_inverse_type="newton", coarsest_matrix_free_polys=True, coarsest_poly_order=10)),
 }
