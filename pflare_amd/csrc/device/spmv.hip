@@ -922,10 +922,11 @@ __device__ __forceinline__ int val_slot(int s, int n) {
 //   value dictionary (vdict_on; multi-base blocks of <= 512 entries): the block's values have at most MB_MAX_ND distinct bit
 //     patterns and the dictionary form (8 nd + 512 bytes) is at most 5/8 of the plain values: dev.hpp.
 __global__ __launch_bounds__(BLOCK) void k_block_pack(int64_t nblocks, int64_t nnz, int64_t m, BlkDesc* __restrict__ blk, int32_t* col,
-                                                     double* val, int mb_on, int mb_max_rows, int vdict_on) {
-  // (the values are rearranged IN PLACE: a block's values are all in registers - eight a lane - before its first store)
+                                                     double* __restrict__ val, int mb_on, int mb_max_rows, int vdict_on) {
+  // (values: a block that gets a dictionary, or the packed form, rewrites its values IN PLACE - all of them in registers, eight
+  // a lane, before the first store; every other block leaves them as they are and k_val_compact puts them into the
+  // interleaved placement on its way to the final array)
   __shared__ unsigned long long keys_all[WAVES_PER_BLOCK][BLK_NNZ];
-  __shared__ double vals_all[WAVES_PER_BLOCK][BLK_NNZ];
   double* const oval = val;
   __shared__ uint32_t tab_all[WAVES_PER_BLOCK][MB_MAX_WIN];
   __shared__ unsigned short word_all[WAVES_PER_BLOCK][BLK_NNZ];
@@ -943,12 +944,7 @@ __global__ __launch_bounds__(BLOCK) void k_block_pack(int64_t nblocks, int64_t n
     if (lane == 0) { blk[b].nb = (int32_t)nbl; blk[b].nr = nrows; blk[b].ip = 4 * nbl; }
     uint32_t* oidx = reinterpret_cast<uint32_t*>(col);
     if (nbl == 0 || nbl > BLK_NNZ) {
-      // one long row (or an empty block): row-major order; the first 512 values in the interleaved placement
-      if (nbl) {
-        double head[EPL];
-        for (int u = 0; u < EPL; u++) head[u] = val[p0 + u * WAVE + lane];
-        for (int u = 0; u < EPL; u++) oval[p0 + val_slot(u * WAVE + lane, BLK_NNZ)] = head[u];
-      }
+      // one long row (or an empty block): row-major order; k_val_compact gives the first 512 values the interleaved placement
       if (nbl == 0 || !mb_on) continue;      // raw: the absolute columns are in place already
       // multi-base form of a long row: its distinct windows (column >> ob) are collected in a small hash set in LDS (the row
       // is too long to sort here); a window's base is its smallest column, its number its rank among the row's windows
@@ -1018,8 +1014,6 @@ __global__ __launch_bounds__(BLOCK) void k_block_pack(int64_t nblocks, int64_t n
       continue;
     }
     const int nb = (int)nbl;
-    double vreg[EPL];
-    for (int u = 0; u < EPL; u++) vreg[u] = u * WAVE + lane < nb ? val[p0 + u * WAVE + lane] : 0.0;
     int P2 = WAVE; while (P2 < nb) P2 <<= 1;
     for (int i = lane; i < P2; i += WAVE)
       keys[i] = i < nb ? (((unsigned long long)(uint32_t)col[p0 + i]) << 16) | (unsigned long long)i : ~0ull;
@@ -1085,22 +1079,35 @@ __global__ __launch_bounds__(BLOCK) void k_block_pack(int64_t nblocks, int64_t n
       int ndv = 0;
       if (vdict_on && nb >= 2 * WAVE) {
         constexpr unsigned long long EMPTYV = ~0ull;
+        double vreg[EPL];
+        for (int u = 0; u < EPL; u++) vreg[u] = u * WAVE + lane < nb ? val[p0 + u * WAVE + lane] : 0.0;
         for (int i = lane; i < BLK_NNZ; i += WAVE) keys[i] = EMPTYV;
         lds_sync();
         bool bad = false;
-        for (int u = 0; u < EPL; u++) {
-          if (u * WAVE + lane >= nb) continue;
-          const unsigned long long v = (unsigned long long)__double_as_longlong(vreg[u]);
-          if (v == EMPTYV) { bad = true; continue; }
-          uint32_t h = (uint32_t)((v * 0x9E3779B97F4A7C15ull) >> 55);      // 9 bits
-          // (the set has as many slots as a block has entries, so every pattern finds one; the probe count is bounded all the same)
-          for (int probes = 0;; probes++) {
-            const unsigned long long old = atomicCAS(&keys[h], EMPTYV, v);
-            if (old == EMPTYV || old == v) break;
-            if (probes == BLK_NNZ) { bad = true; break; }
-            h = (h + 1) & (BLK_NNZ - 1);
+        // (a block whose values are all different - every block of the deeper levels - is given up as soon as the set holds more
+        // patterns than a dictionary may have: after five of its eight rounds, before the set fills up and the probes grow long)
+        const int most = MB_MAX_ND < (5 * nb) / 8 - WAVE ? MB_MAX_ND : (5 * nb) / 8 - WAVE;
+        int held = 0;
+        for (int u = 0; u < EPL && held <= most; u++) {
+          bool fresh = false;
+          if (u * WAVE + lane < nb) {
+            const unsigned long long v = (unsigned long long)__double_as_longlong(vreg[u]);
+            if (v == EMPTYV) bad = true;
+            else {
+              uint32_t h = (uint32_t)((v * 0x9E3779B97F4A7C15ull) >> 55);      // 9 bits
+              // (the set has as many slots as a block has entries, so every pattern finds one; the probe count is bounded all the same)
+              for (int probes = 0;; probes++) {
+                const unsigned long long old = atomicCAS(&keys[h], EMPTYV, v);
+                if (old == EMPTYV) fresh = true;
+                if (old == EMPTYV || old == v) break;
+                if (probes == BLK_NNZ) { bad = true; break; }
+                h = (h + 1) & (BLK_NNZ - 1);
+              }
+            }
           }
+          held += __popcll(__ballot(fresh));
         }
+        if (held > most) bad = true;
         lds_sync();
         int cnt = 0;
         for (int i = lane; i < BLK_NNZ; i += WAVE) cnt += keys[i] != EMPTYV ? 1 : 0;
@@ -1136,25 +1143,26 @@ __global__ __launch_bounds__(BLOCK) void k_block_pack(int64_t nblocks, int64_t n
         }
         lds_sync();
       }
-      if (!ndv) for (int u = 0; u < EPL; u++) if (u * WAVE + lane < nb) oval[p0 + val_slot(u * WAVE + lane, nb)] = vreg[u];
       if (lane == 0) { blk[b].cbase = -2 - (ob | (nwin << MB_WIN_SHIFT) | (ndv << MB_ND_SHIFT)); blk[b].ip = 4 * (int64_t)(nwin + nd); }
     } else if (can_pack && (!mb_on || nrows > mb_max_rows)) {
       // packed: the multi-base form is off, or the block has more rows than mb16_max_rows admits to it (the documented
       // meaning of that knob: such blocks keep the packed form of rounds 2-3 and run in the *_g kernels).  With the
       // multi-base form on, a block that was ADMITTED but fits no table stays raw: the lean kernels take it, and a launch
       // of the *_g kernels for a handful of one-entry blocks per operator costs more than their 4-byte words.
-      double* vl = vals_all[threadIdx.x >> 6];
-      for (int u = 0; u < EPL; u++) if (u * WAVE + lane < nb) vl[u * WAVE + lane] = vreg[u];
-      lds_sync();
-      for (int i = lane; i < nb; i += WAVE) {
+      // (in place: the values of this lane's sorted slots are gathered into registers first, every load of the wave before its
+      // first store)
+      double vsel[EPL];
+      for (int u = 0; u < EPL; u++) { const int i = u * WAVE + lane; vsel[u] = i < nb ? val[p0 + (int)(keys[i] & 0xffffull)] : 0.0; }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      for (int u = 0; u < EPL; u++) {
+        const int i = u * WAVE + lane;
+        if (i >= nb) continue;
         const unsigned long long k = keys[i];
         const int pos = (int)(k & 0xffffull);
         oidx[p0 + i] = ((uint32_t)((int32_t)(k >> 16) - cmin) << (POS_BITS + 3)) | (uint32_t)(pos + 1);
-        oval[p0 + val_slot(i, nb)] = vl[pos];
+        oval[p0 + val_slot(i, nb)] = vsel[u];
       }
       if (lane == 0) blk[b].cbase = cmin;
-    } else {
-      for (int u = 0; u < EPL; u++) if (u * WAVE + lane < nb) oval[p0 + val_slot(u * WAVE + lane, nb)] = vreg[u];
     }
     lds_sync();
   }
@@ -1248,7 +1256,9 @@ __global__ __launch_bounds__(BLOCK) void k_val_bytes(int64_t n, const BlkDesc* _
   }
 }
 // the value regions back to back: k_val_bytes gave each block's bytes; the region is copied from where k_block_pack left it
-// (the block's first non-zero in `src`) to its offset in the compact array, and the descriptor follows
+// (the block's first non-zero in `src`) to its offset in the compact array, and the descriptor follows.  Dictionary and
+// packed blocks were rewritten in place and are copied as they are; the others are still in row-major order and take the
+// interleaved placement here (val_slot; a long row: its first 512 entries)
 __global__ __launch_bounds__(BLOCK) void k_val_compact(int64_t nblocks, BlkDesc* __restrict__ blk, const int64_t* __restrict__ sz, const int64_t* __restrict__ off,
                                                       const double* __restrict__ src, double* __restrict__ dst) {
   const int lane = threadIdx.x & (WAVE - 1);
@@ -1256,7 +1266,15 @@ __global__ __launch_bounds__(BLOCK) void k_val_compact(int64_t nblocks, BlkDesc*
   const int64_t nwaves = ((int64_t)gridDim.x * BLOCK) >> 6;
   for (int64_t b = wave; b < nblocks; b += nwaves) {
     const int64_t nd = sz[b] >> 3, o = off[b] >> 3, p0 = blk[b].p0;
-    for (int64_t k = lane; k < nd; k += WAVE) dst[o + k] = src[p0 + k];
+    const int32_t cbase = blk[b].cbase;
+    const bool as_is = cbase >= 0 || (cbase <= -2 && mb_nd(mb_meta(blk[b])) > 0);
+    if (as_is) {
+      for (int64_t k = lane; k < nd; k += WAVE) dst[o + k] = src[p0 + k];
+    } else {
+      const int n512 = (int)(nd < BLK_NNZ ? nd : BLK_NNZ);
+      for (int k = lane; k < n512; k += WAVE) dst[o + val_slot(k, n512)] = src[p0 + k];
+      for (int64_t k = BLK_NNZ + lane; k < nd; k += WAVE) dst[o + k] = src[p0 + k];
+    }
     if (lane == 0) blk[b].p0 = o;
   }
 }
@@ -1335,7 +1353,7 @@ void devmat_from_csr_device(int64_t m, int64_t n, const int64_t* d_rp, const int
   // (the values are rearranged in place in tval and then laid back to back in the final array)
   const int g = (int)std::min<int64_t>((out.nblocks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, 4096);
   // kinds, values and index regions (in place over tcol), then the regions back to back
-  hipLaunchKernelGGL(k_block_pack, dim3(g < 1 ? 1 : g), dim3(BLOCK), 0, s, out.nblocks, out.nnz, m, out.blk, tcol, tval, g_mb16, g_mb16_max_rows, g_vdict);
+  hipLaunchKernelGGL(k_block_pack, dim3(g < 1 ? 1 : g), dim3(BLOCK), 0, s, out.nblocks, out.nnz, m, out.blk, tcol, tval, g_mb16, g_mb16_max_rows, cached ? 0 : g_vdict);      // (a cached conversion serves a few setup products: no dictionary search)
   int64_t* d_sz = (int64_t*)dev_alloc(sizeof(int64_t) * (size_t)out.nblocks);
   int64_t* d_off = (int64_t*)dev_alloc(sizeof(int64_t) * (size_t)out.nblocks);
   hipLaunchKernelGGL(k_region_sizes, dim3(grid1d(out.nblocks)), dim3(BLOCK), 0, s, out.nblocks, out.blk, d_sz);
