@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--recipe", default="trunc", choices=sorted(RECIPES))
     ap.add_argument("--max-levels", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=8, help="Krylov iterations of one CPU baseline sample (about 2 s each at 464^3 on 32 threads)")
+    ap.add_argument("--cpu-iters", type=int, default=5, help="Krylov iterations of one CPU baseline sample (1.5-2 s each at 464^3 on 16 threads: three samples = 25-30 s of CPU work)")
     ap.add_argument("--cpu-samples", type=int, default=3, help="CPU baseline samples (each --cpu-iters iterations from x0 = 1); the median is reported")
     ap.add_argument("--graph", type=int, default=0)
     ap.add_argument("--profile-kernels", type=int, default=1)

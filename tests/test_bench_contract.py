@@ -1,5 +1,5 @@
 """The bench.py output contract, checked on the committed line of the round's final default run
-(profiles/r05_final4_bench464_default.json): every key the driver and the judge read is there with the right type,
+(profiles/r05_final5_bench464_default.json): every key the driver and the judge read is there with the right type,
 the workload is BASELINE configs[2] (3D advection, 464^3), and the derived fields are consistent."""
 import json
 import os
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_honours_the_contract():
-    with open(os.path.join(ROOT, "profiles", "r05_final4_bench464_default.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r05_final5_bench464_default.json")) as f:
         d = json.loads(f.read().strip().splitlines()[-1])
     for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                  ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
