@@ -10,7 +10,7 @@ library takes) are returned in `other`; nothing is dropped silently.
 """
 import shlex
 
-__all__ = ["parse_petsc_args", "build"]
+__all__ = ["parse_petsc_args", "build", "matrix"]
 
 _KSP = {"ksp_type": ("ksp_type", str), "ksp_pc_side": ("pc_side", str), "ksp_norm_type": ("norm_type", str),
         "ksp_rtol": ("rtol", float), "ksp_atol": ("atol", float), "ksp_divtol": ("divtol", float),
@@ -49,11 +49,15 @@ def _is_number(tok):
 
 
 def parse_petsc_args(line):
-    """-> dict(pc_type, pc, ksp, gen, other): `pc` the -pc_air_* / -pc_pflareinv_* options without their prefix (a flag
+    """-> dict(program, pc_type, pc, ksp, gen, other): `program` the driver's name if the line starts with one, `pc` the -pc_air_* / -pc_pflareinv_* options without their prefix (a flag
     given without a value is True, as PetscOptionsBool reads it), `ksp` keyword arguments of pflare_amd.KSP, `gen` those
     of HostMat.adv_diff_fd / adv_1d, `other` everything else (name -> value)."""
     toks = shlex.split(line) if isinstance(line, str) else list(line)
-    out = dict(pc_type=None, pc={}, ksp={}, gen={}, other={})
+    out = dict(program=None, pc_type=None, pc={}, ksp={}, gen={}, other={})
+    if toks and not toks[0].startswith("-"):
+        out["program"] = toks[0].rsplit("/", 1)[-1]
+        if out["program"] == "adv_1d":
+            out["pc_type"] = "air"          # the driver sets it itself (tests/adv_1d.c:142)
     i = 0
     while i < len(toks):
         t = toks[i]
@@ -87,10 +91,19 @@ def parse_petsc_args(line):
 
 def build(line):
     """The objects of one command line: (pc, ksp, gen, other) with pc a PCAIR / PCPFLAREINV carrying the line's options
-    (not set up), ksp a KSP, gen the generator's keyword arguments."""
+    (not set up), ksp a KSP, gen the generator's keyword arguments (`matrix(line)` builds the operator)."""
     from .pc import KSP, PCAIR, PCPFLAREINV
     o = parse_petsc_args(line)
     if o["pc_type"] not in ("air", "pflareinv"):
         raise ValueError(f"-pc_type {o['pc_type']}: this build provides the PC types 'air' and 'pflareinv'")
     pc = (PCAIR if o["pc_type"] == "air" else PCPFLAREINV)(**o["pc"])
     return pc, KSP(**o["ksp"]), o["gen"], o["other"]
+
+
+def matrix(line):
+    """The operator the line's driver assembles: tests/adv_1d.c (-n, the driver's default 100, tests/adv_1d.c:21) or tests/adv_diff_fd.c."""
+    from .pc import HostMat
+    o = parse_petsc_args(line)
+    if o["program"] == "adv_1d":
+        return HostMat.adv_1d(o["gen"].get("n", 100))
+    return HostMat.adv_diff_fd(**o["gen"])

@@ -21,6 +21,17 @@ LINES = {
                           "-pc_air_coarsest_inverse_type newton -pc_air_coarsest_poly_order 10 -pc_air_coarsest_matrix_free_polys "
                           "-pc_air_auto_truncate_start_level 1 -pc_air_auto_truncate_tol 1e-2 -ksp_max_it 3 "
                           "-pc_air_a_drop 1e-3 -pc_air_inverse_type power"),
+    "fc_smoothing_300": ("300", "./adv_diff_fd -da_grid_x 8 -da_grid_y 8 -pc_type air -ksp_max_it 3 -pc_air_smooth_type fc"),
+    "neumann_398": ("398", "./adv_diff_fd -u 0 -v 0 -alpha 1.0 -da_grid_x 8 -da_grid_y 8 -pc_type air -pc_air_inverse_type neumann -ksp_max_it 5 -pc_air_a_drop 1e-3"),
+    "neumann_mf_400": ("400-401", "./adv_diff_fd -u 0 -v 0 -alpha 1.0 -da_grid_x 8 -da_grid_y 8 -pc_type air -pc_air_inverse_type neumann "
+                       "-pc_air_matrix_free_polys -ksp_max_it 5 -pc_air_a_drop 1e-3"),
+    "adv_1d_538": ("538-540", "./adv_1d -n 1000 -ksp_rtol 1e-10 -ksp_atol 1e-50 -ksp_pc_side right "
+                   "-pc_air_coarsest_inverse_type newton -pc_air_coarsest_poly_order 10 -pc_air_coarsest_matrix_free_polys -ksp_max_it 2 "
+                   "-pc_air_a_drop 1e-3 -pc_air_inverse_type power"),
+    "improve_w_708": ("708-709", "./adv_diff_fd -da_grid_x 50 -da_grid_y 50 -pc_type air -pc_air_one_point_classical_prolong 0 "
+                      "-pc_air_improve_w_its 1 -ksp_max_it 4	-pc_air_a_drop 1e-3 -pc_air_inverse_type power"),
+    "newton_order_3_715": ("713-717, order 3", "./adv_diff_fd -da_grid_x 50 -da_grid_y 50 -pc_type air -pc_air_inverse_type newton -pc_air_poly_order 3 "
+                           "-pc_air_inverse_sparsity_order 3 -ksp_norm_type unpreconditioned -ksp_max_it 6"),
     "lump_drop_100_1123": ("1121-1124, size 100", "./adv_diff_fd -da_grid_x 100 -da_grid_y 100 -pc_type air -ksp_pc_side right "
                            "-ksp_rtol 1e-10 -ksp_atol 1e-50 -pc_air_a_lump -pc_air_a_drop 1e-5 -pc_air_strong_threshold 0.99 -ksp_max_it 6"),
 }
@@ -56,6 +67,10 @@ def test_build_gives_the_objects_without_a_device():
     assert ksp.o.max_it == 6 and ksp.o.pc_side == 1 and ksp.o.rtol == 1e-10
     pc, _, _, _ = build(LINES["newton_mf_50_552"][1])
     assert isinstance(pc, P.PCPFLAREINV)
+    o = __import__("pflare_amd.options", fromlist=["parse_petsc_args"]).parse_petsc_args(LINES["adv_1d_538"][1])
+    assert o["program"] == "adv_1d" and o["pc_type"] == "air" and o["gen"] == dict(n=1000)      # tests/adv_1d.c:142 sets the type
+    from pflare_amd.options import matrix
+    assert matrix(LINES["adv_1d_538"][1]).shape == (1000, 1000) and matrix(LINES["fc_smoothing_300"][1]).shape == (64, 64)
     with pytest.raises(ValueError):
         build("./adv_diff_fd -pc_type hypre")
     with pytest.raises(P.AirhipError):           # an option this build does not have is refused by the library, not ignored
@@ -69,8 +84,9 @@ def test_reference_line_converges_as_the_reference_requires(gpu, name):
     import pflare_amd as P
     from pflare_amd.options import build
     from oracle import c_oracle
+    from pflare_amd.options import matrix
     pc, ksp, gen, other = build(LINES[name][1])
-    A = P.HostMat.adv_diff_fd(**gen)
+    A = matrix(LINES[name][1])
     n = A.shape[0]
     pc.setup(A)
     b = torch.zeros(n, dtype=torch.float64, device="cuda")
