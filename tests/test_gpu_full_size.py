@@ -17,27 +17,62 @@ def _lcg(n, shift=12345):
     return ((np.uint64(1103515245) * (i + np.uint64(shift))) % np.uint64(2 ** 31)).astype(np.float64) / 2.0 ** 30 - 1.0
 
 
+def _brick_keys(B=16):
+    nbk = (M + B - 1) // B
+    ax = np.arange(M, dtype=np.int64)
+    bi, li = ax // B, ax % B
+    key = ((bi[:, None, None] * nbk + bi[None, :, None]) * nbk + bi[None, None, :]) * B ** 3 \
+        + (li[:, None, None] * B + li[None, :, None]) * B + li[None, None, :]
+    return key.reshape(-1)
+
+
+def test_config3_464_matrix_free_smoother_against_the_c_oracle(gpu):
+    """the "GMRES-polynomial smoother" variant of config 3 applied matrix-free (-pc_air_matrix_free_polys, bench.py --recipe
+    trunc_mf) at full size: one V-cycle - with the fused first sweep on G = A_fc + A_ff W and the polynomial as `M` - against
+    the oracle's sequence of the reference's products on the same hierarchy, and the solve's iteration count"""
+    import torch
+    import pflare_amd as P
+    from oracle import c_oracle
+    free, _ = torch.cuda.mem_get_info()
+    if free < 200 * 2 ** 30:
+        pytest.skip(f"needs ~200 GB of device memory, {free / 2 ** 30:.0f} GiB are free")
+    A = P.HostMat.adv_diff_fd(dim=3, M=M, N=M, P=M)
+    n = A.shape[0]
+    pc = P.PCAIR(a_lump=True, auto_truncate_start_level=1, auto_truncate_tol=1e-1, matrix_free_polys=True,
+                 coarsest_inverse_type="newton", coarsest_matrix_free_polys=True, coarsest_poly_order=10)
+    pc.set_ordering_hint(_brick_keys())
+    pc.setup(A)
+    assert 12 <= pc.num_levels <= 18
+    ch = c_oracle.CHierarchy(pc, copy=False)
+    x = _lcg(n)
+    z = torch.empty(n, dtype=torch.float64, device="cuda")
+    pc.apply(torch.from_numpy(x).cuda(), z)
+    zr = ch.vcycle(x)
+    assert np.linalg.norm(z.cpu().numpy() - zr) <= 1e-10 * np.linalg.norm(zr)
+    del zr, ch, z
+    b = torch.zeros(n, dtype=torch.float64, device="cuda"); sol = torch.ones_like(b)
+    res = P.KSP("gmres", pc_side="right", rtol=1e-10, atol=1e-50, max_it=30).solve(b, sol, pc=pc)
+    assert res["reason"] > 0 and 10 <= res["its"] <= 14 and res["pc_applies"] == res["its"], res
+    # the next test needs the device to itself
+    del pc, b, sol, res
+    import gc
+    gc.collect(); torch.cuda.empty_cache()
+
+
 def test_config3_464_vcycle_against_the_c_oracle_linearity_and_true_residual(gpu):
     import torch
     import pflare_amd as P
     from oracle import c_oracle
     free, _ = torch.cuda.mem_get_info()
     if free < 200 * 2 ** 30:
-        pytest.skip("needs ~200 GB of device memory")
+        pytest.skip(f"needs ~200 GB of device memory, {free / 2 ** 30:.0f} GiB are free")
     A = P.HostMat.adv_diff_fd(dim=3, M=M, N=M, P=M)
     n = A.shape[0]
     assert n == 99897344
     pc = P.PCAIR(a_lump=True, auto_truncate_start_level=1, auto_truncate_tol=1e-1, coarsest_inverse_type="newton",
                  coarsest_matrix_free_polys=True, coarsest_poly_order=10)
     # bench.py's layout hint: grid points grouped in 16^3 bricks (the operator keeps the reference numbering)
-    B = 16
-    nbk = (M + B - 1) // B
-    ax = np.arange(M, dtype=np.int64)
-    bi, li = ax // B, ax % B
-    key = ((bi[:, None, None] * nbk + bi[None, :, None]) * nbk + bi[None, None, :]) * B ** 3 \
-        + (li[:, None, None] * B + li[None, :, None]) * B + li[None, None, :]
-    pc.set_ordering_hint(key.reshape(-1))
-    del key
+    pc.set_ordering_hint(_brick_keys())
     pc.setup(A)
     assert 12 <= pc.num_levels <= 18                   # 15 with the committed setup (bit-reproducible)
     # ---- one V-cycle against the oracle on the same hierarchy
